@@ -1,0 +1,217 @@
+/*
+ * ryg_rans_amd.h -- C ABI of the MI355X-native interleaved rANS coder.
+ *
+ * Drop-in boundary for the encode/decode hot path of rygorous/ryg_rans.  The
+ * reference is header-only: its "API" is the inline per-symbol primitives
+ * (rans_byte.h, rans64.h, rans_word_sse41.h) plus the driver LOOPS in the mains
+ * that define the interleaved stream layout.  A per-symbol inline call cannot
+ * cross to a device, so this ABI replaces one reference driver loop per call:
+ *
+ *   reference loop (what a maintainer deletes)            this ABI
+ *   ---------------------------------------------------   --------------------------
+ *   SymbolStats::count_freqs       main.cpp:59-66         rans_amd_count_freqs[_host]
+ *   SymbolStats::normalize_freqs   main.cpp:75-129        rans_amd_normalize_freqs
+ *   cum2sym / RansEncSymbolInit /  main.cpp:143-162       rans_amd_model_create
+ *   RansWordTablesInitSymbol       main_simd.cpp:141-143    (tables staged for LDS)
+ *   make_alias_table               main_alias.cpp:147-237
+ *   N-way encode loop + flush      main.cpp:226-246,      rans_amd_encode[_host]
+ *                                  main64.cpp:228-248,
+ *                                  main_simd.cpp:287-300,
+ *                                  main_alias.cpp:353-373
+ *   N-way decode loop              main.cpp:259-280,      rans_amd_decode[_host]
+ *                                  main64.cpp:261-282,
+ *                                  main_simd.cpp:313-332,
+ *                                  main_alias.cpp:386-405
+ *
+ * Streams are bit-exact with the reference formats: a
+ * stream produced by the reference's N-way loop decodes here and vice versa.
+ * The per-symbol RansEnc / RansDec / Rans64 / RansWord inline API is re-provided
+ * for host code in include/ryg_rans_amd/compat/.
+ *
+ * One N-way stream is one wavefront's worth of sequential work, so inputs that
+ * should fill a GPU are cut into CHUNKS of chunk_syms symbols; every chunk is an
+ * independent, self-contained reference-format stream and a small index
+ * (offsets/lengths) says where each one lives.  With chunk_syms >= n there is
+ * exactly one chunk and the container IS the raw reference stream.
+ *
+ * Conventions
+ *   - every function returns a rans_amd_status (0 = ok); no exceptions cross the ABI;
+ *   - pointers named d_* are DEVICE memory on the context's GPU, h_* / unprefixed
+ *     are host memory; `stream` is a hipStream_t passed as void* (NULL = default
+ *     stream); device entry points are asynchronous on that stream unless stated;
+ *   - device buffers must come from hipMalloc-like allocators (base 16-byte
+ *     aligned, size padded to 16): kernels fetch the stream in aligned 16-byte
+ *     granules and may touch the padding of the last granule, never beyond;
+ *   - all streams are little-endian (as the reference on x86, README:12).
+ */
+#ifndef RYG_RANS_AMD_H
+#define RYG_RANS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RANS_AMD_VERSION 100 /* 0.1.0 */
+
+typedef enum rans_amd_status {
+    RANS_AMD_OK = 0,
+    RANS_AMD_E_ARG = 1,         /* NULL pointer, zero size, bad enum */
+    RANS_AMD_E_MODEL = 2,       /* frequencies do not sum to 1<<scale_bits, freq==M, symbol with freq 0 */
+    RANS_AMD_E_SPACE = 3,       /* output buffer too small */
+    RANS_AMD_E_CORRUPT = 4,     /* decoder: final state != L, cursor != end of stream, read past end */
+    RANS_AMD_E_UNSUPPORTED = 5, /* n_ways / scale_bits / alphabet outside what the kernels implement */
+    RANS_AMD_E_HIP = 6,         /* HIP runtime error (see rans_amd_last_error) */
+    RANS_AMD_E_NOMEM = 7
+} rans_amd_status;
+
+/* Bitstream formats. */
+typedef enum rans_amd_format {
+    RANS_AMD_FMT_BYTE = 0,  /* rans_byte.h:   u32 state, L=2^23, 8-bit renorm, scale_bits <= 16 */
+    RANS_AMD_FMT_WORD = 1,  /* rans_word_sse41.h: u32 state, L=2^16, 16-bit renorm, scale_bits == 12 */
+    RANS_AMD_FMT_R64 = 2,   /* rans64.h:      u64 state, L=2^31, 32-bit renorm, scale_bits <= 31 */
+    RANS_AMD_FMT_ALIAS = 3  /* rans_byte.h stream, alias-method symbol map (main_alias.cpp:241-267) */
+} rans_amd_format;
+
+/* Host images of the model tables, for inspection and parity tests. */
+typedef enum rans_amd_table {
+    RANS_AMD_TAB_FREQS = 0,        /* u32[nsyms]                                       */
+    RANS_AMD_TAB_CUM_FREQS = 1,    /* u32[nsyms+1]                                     */
+    RANS_AMD_TAB_CUM2SYM = 2,      /* u8[M] (nsyms<=256) or u16[M]; main.cpp:145-148   */
+    RANS_AMD_TAB_WORD_SLOTS = 3,   /* RansWordTables image: {u16 freq,u16 bias}[4096] + u8 slot2sym[4096] */
+    RANS_AMD_TAB_ALIAS_DIVIDER = 4,     /* u32[nsyms]   main_alias.cpp:57      */
+    RANS_AMD_TAB_ALIAS_SLOT_ADJUST = 5, /* u32[2*nsyms] main_alias.cpp:58      */
+    RANS_AMD_TAB_ALIAS_SLOT_FREQS = 6,  /* u32[2*nsyms] main_alias.cpp:59      */
+    RANS_AMD_TAB_ALIAS_SYM_ID = 7,      /* u8/u16[2*nsyms] main_alias.cpp:60   */
+    RANS_AMD_TAB_ALIAS_REMAP = 8,       /* u32[M]       main_alias.cpp:63      */
+    RANS_AMD_TAB_ENC_SYMBOLS = 9,  /* RansEncSymbol[nsyms] (16 B each, rans_byte.h:159-165) or
+                                      Rans64EncSymbol[nsyms] (24 B each, rans64.h:152-158) for FMT_R64 */
+    RANS_AMD_TAB_DEC_SYMBOLS = 10  /* RansDecSymbol[nsyms] (4 B) or Rans64DecSymbol[nsyms] (8 B) */
+} rans_amd_table;
+
+typedef struct rans_amd_ctx rans_amd_ctx;     /* one per (process, GPU); thread-compatible */
+typedef struct rans_amd_model rans_amd_model; /* immutable after creation; shareable across streams */
+
+/* ---- library / context ------------------------------------------------- */
+
+int rans_amd_version(void);
+const char *rans_amd_status_string(int status);
+/* Text of the most recent failure on this thread ("" if none). */
+const char *rans_amd_last_error(void);
+
+/* Number of visible GPUs (hipGetDeviceCount); 0 when there is none. */
+int rans_amd_device_count(void);
+
+/* Bind a context to GPU `device`.  Fails with RANS_AMD_E_HIP when no GPU is
+ * usable: there is no CPU fallback anywhere in this library. */
+int rans_amd_ctx_create(int device, rans_amd_ctx **out_ctx);
+int rans_amd_ctx_destroy(rans_amd_ctx *ctx);
+/* Drop cached device workspaces (encode scratch). */
+int rans_amd_ctx_trim(rans_amd_ctx *ctx);
+
+/* ---- model building (SymbolStats, main.cpp:49-129) ---------------------- */
+
+/* Histogram of n symbols (sym_bytes 1 or 2) into freqs[nsyms]; symbols >= nsyms
+ * are an error.  Host version replaces count_freqs (main.cpp:59-66). */
+int rans_amd_count_freqs_host(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *freqs);
+/* Device version: d_syms on the GPU, result copied to host freqs (synchronises `stream`). */
+int rans_amd_count_freqs(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, int sym_bytes, uint32_t nsyms,
+                         uint32_t *freqs, void *stream);
+
+/* In place: raw counts -> frequencies summing to target_total, exactly as
+ * SymbolStats::normalize_freqs (main.cpp:75-129): 64-bit rescale of the
+ * cumulative table, then every present symbol squeezed to 0 steals one slot from
+ * the narrowest symbol wider than 1 (lowest index on ties).  cum_freqs gets
+ * nsyms+1 entries.  Requires target_total >= nsyms. */
+int rans_amd_normalize_freqs(uint32_t *freqs, uint32_t *cum_freqs, uint32_t nsyms, uint32_t target_total);
+
+/* Build every host/device table the given format needs from NORMALISED
+ * frequencies (sum == 1<<scale_bits) and upload them.
+ *   BYTE : cum2sym[M] + RansDecSymbol/RansEncSymbol per symbol   (scale_bits <= 16)
+ *   WORD : RansWordTables slots                                  (scale_bits == 12, nsyms <= 256)
+ *   R64  : cum2sym[M] + Rans64Dec/EncSymbol                      (scale_bits <= 16 on the GPU path)
+ *   ALIAS: divider/slot_adjust/slot_freqs/sym_id (+alias_remap)  (nsyms a power of two dividing M)
+ * A model in which one symbol owns the whole range (freq == M) is rejected with
+ * RANS_AMD_E_MODEL (outside the reference's working range).
+ * ctx may be NULL: the model is then host-only (its tables can be exported with
+ * rans_amd_model_table, encode/decode reject it with RANS_AMD_E_ARG). */
+int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_freqs, uint32_t nsyms,
+                          uint32_t scale_bits, rans_amd_model **out_model);
+int rans_amd_model_destroy(rans_amd_model *model);
+int rans_amd_model_format(const rans_amd_model *model);
+uint32_t rans_amd_model_scale_bits(const rans_amd_model *model);
+uint32_t rans_amd_model_nsyms(const rans_amd_model *model);
+/* Bytes per symbol in uncompressed buffers: 1 when nsyms <= 256, else 2. */
+int rans_amd_model_sym_bytes(const rans_amd_model *model);
+/* Copy the host image of a table; *size receives its byte size (call with
+ * dst == NULL to query).  RANS_AMD_E_ARG if the model has no such table. */
+int rans_amd_model_table(const rans_amd_model *model, int which, void *dst, size_t cap, size_t *size);
+
+/* ---- chunk layout -------------------------------------------------------- */
+
+/* ceil(n / chunk_syms); 0 for n == 0. */
+uint64_t rans_amd_num_chunks(uint64_t n, uint32_t chunk_syms);
+/* Worst-case bytes of ONE chunk stream (states + renorm units), rounded up to 16. */
+uint64_t rans_amd_chunk_bound(int format, uint32_t chunk_syms, uint32_t n_ways);
+/* Worst-case bytes of the whole container for n symbols. */
+uint64_t rans_amd_encode_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms);
+/* 1 if (format, n_ways) has a GPU kernel: n_ways in 1..64 or a multiple of 64 up to 512. */
+int rans_amd_ways_supported(int format, uint32_t n_ways);
+
+/* ---- bulk encode / decode on device-resident data ------------------------- */
+
+/* Encode n symbols at d_syms (u8, or u16 when nsyms > 256) into d_out.
+ * Chunk c covers symbols [c*chunk_syms, min(n, (c+1)*chunk_syms)) and becomes an
+ * n_ways-interleaved reference-format stream at d_out + d_offsets[c] (16-byte
+ * aligned) of d_lengths[c] bytes; d_offsets has nchunks+1 entries, the last one
+ * is the container size.  If h_total_bytes != NULL the call synchronises
+ * `stream` and stores the container size; it then also reports
+ * RANS_AMD_E_SPACE if out_cap was too small and RANS_AMD_E_MODEL if a symbol
+ * with frequency 0 was met. */
+int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,
+                    uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t out_cap,
+                    uint64_t *d_offsets, uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream);
+
+/* Decode a container.  d_out receives n symbols.  Every chunk is checked the way
+ * the reference's streams allow (all final states == L, cursor == end of the
+ * chunk's stream, no read past it); failures are counted on the device.  If
+ * h_bad_chunks != NULL the call synchronises `stream`, stores the number of
+ * failed chunks and returns RANS_AMD_E_CORRUPT when it is non-zero.  Otherwise
+ * the call is asynchronous; fetch the count later with rans_amd_decode_errors.
+ * No kernel ever reads outside the 16-byte granules covering
+ * [d_container, d_container + container_bytes). */
+int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_container,
+                    uint64_t container_bytes, const uint64_t *d_offsets, const uint32_t *d_lengths,
+                    uint64_t n, uint32_t n_ways, uint32_t chunk_syms, void *d_out,
+                    uint64_t *h_bad_chunks, void *stream);
+/* Synchronise `stream` and return (and reset) the failed-chunk count accumulated
+ * by asynchronous rans_amd_decode calls on this context. */
+int rans_amd_decode_errors(rans_amd_ctx *ctx, uint64_t *h_bad_chunks, void *stream);
+
+/* ---- host-buffer convenience: one raw reference-format stream -------------- */
+
+/* Exactly the reference encoder loops: the stream is written BACKWARDS and ends
+ * at buf + cap (rans_byte.h:22-26); *out_len receives its length, i.e. the
+ * stream is buf[cap - *out_len, cap).  Runs on the GPU (copies in/out). */
+int rans_amd_encode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const void *syms, uint64_t n,
+                         uint32_t n_ways, uint8_t *buf, uint64_t cap, uint64_t *out_len);
+/* Decode one raw n_ways stream of exactly len bytes into n symbols. */
+int rans_amd_decode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const uint8_t *stream_bytes,
+                         uint64_t len, uint64_t n, uint32_t n_ways, void *out);
+
+/* ---- measurement helpers ---------------------------------------------------- */
+
+/* Duration in milliseconds of the most recent decode / encode kernel group that
+ * was launched with timing enabled (HIP events recorded on the launch stream).
+ * Synchronises those events. */
+int rans_amd_set_timing(rans_amd_ctx *ctx, int enabled);
+int rans_amd_last_kernel_ms(rans_amd_ctx *ctx, float *decode_ms, float *encode_ms);
+/* Name of the dominant device kernel the last decode used (for profile matching). */
+const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RYG_RANS_AMD_H */

@@ -1,0 +1,294 @@
+"""ryg_rans_amd -- MI355X-native interleaved rANS coder (Python test/bench driver).
+
+This package is a thin ctypes binding of the C ABI in include/ryg_rans_amd.h
+(built from ryg_rans_amd/csrc into ryg_rans_amd/lib/libryg_rans_amd.so).  All
+encode/decode work happens in the hand-written HIP kernels behind that ABI; there
+is no Python or CPU implementation of the hot path here, and importing the
+package fails loudly when the shared object is missing.
+
+PyTorch is only plumbing: device buffers are torch tensors whose data_ptr() is
+handed to the C ABI, and the current torch stream is the launch stream.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libryg_rans_amd.so")
+
+FMT_BYTE, FMT_WORD, FMT_R64, FMT_ALIAS = 0, 1, 2, 3
+FORMAT_NAMES = {FMT_BYTE: "byte", FMT_WORD: "word", FMT_R64: "r64", FMT_ALIAS: "alias"}
+
+OK, E_ARG, E_MODEL, E_SPACE, E_CORRUPT, E_UNSUPPORTED, E_HIP, E_NOMEM = range(8)
+
+(TAB_FREQS, TAB_CUM_FREQS, TAB_CUM2SYM, TAB_WORD_SLOTS, TAB_ALIAS_DIVIDER, TAB_ALIAS_SLOT_ADJUST,
+ TAB_ALIAS_SLOT_FREQS, TAB_ALIAS_SYM_ID, TAB_ALIAS_REMAP, TAB_ENC_SYMBOLS, TAB_DEC_SYMBOLS) = range(11)
+
+# every symbol include/ryg_rans_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "rans_amd_version", "rans_amd_status_string", "rans_amd_last_error", "rans_amd_device_count",
+    "rans_amd_ctx_create", "rans_amd_ctx_destroy", "rans_amd_ctx_trim",
+    "rans_amd_count_freqs_host", "rans_amd_count_freqs", "rans_amd_normalize_freqs",
+    "rans_amd_model_create", "rans_amd_model_destroy", "rans_amd_model_format", "rans_amd_model_scale_bits",
+    "rans_amd_model_nsyms", "rans_amd_model_sym_bytes", "rans_amd_model_table",
+    "rans_amd_num_chunks", "rans_amd_chunk_bound", "rans_amd_encode_bound", "rans_amd_ways_supported",
+    "rans_amd_encode", "rans_amd_decode", "rans_amd_decode_errors",
+    "rans_amd_encode_host", "rans_amd_decode_host",
+    "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel",
+]
+
+
+class RansAmdError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__("%s: status %d (%s)%s" % (where, status, _status_string(status),
+                                                   (": " + detail) if detail else ""))
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "ryg_rans_amd: %s is missing -- build it with `make -C ryg_rans_amd/csrc` "
+            "(or __graft_entry__.build()); there is no fallback implementation" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    sig = {
+        "rans_amd_version": (i32, []),
+        "rans_amd_status_string": (C.c_char_p, [i32]),
+        "rans_amd_last_error": (C.c_char_p, []),
+        "rans_amd_device_count": (i32, []),
+        "rans_amd_ctx_create": (i32, [i32, C.POINTER(vp)]),
+        "rans_amd_ctx_destroy": (i32, [vp]),
+        "rans_amd_ctx_trim": (i32, [vp]),
+        "rans_amd_count_freqs_host": (i32, [vp, u64, i32, u32, u32p]),
+        "rans_amd_count_freqs": (i32, [vp, vp, u64, i32, u32, u32p, vp]),
+        "rans_amd_normalize_freqs": (i32, [u32p, u32p, u32, u32]),
+        "rans_amd_model_create": (i32, [vp, i32, u32p, u32, u32, C.POINTER(vp)]),
+        "rans_amd_model_destroy": (i32, [vp]),
+        "rans_amd_model_format": (i32, [vp]),
+        "rans_amd_model_scale_bits": (u32, [vp]),
+        "rans_amd_model_nsyms": (u32, [vp]),
+        "rans_amd_model_sym_bytes": (i32, [vp]),
+        "rans_amd_model_table": (i32, [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "rans_amd_num_chunks": (u64, [u64, u32]),
+        "rans_amd_chunk_bound": (u64, [i32, u32, u32]),
+        "rans_amd_encode_bound": (u64, [i32, u64, u32, u32]),
+        "rans_amd_ways_supported": (i32, [i32, u32]),
+        "rans_amd_encode": (i32, [vp, vp, vp, u64, u32, u32, vp, u64, vp, vp, u64p, vp]),
+        "rans_amd_decode": (i32, [vp, vp, vp, u64, vp, vp, u64, u32, u32, vp, u64p, vp]),
+        "rans_amd_decode_errors": (i32, [vp, u64p, vp]),
+        "rans_amd_encode_host": (i32, [vp, vp, vp, u64, u32, vp, u64, u64p]),
+        "rans_amd_decode_host": (i32, [vp, vp, vp, u64, u64, u32, vp]),
+        "rans_amd_set_timing": (i32, [vp, i32]),
+        "rans_amd_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "rans_amd_last_decode_kernel": (C.c_char_p, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = _load()
+
+
+def _status_string(status):
+    return _lib.rans_amd_status_string(status).decode()
+
+
+def _check(status, where):
+    if status != OK:
+        raise RansAmdError(status, where, _lib.rans_amd_last_error().decode())
+
+
+def lib():
+    """The raw ctypes handle (for ABI-level tests)."""
+    return _lib
+
+
+def device_count():
+    return int(_lib.rans_amd_device_count())
+
+
+# ---- model building on the host (SymbolStats, main.cpp:49-129) -----------------
+
+def count_freqs(syms, nsyms):
+    syms = np.ascontiguousarray(syms)
+    assert syms.dtype in (np.uint8, np.uint16)
+    out = np.zeros(nsyms, dtype=np.uint32)
+    _check(_lib.rans_amd_count_freqs_host(syms.ctypes.data, syms.size, syms.dtype.itemsize, nsyms,
+                                          out.ctypes.data_as(C.POINTER(C.c_uint32))), "count_freqs")
+    return out
+
+
+def normalize_freqs(counts, target_total):
+    f = np.array(counts, dtype=np.uint32, copy=True)
+    cum = np.zeros(f.size + 1, dtype=np.uint32)
+    _check(_lib.rans_amd_normalize_freqs(f.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         cum.ctypes.data_as(C.POINTER(C.c_uint32)), f.size, target_total),
+           "normalize_freqs")
+    return f, cum
+
+
+def num_chunks(n, chunk_syms):
+    return int(_lib.rans_amd_num_chunks(n, chunk_syms))
+
+
+def chunk_bound(fmt, chunk_syms, n_ways):
+    return int(_lib.rans_amd_chunk_bound(fmt, chunk_syms, n_ways))
+
+
+def encode_bound(fmt, n, n_ways, chunk_syms):
+    return int(_lib.rans_amd_encode_bound(fmt, n, n_ways, chunk_syms))
+
+
+def ways_supported(fmt, n_ways):
+    return bool(_lib.rans_amd_ways_supported(fmt, n_ways))
+
+
+class Context:
+    """One per (process, GPU).  Raises RansAmdError(E_HIP) when no GPU is usable."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(_lib.rans_amd_ctx_create(device, C.byref(self._h)), "ctx_create")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.rans_amd_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- measurement
+    def set_timing(self, on=True):
+        _check(_lib.rans_amd_set_timing(self._h, int(on)), "set_timing")
+
+    def last_kernel_ms(self):
+        d, e = C.c_float(-1), C.c_float(-1)
+        _check(_lib.rans_amd_last_kernel_ms(self._h, C.byref(d), C.byref(e)), "last_kernel_ms")
+        return d.value, e.value
+
+    def last_decode_kernel(self):
+        return _lib.rans_amd_last_decode_kernel(self._h).decode()
+
+    # -- model
+    def model(self, fmt, norm_freqs, scale_bits):
+        return Model(self, fmt, norm_freqs, scale_bits)
+
+    def model_for(self, fmt, syms, nsyms, scale_bits):
+        """count_freqs + normalize_freqs + table build, like every reference main does."""
+        f, _ = normalize_freqs(count_freqs(syms, nsyms), 1 << scale_bits)
+        return Model(self, fmt, f, scale_bits)
+
+    def count_freqs_device(self, d_syms, nsyms):
+        """Histogram of a device tensor (uint8 / int16-viewed-uint16) on the GPU."""
+        out = np.zeros(nsyms, dtype=np.uint32)
+        _check(_lib.rans_amd_count_freqs(self._h, d_syms.data_ptr(), d_syms.numel(), d_syms.element_size(), nsyms,
+                                         out.ctypes.data_as(C.POINTER(C.c_uint32)), _torch_stream()),
+               "count_freqs(device)")
+        return out
+
+    # -- raw single-stream convenience (host buffers, reference stream layout)
+    def encode_host(self, model, syms, n_ways):
+        syms = np.ascontiguousarray(syms)
+        cap = chunk_bound(model.fmt, max(int(syms.size), 1), n_ways) + 16
+        buf = np.zeros(cap, dtype=np.uint8)
+        out_len = C.c_uint64(0)
+        _check(_lib.rans_amd_encode_host(self._h, model._h, syms.ctypes.data, syms.size, n_ways, buf.ctypes.data,
+                                         cap, C.byref(out_len)), "encode_host")
+        return buf[cap - out_len.value:].copy()
+
+    def decode_host(self, model, stream, n, n_ways, check=True):
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        out = np.zeros(n, dtype=np.uint8 if model.sym_bytes == 1 else np.uint16)
+        rc = _lib.rans_amd_decode_host(self._h, model._h, stream.ctypes.data, stream.size, n, n_ways,
+                                       out.ctypes.data)
+        if check:
+            _check(rc, "decode_host")
+            return out
+        return out, rc
+
+    # -- bulk, device-resident (torch tensors)
+    def encode(self, model, d_syms, n_ways, chunk_syms, d_out=None, sync=True):
+        """Returns (d_container, d_offsets, d_lengths, total_bytes)."""
+        import torch
+        n = d_syms.numel()
+        nchunks = num_chunks(n, chunk_syms)
+        cap = encode_bound(model.fmt, n, n_ways, chunk_syms) + 16
+        dev = d_syms.device
+        if d_out is None:
+            d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_offsets = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
+        d_lengths = torch.zeros(max(nchunks, 1), dtype=torch.int32, device=dev)
+        total = C.c_uint64(0)
+        _check(_lib.rans_amd_encode(self._h, model._h, d_syms.data_ptr(), n, n_ways, chunk_syms, d_out.data_ptr(),
+                                    d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
+                                    C.byref(total) if sync else None, _torch_stream()), "encode")
+        return d_out, d_offsets, d_lengths, (total.value if sync else None)
+
+    def decode(self, model, d_container, container_bytes, d_offsets, d_lengths, n, n_ways, chunk_syms, d_out=None,
+               sync=True):
+        import torch
+        if d_out is None:
+            d_out = torch.empty(n, dtype=torch.uint8 if model.sym_bytes == 1 else torch.int16,
+                                device=d_container.device)
+        bad = C.c_uint64(0)
+        _check(_lib.rans_amd_decode(self._h, model._h, d_container.data_ptr(), container_bytes, d_offsets.data_ptr(),
+                                    d_lengths.data_ptr(), n, n_ways, chunk_syms, d_out.data_ptr(),
+                                    C.byref(bad) if sync else None, _torch_stream()), "decode")
+        return d_out
+
+    def decode_errors(self):
+        bad = C.c_uint64(0)
+        rc = _lib.rans_amd_decode_errors(self._h, C.byref(bad), _torch_stream())
+        if rc not in (OK, E_CORRUPT):
+            _check(rc, "decode_errors")
+        return bad.value
+
+
+class Model:
+    def __init__(self, ctx, fmt, norm_freqs, scale_bits):
+        f = np.ascontiguousarray(norm_freqs, dtype=np.uint32)
+        self._h = C.c_void_p()
+        self._ctx = ctx  # keep the context alive
+        _check(_lib.rans_amd_model_create(ctx._h if ctx is not None else None, fmt, f.ctypes.data_as(C.POINTER(C.c_uint32)), f.size, scale_bits,
+                                          C.byref(self._h)), "model_create")
+        self.fmt = fmt
+        self.freqs = f
+        self.nsyms = int(f.size)
+        self.scale_bits = int(scale_bits)
+        self.sym_bytes = int(_lib.rans_amd_model_sym_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.rans_amd_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def table(self, which, dtype=np.uint8):
+        size = C.c_size_t(0)
+        _check(_lib.rans_amd_model_table(self._h, which, None, 0, C.byref(size)), "model_table(size)")
+        buf = np.zeros(size.value, dtype=np.uint8)
+        _check(_lib.rans_amd_model_table(self._h, which, buf.ctypes.data, buf.size, C.byref(size)), "model_table")
+        return buf.view(dtype)
+
+
+def _torch_stream():
+    import torch
+    if not torch.cuda.is_available():
+        return None
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

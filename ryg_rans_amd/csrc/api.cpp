@@ -1,0 +1,695 @@
+// api.cpp -- the extern "C" boundary declared in include/ryg_rans_amd.h.
+//
+// Host-side plumbing only: argument checking, device memory for tables and
+// workspaces, kernel launches (kernels.hip).  There is no CPU implementation of
+// encode/decode behind these entry points: without a usable GPU every call
+// fails with RANS_AMD_E_HIP.
+#include "../../include/ryg_rans_amd.h"
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "model.h"
+
+using namespace rans_amd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char *what)
+{
+    g_last_error = what ? what : "";
+    return status;
+}
+
+int hip_fail(hipError_t e, const char *where)
+{
+    g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+    return RANS_AMD_E_HIP;
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e__ = (expr);                        \
+        if (e__ != hipSuccess)                          \
+            return hip_fail(e__, #expr);                \
+    } while (0)
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t want)
+    {
+        if (want <= bytes)
+            return RANS_AMD_OK;
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+        size_t padded = (want + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&ptr, padded);
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            return hip_fail(e, "hipMalloc(workspace)");
+        }
+        bytes = padded;
+        return RANS_AMD_OK;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+};
+
+} // namespace
+
+struct rans_amd_ctx {
+    int device = 0;
+    int num_cus = 0;
+    // device words: [0] decode error counter (u64), [8] encode flags (u32), [12] histogram flags (u32)
+    uint8_t *d_words = nullptr;
+    DeviceBuffer scratch;   // encode slots
+    DeviceBuffer lengths;   // encode lengths when the caller passes none
+    DeviceBuffer hist;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // dec start/stop, enc start/stop
+    bool timing = false;
+    bool dec_timed = false, enc_timed = false;
+    const char *last_kernel = "";
+    std::mutex mu;
+
+    unsigned long long *d_err() { return reinterpret_cast<unsigned long long *>(d_words); }
+    uint32_t *d_enc_flags() { return reinterpret_cast<uint32_t *>(d_words + 8); }
+    uint32_t *d_hist_flags() { return reinterpret_cast<uint32_t *>(d_words + 12); }
+};
+
+struct rans_amd_model {
+    rans_amd_ctx *ctx = nullptr;
+    HostModel host;
+    void *d_table0 = nullptr;
+    void *d_table1 = nullptr;
+    void *d_enc = nullptr;
+    void *d_remap = nullptr;
+    uint32_t table0_bytes = 0, table1_bytes = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        if (prev != dev)
+            ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+int upload(const void *src, size_t bytes, void **d_out)
+{
+    *d_out = nullptr;
+    if (bytes == 0)
+        return RANS_AMD_OK;
+    const size_t padded = (bytes + 255) & ~size_t(255);
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, padded));
+    hipError_t e = hipMemset(p, 0, padded);
+    if (e == hipSuccess)
+        e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return hip_fail(e, "hipMemcpy(table)");
+    }
+    *d_out = p;
+    return RANS_AMD_OK;
+}
+
+uint32_t unit_bytes(int format) { return format == RANS_AMD_FMT_WORD ? 2u : format == RANS_AMD_FMT_R64 ? 4u : 1u; }
+uint32_t state_bytes(int format) { return format == RANS_AMD_FMT_R64 ? 8u : 4u; }
+
+} // namespace
+
+extern "C" {
+
+int rans_amd_version(void) { return RANS_AMD_VERSION; }
+
+const char *rans_amd_status_string(int status)
+{
+    switch (status) {
+    case RANS_AMD_OK: return "ok";
+    case RANS_AMD_E_ARG: return "invalid argument";
+    case RANS_AMD_E_MODEL: return "invalid frequency model";
+    case RANS_AMD_E_SPACE: return "output buffer too small";
+    case RANS_AMD_E_CORRUPT: return "corrupt stream";
+    case RANS_AMD_E_UNSUPPORTED: return "unsupported configuration";
+    case RANS_AMD_E_HIP: return "HIP runtime error";
+    case RANS_AMD_E_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+const char *rans_amd_last_error(void) { return g_last_error.c_str(); }
+
+int rans_amd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int rans_amd_ctx_create(int device, rans_amd_ctx **out_ctx)
+{
+    if (!out_ctx)
+        return fail(RANS_AMD_E_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(RANS_AMD_E_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= count)
+        return fail(RANS_AMD_E_ARG, "device index out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok)
+        return fail(RANS_AMD_E_HIP, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    rans_amd_ctx *ctx = new (std::nothrow) rans_amd_ctx;
+    if (!ctx)
+        return fail(RANS_AMD_E_NOMEM, "ctx");
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e = hipMalloc(reinterpret_cast<void **>(&ctx->d_words), 256);
+    if (e == hipSuccess)
+        e = hipMemset(ctx->d_words, 0, 256);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipEventCreate(&ctx->ev[i]);
+    if (e != hipSuccess) {
+        rans_amd_ctx_destroy(ctx);
+        return hip_fail(e, "ctx_create");
+    }
+    *out_ctx = ctx;
+    return RANS_AMD_OK;
+}
+
+int rans_amd_ctx_destroy(rans_amd_ctx *ctx)
+{
+    if (!ctx)
+        return RANS_AMD_OK;
+    DeviceGuard guard(ctx->device);
+    ctx->scratch.release();
+    ctx->lengths.release();
+    ctx->hist.release();
+    if (ctx->d_words)
+        (void)hipFree(ctx->d_words);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->ev[i])
+            (void)hipEventDestroy(ctx->ev[i]);
+    delete ctx;
+    return RANS_AMD_OK;
+}
+
+int rans_amd_ctx_trim(rans_amd_ctx *ctx)
+{
+    if (!ctx)
+        return fail(RANS_AMD_E_ARG, "ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->scratch.release();
+    ctx->lengths.release();
+    ctx->hist.release();
+    return RANS_AMD_OK;
+}
+
+/* ---- model ------------------------------------------------------------ */
+
+int rans_amd_count_freqs_host(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *freqs)
+{
+    int rc = count_freqs_host(syms, n, sym_bytes, nsyms, freqs);
+    return rc ? fail(rc, "count_freqs_host: bad argument or symbol outside the alphabet") : rc;
+}
+
+int rans_amd_count_freqs(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, int sym_bytes, uint32_t nsyms,
+                         uint32_t *freqs, void *stream)
+{
+    if (!ctx || !freqs || (n && !d_syms) || (sym_bytes != 1 && sym_bytes != 2) || nsyms == 0 || nsyms > 16384)
+        return fail(RANS_AMD_E_ARG, "count_freqs: bad argument");
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = ctx->hist.reserve((size_t)nsyms * 4);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemsetAsync(ctx->hist.ptr, 0, (size_t)nsyms * 4, s));
+    HIP_TRY(hipMemsetAsync(ctx->d_hist_flags(), 0, 4, s));
+    if (n)
+        HIP_TRY(launch_histogram(d_syms, n, sym_bytes, nsyms, static_cast<uint32_t *>(ctx->hist.ptr),
+                                 ctx->d_hist_flags(), ctx->num_cus, s));
+    uint32_t flags = 0;
+    HIP_TRY(hipMemcpyAsync(freqs, ctx->hist.ptr, (size_t)nsyms * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&flags, ctx->d_hist_flags(), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (flags & 1u)
+        return fail(RANS_AMD_E_ARG, "count_freqs: symbol outside the alphabet");
+    return RANS_AMD_OK;
+}
+
+int rans_amd_normalize_freqs(uint32_t *freqs, uint32_t *cum_freqs, uint32_t nsyms, uint32_t target_total)
+{
+    int rc = normalize_freqs(freqs, cum_freqs, nsyms, target_total);
+    return rc ? fail(rc, "normalize_freqs failed") : rc;
+}
+
+int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_freqs, uint32_t nsyms,
+                          uint32_t scale_bits, rans_amd_model **out_model)
+{
+    if (!out_model)
+        return fail(RANS_AMD_E_ARG, "model_create: NULL argument");
+    *out_model = nullptr;
+    rans_amd_model *m = new (std::nothrow) rans_amd_model;
+    if (!m)
+        return fail(RANS_AMD_E_NOMEM, "model");
+    m->ctx = ctx;
+    int rc = m->host.build(format, norm_freqs, nsyms, scale_bits);
+    if (rc) {
+        delete m;
+        return fail(rc, "model_create: frequencies rejected");
+    }
+    if (!ctx) { // host-only model: tables can be inspected, encode/decode refuse it
+        *out_model = m;
+        return RANS_AMD_OK;
+    }
+    DeviceGuard guard(ctx->device);
+    const HostModel &h = m->host;
+    switch (format) {
+    case RANS_AMD_FMT_WORD:
+        m->table0_bytes = (uint32_t)(h.word_slots.size() * sizeof(WordSlot));
+        rc = upload(h.word_slots.data(), m->table0_bytes, &m->d_table0);
+        break;
+    case RANS_AMD_FMT_BYTE:
+    case RANS_AMD_FMT_R64: {
+        if (h.sym_bytes != 1) { // u16 cum2sym does not fit beside the stream windows; use FMT_ALIAS
+            rc = fail(RANS_AMD_E_UNSUPPORTED, "cum2sym decoders support alphabets up to 256 symbols");
+            break;
+        }
+        std::vector<uint8_t> c2s(h.cum2sym.size());
+        for (size_t i = 0; i < c2s.size(); ++i)
+            c2s[i] = (uint8_t)h.cum2sym[i];
+        m->table0_bytes = (uint32_t)c2s.size();
+        rc = upload(c2s.data(), c2s.size(), &m->d_table0);
+        if (rc == RANS_AMD_OK) {
+            m->table1_bytes = (uint32_t)(h.sym_recs.size() * sizeof(SymRec));
+            rc = upload(h.sym_recs.data(), m->table1_bytes, &m->d_table1);
+        }
+        break;
+    }
+    case RANS_AMD_FMT_ALIAS:
+        m->table0_bytes = (uint32_t)(h.alias_halves.size() * sizeof(AliasHalf));
+        rc = upload(h.alias_halves.data(), m->table0_bytes, &m->d_table0);
+        if (rc == RANS_AMD_OK) {
+            m->table1_bytes = (uint32_t)(h.divider.size() * 4);
+            rc = upload(h.divider.data(), m->table1_bytes, &m->d_table1);
+        }
+        if (rc == RANS_AMD_OK)
+            rc = upload(h.alias_remap.data(), h.alias_remap.size() * 4, &m->d_remap);
+        break;
+    default:
+        rc = RANS_AMD_E_ARG;
+    }
+    if (rc == RANS_AMD_OK)
+        rc = upload(h.enc_recs.data(), h.enc_recs.size() * sizeof(EncRec), &m->d_enc);
+    if (rc == RANS_AMD_OK) {
+        const size_t lds = (size_t)((m->table0_bytes + 15u) & ~15u) + ((m->table1_bytes + 15u) & ~15u) +
+                           (size_t)(kDecBlockThreads / 64) * kRingStride;
+        if (lds > 160 * 1024)
+            rc = fail(RANS_AMD_E_UNSUPPORTED, "decode tables do not fit in LDS");
+    }
+    if (rc) {
+        rans_amd_model_destroy(m);
+        return rc;
+    }
+    *out_model = m;
+    return RANS_AMD_OK;
+}
+
+int rans_amd_model_destroy(rans_amd_model *m)
+{
+    if (!m)
+        return RANS_AMD_OK;
+    if (m->ctx) {
+        DeviceGuard guard(m->ctx->device);
+        for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_remap})
+            if (p)
+                (void)hipFree(p);
+    }
+    delete m;
+    return RANS_AMD_OK;
+}
+
+int rans_amd_model_format(const rans_amd_model *m) { return m ? m->host.format : -1; }
+uint32_t rans_amd_model_scale_bits(const rans_amd_model *m) { return m ? m->host.scale_bits : 0; }
+uint32_t rans_amd_model_nsyms(const rans_amd_model *m) { return m ? m->host.nsyms : 0; }
+int rans_amd_model_sym_bytes(const rans_amd_model *m) { return m ? m->host.sym_bytes : 0; }
+
+int rans_amd_model_table(const rans_amd_model *m, int which, void *dst, size_t cap, size_t *size)
+{
+    if (!m || !size)
+        return fail(RANS_AMD_E_ARG, "model_table: NULL argument");
+    std::vector<uint8_t> img;
+    int rc = m->host.export_table(which, img);
+    if (rc)
+        return fail(rc, "model_table: no such table for this format");
+    *size = img.size();
+    if (!dst)
+        return RANS_AMD_OK;
+    if (cap < img.size())
+        return fail(RANS_AMD_E_SPACE, "model_table: buffer too small");
+    memcpy(dst, img.data(), img.size());
+    return RANS_AMD_OK;
+}
+
+/* ---- layout ------------------------------------------------------------ */
+
+uint64_t rans_amd_num_chunks(uint64_t n, uint32_t chunk_syms)
+{
+    if (chunk_syms == 0)
+        return 0;
+    return (n + chunk_syms - 1) / chunk_syms;
+}
+
+uint64_t rans_amd_chunk_bound(int format, uint32_t chunk_syms, uint32_t n_ways)
+{
+    // units per symbol: <= 2 bytes (byte/alias, scale_bits <= 16), 1 word, 1 dword
+    const uint64_t per_sym = format == RANS_AMD_FMT_R64 ? 4 : 2;
+    const uint64_t b = (uint64_t)chunk_syms * per_sym + (uint64_t)n_ways * state_bytes(format);
+    return (b + 15) & ~uint64_t(15);
+}
+
+uint64_t rans_amd_encode_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
+{
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    if (nchunks == 0)
+        return 16;
+    const uint64_t last = n - (nchunks - 1) * chunk_syms;
+    return (nchunks - 1) * rans_amd_chunk_bound(format, chunk_syms, n_ways) +
+           rans_amd_chunk_bound(format, (uint32_t)last, n_ways);
+}
+
+int rans_amd_ways_supported(int format, uint32_t n_ways) { return ways_supported(format, n_ways) ? 1 : 0; }
+
+/* ---- encode ------------------------------------------------------------- */
+
+int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,
+                    uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
+                    uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream)
+{
+    if (!ctx || !model || !d_out || !d_offsets || !d_lengths || (n && !d_syms) || chunk_syms == 0)
+        return fail(RANS_AMD_E_ARG, "encode: NULL argument or chunk_syms == 0");
+    if (model->ctx != ctx)
+        return fail(RANS_AMD_E_ARG, "encode: model belongs to another context");
+    const int format = model->host.format;
+    if (!ways_supported(format, n_ways))
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode: n_ways must be 1..64, 128, 256 or 512");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0)
+        return fail(RANS_AMD_E_ARG, "encode: d_out must be 16-byte aligned");
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    const uint64_t slot = rans_amd_chunk_bound(format, (uint32_t)(n < chunk_syms ? n : chunk_syms), n_ways);
+    int rc = ctx->scratch.reserve((size_t)(nchunks * slot + 64));
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
+
+    if (ctx->timing)
+        HIP_TRY(hipEventRecord(ctx->ev[2], s));
+    if (nchunks) {
+        EncParams ep;
+        ep.syms = static_cast<const uint8_t *>(d_syms);
+        ep.n = n;
+        ep.nchunks = nchunks;
+        ep.chunk_syms = chunk_syms;
+        ep.n_ways = n_ways;
+        ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr);
+        ep.slot_bytes = slot;
+        ep.lengths = d_lengths;
+        ep.enc_recs = model->d_enc;
+        ep.alias_remap = static_cast<const uint32_t *>(model->d_remap);
+        ep.nsyms = model->host.nsyms;
+        ep.scale_bits = model->host.scale_bits;
+        ep.sym_bytes = (uint32_t)model->host.sym_bytes;
+        ep.flags = ctx->d_enc_flags();
+        HIP_TRY(launch_encode(format, ep, ctx->num_cus, s));
+    }
+    LayoutParams lp;
+    lp.lengths = d_lengths;
+    lp.offsets = d_offsets;
+    lp.nchunks = nchunks;
+    lp.out_cap = out_cap;
+    lp.flags = ctx->d_enc_flags();
+    HIP_TRY(launch_layout(lp, s));
+    if (nchunks) {
+        CompactParams cp;
+        cp.scratch = static_cast<const uint8_t *>(ctx->scratch.ptr);
+        cp.slot_bytes = slot;
+        cp.lengths = d_lengths;
+        cp.offsets = d_offsets;
+        cp.out = static_cast<uint8_t *>(d_out);
+        cp.nchunks = nchunks;
+        cp.flags = ctx->d_enc_flags();
+        HIP_TRY(launch_compact(cp, ctx->num_cus, s));
+    }
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev[3], s));
+        ctx->enc_timed = true;
+    }
+
+    if (h_total_bytes) {
+        uint32_t flags = 0;
+        uint64_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&flags, ctx->d_enc_flags(), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&total, d_offsets + nchunks, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *h_total_bytes = total;
+        if (flags & 1u)
+            return fail(RANS_AMD_E_MODEL, "encode: input holds a symbol with frequency 0");
+        if (flags & 2u)
+            return fail(RANS_AMD_E_SPACE, "encode: container does not fit out_cap");
+    }
+    return RANS_AMD_OK;
+}
+
+/* ---- decode ------------------------------------------------------------- */
+
+int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_container,
+                    uint64_t container_bytes, const uint64_t *d_offsets, const uint32_t *d_lengths, uint64_t n,
+                    uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t *h_bad_chunks, void *stream)
+{
+    if (!ctx || !model || (n && (!d_container || !d_offsets || !d_lengths || !d_out)) || chunk_syms == 0)
+        return fail(RANS_AMD_E_ARG, "decode: NULL argument or chunk_syms == 0");
+    if (model->ctx != ctx)
+        return fail(RANS_AMD_E_ARG, "decode: model belongs to another context");
+    const int format = model->host.format;
+    if (!ways_supported(format, n_ways))
+        return fail(RANS_AMD_E_UNSUPPORTED, "decode: n_ways must be 1..64, 128, 256 or 512");
+    if ((reinterpret_cast<uintptr_t>(d_container) & 15u) != 0)
+        return fail(RANS_AMD_E_ARG, "decode: d_container must be 16-byte aligned");
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    if (nchunks) {
+        DecParams dp;
+        dp.container = static_cast<const uint8_t *>(d_container);
+        dp.container_bytes = container_bytes;
+        dp.offsets = d_offsets;
+        dp.lengths = d_lengths;
+        dp.out = static_cast<uint8_t *>(d_out);
+        dp.n = n;
+        dp.nchunks = nchunks;
+        dp.chunk_syms = chunk_syms;
+        dp.n_ways = n_ways;
+        dp.table0 = model->d_table0;
+        dp.table1 = model->d_table1 ? model->d_table1 : model->d_table0;
+        dp.table0_bytes = model->table0_bytes;
+        dp.table1_bytes = model->table1_bytes;
+        dp.scale_bits = model->host.scale_bits;
+        dp.log2nsyms = model->host.log2nsyms;
+        dp.sym_bytes = (uint32_t)model->host.sym_bytes;
+        dp.err_count = ctx->d_err();
+        if (ctx->timing)
+            HIP_TRY(hipEventRecord(ctx->ev[0], s));
+        HIP_TRY(launch_decode(format, dp, ctx->num_cus, s, &ctx->last_kernel));
+        if (ctx->timing) {
+            HIP_TRY(hipEventRecord(ctx->ev[1], s));
+            ctx->dec_timed = true;
+        }
+    }
+    if (h_bad_chunks) {
+        unsigned long long bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, ctx->d_err(), 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemsetAsync(ctx->d_err(), 0, 8, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *h_bad_chunks = bad;
+        if (bad)
+            return fail(RANS_AMD_E_CORRUPT, "decode: at least one chunk failed its integrity check");
+    }
+    return RANS_AMD_OK;
+}
+
+int rans_amd_decode_errors(rans_amd_ctx *ctx, uint64_t *h_bad_chunks, void *stream)
+{
+    if (!ctx || !h_bad_chunks)
+        return fail(RANS_AMD_E_ARG, "decode_errors: NULL argument");
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, ctx->d_err(), 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(ctx->d_err(), 0, 8, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *h_bad_chunks = bad;
+    return bad ? fail(RANS_AMD_E_CORRUPT, "decode: at least one chunk failed its integrity check") : RANS_AMD_OK;
+}
+
+/* ---- host-buffer wrappers: one raw reference-format stream ----------------- */
+
+int rans_amd_encode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const void *syms, uint64_t n,
+                         uint32_t n_ways, uint8_t *buf, uint64_t cap, uint64_t *out_len)
+{
+    if (!ctx || !model || !buf || !out_len || (n && !syms))
+        return fail(RANS_AMD_E_ARG, "encode_host: NULL argument");
+    if (n > 0xffffffffull - 64)
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode_host: a single stream is limited to 2^32 symbols");
+    const int format = model->host.format;
+    const int sb = model->host.sym_bytes;
+    const uint32_t chunk = (uint32_t)(n ? n : 1);
+    const uint64_t bound = rans_amd_chunk_bound(format, chunk, n_ways);
+    DeviceGuard guard(ctx->device);
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_len = nullptr;
+    int rc = RANS_AMD_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_in), (size_t)(n * sb + 256));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)bound + 256);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_off), 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_len), 64);
+    if (e == hipSuccess && n) e = hipMemcpy(d_in, syms, (size_t)(n * sb), hipMemcpyHostToDevice);
+    uint64_t total = 0;
+    if (e != hipSuccess)
+        rc = hip_fail(e, "encode_host: device staging");
+    if (rc == RANS_AMD_OK)
+        rc = rans_amd_encode(ctx, model, d_in, n, n_ways, chunk, d_out, bound, d_off, d_len, &total, nullptr);
+    if (rc == RANS_AMD_OK && n == 0) {
+        // no chunk was produced: an empty input is still a valid stream of N flushed states
+        rc = fail(RANS_AMD_E_ARG, "encode_host: n == 0");
+    }
+    if (rc == RANS_AMD_OK) {
+        if (total > cap)
+            rc = fail(RANS_AMD_E_SPACE, "encode_host: buffer too small");
+        else {
+            e = hipMemcpy(buf + (cap - total), d_out, (size_t)total, hipMemcpyDeviceToHost);
+            if (e != hipSuccess)
+                rc = hip_fail(e, "encode_host: copy back");
+            *out_len = total;
+        }
+    }
+    for (void *p : {(void *)d_in, (void *)d_out, (void *)d_off, (void *)d_len})
+        if (p)
+            (void)hipFree(p);
+    return rc;
+}
+
+int rans_amd_decode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const uint8_t *stream_bytes, uint64_t len,
+                         uint64_t n, uint32_t n_ways, void *out)
+{
+    if (!ctx || !model || !stream_bytes || (n && !out))
+        return fail(RANS_AMD_E_ARG, "decode_host: NULL argument");
+    if (n == 0 || n > 0xffffffffull - 64 || len > 0xffffffffull)
+        return fail(RANS_AMD_E_UNSUPPORTED, "decode_host: 1 <= n < 2^32 and len < 2^32 required");
+    const int sb = model->host.sym_bytes;
+    DeviceGuard guard(ctx->device);
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_len = nullptr;
+    int rc = RANS_AMD_OK;
+    const uint64_t offs[2] = {0, len};
+    const uint32_t len32 = (uint32_t)len;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_in), (size_t)len + 256);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)(n * sb + 256));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_off), 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_len), 64);
+    if (e == hipSuccess) e = hipMemcpy(d_in, stream_bytes, (size_t)len, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off, offs, sizeof(offs), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_len, &len32, 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+        rc = hip_fail(e, "decode_host: device staging");
+    uint64_t bad = 0;
+    if (rc == RANS_AMD_OK)
+        rc = rans_amd_decode(ctx, model, d_in, len, d_off, d_len, n, n_ways, (uint32_t)n, d_out, &bad, nullptr);
+    if (rc == RANS_AMD_OK || rc == RANS_AMD_E_CORRUPT) {
+        e = hipMemcpy(out, d_out, (size_t)(n * sb), hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = hip_fail(e, "decode_host: copy back");
+    }
+    for (void *p : {(void *)d_in, (void *)d_out, (void *)d_off, (void *)d_len})
+        if (p)
+            (void)hipFree(p);
+    return rc;
+}
+
+/* ---- measurement ----------------------------------------------------------- */
+
+int rans_amd_set_timing(rans_amd_ctx *ctx, int enabled)
+{
+    if (!ctx)
+        return fail(RANS_AMD_E_ARG, "ctx is NULL");
+    ctx->timing = enabled != 0;
+    return RANS_AMD_OK;
+}
+
+int rans_amd_last_kernel_ms(rans_amd_ctx *ctx, float *decode_ms, float *encode_ms)
+{
+    if (!ctx)
+        return fail(RANS_AMD_E_ARG, "ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    if (decode_ms) {
+        *decode_ms = -1.0f;
+        if (ctx->dec_timed) {
+            HIP_TRY(hipEventSynchronize(ctx->ev[1]));
+            HIP_TRY(hipEventElapsedTime(decode_ms, ctx->ev[0], ctx->ev[1]));
+        }
+    }
+    if (encode_ms) {
+        *encode_ms = -1.0f;
+        if (ctx->enc_timed) {
+            HIP_TRY(hipEventSynchronize(ctx->ev[3]));
+            HIP_TRY(hipEventElapsedTime(encode_ms, ctx->ev[2], ctx->ev[3]));
+        }
+    }
+    return RANS_AMD_OK;
+}
+
+const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+} // extern "C"

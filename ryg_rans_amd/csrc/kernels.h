@@ -1,0 +1,86 @@
+// kernels.h -- launch interface between the C-ABI layer (api.cpp) and the HIP
+// kernels (kernels.hip).  Internal; not installed.
+#pragma once
+
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace rans_amd {
+
+// Per-wave LDS stream window (see kernels.hip "stream window").
+constexpr uint32_t kRingBytes = 2048;   // two 1 KiB blocks
+constexpr uint32_t kRingBlock = 1024;   // 64 lanes x 16 B
+constexpr uint32_t kRingMirror = 256;   // copy of ring[0..256) after the end: no wrap inside a sub-step
+constexpr uint32_t kRingStride = kRingBytes + kRingMirror;
+
+constexpr int kDecBlockThreads = 1024; // 16 waves share one table image
+constexpr int kEncBlockThreads = 256;
+
+struct DecParams {
+    const uint8_t *container;
+    uint64_t container_bytes;
+    const uint64_t *offsets;
+    const uint32_t *lengths;
+    uint8_t *out;
+    uint64_t n;
+    uint64_t nchunks;
+    uint32_t chunk_syms;
+    uint32_t n_ways;
+    const void *table0; // word: WordSlot[4096]; byte/r64: cum2sym u8[M]; alias: AliasHalf[2*nsyms]
+    const void *table1; // byte/r64: SymRec[nsyms];  alias: divider u32[nsyms]
+    uint32_t table0_bytes;
+    uint32_t table1_bytes;
+    uint32_t scale_bits;
+    uint32_t log2nsyms;
+    uint32_t sym_bytes;
+    unsigned long long *err_count; // failed chunks (device counter)
+};
+
+struct EncParams {
+    const uint8_t *syms;
+    uint64_t n;
+    uint64_t nchunks;
+    uint32_t chunk_syms;
+    uint32_t n_ways;
+    uint8_t *scratch;     // nchunks slots of slot_bytes each; chunk stream ends at the slot end
+    uint64_t slot_bytes;  // multiple of 16
+    uint32_t *lengths;    // out: stream bytes per chunk
+    const void *enc_recs; // EncRec[nsyms]
+    const uint32_t *alias_remap;
+    uint32_t nsyms;
+    uint32_t scale_bits;
+    uint32_t sym_bytes;
+    uint32_t *flags;      // bit0: symbol with freq 0 / outside alphabet met
+};
+
+struct LayoutParams {
+    const uint32_t *lengths;
+    uint64_t *offsets; // [nchunks+1]
+    uint64_t nchunks;
+    uint64_t out_cap;
+    uint32_t *flags;   // bit1: container does not fit out_cap
+};
+
+struct CompactParams {
+    const uint8_t *scratch;
+    uint64_t slot_bytes;
+    const uint32_t *lengths;
+    const uint64_t *offsets;
+    uint8_t *out;
+    uint64_t nchunks;
+    const uint32_t *flags; // skip everything when bit1 is set
+};
+
+// All launchers return hipSuccess or the launch error; they never synchronise.
+hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name);
+hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream);
+hipError_t launch_layout(const LayoutParams &p, hipStream_t stream);
+hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t stream);
+hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
+                            uint32_t *d_flags, int num_cus, hipStream_t stream);
+
+// (format, n_ways) combinations with a kernel.
+bool ways_supported(int format, uint32_t n_ways);
+
+} // namespace rans_amd

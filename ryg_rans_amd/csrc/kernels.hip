@@ -1,0 +1,920 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for interleaved rANS.
+//
+// Mapping of the reference's hot loops onto the GPU
+// --------------------------------------------------
+// The reference decodes an N-way interleaved stream with N rANS states that take
+// turns: every "round" each state decodes one symbol (table lookup + one
+// multiply-add, no stream access), then the states, in ascending lane order,
+// pull the renormalisation units they need from ONE shared cursor
+// (main.cpp:259-280, main_simd.cpp:313-332).  The SSE4.1 decoder does this for
+// 4 lanes with movemask + pshufb (rans_word_sse41.h:182-227).  Here:
+//
+//   * one wavefront owns one chunk (an independent N-way stream), N = 64*K:
+//     lane l holds states l, l+64, ..., i.e. K states per lane;
+//   * the symbol lookup table lives in LDS, shared by the 16 waves of a block;
+//   * "which lanes renormalise" is a 64-bit ballot; a lane's position in the
+//     stream is popcount(ballot & lanes_below) (v_mbcnt), so the wave consumes
+//     popcount(ballot) consecutive units per sub-step: stream I/O is dense and
+//     in order by construction;
+//   * the compressed stream is pulled through a per-wave LDS window ("ring")
+//     in aligned 1 KiB blocks (16 B per lane, one global_load_dwordx4 per
+//     block), prefetched one block ahead in registers;
+//   * decoded bytes are transposed in registers across 4 rounds (v_perm_b32 +
+//     quad DPP) so a store instruction writes 256 contiguous bytes per wave.
+//
+// No MFMA: the work is integer, table-driven and serial per state.
+// The encoder is the exact mirror (symbols visited last to first, units pushed
+// downwards); it writes every chunk into a worst-case scratch slot, then a
+// layout pass (prefix sum of sizes) and a compaction pass build the container.
+//
+// Bit-exactness: the arithmetic below is the reference's (file:line cited at
+// each step); only its *scheduling* across lanes is new.
+
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ryg_rans_amd.h"
+#include "model.h"
+
+namespace rans_amd {
+
+namespace {
+
+constexpr int FMT_BYTE = RANS_AMD_FMT_BYTE;
+constexpr int FMT_WORD = RANS_AMD_FMT_WORD;
+constexpr int FMT_R64 = RANS_AMD_FMT_R64;
+constexpr int FMT_ALIAS = RANS_AMD_FMT_ALIAS;
+
+enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1 };
+
+template <int FMT> struct FmtTraits;
+template <> struct FmtTraits<FMT_WORD> {
+    using state_t = uint32_t;
+    static constexpr uint32_t kUnit = 2, kStateBytes = 4;
+    static constexpr uint32_t kL = 1u << 16; // rans_word_sse41.h:35
+    static constexpr int kSymByte = 3;        // WordSlot.lo keeps the symbol in its top byte
+};
+template <> struct FmtTraits<FMT_BYTE> {
+    using state_t = uint32_t;
+    static constexpr uint32_t kUnit = 1, kStateBytes = 4;
+    static constexpr uint32_t kL = 1u << 23; // rans_byte.h:50
+    static constexpr int kSymByte = 0;
+};
+template <> struct FmtTraits<FMT_ALIAS> {
+    using state_t = uint32_t;
+    static constexpr uint32_t kUnit = 1, kStateBytes = 4;
+    static constexpr uint32_t kL = 1u << 23;
+    static constexpr int kSymByte = 0;
+};
+template <> struct FmtTraits<FMT_R64> {
+    using state_t = uint64_t;
+    static constexpr uint32_t kUnit = 4, kStateBytes = 8;
+    static constexpr uint64_t kL = 1ull << 31; // rans64.h:59
+    static constexpr int kSymByte = 0;
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t lane_id()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// number of set bits of m strictly below this lane
+__device__ __forceinline__ uint32_t rank_below(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return (uint64_t)uniform((uint32_t)v) | ((uint64_t)uniform((uint32_t)(v >> 32)) << 32);
+}
+
+// explicit global address space: keeps loads/stores as global_* (not flat_*)
+#define RANS_GLOBAL __attribute__((address_space(1)))
+typedef const u32x4 RANS_GLOBAL *gvec_cptr;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// quad_perm DPP: lane i of each quad reads lane P[i]
+template <int P0, int P1, int P2, int P3> __device__ __forceinline__ uint32_t quad_perm(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
+}
+
+// ---------------------------------------------------------------------------
+// Stream window: a 2 KiB ring per wave in LDS, filled in aligned 1 KiB blocks.
+// `rd` = read offset, `avail` = valid bytes ahead of rd, `wr` = offset of the
+// block that is written next.  A block is free as soon as avail <= 1024.  The
+// first 256 bytes of the ring are mirrored behind its end so that a sub-step
+// (which consumes at most 256 bytes) never has to wrap an address.
+// All three are wave-uniform (SGPRs); the refill branch is a scalar branch.
+// ---------------------------------------------------------------------------
+struct StreamWindow {
+    uint8_t *ring;   // LDS, wave-private
+    uint64_t gnext;  // global address of the next 1 KiB block to fetch (wave-uniform)
+    uint64_t glimit; // 16-byte aligned end of the readable container (wave-uniform)
+    uint32_t rd, avail, wr;
+    u32x4 pre; // prefetched block (16 B per lane)
+
+    __device__ __forceinline__ u32x4 fetch(uint32_t lane)
+    {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (gnext + kRingBlock <= glimit) { // whole block readable: wave-uniform fast path
+            gvec_cptr g = reinterpret_cast<gvec_cptr>(gnext);
+            v = __builtin_nontemporal_load(g + lane);
+        } else if (gnext + lane * 16u < glimit) {
+            gvec_cptr g = reinterpret_cast<gvec_cptr>(gnext);
+            v = __builtin_nontemporal_load(g + lane);
+        }
+        gnext += kRingBlock;
+        return v;
+    }
+    __device__ __forceinline__ void put(uint32_t lane, uint32_t at, const u32x4 &v)
+    {
+        *reinterpret_cast<u32x4 *>(ring + at + lane * 16u) = v;
+        if (at == 0 && lane < kRingMirror / 16u)
+            *reinterpret_cast<u32x4 *>(ring + kRingBytes + lane * 16u) = v;
+    }
+    __device__ __forceinline__ void open(uint8_t *lds, uint64_t gaddr, uint64_t limit, uint32_t lane)
+    {
+        ring = lds;
+        glimit = limit;
+        gnext = gaddr & ~uint64_t(15);
+        rd = (uint32_t)(gaddr & 15u);
+        u32x4 b0 = fetch(lane);
+        u32x4 b1 = fetch(lane);
+        pre = fetch(lane);
+        put(lane, 0, b0);
+        put(lane, kRingBlock, b1);
+        wr = 0;
+        avail = kRingBytes - rd;
+    }
+    __device__ __forceinline__ void refill(uint32_t lane)
+    {
+        if (avail <= kRingBlock) {
+            put(lane, wr, pre);
+            wr ^= kRingBlock;
+            avail += kRingBlock;
+            pre = fetch(lane);
+        }
+    }
+    __device__ __forceinline__ void consume(uint32_t bytes)
+    {
+        rd = (rd + bytes) & (kRingBytes - 1);
+        avail -= bytes;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// D step: symbol lookup + state update, no stream access.
+// Returns a word whose byte FmtTraits::kSymByte (u8 alphabets) or low 16 bits
+// hold the symbol.
+// ---------------------------------------------------------------------------
+template <int FMT> struct DecTables {
+    const uint8_t *t0; // LDS
+    const uint8_t *t1; // LDS
+    uint32_t scale_bits;
+    uint32_t mask;
+    uint32_t bucket_shift; // alias: scale_bits - log2(nsyms)
+};
+
+template <int FMT>
+__device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename FmtTraits<FMT>::state_t &x)
+{
+    if constexpr (FMT == FMT_WORD) {
+        // rans_word_sse41.h:123-131 / :151-179: slot = x & 4095;
+        // x = freq * (x >> 12) + bias.  freq < 2^12 and x >> 12 < 2^20, so the
+        // 24-bit multiply-add is exact.
+        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[x & 0xfffu];
+        x = (e.x & 0xffffffu) * (x >> 12) + e.y;
+        return e.x;
+    } else if constexpr (FMT == FMT_BYTE) {
+        // rans_byte.h:125-128 (get), :291-298 (step)
+        const uint32_t cf = x & T.mask;
+        const uint32_t s = T.t0[cf];
+        const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s]; // {freq, start}
+        x = r.x * (x >> T.scale_bits) + cf - r.y;
+        return s;
+    } else if constexpr (FMT == FMT_R64) {
+        // rans64.h:118-121 (get), :286-292 (step)
+        const uint32_t cf = (uint32_t)x & T.mask;
+        const uint32_t s = T.t0[cf];
+        const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s];
+        x = (uint64_t)r.x * (x >> T.scale_bits) + cf - r.y;
+        return s;
+    } else {
+        // main_alias.cpp:252-267; the subtraction wraps in 32 bits on purpose
+        const uint32_t xm = x & T.mask;
+        const uint32_t bucket = xm >> T.bucket_shift;
+        const uint32_t div = reinterpret_cast<const uint32_t *>(T.t1)[bucket];
+        const uint32_t half = 2u * bucket + (xm < div ? 1u : 0u);
+        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[half]; // {freq | sym << 16, adjust}
+        x = (e.x & 0xffffu) * (x >> T.scale_bits) + xm - e.y;
+        return e.x >> 16;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Renormalisation of one sub-step (64 lanes, ascending lane order == ascending
+// stream address).  `active` masks lanes that have no symbol in this round.
+// Returns the bytes consumed (wave-uniform).
+// ---------------------------------------------------------------------------
+template <int FMT>
+__device__ __forceinline__ uint32_t dec_renorm(const StreamWindow &W, typename FmtTraits<FMT>::state_t &x,
+                                               bool active)
+{
+    if constexpr (FMT == FMT_WORD) {
+        // rans_word_sse41.h:134-141 / :182-227
+        const bool need = active && x < (1u << 16);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(need);
+        const uint32_t at = W.rd + 2u * rank_below(m);
+        const uint32_t w = *reinterpret_cast<const uint16_t *>(W.ring + at);
+        x = need ? ((x << 16) | w) : x;
+        return 2u * (uint32_t)__builtin_popcountll(m);
+    } else if constexpr (FMT == FMT_R64) {
+        // rans64.h:305-316
+        const bool need = active && x < (1ull << 31);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(need);
+        const uint32_t at = W.rd + 4u * rank_below(m);
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(W.ring + at);
+        x = need ? ((x << 32) | w) : x;
+        return 4u * (uint32_t)__builtin_popcountll(m);
+    } else {
+        // rans_byte.h:307-318.  With scale_bits <= 16 a lane needs 0, 1 or 2
+        // bytes: x >= 2^7 after D, and a second byte is needed iff x < 2^15.
+        // The first byte read is the more significant one.
+        const bool n1 = active && x < (1u << 23);
+        const bool n2 = active && x < (1u << 15);
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(n1);
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(n2);
+        const uint32_t at = W.rd + rank_below(m1) + rank_below(m2);
+        const uint32_t b0 = W.ring[at];
+        const uint32_t b1 = W.ring[at + 1];
+        const uint32_t x1 = (x << 8) | b0;
+        const uint32_t x2 = (x1 << 8) | b1;
+        x = n2 ? x2 : (n1 ? x1 : x);
+        return (uint32_t)__builtin_popcountll(m1) + (uint32_t)__builtin_popcountll(m2);
+    }
+}
+
+// byte `kSymByte` of `raw` goes to byte J of acc, the other bytes of acc stay
+template <int SYMBYTE, int J> __device__ __forceinline__ uint32_t acc_symbol(uint32_t raw, uint32_t acc)
+{
+    if constexpr (J == 0) {
+        return raw; // fixed up by J == 1
+    } else if constexpr (J == 1) {
+        // byte0 <- acc[SYMBYTE] (round 0's symbol), byte1 <- raw[SYMBYTE]
+        constexpr uint32_t sel = (uint32_t)SYMBYTE | ((4u + SYMBYTE) << 8) | 0x03020000u;
+        return __builtin_amdgcn_perm(raw, acc, sel);
+    } else {
+        constexpr uint32_t ident = 0x03020100u;
+        constexpr uint32_t sel = (ident & ~(0xffu << (8 * J))) | ((4u + SYMBYTE) << (8 * J));
+        return __builtin_amdgcn_perm(raw, acc, sel);
+    }
+}
+
+// 4x4 byte transpose inside each quad of lanes.  In: lane q of a quad holds the
+// bytes of column (4j+q) for rows 0..3.  Out: lane q holds row q, columns
+// 4j..4j+3, i.e. four consecutive output bytes.
+__device__ __forceinline__ uint32_t quad_transpose(uint32_t v, uint32_t sel1, uint32_t sel2)
+{
+    uint32_t o = quad_perm<1, 0, 3, 2>(v);
+    v = __builtin_amdgcn_perm(o, v, sel1);
+    o = quad_perm<2, 3, 0, 1>(v);
+    return __builtin_amdgcn_perm(o, v, sel2);
+}
+
+template <int FMT, int K, int OUT>
+__global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    // ---- stage the tables into LDS (once per block) ----------------------
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1_bytes = (p.table1_bytes + 15u) & ~15u;
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+        const uint4 *g1 = reinterpret_cast<const uint4 *>(p.table1);
+        uint4 *l1 = reinterpret_cast<uint4 *>(smem + t0_bytes);
+        for (uint32_t i = threadIdx.x; i < t1_bytes / 16u; i += blockDim.x)
+            l1[i] = g1[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+
+    DecTables<FMT> T;
+    T.t0 = smem;
+    T.t1 = smem + t0_bytes;
+    T.scale_bits = p.scale_bits;
+    T.mask = (1u << p.scale_bits) - 1u;
+    T.bucket_shift = p.scale_bits - p.log2nsyms;
+
+    uint8_t *ring = smem + t0_bytes + t1_bytes + wave * kRingStride;
+    const uint32_t N = (OUT == OUT_FAST8) ? 64u * K : p.n_ways;
+    const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
+    const uint64_t glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
+
+    // per-lane constants of the output transpose
+    const uint32_t sel1 = (lane & 1u) ? 0x03070105u : 0x06020400u;
+    const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
+    const uint32_t out_lane_off = (lane & 3u) * N + (lane & ~3u);
+
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * waves_per_block + wave; chunk < p.nchunks; chunk += total_waves) {
+        // everything derived from the chunk index is wave-uniform; say so explicitly
+        // so it lives in SGPRs and the loop control below is scalar
+        const uint64_t off = uniform64(p.offsets[chunk]);
+        const uint32_t len = uniform(p.lengths[chunk]);
+        const uint64_t first = chunk * p.chunk_syms;
+        const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        const uint64_t src = cbase + off;
+        uint8_t RANS_GLOBAL *dst = reinterpret_cast<uint8_t RANS_GLOBAL *>(
+            reinterpret_cast<uint64_t>(p.out) + first * p.sym_bytes);
+
+        bool ok = ((off & 15u) == 0) && (len >= N * Tr::kStateBytes) && (off + len <= p.container_bytes);
+        if (!ok) { // wave-uniform
+            if (lane == 0)
+                atomicAdd(p.err_count, 1ull);
+            continue;
+        }
+
+        // ---- initial states: lane 0's first (RansDecInit order, main.cpp:261-262)
+        state_t x[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t idx = k * 64u + lane;
+            x[k] = Tr::kL;
+            if (idx < N) {
+                if constexpr (FMT == FMT_R64) {
+                    const u32x2 v = *(reinterpret_cast<const u32x2 RANS_GLOBAL *>(src) + idx);
+                    x[k] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                } else {
+                    x[k] = *(reinterpret_cast<const uint32_t RANS_GLOBAL *>(src) + idx);
+                }
+            }
+        }
+
+        StreamWindow W;
+        W.open(ring, src + N * Tr::kStateBytes, glimit, lane);
+        uint32_t consumed = N * Tr::kStateBytes;
+
+        const uint32_t rounds = nsym / N;
+        const uint32_t tail = nsym - rounds * N;
+        uint32_t r = 0;
+
+        if constexpr (OUT == OUT_FAST8) {
+            // ---- groups of 4 full rounds, symbols transposed in registers ----
+            const uint32_t groups = rounds >> 2;
+            uint8_t RANS_GLOBAL *gdst = dst;
+            for (uint32_t g = 0; g < groups; ++g) {
+                uint32_t acc[K];
+#define RANS_ROUND(J)                                                              \
+    _Pragma("unroll") for (int k = 0; k < K; ++k)                                  \
+        acc[k] = acc_symbol<Tr::kSymByte, J>(dec_step<FMT>(T, x[k]), acc[k]);      \
+    _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
+        W.refill(lane);                                                            \
+        const uint32_t c = dec_renorm<FMT>(W, x[k], true);                         \
+        W.consume(c);                                                              \
+        consumed += c;                                                             \
+    }
+                RANS_ROUND(0)
+                RANS_ROUND(1)
+                RANS_ROUND(2)
+                RANS_ROUND(3)
+#undef RANS_ROUND
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t v = quad_transpose(acc[k], sel1, sel2);
+                    *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + (out_lane_off + k * 64u)) = v;
+                }
+                gdst += 4u * N;
+            }
+            r = groups << 2;
+        }
+
+        // ---- remaining full rounds and the partial tail round: element stores
+        for (; r <= rounds; ++r) {
+            const uint32_t cnt = (r < rounds) ? N : tail;
+            if (cnt == 0)
+                break;
+            uint8_t RANS_GLOBAL *rdst = dst + (uint64_t)r * N * p.sym_bytes;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t idx = k * 64u + lane;
+                if (idx < cnt) {
+                    uint32_t s = dec_step<FMT>(T, x[k]);
+                    if constexpr (Tr::kSymByte == 3)
+                        s >>= 24;
+                    if (p.sym_bytes == 1)
+                        rdst[idx] = (uint8_t)s;
+                    else
+                        reinterpret_cast<uint16_t RANS_GLOBAL *>(rdst)[idx] = (uint16_t)s;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t idx = k * 64u + lane;
+                W.refill(lane);
+                const uint32_t c = dec_renorm<FMT>(W, x[k], idx < cnt);
+                W.consume(c);
+                consumed += c;
+            }
+        }
+
+        // ---- integrity: every state back at L, cursor exactly at the end ----
+        bool good = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            good = good && (x[k] == Tr::kL);
+        const bool all_good = __builtin_amdgcn_ballot_w64(!good) == 0 && consumed == len;
+        if (!all_good && lane == 0)
+            atomicAdd(p.err_count, 1ull);
+    }
+}
+
+// ===========================================================================
+// Encoder: mirror image of the decoder.  One wave per chunk, symbols visited
+// last round first; within a sub-step the lanes that must emit compact their
+// units below the write cursor in ascending lane order (the decoder will read
+// them back in exactly that order).
+// ===========================================================================
+
+template <int FMT> struct EncTables {
+    const uint4 *recs; // LDS: EncRec {freq, start, rcp, remap}
+    const uint32_t *alias_remap; // global
+    uint32_t scale_bits;
+    uint32_t nsyms;
+};
+
+// exact x / freq and x % freq from the 32-bit reciprocal floor(2^32 / freq):
+// the estimate is never too large and at most 1 too small.
+__device__ __forceinline__ void divmod_rcp(uint32_t x, uint32_t freq, uint32_t rcp, uint32_t &q, uint32_t &rem)
+{
+    q = __umulhi(x, rcp);
+    rem = x - q * freq;
+    if (rem >= freq) {
+        q += 1;
+        rem -= freq;
+    }
+}
+
+// One encoder sub-step for 64 lanes.  `wp` = write cursor (byte offset inside the
+// slot, moves down, wave-uniform).
+template <int FMT>
+__device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename FmtTraits<FMT>::state_t &x,
+                                            uint32_t sym, bool active, uint8_t *slot, uint32_t &wp, bool &bad)
+{
+    const bool in_alphabet = sym < T.nsyms;
+    const uint4 rec = T.recs[in_alphabet ? sym : 0u];
+    const uint32_t freq = rec.x, start = rec.y, rcp = rec.z;
+    if (active && (!in_alphabet || freq == 0)) {
+        bad = true;
+        active = false;
+    }
+
+    if constexpr (FMT == FMT_WORD) {
+        // rans_word_sse41.h:81-93
+        const bool emit = active && x >= (freq << 20);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(emit);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        wp -= 2u * cnt;
+        if (emit)
+            *reinterpret_cast<uint16_t *>(slot + wp + 2u * rank_below(m)) = (uint16_t)(x & 0xffffu);
+        uint32_t y = emit ? (x >> 16) : x;
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        const uint32_t xn = (q << 12) + rem + start;
+        x = active ? xn : x;
+    } else if constexpr (FMT == FMT_R64) {
+        // rans64.h:77-93
+        const uint64_t x_max = ((uint64_t)freq) << (63u - T.scale_bits); // ((L >> sb) << 32) * freq
+        const bool emit = active && x >= x_max;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(emit);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        wp -= 4u * cnt;
+        if (emit)
+            *reinterpret_cast<uint32_t *>(slot + wp + 4u * rank_below(m)) = (uint32_t)x;
+        uint64_t y = emit ? (x >> 32) : x;
+        const uint32_t f = freq ? freq : 1u;
+        const uint64_t q = y / f;
+        const uint64_t rem = y - q * f;
+        const uint64_t xn = (q << T.scale_bits) + rem + start;
+        x = active ? xn : x;
+    } else {
+        // rans_byte.h:62-74 (renorm: 0, 1 or 2 bytes for scale_bits <= 16), :83-90 (put),
+        // main_alias.cpp:241-250 (alias put).  The low byte is emitted first, i.e.
+        // ends up at the higher address.
+        const uint32_t x_max = ((1u << 23 >> T.scale_bits) << 8) * freq;
+        const bool e1 = active && x >= x_max;
+        const bool e2 = e1 && (x >> 8) >= x_max;
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(e1);
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(e2);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m1) + (uint32_t)__builtin_popcountll(m2);
+        wp -= cnt;
+        const uint32_t at = wp + rank_below(m1) + rank_below(m2);
+        if (e2) {
+            slot[at] = (uint8_t)(x >> 8);
+            slot[at + 1] = (uint8_t)x;
+        } else if (e1) {
+            slot[at] = (uint8_t)x;
+        }
+        uint32_t y = e2 ? (x >> 16) : (e1 ? (x >> 8) : x);
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        uint32_t xn;
+        if constexpr (FMT == FMT_ALIAS)
+            xn = (q << T.scale_bits) + (active ? T.alias_remap[rem + start] : 0u);
+        else
+            xn = (q << T.scale_bits) + rem + start;
+        x = active ? xn : x;
+    }
+}
+
+template <int FMT, int K>
+__global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
+        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
+            l[i] = g[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t N = (K > 1) ? 64u * K : p.n_ways;
+
+    EncTables<FMT> T;
+    T.recs = reinterpret_cast<const uint4 *>(smem);
+    T.alias_remap = p.alias_remap;
+    T.scale_bits = p.scale_bits;
+    T.nsyms = p.nsyms;
+
+    bool bad = false;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * waves_per_block + wave; chunk < p.nchunks; chunk += total_waves) {
+        const uint64_t first = chunk * p.chunk_syms;
+        const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        const uint8_t *src = p.syms + first * p.sym_bytes;
+        uint8_t *slot = p.scratch + chunk * p.slot_bytes;
+        uint32_t wp = (uint32_t)p.slot_bytes;
+
+        state_t x[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            x[k] = Tr::kL; // RansEncInit / RansWordEncInit / Rans64EncInit
+
+        const uint32_t rounds = nsym / N;
+        const uint32_t tail = nsym - rounds * N;
+        // rounds from last to first; round `rounds` is the partial one
+        for (uint32_t rr = rounds + 1; rr-- > 0;) {
+            const uint32_t cnt = (rr < rounds) ? N : tail;
+            if (cnt == 0)
+                continue;
+            const uint8_t *rsrc = src + (uint64_t)rr * N * p.sym_bytes;
+            uint32_t sym[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t idx = k * 64u + lane;
+                sym[k] = 0;
+                if (idx < cnt)
+                    sym[k] = p.sym_bytes == 1 ? (uint32_t)rsrc[idx]
+                                              : (uint32_t) reinterpret_cast<const uint16_t *>(rsrc)[idx];
+            }
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                const uint32_t idx = k * 64u + lane;
+                enc_substep<FMT>(T, x[k], sym[k], idx < cnt, slot, wp, bad);
+            }
+        }
+
+        // flush: lane N-1 first, i.e. lane 0's state ends up first in memory
+        // (main.cpp:244-245, main_simd.cpp:298-299)
+        wp -= N * Tr::kStateBytes;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t idx = k * 64u + lane;
+            if (idx < N) {
+                uint8_t *at = slot + wp + idx * Tr::kStateBytes;
+                if constexpr (FMT == FMT_R64) {
+                    reinterpret_cast<uint32_t *>(at)[0] = (uint32_t)x[k];
+                    reinterpret_cast<uint32_t *>(at)[1] = (uint32_t)(x[k] >> 32);
+                } else if constexpr (FMT == FMT_WORD) {
+                    reinterpret_cast<uint16_t *>(at)[0] = (uint16_t)x[k];
+                    reinterpret_cast<uint16_t *>(at)[1] = (uint16_t)(x[k] >> 16);
+                } else {
+                    at[0] = (uint8_t)x[k];
+                    at[1] = (uint8_t)(x[k] >> 8);
+                    at[2] = (uint8_t)(x[k] >> 16);
+                    at[3] = (uint8_t)(x[k] >> 24);
+                }
+            }
+        }
+        if (lane == 0)
+            p.lengths[chunk] = (uint32_t)p.slot_bytes - wp;
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
+        atomicOr(p.flags, 1u);
+}
+
+// ---------------------------------------------------------------------------
+// Layout: offsets[c] = sum_{i<c} align16(lengths[i]); offsets[nchunks] = end of
+// the last stream.  One block; nchunks is small (n / chunk_syms).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_layout(const LayoutParams p)
+{
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint64_t carry;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < p.nchunks; base += blockDim.x) {
+        const uint64_t c = base + threadIdx.x;
+        const uint64_t mine = c < p.nchunks ? (((uint64_t)p.lengths[c] + 15u) & ~uint64_t(15)) : 0;
+        // inclusive scan inside the wave
+        uint64_t v = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = __shfl_up(v, d, 64);
+            if ((int)lane >= d)
+                v += o;
+        }
+        if (lane == 63)
+            wave_sum[wave] = v;
+        __syncthreads();
+        uint64_t before = carry;
+        for (uint32_t w = 0; w < wave; ++w)
+            before += wave_sum[w];
+        if (c < p.nchunks) {
+            p.offsets[c] = before + v - mine;
+            if (c == p.nchunks - 1) {
+                const uint64_t end = before + v - mine + p.lengths[c];
+                p.offsets[p.nchunks] = end;
+                if (before + v > p.out_cap)
+                    atomicOr(p.flags, 2u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1)
+            carry = before + v;
+        __syncthreads();
+    }
+    if (p.nchunks == 0 && threadIdx.x == 0)
+        p.offsets[0] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// Compaction: chunk c's stream sits at the END of its scratch slot (arbitrary
+// alignment); copy it to out + offsets[c] (16-byte aligned).  One wave per
+// chunk, dword granularity; source dwords are realigned with v_alignbyte_b32.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_compact(const CompactParams p)
+{
+    if (*p.flags & 2u)
+        return;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * waves_per_block + wave; chunk < p.nchunks; chunk += total_waves) {
+        const uint32_t len = p.lengths[chunk];
+        const uint8_t *src = p.scratch + (chunk + 1) * p.slot_bytes - len;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(p.out + p.offsets[chunk]);
+        const uintptr_t sa = reinterpret_cast<uintptr_t>(src);
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(sa & ~uintptr_t(3));
+        const uint32_t shift = (uint32_t)(sa & 3u);
+        const uint32_t ndw = (len + 3u) >> 2;
+        for (uint32_t i = lane; i < ndw; i += 64u) {
+            const uint32_t lo = s4[i];
+            // the dword after the slot end is never needed when shift == 0
+            const uint32_t hi = shift ? s4[i + 1] : 0u;
+            dst[i] = __builtin_amdgcn_alignbyte(hi, lo, shift);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Histogram (count_freqs, main.cpp:59-66): per-block LDS histogram, merged
+// with global atomics.
+// ---------------------------------------------------------------------------
+template <int SYM_BYTES> __global__ void __launch_bounds__(256) k_histogram(const void *syms, uint64_t n, uint32_t nsyms,
+                                                                             uint32_t *hist, uint32_t *flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+    for (uint32_t i = threadIdx.x; i < nsyms; i += blockDim.x)
+        h[i] = 0;
+    __syncthreads();
+    bool bad = false;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if constexpr (SYM_BYTES == 1) {
+        const uint8_t *p = static_cast<const uint8_t *>(syms);
+        const uint64_t nvec = (reinterpret_cast<uintptr_t>(p) & 15u) ? 0 : n / 16;
+        const uint4 *pv = reinterpret_cast<const uint4 *>(p);
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+            const uint4 v = pv[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t s = (w[a] >> (8 * b)) & 0xffu;
+                    if (s < nsyms)
+                        atomicAdd(&h[s], 1u);
+                    else
+                        bad = true;
+                }
+        }
+        for (uint64_t i = nvec * 16 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const uint32_t s = p[i];
+            if (s < nsyms)
+                atomicAdd(&h[s], 1u);
+            else
+                bad = true;
+        }
+    } else {
+        const uint16_t *p = static_cast<const uint16_t *>(syms);
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const uint32_t s = p[i];
+            if (s < nsyms)
+                atomicAdd(&h[s], 1u);
+            else
+                bad = true;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nsyms; i += blockDim.x)
+        if (h[i])
+            atomicAdd(&hist[i], h[i]);
+    if (bad)
+        atomicOr(flags, 1u);
+}
+
+// ------------------------------------------------------------------ launchers
+
+template <int FMT, int K, int OUT>
+hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
+{
+    const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
+    const uint32_t waves = kDecBlockThreads / 64;
+    const size_t lds = (size_t)t0 + t1 + (size_t)waves * kRingStride;
+    if (lds > 160 * 1024)
+        return hipErrorInvalidValue;
+    auto kern = k_decode<FMT, K, OUT>;
+    static bool attr_set = false; // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_set = true;
+    }
+    const int blocks_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+    uint64_t want = (p.nchunks + waves - 1) / waves;
+    uint64_t cap = (uint64_t)num_cus * blocks_per_cu;
+    const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    if (name)
+        *name = FMT == FMT_WORD ? "k_decode<word>" : FMT == FMT_BYTE ? "k_decode<byte>"
+                : FMT == FMT_R64 ? "k_decode<r64>" : "k_decode<alias>";
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, hipStream_t s, const char **name)
+{
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)p.chunk_syms) & 3u) == 0;
+    const bool fast = aligned && p.sym_bytes == 1;
+    switch (p.n_ways) {
+    case 64:
+        return fast ? launch_decode_t<FMT, 1, OUT_FAST8>(p, num_cus, s, name)
+                    : launch_decode_t<FMT, 1, OUT_SLOW>(p, num_cus, s, name);
+    case 128:
+        return fast ? launch_decode_t<FMT, 2, OUT_FAST8>(p, num_cus, s, name)
+                    : launch_decode_t<FMT, 2, OUT_SLOW>(p, num_cus, s, name);
+    case 256:
+        return fast ? launch_decode_t<FMT, 4, OUT_FAST8>(p, num_cus, s, name)
+                    : launch_decode_t<FMT, 4, OUT_SLOW>(p, num_cus, s, name);
+    case 512:
+        return fast ? launch_decode_t<FMT, 8, OUT_FAST8>(p, num_cus, s, name)
+                    : launch_decode_t<FMT, 8, OUT_SLOW>(p, num_cus, s, name);
+    default:
+        if (p.n_ways >= 1 && p.n_ways < 64)
+            return launch_decode_t<FMT, 1, OUT_SLOW>(p, num_cus, s, name);
+        return hipErrorInvalidValue;
+    }
+}
+
+template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num_cus, hipStream_t stream)
+{
+    const uint32_t waves = kEncBlockThreads / 64;
+    const size_t lds = (size_t)p.nsyms * sizeof(EncRec);
+    if (lds > 128 * 1024)
+        return hipErrorInvalidValue;
+    auto kern = k_encode<FMT, K>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_set = true;
+    }
+    uint64_t want = (p.nchunks + waves - 1) / waves;
+    uint64_t cap = (uint64_t)num_cus * 8;
+    const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kEncBlockThreads), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int FMT> hipError_t launch_encode_f(const EncParams &p, int num_cus, hipStream_t s)
+{
+    switch (p.n_ways) {
+    case 128: return launch_encode_t<FMT, 2>(p, num_cus, s);
+    case 256: return launch_encode_t<FMT, 4>(p, num_cus, s);
+    case 512: return launch_encode_t<FMT, 8>(p, num_cus, s);
+    default:
+        if (p.n_ways >= 1 && p.n_ways <= 64)
+            return launch_encode_t<FMT, 1>(p, num_cus, s);
+        return hipErrorInvalidValue;
+    }
+}
+
+} // namespace
+
+bool ways_supported(int format, uint32_t n_ways)
+{
+    if (format < 0 || format > 3)
+        return false;
+    return (n_ways >= 1 && n_ways <= 64) || n_ways == 128 || n_ways == 256 || n_ways == 512;
+}
+
+hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name)
+{
+    switch (format) {
+    case FMT_WORD: return launch_decode_f<FMT_WORD>(p, num_cus, stream, kernel_name);
+    case FMT_BYTE: return launch_decode_f<FMT_BYTE>(p, num_cus, stream, kernel_name);
+    case FMT_R64: return launch_decode_f<FMT_R64>(p, num_cus, stream, kernel_name);
+    case FMT_ALIAS: return launch_decode_f<FMT_ALIAS>(p, num_cus, stream, kernel_name);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream)
+{
+    switch (format) {
+    case FMT_WORD: return launch_encode_f<FMT_WORD>(p, num_cus, stream);
+    case FMT_BYTE: return launch_encode_f<FMT_BYTE>(p, num_cus, stream);
+    case FMT_R64: return launch_encode_f<FMT_R64>(p, num_cus, stream);
+    case FMT_ALIAS: return launch_encode_f<FMT_ALIAS>(p, num_cus, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_layout(const LayoutParams &p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t stream)
+{
+    uint64_t want = (p.nchunks + 3) / 4;
+    uint64_t cap = (uint64_t)num_cus * 8;
+    const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
+                            uint32_t *d_flags, int num_cus, hipStream_t stream)
+{
+    const size_t lds = (size_t)nsyms * 4;
+    const uint32_t grid = (uint32_t)num_cus * 4;
+    if (sym_bytes == 1)
+        hipLaunchKernelGGL(k_histogram<1>, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+    else
+        hipLaunchKernelGGL(k_histogram<2>, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+    return hipGetLastError();
+}
+
+} // namespace rans_amd

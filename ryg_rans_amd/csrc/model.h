@@ -1,0 +1,103 @@
+// model.h -- host-side order-0 model and the table images derived from it.
+//
+// Replaces the table-building half of the reference mains (SymbolStats,
+// cum2sym, RansEncSymbolInit/RansDecSymbolInit loops, RansWordTablesInitSymbol,
+// make_alias_table); see include/ryg_rans_amd.h for the file:line map.
+// Pure host C++ (no HIP), so it is unit-testable without a GPU.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace rans_amd {
+
+// Reference struct layouts, reproduced for table export (rans_byte.h:159-171,
+// rans64.h:152-164, rans_word_sse41.h:50-61).  Layout only; code is ours.
+struct EncSymbol32 {
+    uint32_t x_max;
+    uint32_t rcp_freq;
+    uint32_t bias;
+    uint16_t cmpl_freq;
+    uint16_t rcp_shift;
+};
+struct DecSymbol32 {
+    uint16_t start;
+    uint16_t freq;
+};
+struct EncSymbol64 {
+    uint64_t rcp_freq;
+    uint32_t freq;
+    uint32_t bias;
+    uint32_t cmpl_freq;
+    uint32_t rcp_shift;
+};
+struct DecSymbol64 {
+    uint32_t start;
+    uint32_t freq;
+};
+static_assert(sizeof(EncSymbol32) == 16 && sizeof(DecSymbol32) == 4, "layout");
+static_assert(sizeof(EncSymbol64) == 24 && sizeof(DecSymbol64) == 8, "layout");
+
+// Device-side packed records (what the kernels stage into LDS).
+//
+// WordSlot: one record per cumulative slot of the 12-bit word model.
+//   lo = freq (bits 0..11, bits 12..23 zero) | symbol << 24 ; hi = slot - start
+// so the decoder's D step is a single v_mad_u32_u24(lo, x >> 12, hi) and the
+// symbol is the top byte of lo.
+struct WordSlot {
+    uint32_t lo;
+    uint32_t hi;
+};
+// SymRec: per-symbol record for the cum2sym-based decoders (byte / r64).
+struct SymRec {
+    uint32_t freq;
+    uint32_t start;
+};
+// AliasHalf: one half-bucket of the alias table.  lo = freq | symbol << 16.
+struct AliasHalf {
+    uint32_t lo;
+    uint32_t adjust;
+};
+// EncRec: per-symbol encoder record.  q = x / freq is recovered exactly from
+// mulhi(x, rcp) with one correction step; see kernels.hip.
+struct EncRec {
+    uint32_t freq;
+    uint32_t start;
+    uint32_t rcp;   // floor(2^32 / freq), 0xffffffff for freq == 1
+    uint32_t remap; // alias only: offset of this symbol's run in alias_remap (== start)
+};
+
+int count_freqs_host(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *freqs);
+int normalize_freqs(uint32_t *freqs, uint32_t *cum, uint32_t nsyms, uint32_t target_total);
+
+struct HostModel {
+    int format = 0;
+    uint32_t nsyms = 0;
+    uint32_t log2nsyms = 0;
+    uint32_t scale_bits = 0;
+    int sym_bytes = 1;
+
+    std::vector<uint32_t> freqs;    // [nsyms]
+    std::vector<uint32_t> cum;      // [nsyms+1]
+    std::vector<uint16_t> cum2sym;  // [M] (exported as u8 when nsyms <= 256)
+
+    // alias (main_alias.cpp:56-63)
+    std::vector<uint32_t> divider, slot_adjust, slot_freqs, sym_id, alias_remap;
+
+    // device-format records
+    std::vector<WordSlot> word_slots;   // [4096]           FMT_WORD
+    std::vector<SymRec> sym_recs;       // [nsyms]          FMT_BYTE / FMT_R64
+    std::vector<AliasHalf> alias_halves; // [2*nsyms]        FMT_ALIAS
+    std::vector<EncRec> enc_recs;       // [nsyms]          all formats
+
+    // Returns a rans_amd_status.
+    int build(int format, const uint32_t *norm_freqs, uint32_t nsyms, uint32_t scale_bits);
+    // Table export (reference layouts).
+    int export_table(int which, std::vector<uint8_t> &out) const;
+
+  private:
+    int build_alias();
+};
+
+} // namespace rans_amd

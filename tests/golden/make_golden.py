@@ -1,0 +1,52 @@
+"""Generates tests/golden/ref_streams.{json,bin}: streams written by the UNMODIFIED
+reference (oracle/_ref/libryg_ref.so, built from /root/reference by oracle/Makefile)
+on a small seeded input, for every format and N in {1, 2, 8, 64}.  Run here (the
+container with /root/reference); the outputs are committed so that GPU-box tests
+can check the HIP path against reference-made bytes without the reference.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from _oracle import FMT_ALIAS, FMT_BYTE, FMT_R64, FMT_WORD, FMT_NAMES, Oracle, Ref  # noqa: E402
+
+
+def main():
+    ref, orc = Ref(), Oracle()
+    rng = np.random.default_rng(20260925)
+    # text-like skew + every byte value once (freq-1 symbols) + odd length
+    data = np.concatenate([
+        np.minimum(rng.geometric(0.07, 9000) - 1, 255).astype(np.uint8),
+        np.arange(256, dtype=np.uint8),
+        orc.gen_zipf(2747, K=256, s=1.0, seed=1),
+    ])
+    assert data.size == 12003
+    blob = [data]
+    pos = data.size
+    streams = []
+    for fmt, sb in ((FMT_BYTE, 14), (FMT_WORD, 12), (FMT_R64, 14), (FMT_ALIAS, 16)):
+        freqs, _ = ref.build_model(data, 1 << sb)
+        for n_ways in (1, 2, 8, 64):
+            s = ref.encode(fmt, freqs, sb, data, n_ways)
+            back, rc = ref.decode(fmt, freqs, sb, s, data.size, n_ways)
+            assert rc == 0 and np.array_equal(back, data)
+            streams.append({"name": "%s-sb%d-N%d" % (FMT_NAMES[fmt], sb, n_ways), "fmt": fmt, "scale_bits": sb,
+                            "n_ways": n_ways, "offset": pos, "size": int(s.size),
+                            "freqs": [int(v) for v in freqs]})
+            blob.append(s)
+            pos += s.size
+    np.concatenate(blob).tofile(os.path.join(HERE, "ref_streams.bin"))
+    json.dump({"blob": "ref_streams.bin", "input": [0, int(data.size)], "streams": streams,
+               "made_by": "tests/golden/make_golden.py via oracle/_ref (unmodified reference headers)"},
+              open(os.path.join(HERE, "ref_streams.json"), "w"))
+    print("wrote %d streams, %d bytes" % (len(streams), pos))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,227 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the
+C ABI, against the CPU oracle on the same seeded inputs -- bit-exact both ways:
+
+  * encode: every chunk the GPU encoder emits equals the oracle's stream for
+    that chunk byte for byte (so it equals the reference's N-way loop output);
+  * decode: containers produced by the ORACLE decode on the GPU to the input;
+  * committed fixtures made by the unmodified reference (tests/golden/) decode
+    on the GPU and are reproduced by the GPU encoder;
+  * edge cases the reference exercises: n not a multiple of N (tail round),
+    n < N, odd n, symbols that occur once (freq 1), 174 unused symbols,
+    ragged last chunk, one-chunk == raw reference stream;
+  * corruption is detected, never turns into an out-of-bounds access.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from _oracle import FMT_ALIAS, FMT_BYTE, FMT_R64, FMT_WORD, Oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+FORMATS = [(FMT_WORD, 12), (FMT_BYTE, 14), (FMT_BYTE, 16), (FMT_R64, 14), (FMT_ALIAS, 16), (FMT_ALIAS, 12)]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    import ryg_rans_amd as R
+    ctx = R.Context(0)
+    yield R, ctx, torch
+    ctx.close()
+
+
+def _inputs(oracle):
+    rng = np.random.default_rng(7)
+    text_like = np.minimum(rng.geometric(0.06, 200003) - 1, 255).astype(np.uint8)
+    return {
+        "zipf": oracle.gen_zipf(300000, K=256, s=1.0, seed=1),
+        "skew": text_like,
+        "rare": np.concatenate([np.full(50000, 65, np.uint8), np.arange(256, dtype=np.uint8),
+                                np.full(50001, 66, np.uint8)]),
+        "two": (rng.integers(0, 2, 40000) * 255).astype(np.uint8),
+    }
+
+
+def _models(R, ctx, oracle, fmt, sb, data, nsyms=256):
+    counts = oracle.count_freqs(data, nsyms)
+    f, _ = oracle.normalize(counts, 1 << sb)
+    om = oracle.model(f, sb, with_alias=(fmt == FMT_ALIAS))
+    gm = ctx.model(fmt, f, sb)
+    return om, gm
+
+
+@pytest.mark.parametrize("fmt,sb", FORMATS)
+@pytest.mark.parametrize("n_ways", [64, 256, 1, 2, 8, 33, 128, 512])
+def test_single_stream_matches_oracle(gpu, oracle, fmt, sb, n_ways):
+    """chunk_syms >= n: the container is the raw reference-format stream."""
+    R, ctx, torch = gpu
+    for name, data in _inputs(oracle).items():
+        data = data[:60001]
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        want = oracle.encode(fmt, om, data, n_ways)
+        got = ctx.encode_host(gm, data, n_ways)
+        assert got.size == want.size and np.array_equal(got, want), (name, "encode")
+        out = ctx.decode_host(gm, want, data.size, n_ways)
+        assert np.array_equal(out, data), (name, "decode")
+
+
+@pytest.mark.parametrize("fmt,sb", FORMATS)
+@pytest.mark.parametrize("n_ways,chunk_syms", [(64, 4096), (64, 5000), (256, 16384), (32, 1000), (128, 4096)])
+def test_chunked_matches_oracle(gpu, oracle, fmt, sb, n_ways, chunk_syms):
+    R, ctx, torch = gpu
+    data = _inputs(oracle)["zipf"]
+    om, gm = _models(R, ctx, oracle, fmt, sb, data)
+    cont, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk_syms, align=16)
+
+    # GPU decode of the oracle's container
+    d_cont = torch.from_numpy(np.concatenate([cont, np.zeros(64, np.uint8)])).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+    d_out = ctx.decode(gm, d_cont, cont.size, d_offs, d_lens, data.size, n_ways, chunk_syms)
+    assert np.array_equal(d_out.cpu().numpy(), data)
+
+    # GPU encode: same index, same bytes
+    d_syms = torch.from_numpy(data).cuda()
+    g_cont, g_offs, g_lens, total = ctx.encode(gm, d_syms, n_ways, chunk_syms)
+    assert total == cont.size
+    assert np.array_equal(g_offs.cpu().numpy().astype(np.uint64), offs)
+    assert np.array_equal(g_lens.cpu().numpy().astype(np.uint32), lens)
+    g = g_cont.cpu().numpy()
+    for c in range(len(lens)):
+        a, b = int(offs[c]), int(offs[c]) + int(lens[c])
+        assert np.array_equal(g[a:b], cont[a:b]), "chunk %d differs" % c
+
+    # and the GPU decodes its own container
+    d_out2 = ctx.decode(gm, g_cont, total, g_offs, g_lens, data.size, n_ways, chunk_syms)
+    assert torch.equal(d_out2, d_syms)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 255, 256, 257, 4099])
+def test_tiny_and_ragged_sizes(gpu, oracle, n):
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(5000, K=256, s=1.0, seed=3)[:n]
+    for fmt, sb in FORMATS:
+        if len(np.unique(data)) < 2:
+            continue  # one-symbol model is rejected (freq == M)
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        for n_ways in (64, 256, 3):
+            want = oracle.encode(fmt, om, data, n_ways)
+            assert np.array_equal(ctx.encode_host(gm, data, n_ways), want), (fmt, n_ways)
+            assert np.array_equal(ctx.decode_host(gm, want, n, n_ways), data), (fmt, n_ways)
+
+
+def test_alias_4096_symbols(gpu, oracle):
+    """Config 4: 4096-symbol alphabet, 16-bit probabilities, u16 symbols, 64-way."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(400001, K=4096, s=1.0, seed=1)
+    om, gm = _models(R, ctx, oracle, FMT_ALIAS, 16, data, nsyms=4096)
+    for n_ways, chunk in ((64, 8192), (256, 400001)):
+        cont, offs, lens = oracle.encode_chunked(FMT_ALIAS, om, data, n_ways, chunk, align=16)
+        d_syms = torch.from_numpy(data.view(np.int16)).cuda()
+        g_cont, g_offs, g_lens, total = ctx.encode(gm, d_syms, n_ways, chunk)
+        assert total == cont.size
+        assert np.array_equal(g_cont.cpu().numpy()[:total][: cont.size], cont)
+        d_out = ctx.decode(gm, g_cont, total, g_offs, g_lens, data.size, n_ways, chunk)
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint16), data)
+
+
+def test_reference_fixtures(gpu):
+    """Streams written by the UNMODIFIED reference (tests/golden/make_golden.py)."""
+    R, ctx, torch = gpu
+    idx_path = os.path.join(HERE, "golden", "ref_streams.json")
+    if not os.path.exists(idx_path):
+        pytest.skip("fixtures not generated")
+    idx = json.load(open(idx_path))
+    blob = np.fromfile(os.path.join(HERE, "golden", idx["blob"]), dtype=np.uint8)
+    data = blob[idx["input"][0]: idx["input"][0] + idx["input"][1]]
+    for e in idx["streams"]:
+        stream = blob[e["offset"]: e["offset"] + e["size"]]
+        freqs = np.array(e["freqs"], dtype=np.uint32)
+        gm = ctx.model(e["fmt"], freqs, e["scale_bits"])
+        assert np.array_equal(ctx.decode_host(gm, stream, data.size, e["n_ways"]), data), e["name"]
+        assert np.array_equal(ctx.encode_host(gm, data, e["n_ways"]), stream), e["name"]
+
+
+def test_corruption_is_detected(gpu, oracle):
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(100000, K=256, s=1.0, seed=9)
+    for fmt, sb in ((FMT_WORD, 12), (FMT_BYTE, 14), (FMT_R64, 14)):
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        good = oracle.encode(fmt, om, data, 64)
+        # truncated stream
+        out, rc = ctx.decode_host(gm, good[:-8], data.size, 64, check=False)
+        assert rc == R.E_CORRUPT
+        # flipped bit in the payload: either flagged or (rarely) decodes to other data, never crashes
+        bad = good.copy()
+        bad[len(bad) // 3] ^= 0x40
+        out, rc = ctx.decode_host(gm, bad, data.size, 64, check=False)
+        assert rc == R.E_CORRUPT or not np.array_equal(out, data)
+        # wrong n
+        out, rc = ctx.decode_host(gm, good, data.size - 64, 64, check=False)
+        assert rc == R.E_CORRUPT
+
+
+def test_model_errors(gpu, oracle):
+    R, ctx, torch = gpu
+    f = np.zeros(256, np.uint32)
+    f[7] = 4096
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.model(FMT_WORD, f, 12)
+    assert e.value.status == R.E_MODEL
+    f[7] = 4000
+    with pytest.raises(R.RansAmdError):
+        ctx.model(FMT_WORD, f, 12)  # does not sum to M
+    # symbol with frequency 0 in the input
+    f[8] = 96
+    gm = ctx.model(FMT_WORD, f, 12)
+    data = np.array([7, 8, 9, 7] * 100, dtype=np.uint8)
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.encode_host(gm, data, 64)
+    assert e.value.status == R.E_MODEL
+
+
+def test_device_histogram(gpu, oracle):
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(1 << 20, K=256, s=1.0, seed=4)
+    got = ctx.count_freqs_device(torch.from_numpy(data).cuda(), 256)
+    assert np.array_equal(got, oracle.count_freqs(data, 256))
+    data16 = oracle.gen_zipf(300001, K=4096, s=1.0, seed=4)
+    got = ctx.count_freqs_device(torch.from_numpy(data16.view(np.int16)).cuda(), 4096)
+    assert np.array_equal(got, oracle.count_freqs(data16, 4096))
+
+
+def test_full_size_roundtrip_properties(gpu):
+    """BASELINE size (1 GiB): encode -> decode round trip on device, checksum of the
+    output equals checksum of the input, every chunk passes its integrity check."""
+    R, ctx, torch = gpu
+    n = 1 << 30
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    w = 1.0 / torch.arange(1, 257, dtype=torch.float64, device="cuda")
+    cdf = torch.cumsum(w / w.sum(), 0).float()
+    d_syms = torch.empty(n, dtype=torch.uint8, device="cuda")
+    step = 1 << 26
+    for i in range(0, n, step):
+        u = torch.rand(step, device="cuda", generator=g)
+        d_syms[i:i + step] = torch.searchsorted(cdf, u).clamp_(max=255).to(torch.uint8)
+    counts = ctx.count_freqs_device(d_syms, 256)
+    assert int(counts.sum()) == n
+    f, _ = R.normalize_freqs(counts, 4096)
+    gm = ctx.model(FMT_WORD, f, 12)
+    chunk = 32768
+    cont, offs, lens, total = ctx.encode(gm, d_syms, 64, chunk)
+    assert 0.5 * n < total < n
+    out = ctx.decode(gm, cont, total, offs, lens, n, 64, chunk)
+    assert torch.equal(out, d_syms)
+    # a corrupted copy of the container is flagged
+    cont2 = cont.clone()
+    cont2[total // 2] ^= 1
+    out2 = torch.empty_like(out)
+    ctx.decode(gm, cont2, total, offs, lens, n, 64, chunk, d_out=out2, sync=False)
+    assert ctx.decode_errors() >= 1 or not torch.equal(out2, d_syms)
