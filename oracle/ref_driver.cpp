@@ -282,8 +282,8 @@ int ref_decode_word_simd8(const uint32_t *freqs, const uint8_t *stream, size_t n
 // ---- timing helpers for the CPU baseline -----------------------------------
 //
 // `shards` independent 8-way word streams (stream s at streams + offsets[s],
-// n_per symbols each) are decoded by `threads` pthreads, shards dealt round
-// robin.  Returns wall seconds for the whole batch (clock_gettime MONOTONIC via
+// n_per symbols each) are decoded `reps` times by `threads` pthreads, shards dealt
+// round robin.  Returns wall seconds for the whole batch (clock_gettime MONOTONIC via
 // the reference's own timer(), platform.h:47-55).
 
 struct simd8_job {
@@ -292,25 +292,26 @@ struct simd8_job {
     const uint64_t *offsets;
     size_t n_per;
     uint8_t *out;
-    uint32_t shards, threads, tid;
+    uint32_t shards, threads, tid, reps;
 };
 
 static void *simd8_worker(void *p)
 {
     simd8_job *j = (simd8_job *)p;
-    for (uint32_t s = j->tid; s < j->shards; s += j->threads)
-        ref_decode_word_simd8(j->freqs, j->streams + j->offsets[s], j->n_per, j->out + (size_t)s * j->n_per);
+    for (uint32_t rep = 0; rep < j->reps; rep++)
+        for (uint32_t s = j->tid; s < j->shards; s += j->threads)
+            ref_decode_word_simd8(j->freqs, j->streams + j->offsets[s], j->n_per, j->out + (size_t)s * j->n_per);
     return 0;
 }
 
 double ref_time_word_simd8(const uint32_t *freqs, const uint8_t *streams, const uint64_t *offsets, uint32_t shards,
-                           size_t n_per, uint8_t *out, uint32_t threads)
+                           size_t n_per, uint8_t *out, uint32_t threads, uint32_t reps)
 {
     std::vector<pthread_t> th(threads);
     std::vector<simd8_job> jobs(threads);
     double t0 = timer();
     for (uint32_t t = 0; t < threads; t++) {
-        jobs[t] = simd8_job{freqs, streams, offsets, n_per, out, shards, threads, t};
+        jobs[t] = simd8_job{freqs, streams, offsets, n_per, out, shards, threads, t, reps};
         pthread_create(&th[t], 0, simd8_worker, &jobs[t]);
     }
     for (uint32_t t = 0; t < threads; t++)

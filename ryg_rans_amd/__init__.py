@@ -47,6 +47,13 @@ class RansAmdError(RuntimeError):
 
 
 def _load():
+    # torch ships its own libamdhip64.so (SONAME libamdhip64.so.7, same as /opt/rocm's).
+    # Whoever loads first wins; two HIP runtimes in one process see no devices from the
+    # second one.  Load torch's first so that our library binds to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "ryg_rans_amd: %s is missing -- build it with `make -C ryg_rans_amd/csrc` "

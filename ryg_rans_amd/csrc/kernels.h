@@ -11,7 +11,7 @@ namespace rans_amd {
 // Per-wave LDS stream window (see kernels.hip "stream window").
 constexpr uint32_t kRingBytes = 2048;   // two 1 KiB blocks
 constexpr uint32_t kRingBlock = 1024;   // 64 lanes x 16 B
-constexpr uint32_t kRingMirror = 256;   // copy of ring[0..256) after the end: no wrap inside a sub-step
+constexpr uint32_t kRingMirror = 768;   // copy of ring[0..768) after the end: no wrap between checkpoints
 constexpr uint32_t kRingStride = kRingBytes + kRingMirror;
 
 constexpr int kDecBlockThreads = 1024; // 16 waves share one table image

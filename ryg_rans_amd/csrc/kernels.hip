@@ -106,18 +106,30 @@ template <int P0, int P1, int P2, int P3> __device__ __forceinline__ uint32_t qu
 }
 
 // ---------------------------------------------------------------------------
-// Stream window: a 2 KiB ring per wave in LDS, filled in aligned 1 KiB blocks.
-// `rd` = read offset, `avail` = valid bytes ahead of rd, `wr` = offset of the
-// block that is written next.  A block is free as soon as avail <= 1024.  The
-// first 256 bytes of the ring are mirrored behind its end so that a sub-step
-// (which consumes at most 256 bytes) never has to wrap an address.
-// All three are wave-uniform (SGPRs); the refill branch is a scalar branch.
+// Stream window: a 2 KiB ring per wave in LDS, filled in aligned 1 KiB blocks
+// (one global_load_dwordx4 per lane), the next block prefetched in registers.
+//
+//   rd    ring offset of the read cursor at the last checkpoint (< 2048)
+//   adv   bytes consumed since that checkpoint
+//   avail valid bytes ahead of rd at the checkpoint
+//   wr    ring offset of the block that is written next (0 or 1024)
+//
+// checkpoint() folds adv into rd/avail and, when a block is free (avail <=
+// 1024), writes the prefetched block and issues the next fetch.  Between two
+// checkpoints the decoder consumes at most kMaxAdvance bytes and reads at most
+// one more sub-step beyond that, so addresses never wrap between checkpoints:
+// the first kRingMirror bytes of the ring are mirrored behind its end.
+// Everything here is wave-uniform (SGPRs); the refill branch is a scalar branch.
 // ---------------------------------------------------------------------------
+constexpr uint32_t kMaxAdvance = 512;
+static_assert(kRingMirror >= kMaxAdvance + 256, "mirror must cover one checkpoint interval plus one sub-step");
+
 struct StreamWindow {
-    uint8_t *ring;   // LDS, wave-private
-    uint64_t gnext;  // global address of the next 1 KiB block to fetch (wave-uniform)
-    uint64_t glimit; // 16-byte aligned end of the readable container (wave-uniform)
-    uint32_t rd, avail, wr;
+    uint8_t *ring;      // LDS, wave-private
+    uint32_t ring_addr; // the same as a raw LDS byte address (for the asm path)
+    uint64_t gnext;     // global address of the next 1 KiB block to fetch
+    uint64_t glimit;    // 16-byte aligned end of what may be fetched for this chunk
+    uint32_t rd, adv, avail, wr;
     u32x4 pre; // prefetched block (16 B per lane)
 
     __device__ __forceinline__ u32x4 fetch(uint32_t lane)
@@ -142,9 +154,11 @@ struct StreamWindow {
     __device__ __forceinline__ void open(uint8_t *lds, uint64_t gaddr, uint64_t limit, uint32_t lane)
     {
         ring = lds;
+        ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
         glimit = limit;
         gnext = gaddr & ~uint64_t(15);
         rd = (uint32_t)(gaddr & 15u);
+        adv = 0;
         u32x4 b0 = fetch(lane);
         u32x4 b1 = fetch(lane);
         pre = fetch(lane);
@@ -153,8 +167,11 @@ struct StreamWindow {
         wr = 0;
         avail = kRingBytes - rd;
     }
-    __device__ __forceinline__ void refill(uint32_t lane)
+    __device__ __forceinline__ void checkpoint(uint32_t lane)
     {
+        rd = (rd + adv) & (kRingBytes - 1);
+        avail -= adv;
+        adv = 0;
         if (avail <= kRingBlock) {
             put(lane, wr, pre);
             wr ^= kRingBlock;
@@ -162,11 +179,10 @@ struct StreamWindow {
             pre = fetch(lane);
         }
     }
-    __device__ __forceinline__ void consume(uint32_t bytes)
-    {
-        rd = (rd + bytes) & (kRingBytes - 1);
-        avail -= bytes;
-    }
+    // ring offset / LDS address of the read cursor (no wrap between checkpoints)
+    __device__ __forceinline__ uint32_t cursor() const { return rd + adv; }
+    __device__ __forceinline__ uint32_t cursor_addr() const { return ring_addr + rd + adv; }
+    __device__ __forceinline__ void consume(uint32_t bytes) { adv += bytes; }
 };
 
 // ---------------------------------------------------------------------------
@@ -231,7 +247,7 @@ __device__ __forceinline__ uint32_t dec_renorm(const StreamWindow &W, typename F
         // rans_word_sse41.h:134-141 / :182-227
         const bool need = active && x < (1u << 16);
         const uint64_t m = __builtin_amdgcn_ballot_w64(need);
-        const uint32_t at = W.rd + 2u * rank_below(m);
+        const uint32_t at = W.cursor() + 2u * rank_below(m);
         const uint32_t w = *reinterpret_cast<const uint16_t *>(W.ring + at);
         x = need ? ((x << 16) | w) : x;
         return 2u * (uint32_t)__builtin_popcountll(m);
@@ -239,7 +255,7 @@ __device__ __forceinline__ uint32_t dec_renorm(const StreamWindow &W, typename F
         // rans64.h:305-316
         const bool need = active && x < (1ull << 31);
         const uint64_t m = __builtin_amdgcn_ballot_w64(need);
-        const uint32_t at = W.rd + 4u * rank_below(m);
+        const uint32_t at = W.cursor() + 4u * rank_below(m);
         const uint32_t w = *reinterpret_cast<const uint32_t *>(W.ring + at);
         x = need ? ((x << 32) | w) : x;
         return 4u * (uint32_t)__builtin_popcountll(m);
@@ -251,7 +267,7 @@ __device__ __forceinline__ uint32_t dec_renorm(const StreamWindow &W, typename F
         const bool n2 = active && x < (1u << 15);
         const uint64_t m1 = __builtin_amdgcn_ballot_w64(n1);
         const uint64_t m2 = __builtin_amdgcn_ballot_w64(n2);
-        const uint32_t at = W.rd + rank_below(m1) + rank_below(m2);
+        const uint32_t at = W.cursor() + rank_below(m1) + rank_below(m2);
         const uint32_t b0 = W.ring[at];
         const uint32_t b1 = W.ring[at + 1];
         const uint32_t x1 = (x << 8) | b0;
@@ -259,6 +275,36 @@ __device__ __forceinline__ uint32_t dec_renorm(const StreamWindow &W, typename F
         x = n2 ? x2 : (n1 ? x1 : x);
         return (uint32_t)__builtin_popcountll(m1) + (uint32_t)__builtin_popcountll(m2);
     }
+}
+
+// Hand-written renormalisation sub-step of the word format for a FULL wave (all 64
+// lanes hold a state and are active): rans_word_sse41.h:134-141 for 64 lanes at once.
+//   v_cmpx      lanes with x < 2^16 stay enabled; vcc = the same mask
+//   v_mbcnt x2  rank of the lane among the enabled ones = its word index in the stream
+//   ds_read_u16 only the enabled lanes read; v_perm merges (x << 16) | word
+//   s_bcnt1     words consumed by the wave (returned)
+// 5 VALU + 1 LDS + 2 SALU, no branch, no v_cndmask.  exec is restored to all ones,
+// which is what it was (the caller runs this only in wave-uniform full-wave code).
+__device__ __forceinline__ uint32_t renorm_word_full(uint32_t &x, uint32_t cursor_addr, uint32_t k65536)
+{
+    uint32_t t, w, cnt;
+    // gfx940+ hazard: a VALU write of an SGPR/VCC needs 2 wait states before a VALU reads it
+    // as an operand (LLVM GCNHazardRecognizer, VALUWriteSGPRVALURead); hipcc does not pad
+    // inside an asm statement, hence the s_nop 1.
+    asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[x]\n\t"
+                 "s_nop 1\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "v_lshl_add_u32 %[t], %[t], 1, %[cur]\n\t"
+                 "ds_read_u16 %[w], %[t]\n\t"
+                 "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_perm_b32 %[x], %[x], %[w], %[sel]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [x] "+v"(x), [t] "=&v"(t), [w] "=&v"(w), [cnt] "=&s"(cnt)
+                 : [lim] "v"(k65536), [cur] "s"(cursor_addr), [sel] "s"(0x05040100u)
+                 : "vcc", "scc", "memory");
+    return cnt;
 }
 
 // byte `kSymByte` of `raw` goes to byte J of acc, the other bytes of acc stay
@@ -332,9 +378,11 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
     const uint32_t out_lane_off = (lane & 3u) * N + (lane & ~3u);
 
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
-    for (uint64_t chunk = (uint64_t)blockIdx.x * waves_per_block + wave; chunk < p.nchunks; chunk += total_waves) {
+    for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave; chunk_v < p.nchunks;
+         chunk_v += total_waves) {
         // everything derived from the chunk index is wave-uniform; say so explicitly
         // so it lives in SGPRs and the loop control below is scalar
+        const uint64_t chunk = uniform64(chunk_v);
         const uint64_t off = uniform64(p.offsets[chunk]);
         const uint32_t len = uniform(p.lengths[chunk]);
         const uint64_t first = chunk * p.chunk_syms;
@@ -367,25 +415,35 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
         }
 
         StreamWindow W;
-        W.open(ring, src + N * Tr::kStateBytes, glimit, lane);
+        // fetch nothing beyond this chunk's own stream (rounded up to the 16-byte granule)
+        const uint64_t climit = (src + len + 15u) & ~uint64_t(15);
+        W.open(ring, src + N * Tr::kStateBytes, climit < glimit ? climit : glimit, lane);
         uint32_t consumed = N * Tr::kStateBytes;
 
-        const uint32_t rounds = nsym / N;
-        const uint32_t tail = nsym - rounds * N;
+        const uint32_t rounds = uniform(nsym / N);
+        const uint32_t tail = uniform(nsym - rounds * N);
         uint32_t r = 0;
+        // sub-steps between two window checkpoints: at most kMaxAdvance bytes are consumed
+        constexpr int kCheckEvery = (FMT == FMT_R64) ? 2 : 4;
 
         if constexpr (OUT == OUT_FAST8) {
             // ---- groups of 4 full rounds, symbols transposed in registers ----
             const uint32_t groups = rounds >> 2;
             uint8_t RANS_GLOBAL *gdst = dst;
+            const uint32_t k65536 = 0x10000u + (lane >> 6); // a VGPR holding 2^16 (lane < 64)
             for (uint32_t g = 0; g < groups; ++g) {
                 uint32_t acc[K];
 #define RANS_ROUND(J)                                                              \
     _Pragma("unroll") for (int k = 0; k < K; ++k)                                  \
         acc[k] = acc_symbol<Tr::kSymByte, J>(dec_step<FMT>(T, x[k]), acc[k]);      \
     _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
-        W.refill(lane);                                                            \
-        const uint32_t c = dec_renorm<FMT>(W, x[k], true);                         \
+        if ((J * K + k) % kCheckEvery == 0)                                        \
+            W.checkpoint(lane);                                                    \
+        uint32_t c;                                                                \
+        if constexpr (FMT == FMT_WORD)                                             \
+            c = 2u * renorm_word_full(x[k], W.cursor_addr(), k65536);              \
+        else                                                                       \
+            c = dec_renorm<FMT>(W, x[k], true);                                    \
         W.consume(c);                                                              \
         consumed += c;                                                             \
     }
@@ -426,7 +484,7 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const uint32_t idx = k * 64u + lane;
-                W.refill(lane);
+                W.checkpoint(lane);
                 const uint32_t c = dec_renorm<FMT>(W, x[k], idx < cnt);
                 W.consume(c);
                 consumed += c;

@@ -189,7 +189,7 @@ class Ref:
                                       C.POINTER(C.c_size_t)]
         lib.ref_decode_u8.argtypes = [C.c_int, u32p, C.c_uint32, u8p, C.c_size_t, C.c_size_t, C.c_uint32, u8p]
         lib.ref_decode_word_simd8.argtypes = [u32p, u8p, C.c_size_t, u8p]
-        lib.ref_time_word_simd8.argtypes = [u32p, u8p, u64p, C.c_uint32, C.c_size_t, u8p, C.c_uint32]
+        lib.ref_time_word_simd8.argtypes = [u32p, u8p, u64p, C.c_uint32, C.c_size_t, u8p, C.c_uint32, C.c_uint32]
         lib.ref_time_word_simd8.restype = C.c_double
         lib.ref_rdtsc.restype = C.c_uint64
         lib.ref12_build_model.argtypes = [u16p, C.c_size_t, C.c_uint32, u32p, u32p]

@@ -126,7 +126,11 @@ def test_alias_4096_symbols(gpu, oracle):
         d_syms = torch.from_numpy(data.view(np.int16)).cuda()
         g_cont, g_offs, g_lens, total = ctx.encode(gm, d_syms, n_ways, chunk)
         assert total == cont.size
-        assert np.array_equal(g_cont.cpu().numpy()[:total][: cont.size], cont)
+        g = g_cont.cpu().numpy()
+        assert np.array_equal(g_offs.cpu().numpy().astype(np.uint64), offs)
+        for c in range(len(lens)):  # bytes between chunks are alignment padding, not stream
+            a, b = int(offs[c]), int(offs[c]) + int(lens[c])
+            assert np.array_equal(g[a:b], cont[a:b]), "chunk %d differs" % c
         d_out = ctx.decode(gm, g_cont, total, g_offs, g_lens, data.size, n_ways, chunk)
         assert np.array_equal(d_out.cpu().numpy().view(np.uint16), data)
 
