@@ -34,6 +34,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ryg_rans_amd.h"
 #include "model.h"
@@ -47,7 +48,7 @@ constexpr int FMT_WORD = RANS_AMD_FMT_WORD;
 constexpr int FMT_R64 = RANS_AMD_FMT_R64;
 constexpr int FMT_ALIAS = RANS_AMD_FMT_ALIAS;
 
-enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1 };
+enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST8_NOASM = 2 }; // 2: compiler-scheduled renorm (A/B knob)
 
 template <int FMT> struct FmtTraits;
 template <> struct FmtTraits<FMT_WORD> {
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
     T.bucket_shift = p.scale_bits - p.log2nsyms;
 
     uint8_t *ring = smem + t0_bytes + t1_bytes + wave * kRingStride;
-    const uint32_t N = (OUT == OUT_FAST8) ? 64u * K : p.n_ways;
+    const uint32_t N = (OUT != OUT_SLOW) ? 64u * K : p.n_ways;
     const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
     const uint64_t glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
 
@@ -426,7 +427,7 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
         // sub-steps between two window checkpoints: at most kMaxAdvance bytes are consumed
         constexpr int kCheckEvery = (FMT == FMT_R64) ? 2 : 4;
 
-        if constexpr (OUT == OUT_FAST8) {
+        if constexpr (OUT != OUT_SLOW) {
             // ---- groups of 4 full rounds, symbols transposed in registers ----
             const uint32_t groups = rounds >> 2;
             uint8_t RANS_GLOBAL *gdst = dst;
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
         if ((J * K + k) % kCheckEvery == 0)                                        \
             W.checkpoint(lane);                                                    \
         uint32_t c;                                                                \
-        if constexpr (FMT == FMT_WORD)                                             \
+        if constexpr (FMT == FMT_WORD && OUT == OUT_FAST8)                         \
             c = 2u * renorm_word_full(x[k], W.cursor_addr(), k65536);              \
         else                                                                       \
             c = dec_renorm<FMT>(W, x[k], true);                                    \
@@ -862,6 +863,15 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
 {
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)p.chunk_syms) & 3u) == 0;
     const bool fast = aligned && p.sym_bytes == 1;
+    static const bool no_asm = getenv("RANS_AMD_NO_ASM") != nullptr; // A/B knob for the word renorm
+    if (FMT == FMT_WORD && fast && no_asm) {
+        switch (p.n_ways) {
+        case 64: return launch_decode_t<FMT_WORD, 1, OUT_FAST8_NOASM>(p, num_cus, s, name);
+        case 128: return launch_decode_t<FMT_WORD, 2, OUT_FAST8_NOASM>(p, num_cus, s, name);
+        case 256: return launch_decode_t<FMT_WORD, 4, OUT_FAST8_NOASM>(p, num_cus, s, name);
+        default: break;
+        }
+    }
     switch (p.n_ways) {
     case 64:
         return fast ? launch_decode_t<FMT, 1, OUT_FAST8>(p, num_cus, s, name)

@@ -1,0 +1,87 @@
+"""include/ryg_rans_amd/compat/: the per-symbol RansEnc*/RansDec*/Rans64*/RansWord* API,
+re-provided for host code.  Checked (CPU only) against the oracle byte for byte, and --
+where /root/reference exists -- by building the reference's own mains UNCHANGED against
+these headers and comparing their output with the README's known answers."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from _oracle import FMT_BYTE, FMT_R64, FMT_WORD
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+COMPAT = os.path.join(ROOT, "include", "ryg_rans_amd", "compat")
+BUILD = os.path.join(ROOT, "build", "compat")
+
+
+@pytest.fixture(scope="module")
+def drv():
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "libcompat_driver.so")
+    subprocess.run(["g++", "-O2", "-msse4.1", "-shared", "-fPIC", "-I", COMPAT, "-o", so,
+                    os.path.join(HERE, "compat_driver.cpp")], check=True)
+    lib = C.CDLL(so)
+    u8p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+    lib.compat_encode.argtypes = [C.c_int, u32p, u32p, C.c_uint32, u8p, C.c_size_t, C.c_uint32, u8p, C.c_size_t,
+                                  C.POINTER(C.c_size_t)]
+    lib.compat_decode.argtypes = [C.c_int, u32p, u32p, C.c_uint32, u8p, C.c_size_t, C.c_size_t, C.c_uint32, u8p]
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def test_struct_layouts(drv):
+    assert [drv.compat_sizeof(i) for i in range(7)] == [16, 4, 24, 8, 4, 20480, 16]
+
+
+@pytest.mark.parametrize("fmt,cfmt,sb", [(FMT_BYTE, 0, 14), (FMT_BYTE, 4, 16), (FMT_BYTE, 0, 9), (FMT_WORD, 1, 12),
+                                         (FMT_R64, 2, 14), (FMT_R64, 2, 20)])
+def test_streams_equal_oracle(drv, oracle, fmt, cfmt, sb):
+    rng = np.random.default_rng(3)
+    inputs = [oracle.gen_zipf(50003, K=256, s=1.0, seed=4),
+              np.concatenate([np.zeros(9000, np.uint8), np.arange(256, dtype=np.uint8)]),
+              rng.integers(0, 256, 777, dtype=np.uint8)]
+    for data in inputs:
+        f, cum = oracle.normalize(oracle.count_freqs(data, 256), 1 << sb)
+        model = oracle.model(f, sb)
+        for N in (1, 2, 8, 64, 5):
+            want = oracle.encode(fmt, model, data, N)
+            cap = (data.size * 4 + N * 8 + 64) & ~7
+            buf = np.zeros(cap + 16, np.uint8)
+            out_len = C.c_size_t(0)
+            assert drv.compat_encode(cfmt, _p(f, C.c_uint32), _p(cum, C.c_uint32), sb, _p(data, C.c_uint8), data.size,
+                                     N, _p(buf, C.c_uint8), cap, C.byref(out_len)) == 0
+            got = buf[cap - out_len.value:cap]
+            assert np.array_equal(got, want), (N,)
+            if cfmt == 4:
+                continue
+            padded = np.concatenate([want, np.zeros(16, np.uint8)])
+            out = np.zeros(data.size, np.uint8)
+            assert drv.compat_decode(cfmt, _p(f, C.c_uint32), _p(cum, C.c_uint32), sb, _p(padded, C.c_uint8),
+                                     want.size, data.size, N, _p(out, C.c_uint8)) == 0
+            assert np.array_equal(out, data), (N,)
+
+
+def test_reference_mains_build_unchanged_against_compat_headers(book1):
+    """The drop-in claim for the per-symbol API: the reference's four sample programs, fed to
+    the compiler from stdin (so their own directory is not on the include path), compile
+    against OUR headers and reproduce the published sizes (README:48,62,82,96,110)."""
+    want = {"main": ["rANS: 435113 bytes", "interleaved rANS: 435117 bytes"],
+            "main64": ["rANS: 435116 bytes", "interleaved rANS: 435120 bytes"],
+            "main_simd": ["rANS: 435604 bytes", "interleaved rANS: 435606 bytes", "SIMD rANS: 435626 bytes"],
+            "main_alias": ["rANS: 435059 bytes", "interleaved rANS: 435063 bytes"]}
+    os.makedirs(BUILD, exist_ok=True)
+    for name, lines in want.items():
+        exe = os.path.join(BUILD, name)
+        with open("/root/reference/%s.cpp" % name, "rb") as src:
+            subprocess.run(["g++", "-x", "c++", "-O2", "-msse4.1", "-w", "-I", COMPAT, "-o", exe, "-"], stdin=src,
+                           check=True)
+        out = subprocess.run([exe], cwd="/root/reference", capture_output=True, text=True, check=True).stdout
+        for line in lines:
+            assert line in out, (name, line)
+        assert out.count("decode ok!") == len(lines) and "ERROR" not in out
