@@ -48,7 +48,13 @@ constexpr int FMT_WORD = RANS_AMD_FMT_WORD;
 constexpr int FMT_R64 = RANS_AMD_FMT_R64;
 constexpr int FMT_ALIAS = RANS_AMD_FMT_ALIAS;
 
-enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST8_NOASM = 2 }; // 2: compiler-scheduled renorm (A/B knob)
+// OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
+// symbols transposed in registers.  OUT_FAST8_NOASM: same with the compiler-scheduled renorm
+// (A/B knob).  OUT_FAST8_LDS: symbols staged through a 256-byte LDS tile per wave
+// (ds_write_b8 per round, one ds_read_b32 + global_store_dword per 4 rounds; K == 1 only).
+// OUT_FAST16: u16 symbols, 2 rounds packed per dword and swapped between lane pairs.
+enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST8_NOASM = 2, OUT_FAST8_LDS = 3, OUT_FAST16 = 4 };
+constexpr uint32_t kOutTileBytes = 256;
 
 template <int FMT> struct FmtTraits;
 template <> struct FmtTraits<FMT_WORD> {
@@ -369,6 +375,8 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
     T.bucket_shift = p.scale_bits - p.log2nsyms;
 
     uint8_t *ring = smem + t0_bytes + t1_bytes + wave * kRingStride;
+    uint8_t *tile = smem + t0_bytes + t1_bytes + waves_per_block * kRingStride + wave * kOutTileBytes; // OUT_FAST8_LDS
+    static_assert(OUT != OUT_FAST8_LDS || K == 1, "the LDS output tile holds 4 rounds of 64 symbols");
     const uint32_t N = (OUT != OUT_SLOW) ? 64u * K : p.n_ways;
     const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
     const uint64_t glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
@@ -427,6 +435,41 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
         // sub-steps between two window checkpoints: at most kMaxAdvance bytes are consumed
         constexpr int kCheckEvery = (FMT == FMT_R64) ? 2 : 4;
 
+        if constexpr (OUT == OUT_FAST16) {
+            // ---- pairs of full rounds, u16 symbols: lane 2i ends up with round r's symbols of
+            // lanes 2i,2i+1 and lane 2i+1 with round r+1's: one dword store per lane and pair
+            const uint32_t pairs = rounds >> 1;
+            uint8_t RANS_GLOBAL *gdst = dst;
+            const uint32_t sel16 = (lane & 1u) ? 0x03020706u : 0x05040100u;
+            const uint32_t lane_off16 = ((lane & 1u) * N + (lane & ~1u)) * 2u;
+            for (uint32_t g = 0; g < pairs; ++g) {
+                uint32_t acc[K];
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint32_t s16 = dec_step<FMT>(T, x[k]) & 0xffffu;
+                        acc[k] = J == 0 ? s16 : (acc[k] | (s16 << 16));
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if ((J * K + k) % kCheckEvery == 0)
+                            W.checkpoint(lane);
+                        const uint32_t c = dec_renorm<FMT>(W, x[k], true);
+                        W.consume(c);
+                        consumed += c;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t o = quad_perm<1, 0, 3, 2>(acc[k]);
+                    const uint32_t v = __builtin_amdgcn_perm(o, acc[k], sel16);
+                    *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + (lane_off16 + k * 128u)) = v;
+                }
+                gdst += 4u * N;
+            }
+            r = pairs << 1;
+        } else
         if constexpr (OUT != OUT_SLOW) {
             // ---- groups of 4 full rounds, symbols transposed in registers ----
             const uint32_t groups = rounds >> 2;
@@ -435,13 +478,18 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
             for (uint32_t g = 0; g < groups; ++g) {
                 uint32_t acc[K];
 #define RANS_ROUND(J)                                                              \
-    _Pragma("unroll") for (int k = 0; k < K; ++k)                                  \
-        acc[k] = acc_symbol<Tr::kSymByte, J>(dec_step<FMT>(T, x[k]), acc[k]);      \
+    _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
+        const uint32_t raw = dec_step<FMT>(T, x[k]);                               \
+        if constexpr (OUT == OUT_FAST8_LDS)                                        \
+            tile[J * 64 + lane] = (uint8_t)(raw >> (8 * Tr::kSymByte));            \
+        else                                                                       \
+            acc[k] = acc_symbol<Tr::kSymByte, J>(raw, acc[k]);                     \
+    }                                                                              \
     _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
         if ((J * K + k) % kCheckEvery == 0)                                        \
             W.checkpoint(lane);                                                    \
         uint32_t c;                                                                \
-        if constexpr (FMT == FMT_WORD && OUT == OUT_FAST8)                         \
+        if constexpr (FMT == FMT_WORD && (OUT == OUT_FAST8 || OUT == OUT_FAST8_LDS)) \
             c = 2u * renorm_word_full(x[k], W.cursor_addr(), k65536);              \
         else                                                                       \
             c = dec_renorm<FMT>(W, x[k], true);                                    \
@@ -453,10 +501,16 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
                 RANS_ROUND(2)
                 RANS_ROUND(3)
 #undef RANS_ROUND
+                if constexpr (OUT == OUT_FAST8_LDS) {
+                    // LDS ops of one wave execute in order: the read sees the four writes
+                    const uint32_t v = reinterpret_cast<const uint32_t *>(tile)[lane];
+                    *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + lane * 4u) = v;
+                } else {
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const uint32_t v = quad_transpose(acc[k], sel1, sel2);
-                    *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + (out_lane_off + k * 64u)) = v;
+                    for (int k = 0; k < K; ++k) {
+                        const uint32_t v = quad_transpose(acc[k], sel1, sel2);
+                        *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + (out_lane_off + k * 64u)) = v;
+                    }
                 }
                 gdst += 4u * N;
             }
@@ -836,7 +890,7 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
 {
     const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
     const uint32_t waves = kDecBlockThreads / 64;
-    const size_t lds = (size_t)t0 + t1 + (size_t)waves * kRingStride;
+    const size_t lds = (size_t)t0 + t1 + (size_t)waves * kRingStride + (OUT == OUT_FAST8_LDS ? waves * kOutTileBytes : 0);
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
     auto kern = k_decode<FMT, K, OUT>;
@@ -863,7 +917,18 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
 {
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)p.chunk_syms) & 3u) == 0;
     const bool fast = aligned && p.sym_bytes == 1;
+    if (aligned && p.sym_bytes == 2) {
+        switch (p.n_ways) {
+        case 64: return launch_decode_t<FMT, 1, OUT_FAST16>(p, num_cus, s, name);
+        case 128: return launch_decode_t<FMT, 2, OUT_FAST16>(p, num_cus, s, name);
+        case 256: return launch_decode_t<FMT, 4, OUT_FAST16>(p, num_cus, s, name);
+        default: break;
+        }
+    }
     static const bool no_asm = getenv("RANS_AMD_NO_ASM") != nullptr; // A/B knob for the word renorm
+    static const bool lds_out = getenv("RANS_AMD_LDS_OUT") != nullptr; // A/B knob: LDS-staged output
+    if (fast && lds_out && p.n_ways == 64)
+        return launch_decode_t<FMT, 1, OUT_FAST8_LDS>(p, num_cus, s, name);
     if (FMT == FMT_WORD && fast && no_asm) {
         switch (p.n_ways) {
         case 64: return launch_decode_t<FMT_WORD, 1, OUT_FAST8_NOASM>(p, num_cus, s, name);
