@@ -296,6 +296,11 @@ int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_fr
         *out_model = m;
         return RANS_AMD_OK;
     }
+    if ((format == RANS_AMD_FMT_BYTE || format == RANS_AMD_FMT_ALIAS) && scale_bits < 8) {
+        // the byte-format kernels multiply freq * (x >> scale_bits) in 24 bits (x < 2^31)
+        delete m;
+        return fail(RANS_AMD_E_UNSUPPORTED, "model_create: the GPU byte/alias coders need scale_bits >= 8");
+    }
     DeviceGuard guard(ctx->device);
     const HostModel &h = m->host;
     switch (format) {

@@ -220,7 +220,8 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         const uint32_t cf = x & T.mask;
         const uint32_t s = T.t0[cf];
         const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s]; // {freq, start}
-        x = r.x * (x >> T.scale_bits) + cf - r.y;
+        // freq <= 2^16 and x >> scale_bits < 2^23 (scale_bits >= 8): 24-bit multiply is exact
+        x = (r.x & 0xffffffu) * ((x >> T.scale_bits) & 0xffffffu) + cf - r.y;
         return s;
     } else if constexpr (FMT == FMT_R64) {
         // rans64.h:118-121 (get), :286-292 (step)
@@ -236,7 +237,7 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         const uint32_t div = reinterpret_cast<const uint32_t *>(T.t1)[bucket];
         const uint32_t half = 2u * bucket + (xm < div ? 1u : 0u);
         const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[half]; // {freq | sym << 16, adjust}
-        x = (e.x & 0xffffu) * (x >> T.scale_bits) + xm - e.y;
+        x = (e.x & 0xffffu) * ((x >> T.scale_bits) & 0xffffffu) + xm - e.y;
         return e.x >> 16;
     }
 }
@@ -312,6 +313,43 @@ __device__ __forceinline__ uint32_t renorm_word_full(uint32_t &x, uint32_t curso
                  : [lim] "v"(k65536), [cur] "s"(cursor_addr), [sel] "s"(0x05040100u)
                  : "vcc", "scc", "memory");
     return cnt;
+}
+
+// Same for the byte formats (rans_byte.h:307-318): a lane needs 0, 1 or 2 bytes
+// (x < 2^23, x < 2^15); its offset in the stream is the sum of both masks' ranks; the
+// first byte is the more significant one.  9 VALU + 2 LDS, no branch.  Returns bytes consumed.
+__device__ __forceinline__ uint32_t renorm_byte_full(uint32_t &x, uint32_t cursor_addr, uint32_t k2p23, uint32_t k2p15)
+{
+    uint32_t t, b0, b1, c1, c2;
+    uint64_t m1;
+    asm volatile("v_cmp_gt_u32_e32 vcc, %[l23], %[x]\n\t"
+                 "s_nop 1\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "s_mov_b64 %[m1], vcc\n\t"
+                 "s_bcnt1_i32_b64 %[c1], vcc\n\t"
+                 "v_cmp_gt_u32_e32 vcc, %[l15], %[x]\n\t"
+                 "v_add_u32_e32 %[t], %[cur], %[t]\n\t"
+                 "s_nop 0\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, %[t]\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "s_bcnt1_i32_b64 %[c2], vcc\n\t"
+                 "s_mov_b64 exec, %[m1]\n\t"
+                 "ds_read_u8 %[b0], %[t]\n\t"
+                 "s_mov_b64 exec, vcc\n\t"
+                 "ds_read_u8 %[b1], %[t] offset:1\n\t"
+                 "s_mov_b64 exec, %[m1]\n\t"
+                 "s_waitcnt lgkmcnt(1)\n\t"
+                 "v_lshl_or_b32 %[x], %[x], 8, %[b0]\n\t"
+                 "s_mov_b64 exec, vcc\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_lshl_or_b32 %[x], %[x], 8, %[b1]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [x] "+v"(x), [t] "=&v"(t), [b0] "=&v"(b0), [b1] "=&v"(b1), [c1] "=&s"(c1), [c2] "=&s"(c2),
+                   [m1] "=&s"(m1)
+                 : [l23] "v"(k2p23), [l15] "v"(k2p15), [cur] "s"(cursor_addr)
+                 : "vcc", "scc", "memory");
+    return c1 + c2;
 }
 
 // byte `kSymByte` of `raw` goes to byte J of acc, the other bytes of acc stay
@@ -442,6 +480,7 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
             uint8_t RANS_GLOBAL *gdst = dst;
             const uint32_t sel16 = (lane & 1u) ? 0x03020706u : 0x05040100u;
             const uint32_t lane_off16 = ((lane & 1u) * N + (lane & ~1u)) * 2u;
+            const uint32_t k2p23 = (1u << 23) + (lane >> 6), k2p15 = (1u << 15) + (lane >> 6);
             for (uint32_t g = 0; g < pairs; ++g) {
                 uint32_t acc[K];
 #pragma unroll
@@ -455,7 +494,11 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
                     for (int k = 0; k < K; ++k) {
                         if ((J * K + k) % kCheckEvery == 0)
                             W.checkpoint(lane);
-                        const uint32_t c = dec_renorm<FMT>(W, x[k], true);
+                        uint32_t c;
+                        if constexpr (FMT == FMT_BYTE || FMT == FMT_ALIAS)
+                            c = renorm_byte_full(x[k], W.cursor_addr(), k2p23, k2p15);
+                        else
+                            c = dec_renorm<FMT>(W, x[k], true);
                         W.consume(c);
                         consumed += c;
                     }
@@ -474,7 +517,8 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
             // ---- groups of 4 full rounds, symbols transposed in registers ----
             const uint32_t groups = rounds >> 2;
             uint8_t RANS_GLOBAL *gdst = dst;
-            const uint32_t k65536 = 0x10000u + (lane >> 6); // a VGPR holding 2^16 (lane < 64)
+            const uint32_t k65536 = 0x10000u + (lane >> 6); // VGPRs holding the renorm limits (lane < 64)
+            const uint32_t k2p23 = (1u << 23) + (lane >> 6), k2p15 = (1u << 15) + (lane >> 6);
             for (uint32_t g = 0; g < groups; ++g) {
                 uint32_t acc[K];
 #define RANS_ROUND(J)                                                              \
@@ -491,6 +535,8 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
         uint32_t c;                                                                \
         if constexpr (FMT == FMT_WORD && (OUT == OUT_FAST8 || OUT == OUT_FAST8_LDS)) \
             c = 2u * renorm_word_full(x[k], W.cursor_addr(), k65536);              \
+        else if constexpr ((FMT == FMT_BYTE || FMT == FMT_ALIAS) && OUT == OUT_FAST8) \
+            c = renorm_byte_full(x[k], W.cursor_addr(), k2p23, k2p15);             \
         else                                                                       \
             c = dec_renorm<FMT>(W, x[k], true);                                    \
         W.consume(c);                                                              \
@@ -748,6 +794,283 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
         atomicOr(p.flags, 1u);
 }
 
+// ===========================================================================
+// Lane-per-stream kernels for narrow interleaves (N = 1, 2, 4, 8; BASELINE config 2 is
+// the reference's 2-way rans64 loop, main64.cpp:224-287).  An N-way stream with N << 64
+// cannot feed a wavefront, so here every LANE owns a whole chunk: its N states live in
+// registers, it walks its own stream with its own pointer (the renormalisation order
+// inside a chunk is the sequential reference order, no cross-lane work at all), and a
+// wave decodes 64 chunks at once.  Tables are shared through LDS as before.
+// ===========================================================================
+
+template <int FMT>
+__device__ __forceinline__ void lane_renorm(typename FmtTraits<FMT>::state_t &x, const uint8_t RANS_GLOBAL *&rp,
+                                            const uint8_t RANS_GLOBAL *end, bool active, bool &bad)
+{
+    if constexpr (FMT == FMT_WORD) {
+        if (active && x < (1u << 16)) { // rans_word_sse41.h:134-141
+            uint32_t w = 0;
+            if (rp + 2 <= end)
+                w = *reinterpret_cast<const uint16_t RANS_GLOBAL *>(rp);
+            else
+                bad = true;
+            rp += 2;
+            x = (x << 16) | w;
+        }
+    } else if constexpr (FMT == FMT_R64) {
+        if (active && x < (1ull << 31)) { // rans64.h:305-316
+            uint32_t w = 0;
+            if (rp + 4 <= end)
+                w = *reinterpret_cast<const uint32_t RANS_GLOBAL *>(rp);
+            else
+                bad = true;
+            rp += 4;
+            x = (x << 32) | w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) // rans_byte.h:307-318, at most two bytes for scale_bits <= 16
+            if (active && x < (1u << 23)) {
+                uint32_t b = 0;
+                if (rp < end)
+                    b = *rp;
+                else
+                    bad = true;
+                rp += 1;
+                x = (x << 8) | b;
+            }
+    }
+}
+
+template <int FMT, int NW>
+__global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1_bytes = (p.table1_bytes + 15u) & ~15u;
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+        const uint4 *g1 = reinterpret_cast<const uint4 *>(p.table1);
+        uint4 *l1 = reinterpret_cast<uint4 *>(smem + t0_bytes);
+        for (uint32_t i = threadIdx.x; i < t1_bytes / 16u; i += blockDim.x)
+            l1[i] = g1[i];
+    }
+    __syncthreads();
+
+    DecTables<FMT> T;
+    T.t0 = smem;
+    T.t1 = smem + t0_bytes;
+    T.scale_bits = p.scale_bits;
+    T.mask = (1u << p.scale_bits) - 1u;
+    T.bucket_shift = p.scale_bits - p.log2nsyms;
+
+    const uint8_t RANS_GLOBAL *cbase = (const uint8_t RANS_GLOBAL *)p.container;
+    const bool dword_out = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 3u) == 0;
+    uint32_t nbad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; chunk < p.nchunks; chunk += stride) {
+        const uint64_t off = p.offsets[chunk];
+        const uint32_t len = p.lengths[chunk];
+        const uint64_t first = chunk * p.chunk_syms;
+        const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        if ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off + len > p.container_bytes) {
+            nbad++;
+            continue;
+        }
+        const uint8_t RANS_GLOBAL *src = cbase + off;
+        const uint8_t RANS_GLOBAL *end = src + len;
+        uint8_t RANS_GLOBAL *dst = (uint8_t RANS_GLOBAL *)p.out + first * p.sym_bytes;
+
+        state_t x[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l) { // RansDecInit order: lane 0's state first
+            if constexpr (FMT == FMT_R64) {
+                const u32x2 v = reinterpret_cast<const u32x2 RANS_GLOBAL *>(src)[l];
+                x[l] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            } else {
+                x[l] = reinterpret_cast<const uint32_t RANS_GLOBAL *>(src)[l];
+            }
+        }
+        const uint8_t RANS_GLOBAL *rp = src + NW * Tr::kStateBytes;
+        bool bad = false;
+
+        const uint32_t rounds = nsym / NW;
+        const uint32_t tail = nsym - rounds * NW;
+        uint32_t i = 0; // symbol index inside the chunk
+        if (dword_out) {
+            // 4 symbols per dword store: 4/NW rounds (NW <= 4) or NW/4 stores per round (NW == 8)
+            constexpr int kRoundsPerGroup = NW >= 4 ? 1 : 4 / NW;
+            constexpr int kDwords = NW >= 4 ? NW / 4 : 1;
+            const uint32_t groups = rounds / kRoundsPerGroup;
+            for (uint32_t g = 0; g < groups; ++g) {
+                uint32_t pack[kDwords];
+#pragma unroll
+                for (int d = 0; d < kDwords; ++d)
+                    pack[d] = 0;
+#pragma unroll
+                for (int rr = 0; rr < kRoundsPerGroup; ++rr) {
+#pragma unroll
+                    for (int l = 0; l < NW; ++l) {
+                        uint32_t sy = dec_step<FMT>(T, x[l]);
+                        if constexpr (Tr::kSymByte == 3)
+                            sy >>= 24;
+                        const int pos = rr * NW + l;
+                        pack[pos / 4] |= (sy & 0xffu) << (8 * (pos % 4));
+                    }
+#pragma unroll
+                    for (int l = 0; l < NW; ++l)
+                        lane_renorm<FMT>(x[l], rp, end, true, bad);
+                }
+#pragma unroll
+                for (int d = 0; d < kDwords; ++d)
+                    reinterpret_cast<uint32_t RANS_GLOBAL *>(dst + i)[d] = pack[d];
+                i += 4 * kDwords;
+            }
+        }
+        // remaining rounds + tail: element stores
+        while (i < nsym) {
+            const uint32_t cnt = nsym - i < (uint32_t)NW ? nsym - i : (uint32_t)NW;
+#pragma unroll
+            for (int l = 0; l < NW; ++l)
+                if ((uint32_t)l < cnt) {
+                    uint32_t sy = dec_step<FMT>(T, x[l]);
+                    if constexpr (Tr::kSymByte == 3)
+                        sy >>= 24;
+                    if (p.sym_bytes == 1)
+                        dst[i + l] = (uint8_t)sy;
+                    else
+                        reinterpret_cast<uint16_t RANS_GLOBAL *>(dst)[i + l] = (uint16_t)sy;
+                }
+#pragma unroll
+            for (int l = 0; l < NW; ++l)
+                lane_renorm<FMT>(x[l], rp, end, (uint32_t)l < cnt, bad);
+            i += cnt;
+        }
+        (void)tail;
+#pragma unroll
+        for (int l = 0; l < NW; ++l)
+            bad = bad || (x[l] != Tr::kL);
+        if (bad || rp != end)
+            nbad++;
+    }
+    if (nbad)
+        atomicAdd(p.err_count, (unsigned long long)nbad);
+}
+
+template <int FMT, int NW>
+__global__ void __launch_bounds__(256) k_encode_lanes(const EncParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
+        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
+            l[i] = g[i];
+    }
+    __syncthreads();
+    const uint4 *recs = reinterpret_cast<const uint4 *>(smem);
+
+    bool bad = false;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; chunk < p.nchunks; chunk += stride) {
+        const uint64_t first = chunk * p.chunk_syms;
+        const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + first * p.sym_bytes;
+        uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + chunk * p.slot_bytes;
+        uint8_t RANS_GLOBAL *wp = slot + p.slot_bytes;
+
+        state_t x[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l)
+            x[l] = Tr::kL;
+
+        // symbol i belongs to state i mod NW; visit i = nsym-1 .. 0 (main.cpp:233-243)
+        uint32_t i = nsym;
+        while (i > 0) {
+            const uint32_t base = (i - 1) / NW * NW; // first symbol of this round
+            const uint32_t cnt = i - base;
+#pragma unroll
+            for (int l = NW - 1; l >= 0; --l) {
+                if ((uint32_t)l >= cnt)
+                    continue;
+                const uint32_t sym = p.sym_bytes == 1
+                                         ? (uint32_t)src[base + l]
+                                         : (uint32_t) reinterpret_cast<const uint16_t RANS_GLOBAL *>(src)[base + l];
+                const bool known = sym < p.nsyms;
+                const uint4 rec = recs[known ? sym : 0u];
+                const uint32_t freq = rec.x, start = rec.y, rcp = rec.z;
+                if (!known || freq == 0) {
+                    bad = true;
+                    continue;
+                }
+                if constexpr (FMT == FMT_WORD) {
+                    uint32_t y = x[l];
+                    if (y >= (freq << 20)) {
+                        wp -= 2;
+                        *reinterpret_cast<uint16_t RANS_GLOBAL *>(wp) = (uint16_t)y;
+                        y >>= 16;
+                    }
+                    uint32_t q, rem;
+                    divmod_rcp(y, freq, rcp, q, rem);
+                    x[l] = (q << 12) + rem + start;
+                } else if constexpr (FMT == FMT_R64) {
+                    uint64_t y = x[l];
+                    if (y >= (((uint64_t)freq) << (63u - p.scale_bits))) {
+                        wp -= 4;
+                        *reinterpret_cast<uint32_t RANS_GLOBAL *>(wp) = (uint32_t)y;
+                        y >>= 32;
+                    }
+                    const uint64_t q = y / freq;
+                    x[l] = (q << p.scale_bits) + (y - q * freq) + start;
+                } else {
+                    uint32_t y = x[l];
+                    const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        if (y >= x_max) {
+                            *--wp = (uint8_t)y;
+                            y >>= 8;
+                        }
+                    uint32_t q, rem;
+                    divmod_rcp(y, freq, rcp, q, rem);
+                    if constexpr (FMT == FMT_ALIAS)
+                        x[l] = (q << p.scale_bits) + p.alias_remap[rem + start];
+                    else
+                        x[l] = (q << p.scale_bits) + rem + start;
+                }
+            }
+            i = base;
+        }
+        // flush states NW-1 .. 0 (lane 0's first in memory)
+#pragma unroll
+        for (int l = NW - 1; l >= 0; --l) {
+            wp -= Tr::kStateBytes;
+            if constexpr (FMT == FMT_R64) {
+                reinterpret_cast<uint32_t RANS_GLOBAL *>(wp)[0] = (uint32_t)x[l];
+                reinterpret_cast<uint32_t RANS_GLOBAL *>(wp)[1] = (uint32_t)(x[l] >> 32);
+            } else if constexpr (FMT == FMT_WORD) {
+                reinterpret_cast<uint16_t RANS_GLOBAL *>(wp)[0] = (uint16_t)x[l];
+                reinterpret_cast<uint16_t RANS_GLOBAL *>(wp)[1] = (uint16_t)(x[l] >> 16);
+            } else {
+                wp[0] = (uint8_t)x[l];
+                wp[1] = (uint8_t)(x[l] >> 8);
+                wp[2] = (uint8_t)(x[l] >> 16);
+                wp[3] = (uint8_t)(x[l] >> 24);
+            }
+        }
+        p.lengths[chunk] = (uint32_t)((slot + p.slot_bytes) - wp);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane_id() == 0)
+        atomicOr(p.flags, 1u);
+}
+
 // ---------------------------------------------------------------------------
 // Layout: offsets[c] = sum_{i<c} align16(lengths[i]); offsets[nchunks] = end of
 // the last stream.  One block; nchunks is small (n / chunk_syms).
@@ -913,8 +1236,43 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     return hipGetLastError();
 }
 
+template <int FMT, int NW>
+hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
+{
+    const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
+    const size_t lds = (size_t)t0 + t1;
+    auto kern = k_decode_lanes<FMT, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_set = true;
+    }
+    const uint64_t want = (p.nchunks + 255) / 256;
+    const uint64_t cap = (uint64_t)num_cus * (lds * 4 <= 160 * 1024 ? 4 : (lds * 2 <= 160 * 1024 ? 2 : 1));
+    const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    if (name)
+        *name = "k_decode_lanes";
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+// narrow interleaves with enough chunks to fill wavefronts: one chunk per lane
+constexpr uint64_t kLaneKernelMinChunks = 64;
+
 template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, hipStream_t s, const char **name)
 {
+    if (p.nchunks >= kLaneKernelMinChunks) {
+        switch (p.n_ways) {
+        case 1: return launch_decode_lanes_t<FMT, 1>(p, num_cus, s, name);
+        case 2: return launch_decode_lanes_t<FMT, 2>(p, num_cus, s, name);
+        case 4: return launch_decode_lanes_t<FMT, 4>(p, num_cus, s, name);
+        case 8: return launch_decode_lanes_t<FMT, 8>(p, num_cus, s, name);
+        default: break;
+        }
+    }
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)p.chunk_syms) & 3u) == 0;
     const bool fast = aligned && p.sym_bytes == 1;
     if (aligned && p.sym_bytes == 2) {
@@ -979,8 +1337,38 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     return hipGetLastError();
 }
 
+template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, int num_cus, hipStream_t stream)
+{
+    const size_t lds = (size_t)p.nsyms * sizeof(EncRec);
+    if (lds > 128 * 1024)
+        return hipErrorInvalidValue;
+    auto kern = k_encode_lanes<FMT, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_set = true;
+    }
+    const uint64_t want = (p.nchunks + 255) / 256;
+    const uint64_t cap = (uint64_t)num_cus * 8;
+    const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
 template <int FMT> hipError_t launch_encode_f(const EncParams &p, int num_cus, hipStream_t s)
 {
+    if (p.nchunks >= kLaneKernelMinChunks) {
+        switch (p.n_ways) {
+        case 1: return launch_encode_lanes_t<FMT, 1>(p, num_cus, s);
+        case 2: return launch_encode_lanes_t<FMT, 2>(p, num_cus, s);
+        case 4: return launch_encode_lanes_t<FMT, 4>(p, num_cus, s);
+        case 8: return launch_encode_lanes_t<FMT, 8>(p, num_cus, s);
+        default: break;
+        }
+    }
     switch (p.n_ways) {
     case 128: return launch_encode_t<FMT, 2>(p, num_cus, s);
     case 256: return launch_encode_t<FMT, 4>(p, num_cus, s);

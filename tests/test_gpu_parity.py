@@ -72,7 +72,8 @@ def test_single_stream_matches_oracle(gpu, oracle, fmt, sb, n_ways):
 
 
 @pytest.mark.parametrize("fmt,sb", FORMATS)
-@pytest.mark.parametrize("n_ways,chunk_syms", [(64, 4096), (64, 5000), (256, 16384), (32, 1000), (128, 4096)])
+@pytest.mark.parametrize("n_ways,chunk_syms", [(64, 4096), (64, 5000), (256, 16384), (32, 1000), (128, 4096),
+                                               (2, 512), (1, 1000), (4, 2048), (8, 4096), (2, 4095)])
 def test_chunked_matches_oracle(gpu, oracle, fmt, sb, n_ways, chunk_syms):
     R, ctx, torch = gpu
     data = _inputs(oracle)["zipf"]

@@ -71,7 +71,11 @@ def main():
     run(ctx, "C1-on-GPU byte sb14 64-way", R.FMT_BYTE, 14, 256, 1 << big, 64, 32768)
     run(ctx, "byte sb16 64-way", R.FMT_BYTE, 16, 256, 1 << big, 64, 32768)
     run(ctx, "r64 sb14 64-way", R.FMT_R64, 14, 256, 1 << big, 64, 32768)
-    run(ctx, "C2 r64 sb14 2-way 256 MiB", R.FMT_R64, 14, 256, 1 << 28, 2, 4096, reps=2)
+    run(ctx, "C2 r64 sb14 2-way 256 MiB", R.FMT_R64, 14, 256, 1 << 28, 2, 4096, reps=3)
+    run(ctx, "C2 r64 2-way, 512-symbol chunks", R.FMT_R64, 14, 256, 1 << 28, 2, 512, reps=3)
+    run(ctx, "C2 r64 2-way, 1024-symbol chunks", R.FMT_R64, 14, 256, 1 << 28, 2, 1024, reps=3)
+    run(ctx, "word 2-way, 1024-symbol chunks", R.FMT_WORD, 12, 256, 1 << 28, 2, 1024, reps=3)
+    run(ctx, "byte 2-way, 1024-symbol chunks", R.FMT_BYTE, 14, 256, 1 << 28, 2, 1024, reps=3)
     run(ctx, "alias 256 sym sb16 64-way", R.FMT_ALIAS, 16, 256, 1 << big, 64, 32768)
     run(ctx, "C4 alias 4096 sym sb16 64-way (u16)", R.FMT_ALIAS, 16, 4096, 1 << (big - 1), 64, 32768)
 
