@@ -633,7 +633,8 @@ __device__ __forceinline__ void divmod_rcp(uint32_t x, uint32_t freq, uint32_t r
 // slot, moves down, wave-uniform).
 template <int FMT>
 __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename FmtTraits<FMT>::state_t &x,
-                                            uint32_t sym, bool active, uint8_t *slot, uint32_t &wp, bool &bad)
+                                            uint32_t sym, bool active, uint8_t RANS_GLOBAL *slot, uint32_t &wp,
+                                            bool &bad)
 {
     const bool in_alphabet = sym < T.nsyms;
     const uint4 rec = T.recs[in_alphabet ? sym : 0u];
@@ -650,7 +651,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
         wp -= 2u * cnt;
         if (emit)
-            *reinterpret_cast<uint16_t *>(slot + wp + 2u * rank_below(m)) = (uint16_t)(x & 0xffffu);
+            *reinterpret_cast<uint16_t RANS_GLOBAL *>(slot + wp + 2u * rank_below(m)) = (uint16_t)(x & 0xffffu);
         uint32_t y = emit ? (x >> 16) : x;
         uint32_t q, rem;
         divmod_rcp(y, freq, rcp, q, rem);
@@ -664,7 +665,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
         wp -= 4u * cnt;
         if (emit)
-            *reinterpret_cast<uint32_t *>(slot + wp + 4u * rank_below(m)) = (uint32_t)x;
+            *reinterpret_cast<uint32_t RANS_GLOBAL *>(slot + wp + 4u * rank_below(m)) = (uint32_t)x;
         uint64_t y = emit ? (x >> 32) : x;
         const uint32_t f = freq ? freq : 1u;
         const uint64_t q = y / f;
@@ -729,11 +730,18 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
 
     bool bad = false;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
-    for (uint64_t chunk = (uint64_t)blockIdx.x * waves_per_block + wave; chunk < p.nchunks; chunk += total_waves) {
+    // per-lane constants of the 4x4 byte transpose (same lane mapping as the decoder's stores)
+    const uint32_t sel1 = (lane & 1u) ? 0x03070105u : 0x06020400u;
+    const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
+    const uint32_t in_lane_off = (lane & 3u) * N + (lane & ~3u);
+
+    for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave; chunk_v < p.nchunks;
+         chunk_v += total_waves) {
+        const uint64_t chunk = uniform64(chunk_v);
         const uint64_t first = chunk * p.chunk_syms;
         const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
-        const uint8_t *src = p.syms + first * p.sym_bytes;
-        uint8_t *slot = p.scratch + chunk * p.slot_bytes;
+        const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + first * p.sym_bytes;
+        uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + chunk * p.slot_bytes;
         uint32_t wp = (uint32_t)p.slot_bytes;
 
         state_t x[K];
@@ -741,14 +749,21 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
         for (int k = 0; k < K; ++k)
             x[k] = Tr::kL; // RansEncInit / RansWordEncInit / Rans64EncInit
 
-        const uint32_t rounds = nsym / N;
-        const uint32_t tail = nsym - rounds * N;
+        const uint32_t rounds = uniform(nsym / N);
+        const uint32_t tail = uniform(nsym - rounds * N);
+        // Fast input path: full waves, u8 symbols, dword-aligned rows -> symbols of 4 rounds
+        // arrive as one coalesced dword per lane and are transposed in registers; loads run
+        // one super-group (16 rounds) ahead of the arithmetic.
+        const bool fast_in = p.sym_bytes == 1 && N == p.n_ways && (N & 63u) == 0 &&
+                             ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 3u) == 0;
+        const uint32_t fast_rounds = fast_in ? (rounds & ~15u) : 0u;
+
         // rounds from last to first; round `rounds` is the partial one
-        for (uint32_t rr = rounds + 1; rr-- > 0;) {
+        for (uint32_t rr = rounds + 1; rr-- > fast_rounds;) {
             const uint32_t cnt = (rr < rounds) ? N : tail;
             if (cnt == 0)
                 continue;
-            const uint8_t *rsrc = src + (uint64_t)rr * N * p.sym_bytes;
+            const uint8_t RANS_GLOBAL *rsrc = src + (uint64_t)rr * N * p.sym_bytes;
             uint32_t sym[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -756,12 +771,47 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
                 sym[k] = 0;
                 if (idx < cnt)
                     sym[k] = p.sym_bytes == 1 ? (uint32_t)rsrc[idx]
-                                              : (uint32_t) reinterpret_cast<const uint16_t *>(rsrc)[idx];
+                                              : (uint32_t) reinterpret_cast<const uint16_t RANS_GLOBAL *>(rsrc)[idx];
             }
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
                 const uint32_t idx = k * 64u + lane;
                 enc_substep<FMT>(T, x[k], sym[k], idx < cnt, slot, wp, bad);
+            }
+        }
+
+        if (fast_rounds) {
+            uint32_t cur[4][K], nxt[4][K];
+            auto load_super = [&](uint32_t (&dstq)[4][K], uint32_t sg) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        dstq[j][k] = *reinterpret_cast<const uint32_t RANS_GLOBAL *>(
+                            src + (uint64_t)(sg * 16u + j * 4u) * N + in_lane_off + k * 64u);
+            };
+            uint32_t sg = fast_rounds >> 4;
+            load_super(cur, sg - 1);
+            while (sg-- > 0) {
+                if (sg > 0)
+                    load_super(nxt, sg - 1);
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    uint32_t t[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        t[k] = quad_transpose(cur[j][k], sel1, sel2);
+#pragma unroll
+                    for (int J = 3; J >= 0; --J)
+#pragma unroll
+                        for (int k = K - 1; k >= 0; --k)
+                            enc_substep<FMT>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        cur[j][k] = nxt[j][k];
             }
         }
 
@@ -772,13 +822,13 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
         for (int k = 0; k < K; ++k) {
             const uint32_t idx = k * 64u + lane;
             if (idx < N) {
-                uint8_t *at = slot + wp + idx * Tr::kStateBytes;
+                uint8_t RANS_GLOBAL *at = slot + wp + idx * Tr::kStateBytes;
                 if constexpr (FMT == FMT_R64) {
-                    reinterpret_cast<uint32_t *>(at)[0] = (uint32_t)x[k];
-                    reinterpret_cast<uint32_t *>(at)[1] = (uint32_t)(x[k] >> 32);
+                    reinterpret_cast<uint32_t RANS_GLOBAL *>(at)[0] = (uint32_t)x[k];
+                    reinterpret_cast<uint32_t RANS_GLOBAL *>(at)[1] = (uint32_t)(x[k] >> 32);
                 } else if constexpr (FMT == FMT_WORD) {
-                    reinterpret_cast<uint16_t *>(at)[0] = (uint16_t)x[k];
-                    reinterpret_cast<uint16_t *>(at)[1] = (uint16_t)(x[k] >> 16);
+                    reinterpret_cast<uint16_t RANS_GLOBAL *>(at)[0] = (uint16_t)x[k];
+                    reinterpret_cast<uint16_t RANS_GLOBAL *>(at)[1] = (uint16_t)(x[k] >> 16);
                 } else {
                     at[0] = (uint8_t)x[k];
                     at[1] = (uint8_t)(x[k] >> 8);
