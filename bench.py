@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=32768, help="symbols per independent chunk stream")
     ap.add_argument("--format", default="word", choices=["word", "byte", "r64", "alias"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for dry runs)")
+    ap.add_argument("--all-on-device", type=int, default=None,
+                    help="dry-run aid: every rank uses this GPU (needs --backend gloo)")
     ap.add_argument("--cpu-shard-log2", type=int, default=25, help="CPU baseline: symbols per host thread")
     return ap.parse_args()
 
@@ -169,17 +172,21 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    gpu_index = local_rank if args.all_on_device is None else args.all_on_device
+    torch.cuda.set_device(gpu_index)
+    device = torch.device("cuda", gpu_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     fmt = {"word": R.FMT_WORD, "byte": R.FMT_BYTE, "r64": R.FMT_R64, "alias": R.FMT_ALIAS}[args.format]
     sb = {"word": 12, "byte": 14, "r64": 14, "alias": 16}[args.format]
     n = 1 << args.log2n
 
     # ---- setup (untimed): data, model, GPU encode ------------------------------
-    ctx = R.Context(local_rank)
+    ctx = R.Context(gpu_index)
     d_syms = gen_zipf_bytes(torch, n, seed=rank + 1, device=device)
     counts = ctx.count_freqs_device(d_syms, 256)
     freqs, _ = R.normalize_freqs(counts, 1 << sb)
@@ -219,7 +226,8 @@ def main():
 
     from ryg_rans_amd.sharding import ShardRecord, aggregate, gather_records
     rec = ShardRecord(elapsed, float(n), float(total), kernel_ms, 1.0 if (exact and bad == 0) else 0.0)
-    records = gather_records(rec, device=device)  # the only payload RCCL carries: 40 bytes per rank
+    # the only payload RCCL carries: 40 bytes per rank
+    records = gather_records(rec, device=device if args.backend == "nccl" else "cpu")
 
     if rank == 0:
         agg = aggregate(records, args.steps)

@@ -53,7 +53,8 @@ constexpr int FMT_ALIAS = RANS_AMD_FMT_ALIAS;
 // (A/B knob).  OUT_FAST8_LDS: symbols staged through a 256-byte LDS tile per wave
 // (ds_write_b8 per round, one ds_read_b32 + global_store_dword per 4 rounds; K == 1 only).
 // OUT_FAST16: u16 symbols, 2 rounds packed per dword and swapped between lane pairs.
-enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST8_NOASM = 2, OUT_FAST8_LDS = 3, OUT_FAST16 = 4 };
+// OUT_FAST8_BYTE: one global_store_byte per lane and round (64 contiguous bytes per wave), no transpose.
+enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST8_NOASM = 2, OUT_FAST8_LDS = 3, OUT_FAST16 = 4, OUT_FAST8_BYTE = 5 };
 constexpr uint32_t kOutTileBytes = 256;
 
 template <int FMT> struct FmtTraits;
@@ -526,6 +527,8 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
         const uint32_t raw = dec_step<FMT>(T, x[k]);                               \
         if constexpr (OUT == OUT_FAST8_LDS)                                        \
             tile[J * 64 + lane] = (uint8_t)(raw >> (8 * Tr::kSymByte));            \
+        else if constexpr (OUT == OUT_FAST8_BYTE)                                  \
+            gdst[J * N + k * 64 + lane] = (uint8_t)(raw >> (8 * Tr::kSymByte));    \
         else                                                                       \
             acc[k] = acc_symbol<Tr::kSymByte, J>(raw, acc[k]);                     \
     }                                                                              \
@@ -533,9 +536,9 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
         if ((J * K + k) % kCheckEvery == 0)                                        \
             W.checkpoint(lane);                                                    \
         uint32_t c;                                                                \
-        if constexpr (FMT == FMT_WORD && (OUT == OUT_FAST8 || OUT == OUT_FAST8_LDS)) \
+        if constexpr (FMT == FMT_WORD && (OUT == OUT_FAST8 || OUT == OUT_FAST8_LDS || OUT == OUT_FAST8_BYTE)) \
             c = 2u * renorm_word_full(x[k], W.cursor_addr(), k65536);              \
-        else if constexpr ((FMT == FMT_BYTE || FMT == FMT_ALIAS) && OUT == OUT_FAST8) \
+        else if constexpr ((FMT == FMT_BYTE || FMT == FMT_ALIAS) && (OUT == OUT_FAST8 || OUT == OUT_FAST8_BYTE)) \
             c = renorm_byte_full(x[k], W.cursor_addr(), k2p23, k2p15);             \
         else                                                                       \
             c = dec_renorm<FMT>(W, x[k], true);                                    \
@@ -551,7 +554,7 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
                     // LDS ops of one wave execute in order: the read sees the four writes
                     const uint32_t v = reinterpret_cast<const uint32_t *>(tile)[lane];
                     *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + lane * 4u) = v;
-                } else {
+                } else if constexpr (OUT != OUT_FAST8_BYTE) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const uint32_t v = quad_transpose(acc[k], sel1, sel2);
@@ -1337,6 +1340,10 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
     static const bool lds_out = getenv("RANS_AMD_LDS_OUT") != nullptr; // A/B knob: LDS-staged output
     if (fast && lds_out && p.n_ways == 64)
         return launch_decode_t<FMT, 1, OUT_FAST8_LDS>(p, num_cus, s, name);
+    static const bool byte_out = getenv("RANS_AMD_BYTE_OUT") != nullptr; // A/B knob: per-round byte stores
+    if (p.sym_bytes == 1 && byte_out && (p.n_ways == 64 || p.n_ways == 128))
+        return p.n_ways == 64 ? launch_decode_t<FMT, 1, OUT_FAST8_BYTE>(p, num_cus, s, name)
+                              : launch_decode_t<FMT, 2, OUT_FAST8_BYTE>(p, num_cus, s, name);
     if (FMT == FMT_WORD && fast && no_asm) {
         switch (p.n_ways) {
         case 64: return launch_decode_t<FMT_WORD, 1, OUT_FAST8_NOASM>(p, num_cus, s, name);
