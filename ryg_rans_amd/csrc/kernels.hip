@@ -856,42 +856,67 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
 // wave decodes 64 chunks at once.  Tables are shared through LDS as before.
 // ===========================================================================
 
+// Per-lane stream window for the lane-per-stream decoder: 16 bytes of the lane's own stream
+// in registers plus the next 16 prefetched, so that a lane touches global memory once per
+// 16 stream bytes (a dword-per-unit walk would issue 4-16x as many scattered accesses).
+struct LaneWindow {
+    u32x4 win, pre;
+    uint64_t next;  // global address of the 16 bytes after `pre`
+    uint64_t limit; // 16-byte aligned end of the readable container
+    uint32_t pos;   // byte position inside win (0..15)
+    uint32_t used;  // stream bytes consumed so far
+
+    __device__ __forceinline__ u32x4 fetch(uint64_t a)
+    {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (a < limit)
+            v = *reinterpret_cast<const u32x4 RANS_GLOBAL *>(a);
+        return v;
+    }
+    __device__ __forceinline__ void open(uint64_t addr, uint64_t lim)
+    {
+        limit = lim;
+        const uint64_t base = addr & ~uint64_t(15);
+        pos = (uint32_t)(addr & 15u);
+        used = 0;
+        win = fetch(base);
+        pre = fetch(base + 16);
+        next = base + 32;
+    }
+    template <int UNIT> __device__ __forceinline__ uint32_t take()
+    {
+        const uint32_t d = pos >> 2;
+        uint32_t w = d == 0 ? win.x : d == 1 ? win.y : d == 2 ? win.z : win.w;
+        if constexpr (UNIT == 2)
+            w = (w >> ((pos & 2u) * 8u)) & 0xffffu;
+        else if constexpr (UNIT == 1)
+            w = (w >> ((pos & 3u) * 8u)) & 0xffu;
+        pos += UNIT;
+        used += UNIT;
+        if (pos == 16u) {
+            win = pre;
+            pre = fetch(next);
+            next += 16;
+            pos = 0;
+        }
+        return w;
+    }
+};
+
 template <int FMT>
-__device__ __forceinline__ void lane_renorm(typename FmtTraits<FMT>::state_t &x, const uint8_t RANS_GLOBAL *&rp,
-                                            const uint8_t RANS_GLOBAL *end, bool active, bool &bad)
+__device__ __forceinline__ void lane_renorm(typename FmtTraits<FMT>::state_t &x, LaneWindow &W, bool active)
 {
     if constexpr (FMT == FMT_WORD) {
-        if (active && x < (1u << 16)) { // rans_word_sse41.h:134-141
-            uint32_t w = 0;
-            if (rp + 2 <= end)
-                w = *reinterpret_cast<const uint16_t RANS_GLOBAL *>(rp);
-            else
-                bad = true;
-            rp += 2;
-            x = (x << 16) | w;
-        }
+        if (active && x < (1u << 16)) // rans_word_sse41.h:134-141
+            x = (x << 16) | W.take<2>();
     } else if constexpr (FMT == FMT_R64) {
-        if (active && x < (1ull << 31)) { // rans64.h:305-316
-            uint32_t w = 0;
-            if (rp + 4 <= end)
-                w = *reinterpret_cast<const uint32_t RANS_GLOBAL *>(rp);
-            else
-                bad = true;
-            rp += 4;
-            x = (x << 32) | w;
-        }
+        if (active && x < (1ull << 31)) // rans64.h:305-316
+            x = (x << 32) | W.take<4>();
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) // rans_byte.h:307-318, at most two bytes for scale_bits <= 16
-            if (active && x < (1u << 23)) {
-                uint32_t b = 0;
-                if (rp < end)
-                    b = *rp;
-                else
-                    bad = true;
-                rp += 1;
-                x = (x << 8) | b;
-            }
+            if (active && x < (1u << 23))
+                x = (x << 8) | W.take<1>();
     }
 }
 
@@ -923,7 +948,8 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
     T.bucket_shift = p.scale_bits - p.log2nsyms;
 
     const uint8_t RANS_GLOBAL *cbase = (const uint8_t RANS_GLOBAL *)p.container;
-    const bool dword_out = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 3u) == 0;
+    const uint64_t glimit = (reinterpret_cast<uint64_t>(p.container) + p.container_bytes + 15u) & ~uint64_t(15);
+    const bool wide_out = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 15u) == 0;
     uint32_t nbad = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; chunk < p.nchunks; chunk += stride) {
@@ -936,7 +962,6 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
             continue;
         }
         const uint8_t RANS_GLOBAL *src = cbase + off;
-        const uint8_t RANS_GLOBAL *end = src + len;
         uint8_t RANS_GLOBAL *dst = (uint8_t RANS_GLOBAL *)p.out + first * p.sym_bytes;
 
         state_t x[NW];
@@ -949,22 +974,19 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
                 x[l] = reinterpret_cast<const uint32_t RANS_GLOBAL *>(src)[l];
             }
         }
-        const uint8_t RANS_GLOBAL *rp = src + NW * Tr::kStateBytes;
+        LaneWindow W;
+        W.open(reinterpret_cast<uint64_t>(p.container) + off + NW * Tr::kStateBytes, glimit);
         bool bad = false;
 
         const uint32_t rounds = nsym / NW;
         const uint32_t tail = nsym - rounds * NW;
         uint32_t i = 0; // symbol index inside the chunk
-        if (dword_out) {
-            // 4 symbols per dword store: 4/NW rounds (NW <= 4) or NW/4 stores per round (NW == 8)
-            constexpr int kRoundsPerGroup = NW >= 4 ? 1 : 4 / NW;
-            constexpr int kDwords = NW >= 4 ? NW / 4 : 1;
+        if (wide_out) {
+            // 16 symbols per 16-byte store: 16/NW rounds per group
+            constexpr int kRoundsPerGroup = 16 / NW;
             const uint32_t groups = rounds / kRoundsPerGroup;
             for (uint32_t g = 0; g < groups; ++g) {
-                uint32_t pack[kDwords];
-#pragma unroll
-                for (int d = 0; d < kDwords; ++d)
-                    pack[d] = 0;
+                u32x4 pack = {0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int rr = 0; rr < kRoundsPerGroup; ++rr) {
 #pragma unroll
@@ -972,17 +994,17 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
                         uint32_t sy = dec_step<FMT>(T, x[l]);
                         if constexpr (Tr::kSymByte == 3)
                             sy >>= 24;
+                        constexpr int dummy = 0;
+                        (void)dummy;
                         const int pos = rr * NW + l;
                         pack[pos / 4] |= (sy & 0xffu) << (8 * (pos % 4));
                     }
 #pragma unroll
                     for (int l = 0; l < NW; ++l)
-                        lane_renorm<FMT>(x[l], rp, end, true, bad);
+                        lane_renorm<FMT>(x[l], W, true);
                 }
-#pragma unroll
-                for (int d = 0; d < kDwords; ++d)
-                    reinterpret_cast<uint32_t RANS_GLOBAL *>(dst + i)[d] = pack[d];
-                i += 4 * kDwords;
+                *reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i) = pack;
+                i += 16;
             }
         }
         // remaining rounds + tail: element stores
@@ -1001,14 +1023,14 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
                 }
 #pragma unroll
             for (int l = 0; l < NW; ++l)
-                lane_renorm<FMT>(x[l], rp, end, (uint32_t)l < cnt, bad);
+                lane_renorm<FMT>(x[l], W, (uint32_t)l < cnt);
             i += cnt;
         }
         (void)tail;
 #pragma unroll
         for (int l = 0; l < NW; ++l)
             bad = bad || (x[l] != Tr::kL);
-        if (bad || rp != end)
+        if (bad || W.used + NW * Tr::kStateBytes != len)
             nbad++;
     }
     if (nbad)
