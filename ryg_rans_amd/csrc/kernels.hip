@@ -632,6 +632,20 @@ __device__ __forceinline__ void divmod_rcp(uint32_t x, uint32_t freq, uint32_t r
     }
 }
 
+// 64-bit variant for rans64 (state < 2^63): Alverson reciprocal, exact for freq >= 2; freq == 1
+// (rcp = 2^64 - 1, q = x - 1) is fixed by the correction step.  rec = {freq | rshift << 24, start,
+// rcp lo, rcp hi} (model.cpp).
+__device__ __forceinline__ void divmod_rcp64(uint64_t x, uint32_t freq, const uint4 &rec, uint64_t &q, uint64_t &rem)
+{
+    const uint64_t rcp = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
+    q = __umul64hi(x, rcp) >> (rec.x >> 24);
+    rem = x - q * freq;
+    if (rem >= freq) {
+        q += 1;
+        rem -= freq;
+    }
+}
+
 // One encoder sub-step for 64 lanes.  `wp` = write cursor (byte offset inside the
 // slot, moves down, wave-uniform).
 template <int FMT>
@@ -641,7 +655,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 {
     const bool in_alphabet = sym < T.nsyms;
     const uint4 rec = T.recs[in_alphabet ? sym : 0u];
-    const uint32_t freq = rec.x, start = rec.y, rcp = rec.z;
+    const uint32_t freq = (FMT == FMT_R64) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
     if (active && (!in_alphabet || freq == 0)) {
         bad = true;
         active = false;
@@ -670,9 +684,8 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         if (emit)
             *reinterpret_cast<uint32_t RANS_GLOBAL *>(slot + wp + 4u * rank_below(m)) = (uint32_t)x;
         uint64_t y = emit ? (x >> 32) : x;
-        const uint32_t f = freq ? freq : 1u;
-        const uint64_t q = y / f;
-        const uint64_t rem = y - q * f;
+        uint64_t q, rem;
+        divmod_rcp64(y, freq, rec, q, rem);
         const uint64_t xn = (q << T.scale_bits) + rem + start;
         x = active ? xn : x;
     } else {
@@ -1037,8 +1050,61 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
         atomicAdd(p.err_count, (unsigned long long)nbad);
 }
 
+// one symbol of the sequential reference encoder (RansEncPut / RansWordEncPut / Rans64EncPut /
+// RansEncPutAlias) for a lane-private state and write pointer
+template <int FMT>
+__device__ __forceinline__ void lane_put(typename FmtTraits<FMT>::state_t &x, uint32_t sym, const uint4 *recs,
+                                         const EncParams &p, uint8_t RANS_GLOBAL *&wp, bool &bad)
+{
+    const bool known = sym < p.nsyms;
+    const uint4 rec = recs[known ? sym : 0u];
+    const uint32_t freq = (FMT == FMT_R64) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
+    if (!known || freq == 0) {
+        bad = true;
+        return;
+    }
+    if constexpr (FMT == FMT_WORD) {
+        uint32_t y = x;
+        if (y >= (freq << 20)) {
+            wp -= 2;
+            *reinterpret_cast<uint16_t RANS_GLOBAL *>(wp) = (uint16_t)y;
+            y >>= 16;
+        }
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        x = (q << 12) + rem + start;
+    } else if constexpr (FMT == FMT_R64) {
+        uint64_t y = x;
+        if (y >= (((uint64_t)freq) << (63u - p.scale_bits))) {
+            wp -= 4;
+            *reinterpret_cast<uint32_t RANS_GLOBAL *>(wp) = (uint32_t)y;
+            y >>= 32;
+        }
+        uint64_t q, rem;
+        divmod_rcp64(y, freq, rec, q, rem);
+        x = (q << p.scale_bits) + rem + start;
+    } else {
+        uint32_t y = x;
+        const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (y >= x_max) {
+                *--wp = (uint8_t)y;
+                y >>= 8;
+            }
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        if constexpr (FMT == FMT_ALIAS)
+            x = (q << p.scale_bits) + p.alias_remap[rem + start];
+        else
+            x = (q << p.scale_bits) + rem + start;
+    }
+}
+
+// Lane-per-stream encoder, second generation: symbols arrive as 16-byte per-lane loads
+// (one scattered access per 16 symbols instead of per symbol), one group prefetched.
 template <int FMT, int NW>
-__global__ void __launch_bounds__(256) k_encode_lanes(const EncParams p)
+__global__ void __launch_bounds__(256) k_encode_lanes16(const EncParams p)
 {
     using Tr = FmtTraits<FMT>;
     using state_t = typename Tr::state_t;
@@ -1051,6 +1117,7 @@ __global__ void __launch_bounds__(256) k_encode_lanes(const EncParams p)
     }
     __syncthreads();
     const uint4 *recs = reinterpret_cast<const uint4 *>(smem);
+    const bool wide_in = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 15u) == 0;
 
     bool bad = false;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -1066,62 +1133,32 @@ __global__ void __launch_bounds__(256) k_encode_lanes(const EncParams p)
         for (int l = 0; l < NW; ++l)
             x[l] = Tr::kL;
 
-        // symbol i belongs to state i mod NW; visit i = nsym-1 .. 0 (main.cpp:233-243)
-        uint32_t i = nsym;
-        while (i > 0) {
-            const uint32_t base = (i - 1) / NW * NW; // first symbol of this round
-            const uint32_t cnt = i - base;
+        // symbol i belongs to state i mod NW; visit i = nsym-1 .. 0 (main.cpp:233-243).
+        // [0, fast_end) is walked in 16-symbol groups; the ragged top part one by one.
+        const uint32_t fast_end = wide_in ? (nsym & ~15u) : 0u;
+        for (uint32_t i = nsym; i > fast_end; --i) {
+            const uint32_t sym = p.sym_bytes == 1 ? (uint32_t)src[i - 1]
+                                                  : (uint32_t) reinterpret_cast<const uint16_t RANS_GLOBAL *>(src)[i - 1];
+            const uint32_t l = (i - 1) % NW;
 #pragma unroll
-            for (int l = NW - 1; l >= 0; --l) {
-                if ((uint32_t)l >= cnt)
-                    continue;
-                const uint32_t sym = p.sym_bytes == 1
-                                         ? (uint32_t)src[base + l]
-                                         : (uint32_t) reinterpret_cast<const uint16_t RANS_GLOBAL *>(src)[base + l];
-                const bool known = sym < p.nsyms;
-                const uint4 rec = recs[known ? sym : 0u];
-                const uint32_t freq = rec.x, start = rec.y, rcp = rec.z;
-                if (!known || freq == 0) {
-                    bad = true;
-                    continue;
-                }
-                if constexpr (FMT == FMT_WORD) {
-                    uint32_t y = x[l];
-                    if (y >= (freq << 20)) {
-                        wp -= 2;
-                        *reinterpret_cast<uint16_t RANS_GLOBAL *>(wp) = (uint16_t)y;
-                        y >>= 16;
-                    }
-                    uint32_t q, rem;
-                    divmod_rcp(y, freq, rcp, q, rem);
-                    x[l] = (q << 12) + rem + start;
-                } else if constexpr (FMT == FMT_R64) {
-                    uint64_t y = x[l];
-                    if (y >= (((uint64_t)freq) << (63u - p.scale_bits))) {
-                        wp -= 4;
-                        *reinterpret_cast<uint32_t RANS_GLOBAL *>(wp) = (uint32_t)y;
-                        y >>= 32;
-                    }
-                    const uint64_t q = y / freq;
-                    x[l] = (q << p.scale_bits) + (y - q * freq) + start;
-                } else {
-                    uint32_t y = x[l];
-                    const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq;
+            for (int ll = 0; ll < NW; ++ll) // static register indexing
+                if ((uint32_t)ll == l)
+                    lane_put<FMT>(x[ll], sym, recs, p, wp, bad);
+        }
+        if (fast_end) {
+            const u32x4 RANS_GLOBAL *g16 = reinterpret_cast<const u32x4 RANS_GLOBAL *>(src);
+            uint32_t g = fast_end >> 4;
+            u32x4 cur = g16[g - 1], nxt = cur;
+            while (g-- > 0) {
+                if (g > 0)
+                    nxt = g16[g - 1];
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        if (y >= x_max) {
-                            *--wp = (uint8_t)y;
-                            y >>= 8;
-                        }
-                    uint32_t q, rem;
-                    divmod_rcp(y, freq, rcp, q, rem);
-                    if constexpr (FMT == FMT_ALIAS)
-                        x[l] = (q << p.scale_bits) + p.alias_remap[rem + start];
-                    else
-                        x[l] = (q << p.scale_bits) + rem + start;
+                for (int j = 15; j >= 0; --j) {
+                    const uint32_t sym = (cur[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    lane_put<FMT>(x[j % NW], sym, recs, p, wp, bad);
                 }
+                cur = nxt;
             }
-            i = base;
         }
         // flush states NW-1 .. 0 (lane 0's first in memory)
 #pragma unroll
@@ -1152,6 +1189,7 @@ __global__ void __launch_bounds__(256) k_encode_lanes(const EncParams p)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_layout(const LayoutParams p)
 {
+    constexpr int kPer = 8; // consecutive chunks per thread -> 8192 chunks per block pass
     __shared__ uint64_t wave_sum[16];
     __shared__ uint64_t carry;
     const uint32_t lane = lane_id();
@@ -1159,10 +1197,16 @@ __global__ void __launch_bounds__(1024) k_layout(const LayoutParams p)
     if (threadIdx.x == 0)
         carry = 0;
     __syncthreads();
-    for (uint64_t base = 0; base < p.nchunks; base += blockDim.x) {
-        const uint64_t c = base + threadIdx.x;
-        const uint64_t mine = c < p.nchunks ? (((uint64_t)p.lengths[c] + 15u) & ~uint64_t(15)) : 0;
-        // inclusive scan inside the wave
+    for (uint64_t base = 0; base < p.nchunks; base += (uint64_t)blockDim.x * kPer) {
+        const uint64_t c0 = base + (uint64_t)threadIdx.x * kPer;
+        uint64_t sz[kPer];
+        uint64_t mine = 0;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            sz[i] = c0 + i < p.nchunks ? (((uint64_t)p.lengths[c0 + i] + 15u) & ~uint64_t(15)) : 0;
+            mine += sz[i];
+        }
+        // inclusive scan of the per-thread sums inside the wave
         uint64_t v = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1176,14 +1220,19 @@ __global__ void __launch_bounds__(1024) k_layout(const LayoutParams p)
         uint64_t before = carry;
         for (uint32_t w = 0; w < wave; ++w)
             before += wave_sum[w];
-        if (c < p.nchunks) {
-            p.offsets[c] = before + v - mine;
-            if (c == p.nchunks - 1) {
-                const uint64_t end = before + v - mine + p.lengths[c];
-                p.offsets[p.nchunks] = end;
-                if (before + v > p.out_cap)
-                    atomicOr(p.flags, 2u);
+        uint64_t at = before + v - mine;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const uint64_t c = c0 + i;
+            if (c < p.nchunks) {
+                p.offsets[c] = at;
+                if (c == p.nchunks - 1) {
+                    p.offsets[p.nchunks] = at + p.lengths[c];
+                    if (at + sz[i] > p.out_cap)
+                        atomicOr(p.flags, 2u);
+                }
             }
+            at += sz[i];
         }
         __syncthreads();
         if (threadIdx.x == blockDim.x - 1)
@@ -1421,7 +1470,7 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, 
     const size_t lds = (size_t)p.nsyms * sizeof(EncRec);
     if (lds > 128 * 1024)
         return hipErrorInvalidValue;
-    auto kern = k_encode_lanes<FMT, NW>;
+    auto kern = k_encode_lanes16<FMT, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -66,6 +66,7 @@ struct EncRec {
     uint32_t start;
     uint32_t rcp;   // floor(2^32 / freq), 0xffffffff for freq == 1
     uint32_t remap; // alias only: offset of this symbol's run in alias_remap (== start)
+    // FMT_R64 reuses the slots as {freq | rshift << 24, start, rcp64 lo, rcp64 hi} (model.cpp)
 };
 
 int count_freqs_host(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *freqs);

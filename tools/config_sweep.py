@@ -60,7 +60,14 @@ def run(ctx, name, fmt, sb, nsyms, n, ways, chunk, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="substring filter on the config name")
     a = ap.parse_args()
+    global run
+    run_all = run
+
+    def run(ctx, name, *rest, **kw):  # noqa: F811
+        if a.only in name:
+            run_all(ctx, name, *rest, **kw)
     ctx = R.Context(0)
     big = 28 if a.quick else 30
     print("| config | Mi symbols | ways | chunk | stream B/sym | enc ms | enc GB/s | dec ms | dec GB/s (out) | dec frac of 8 TB/s (in+out) | round trip |")
