@@ -270,9 +270,20 @@ def main():
                 "per_wave_round_of_64": round(k_s * MAX_CLOCK_HZ / n * 64 * 8192, 1),
             },
         }
-        tj = os.environ.get("RANS_TRAFFIC_JSON")
-        if tj and os.path.exists(tj):
-            result["roofline"]["traffic"] = json.load(open(tj)).get("hbm_bytes_per_launch")
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this very command
+        # (tools/profile.sh -> tools/summarize_profile.py -> profiles/<tag>_traffic.json); PMC passes
+        # cannot share a process with the timed run, so the committed measurement is quoted when it
+        # was taken on the same workload, else null.
+        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r01_traffic.json"))
+        default_workload = (args.format == "word" and args.ways == 64 and args.chunk == 32768 and args.log2n == 30)
+        if os.path.exists(tj) and default_workload:
+            try:
+                t = json.load(open(tj))
+                result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+                result["roofline"]["traffic_source"] = os.path.relpath(tj, ROOT) + \
+                    " (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes)"
+            except (OSError, ValueError):
+                pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(d_syms, freqs, n, args.cpu_shard_log2)

@@ -440,6 +440,8 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     const uint64_t slot = rans_amd_chunk_bound(format, (uint32_t)(n < chunk_syms ? n : chunk_syms), n_ways);
+    if (slot > 0xfffffff0ull) // chunk stream lengths and in-slot cursors are 32-bit
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode: chunk_syms too large (a chunk's stream must stay below 4 GiB)");
     int rc = ctx->scratch.reserve((size_t)(nchunks * slot + 64));
     if (rc)
         return rc;
