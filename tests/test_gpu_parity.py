@@ -230,3 +230,14 @@ def test_full_size_roundtrip_properties(gpu):
     out2 = torch.empty_like(out)
     ctx.decode(gm, cont2, total, offs, lens, n, 64, chunk, d_out=out2, sync=False)
     assert ctx.decode_errors() >= 1 or not torch.equal(out2, d_syms)
+
+
+def test_native_cpp_example(gpu):
+    """examples/roundtrip.cpp: a C++ host using only the C ABI (built by __graft_entry__.build())."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "build", "roundtrip")
+    if not os.path.exists(exe):
+        pytest.skip("build/roundtrip not built")
+    for fmt, ways in (("word", "64"), ("byte", "64"), ("r64", "2"), ("alias", "256")):
+        out = subprocess.run([exe, "-", fmt, ways], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "decode ok!" in out.stdout, (fmt, out.stdout, out.stderr)
