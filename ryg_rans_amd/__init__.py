@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libryg_rans_amd.so")
+# RANS_AMD_LIB: load an alternative build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("RANS_AMD_LIB") or os.path.join(_HERE, "lib", "libryg_rans_amd.so")
 
 FMT_BYTE, FMT_WORD, FMT_R64, FMT_ALIAS = 0, 1, 2, 3
 FORMAT_NAMES = {FMT_BYTE: "byte", FMT_WORD: "word", FMT_R64: "r64", FMT_ALIAS: "alias"}

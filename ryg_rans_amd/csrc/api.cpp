@@ -85,6 +85,7 @@ struct rans_amd_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // dec start/stop, enc start/stop
     bool timing = false;
     bool dec_timed = false, enc_timed = false;
+    uint32_t launch_seq = 0; // selects one of kWorkSlots chunk counters at d_words + 256
     const char *last_kernel = "";
     std::mutex mu;
 
@@ -196,9 +197,10 @@ int rans_amd_ctx_create(int device, rans_amd_ctx **out_ctx)
         return fail(RANS_AMD_E_NOMEM, "ctx");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    e = hipMalloc(reinterpret_cast<void **>(&ctx->d_words), 256);
+    const size_t words_bytes = 256 + (size_t)kWorkSlots * kWorkPools * kWorkPoolStride * 4;
+    e = hipMalloc(reinterpret_cast<void **>(&ctx->d_words), words_bytes);
     if (e == hipSuccess)
-        e = hipMemset(ctx->d_words, 0, 256);
+        e = hipMemset(ctx->d_words, 0, words_bytes);
     for (int i = 0; i < 4 && e == hipSuccess; ++i)
         e = hipEventCreate(&ctx->ev[i]);
     if (e != hipSuccess) {
@@ -544,12 +546,49 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         dp.log2nsyms = model->host.log2nsyms;
         dp.sym_bytes = (uint32_t)model->host.sym_bytes;
         dp.err_count = ctx->d_err();
+        // dynamic chunk hand-out: a 4-byte counter zeroed in stream order ahead of the kernel
+        // A/B knob (RANS_AMD_STATIC_SCHED=1 restores static striding).
+        static const bool static_sched = getenv("RANS_AMD_STATIC_SCHED") != nullptr;
+        // Counters form a ring of 64 slots (all zero at context creation); launch i uses slot
+        // i % 64 and re-zeroes slot (i + 32) % 64 from inside the kernel, so no memset node is
+        // needed and up to 32 decode launches of one context may be in flight at once.
+        dp.work_counter = nullptr;
+        dp.work_counter_reset = nullptr;
+        if (!static_sched && nchunks < 0xffffffffull) {
+            unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);
+            const uint32_t per_slot = kWorkPools * kWorkPoolStride;
+            dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * per_slot;
+            dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * per_slot;
+            ctx->launch_seq++;
+        }
+        // debug timeline (RANS_AMD_TRACE=<file>): per-wave start/end ticks and XCD, written after a sync
+        static const char *trace_path = getenv("RANS_AMD_TRACE");
+        const size_t trace_words = 3u * 2u * 16u * (size_t)ctx->num_cus;
+        dp.trace = nullptr;
+        if (trace_path) {
+            int trc = ctx->hist.reserve(trace_words * 8 + (size_t)65536 * 4);
+            if (trc)
+                return trc;
+            dp.trace = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(ctx->hist.ptr) + 65536 * 4);
+            HIP_TRY(hipMemsetAsync(dp.trace, 0, trace_words * 8, s));
+        }
         if (ctx->timing)
             HIP_TRY(hipEventRecord(ctx->ev[0], s));
         HIP_TRY(launch_decode(format, dp, ctx->num_cus, s, &ctx->last_kernel));
         if (ctx->timing) {
             HIP_TRY(hipEventRecord(ctx->ev[1], s));
             ctx->dec_timed = true;
+        }
+        if (trace_path) {
+            std::vector<unsigned long long> host(trace_words);
+            HIP_TRY(hipMemcpyAsync(host.data(), dp.trace, trace_words * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (FILE *f = fopen(trace_path, "w")) {
+                for (size_t w = 0; w < trace_words / 3; ++w)
+                    if (host[3 * w + 1])
+                        fprintf(f, "%zu %llu %llu %llu\n", w, host[3 * w], host[3 * w + 1], host[3 * w + 2]);
+                fclose(f);
+            }
         }
     }
     if (h_bad_chunks) {

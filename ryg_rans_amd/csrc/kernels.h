@@ -15,6 +15,9 @@ constexpr uint32_t kRingMirror = 768;   // copy of ring[0..768) after the end: n
 constexpr uint32_t kRingStride = kRingBytes + kRingMirror;
 
 constexpr int kDecBlockThreads = 1024; // 16 waves share one table image
+constexpr uint32_t kWorkPools = 8;       // chunk hand-out counters per launch (one per XCD)
+constexpr uint32_t kWorkPoolStride = 16; // in uint32: every counter on its own 64-byte line
+constexpr uint32_t kWorkSlots = 64;      // launches that may reuse the counter ring before wrap
 constexpr int kEncBlockThreads = 256;
 
 struct DecParams {
@@ -35,6 +38,9 @@ struct DecParams {
     uint32_t log2nsyms;
     uint32_t sym_bytes;
     unsigned long long *err_count; // failed chunks (device counter)
+    unsigned int *work_counter;    // next chunk to hand out (zero at launch); NULL = static striding
+    unsigned int *work_counter_reset; // a counter slot of a LATER launch that this launch zeroes
+    unsigned long long *trace;        // debug (RANS_AMD_TRACE): per wave {start, end, xcc} in 100 MHz ticks
 };
 
 struct EncParams {

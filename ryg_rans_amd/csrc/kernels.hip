@@ -213,7 +213,11 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         // rans_word_sse41.h:123-131 / :151-179: slot = x & 4095;
         // x = freq * (x >> 12) + bias.  freq < 2^12 and x >> 12 < 2^20, so the
         // 24-bit multiply-add is exact.
+#ifdef RANS_EXPERIMENT_NOCONFLICT // perf experiment only (wrong results): every lane on its own banks
+        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[((x & 0xfc0u) | (lane_id() & 63u))];
+#else
         const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[x & 0xfffu];
+#endif
         x = (e.x & 0xffffffu) * (x >> 12) + e.y;
         return e.x;
     } else if constexpr (FMT == FMT_BYTE) {
@@ -381,11 +385,12 @@ __device__ __forceinline__ uint32_t quad_transpose(uint32_t v, uint32_t sel1, ui
 }
 
 template <int FMT, int K, int OUT>
-__global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
+__global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(const DecParams p)
 {
     using Tr = FmtTraits<FMT>;
     using state_t = typename Tr::state_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
 
     // ---- stage the tables into LDS (once per block) ----------------------
     const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
@@ -425,12 +430,32 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
     const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
     const uint32_t out_lane_off = (lane & 3u) * N + (lane & ~3u);
 
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u;
+    // Chunks are handed out dynamically.  The SIMD arbitrates VALU issue by wave age, so the
+    // waves of the older of a CU's two workgroups run ~20 % faster than the younger ones
+    // (measured: 314 vs 372 us for the same work); with a static split the kernel lasts as long
+    // as the slowest wave while the SIMDs drain.  One atomic per chunk on a single word tops
+    // out near 88 claims/us, so there are kWorkPools counters on separate cache lines; pool =
+    // blockIdx % 8 (= the XCD, as dispatched today; only speed depends on that) owns the chunks
+    // c with c % 8 == pool.
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
-    for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave; chunk_v < p.nchunks;
-         chunk_v += total_waves) {
+    uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint32_t npools = gridDim.x < kWorkPools ? gridDim.x : kWorkPools;
+    const uint32_t pool = blockIdx.x % npools;
+    for (;;) {
+        if (p.work_counter) {
+            uint32_t got = 0;
+            if (lane == 0)
+                got = atomicAdd(p.work_counter + pool * kWorkPoolStride, 1u);
+            chunk_v = (uint64_t)uniform(got) * npools + pool;
+        }
+        if (chunk_v >= p.nchunks)
+            break;
         // everything derived from the chunk index is wave-uniform; say so explicitly
         // so it lives in SGPRs and the loop control below is scalar
         const uint64_t chunk = uniform64(chunk_v);
+        chunk_v += total_waves; // static stride when there is no counter
         const uint64_t off = uniform64(p.offsets[chunk]);
         const uint32_t len = uniform(p.lengths[chunk]);
         const uint64_t first = chunk * p.chunk_syms;
@@ -603,6 +628,12 @@ __global__ void __launch_bounds__(kDecBlockThreads) k_decode(const DecParams p)
         const bool all_good = __builtin_amdgcn_ballot_w64(!good) == 0 && consumed == len;
         if (!all_good && lane == 0)
             atomicAdd(p.err_count, 1ull);
+    }
+    if (p.trace && lane == 0) { // debug timeline: when did this wave start and stop, on which XCD
+        unsigned long long *t = p.trace + 3ull * ((uint64_t)blockIdx.x * waves_per_block + wave);
+        t[0] = t_start;
+        t[1] = wall_clock64();
+        t[2] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11));
     }
 }
 
@@ -960,6 +991,8 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
     T.mask = (1u << p.scale_bits) - 1u;
     T.bucket_shift = p.scale_bits - p.log2nsyms;
 
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
     const uint8_t RANS_GLOBAL *cbase = (const uint8_t RANS_GLOBAL *)p.container;
     const uint64_t glimit = (reinterpret_cast<uint64_t>(p.container) + p.container_bytes + 15u) & ~uint64_t(15);
     const bool wide_out = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 15u) == 0;
