@@ -204,6 +204,7 @@ template <int FMT> struct DecTables {
     uint32_t scale_bits;
     uint32_t mask;
     uint32_t bucket_shift; // alias: scale_bits - log2(nsyms)
+    uint32_t mask12v;      // 0xfff held in a VGPR (a literal operand makes v_and a 3.5-cycle op)
 };
 
 template <int FMT>
@@ -213,11 +214,7 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         // rans_word_sse41.h:123-131 / :151-179: slot = x & 4095;
         // x = freq * (x >> 12) + bias.  freq < 2^12 and x >> 12 < 2^20, so the
         // 24-bit multiply-add is exact.
-#ifdef RANS_EXPERIMENT_NOCONFLICT // perf experiment only (wrong results): every lane on its own banks
-        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[((x & 0xfc0u) | (lane_id() & 63u))];
-#else
-        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[x & 0xfffu];
-#endif
+        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[x & T.mask12v];
         x = (e.x & 0xffffffu) * (x >> 12) + e.y;
         return e.x;
     } else if constexpr (FMT == FMT_BYTE) {
@@ -378,6 +375,8 @@ template <int SYMBYTE, int J> __device__ __forceinline__ uint32_t acc_symbol(uin
 // 4j..4j+3, i.e. four consecutive output bytes.
 __device__ __forceinline__ uint32_t quad_transpose(uint32_t v, uint32_t sel1, uint32_t sel2)
 {
+    // (the same shuffles through the LDS crossbar, ds_swizzle, measured 2 % slower: the LDS pipe is
+    // the co-bottleneck of the decoder)
     uint32_t o = quad_perm<1, 0, 3, 2>(v);
     v = __builtin_amdgcn_perm(o, v, sel1);
     o = quad_perm<2, 3, 0, 1>(v);
@@ -417,6 +416,8 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     T.scale_bits = p.scale_bits;
     T.mask = (1u << p.scale_bits) - 1u;
     T.bucket_shift = p.scale_bits - p.log2nsyms;
+    T.mask12v = 0xfffu;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(T.mask12v)); // opaque: keep it in a VGPR
 
     uint8_t *ring = smem + t0_bytes + t1_bytes + wave * kRingStride;
     uint8_t *tile = smem + t0_bytes + t1_bytes + waves_per_block * kRingStride + wave * kOutTileBytes; // OUT_FAST8_LDS
@@ -990,6 +991,8 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
     T.scale_bits = p.scale_bits;
     T.mask = (1u << p.scale_bits) - 1u;
     T.bucket_shift = p.scale_bits - p.log2nsyms;
+    T.mask12v = 0xfffu;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(T.mask12v)); // opaque: keep it in a VGPR
 
     if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
         p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
@@ -1440,14 +1443,17 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
         default: break;
         }
     }
-    static const bool no_asm = getenv("RANS_AMD_NO_ASM") != nullptr; // A/B knob for the word renorm
-    static const bool lds_out = getenv("RANS_AMD_LDS_OUT") != nullptr; // A/B knob: LDS-staged output
-    if (fast && lds_out && p.n_ways == 64)
-        return launch_decode_t<FMT, 1, OUT_FAST8_LDS>(p, num_cus, s, name);
-    static const bool byte_out = getenv("RANS_AMD_BYTE_OUT") != nullptr; // A/B knob: per-round byte stores
-    if (p.sym_bytes == 1 && byte_out && (p.n_ways == 64 || p.n_ways == 128))
-        return p.n_ways == 64 ? launch_decode_t<FMT, 1, OUT_FAST8_BYTE>(p, num_cus, s, name)
-                              : launch_decode_t<FMT, 2, OUT_FAST8_BYTE>(p, num_cus, s, name);
+    // A/B knobs (word format, 64-way only): alternatives that were measured and lost, kept so the
+    // measurements in DESIGN.md can be repeated.
+    static const bool no_asm = getenv("RANS_AMD_NO_ASM") != nullptr;   // compiler-scheduled renorm: -2 %
+    static const bool lds_out = getenv("RANS_AMD_LDS_OUT") != nullptr;  // output via an LDS tile: -7 %
+    static const bool byte_out = getenv("RANS_AMD_BYTE_OUT") != nullptr; // per-round byte stores: -5 %
+    if constexpr (FMT == FMT_WORD) {
+        if (fast && lds_out && p.n_ways == 64)
+            return launch_decode_t<FMT_WORD, 1, OUT_FAST8_LDS>(p, num_cus, s, name);
+        if (fast && byte_out && p.n_ways == 64)
+            return launch_decode_t<FMT_WORD, 1, OUT_FAST8_BYTE>(p, num_cus, s, name);
+    }
     if (FMT == FMT_WORD && fast && no_asm) {
         switch (p.n_ways) {
         case 64: return launch_decode_t<FMT_WORD, 1, OUT_FAST8_NOASM>(p, num_cus, s, name);
