@@ -657,7 +657,9 @@ template <int FMT> struct EncTables {
 __device__ __forceinline__ void divmod_rcp(uint32_t x, uint32_t freq, uint32_t rcp, uint32_t &q, uint32_t &rem)
 {
     q = __umulhi(x, rcp);
-    rem = x - q * freq;
+    // after renormalisation x < 2^(31-scale_bits) * freq (byte, scale_bits >= 8) or 2^20 * freq
+    // (word), so q < 2^23 and freq <= 2^16: the 24-bit multiply (full rate) is exact
+    rem = x - __umul24(q, freq);
     if (rem >= freq) {
         q += 1;
         rem -= freq;
