@@ -201,6 +201,43 @@ int rans_amd_encode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const v
 int rans_amd_decode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const uint8_t *stream_bytes,
                          uint64_t len, uint64_t n, uint32_t n_ways, void *out);
 
+/* ---- container file format (host memory) -----------------------------------------
+ *
+ * The reference keeps n, the tables and the stream start out of band (main.cpp:182,196) and
+ * defines no file format.  These helpers serialise what a decoder needs into ONE
+ * self-describing buffer:
+ *
+ *   [ 80-byte header | u32 freqs[nsyms] | u32 lengths[n_chunks] | pad to 16 | payload ]
+ *
+ * header: magic "RANSAMD1", version, format, scale_bits, nsyms, n_ways, chunk_syms, sym_bytes,
+ * n_symbols, n_chunks, payload_bytes, FNV-1a-64 of header+freqs+lengths.  Chunk c starts at
+ * payload + sum_{i<c} align16(lengths[i]) (rans_amd_offsets_from_lengths) and is a plain
+ * reference-format n_ways stream.  Everything is little endian. */
+typedef struct rans_amd_container_info {
+    uint32_t format;      /* rans_amd_format */
+    uint32_t scale_bits;
+    uint32_t nsyms;
+    uint32_t n_ways;
+    uint32_t chunk_syms;
+    uint32_t sym_bytes;   /* 1 or 2 */
+    uint64_t n_symbols;
+    uint64_t n_chunks;
+    uint64_t payload_bytes; /* == offsets[n_chunks] */
+} rans_amd_container_info;
+
+/* offsets[c] = sum_{i<c} align16(lengths[i]); offsets[n_chunks] = end of the last stream. */
+int rans_amd_offsets_from_lengths(const uint32_t *lengths, uint64_t n_chunks, uint64_t *offsets);
+/* Total bytes of the serialised container described by info. */
+uint64_t rans_amd_container_bytes(const rans_amd_container_info *info);
+/* Serialise.  payload = the container bytes produced by rans_amd_encode (copied to the host). */
+int rans_amd_container_pack(const rans_amd_container_info *info, const uint32_t *norm_freqs,
+                            const uint32_t *lengths, const void *payload, void *dst, uint64_t cap,
+                            uint64_t *out_bytes);
+/* Validate and index a serialised container in place: *freqs, *lengths and *payload point INTO
+ * src.  RANS_AMD_E_CORRUPT on a bad magic/version/checksum or inconsistent sizes. */
+int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container_info *info,
+                             const uint32_t **freqs, const uint32_t **lengths, const void **payload);
+
 /* ---- measurement helpers ---------------------------------------------------- */
 
 /* Duration in milliseconds of the most recent decode / encode kernel group that

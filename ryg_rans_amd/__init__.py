@@ -37,7 +37,16 @@ ABI_SYMBOLS = [
     "rans_amd_encode", "rans_amd_decode", "rans_amd_decode_errors",
     "rans_amd_encode_host", "rans_amd_decode_host",
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel",
+    "rans_amd_offsets_from_lengths", "rans_amd_container_bytes", "rans_amd_container_pack",
+    "rans_amd_container_parse",
 ]
+
+
+class ContainerInfo(C.Structure):
+    """rans_amd_container_info"""
+    _fields_ = [("format", C.c_uint32), ("scale_bits", C.c_uint32), ("nsyms", C.c_uint32), ("n_ways", C.c_uint32),
+                ("chunk_syms", C.c_uint32), ("sym_bytes", C.c_uint32), ("n_symbols", C.c_uint64),
+                ("n_chunks", C.c_uint64), ("payload_bytes", C.c_uint64)]
 
 
 class RansAmdError(RuntimeError):
@@ -92,6 +101,11 @@ def _load():
         "rans_amd_set_timing": (i32, [vp, i32]),
         "rans_amd_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "rans_amd_last_decode_kernel": (C.c_char_p, [vp]),
+        "rans_amd_offsets_from_lengths": (i32, [u32p, u64, u64p]),
+        "rans_amd_container_bytes": (u64, [C.POINTER(ContainerInfo)]),
+        "rans_amd_container_pack": (i32, [C.POINTER(ContainerInfo), u32p, u32p, vp, vp, u64, u64p]),
+        "rans_amd_container_parse": (i32, [vp, u64, C.POINTER(ContainerInfo), C.POINTER(u32p), C.POINTER(u32p),
+                                         C.POINTER(vp)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -293,6 +307,53 @@ class Model:
         buf = np.zeros(size.value, dtype=np.uint8)
         _check(_lib.rans_amd_model_table(self._h, which, buf.ctypes.data, buf.size, C.byref(size)), "model_table")
         return buf.view(dtype)
+
+
+# ---- container file format (include/ryg_rans_amd.h "container file format") -------------
+
+def offsets_from_lengths(lengths):
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    offs = np.zeros(lengths.size + 1, dtype=np.uint64)
+    _check(_lib.rans_amd_offsets_from_lengths(lengths.ctypes.data_as(C.POINTER(C.c_uint32)), lengths.size,
+                                              offs.ctypes.data_as(C.POINTER(C.c_uint64))), "offsets_from_lengths")
+    return offs
+
+
+def pack_container(fmt, norm_freqs, scale_bits, n_symbols, n_ways, chunk_syms, lengths, payload):
+    """Serialise model + index + payload (host numpy arrays) into one self-describing uint8 array."""
+    f = np.ascontiguousarray(norm_freqs, dtype=np.uint32)
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    info = ContainerInfo(fmt, scale_bits, f.size, n_ways, chunk_syms, 1 if f.size <= 256 else 2, n_symbols,
+                         num_chunks(n_symbols, chunk_syms), payload.size)
+    if lengths.size != info.n_chunks:
+        raise RansAmdError(E_ARG, "container_pack", "len(lengths) != number of chunks")
+    total = int(_lib.rans_amd_container_bytes(C.byref(info)))
+    if total == 0:
+        raise RansAmdError(E_ARG, "container_bytes", "inconsistent container description")
+    out = np.zeros(total, dtype=np.uint8)
+    wrote = C.c_uint64(0)
+    _check(_lib.rans_amd_container_pack(C.byref(info), f.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        lengths.ctypes.data_as(C.POINTER(C.c_uint32)), payload.ctypes.data,
+                                        out.ctypes.data, out.size, C.byref(wrote)), "container_pack")
+    return out[:wrote.value]
+
+
+def parse_container(blob):
+    """-> (ContainerInfo, freqs, lengths, payload) as numpy views into `blob` (validated)."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    info = ContainerInfo()
+    pf, pl, pp = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.c_void_p()
+    _check(_lib.rans_amd_container_parse(blob.ctypes.data, blob.size, C.byref(info), C.byref(pf), C.byref(pl),
+                                         C.byref(pp)), "container_parse")
+    base = blob.ctypes.data
+    f_off = C.addressof(pf.contents) - base
+    l_off = f_off + 4 * info.nsyms
+    p_off = pp.value - base
+    freqs = blob[f_off:f_off + 4 * info.nsyms].view(np.uint32)
+    lengths = blob[l_off:l_off + 4 * info.n_chunks].view(np.uint32)
+    payload = blob[p_off:p_off + info.payload_bytes]
+    return info, freqs, lengths, payload
 
 
 def _torch_stream():

@@ -1,0 +1,189 @@
+// container.cpp -- serialised form of a chunked rANS container (host memory only, no HIP).
+// The reference has no file format (main.cpp:182,196 keep n, tables and stream start out of
+// band); this is the self-describing wrapper SURVEY.md 8(f) item 2 asks for.  See
+// include/ryg_rans_amd.h for the layout.
+#include "../../include/ryg_rans_amd.h"
+
+#include <cstring>
+
+namespace {
+
+constexpr char kMagic[8] = {'R', 'A', 'N', 'S', 'A', 'M', 'D', '1'};
+constexpr uint32_t kVersion = 1;
+constexpr uint64_t kHeaderBytes = 80;
+
+// fixed 80-byte little-endian header
+struct Header {
+    char magic[8];
+    uint32_t version;
+    uint32_t format;
+    uint32_t scale_bits;
+    uint32_t nsyms;
+    uint32_t n_ways;
+    uint32_t chunk_syms;
+    uint32_t sym_bytes;
+    uint32_t reserved;
+    uint64_t n_symbols;
+    uint64_t n_chunks;
+    uint64_t payload_bytes;
+    uint64_t reserved2;
+    uint64_t checksum; // FNV-1a 64 over the header with this field zero, then freqs, then lengths
+};
+static_assert(sizeof(Header) == kHeaderBytes, "header layout");
+
+uint64_t fnv1a(uint64_t h, const void *data, uint64_t n)
+{
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    for (uint64_t i = 0; i < n; ++i) {
+        h ^= p[i];
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
+uint64_t align16(uint64_t v) { return (v + 15) & ~uint64_t(15); }
+
+bool info_sane(const rans_amd_container_info *i)
+{
+    if (!i || i->format > RANS_AMD_FMT_ALIAS || i->nsyms == 0 || i->nsyms > 65536 || i->scale_bits == 0 ||
+        i->scale_bits > 31 || i->chunk_syms == 0 || i->n_ways == 0 || (i->sym_bytes != 1 && i->sym_bytes != 2))
+        return false;
+    const uint64_t want_chunks = (i->n_symbols + i->chunk_syms - 1) / i->chunk_syms;
+    return want_chunks == i->n_chunks && i->n_chunks < (1ull << 40);
+}
+
+uint64_t meta_bytes(const rans_amd_container_info *i)
+{
+    return align16(kHeaderBytes + 4ull * i->nsyms + 4ull * i->n_chunks);
+}
+
+} // namespace
+
+extern "C" {
+
+int rans_amd_offsets_from_lengths(const uint32_t *lengths, uint64_t n_chunks, uint64_t *offsets)
+{
+    if (!offsets || (n_chunks && !lengths))
+        return RANS_AMD_E_ARG;
+    uint64_t at = 0;
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        offsets[c] = at;
+        if (c + 1 == n_chunks) {
+            offsets[n_chunks] = at + lengths[c];
+            return RANS_AMD_OK;
+        }
+        at += align16(lengths[c]);
+    }
+    offsets[0] = 0;
+    return RANS_AMD_OK;
+}
+
+uint64_t rans_amd_container_bytes(const rans_amd_container_info *info)
+{
+    if (!info_sane(info))
+        return 0;
+    return meta_bytes(info) + info->payload_bytes;
+}
+
+int rans_amd_container_pack(const rans_amd_container_info *info, const uint32_t *norm_freqs, const uint32_t *lengths,
+                            const void *payload, void *dst, uint64_t cap, uint64_t *out_bytes)
+{
+    if (!info_sane(info) || !norm_freqs || !dst || (info->n_chunks && (!lengths || !payload)))
+        return RANS_AMD_E_ARG;
+    // the index must describe exactly payload_bytes
+    uint64_t at = 0;
+    for (uint64_t c = 0; c < info->n_chunks; ++c)
+        at = (c + 1 == info->n_chunks) ? at + lengths[c] : at + align16(lengths[c]);
+    if (at != info->payload_bytes)
+        return RANS_AMD_E_ARG;
+    uint64_t sum = 0;
+    for (uint32_t s = 0; s < info->nsyms; ++s)
+        sum += norm_freqs[s];
+    if (sum != (1ull << info->scale_bits))
+        return RANS_AMD_E_MODEL;
+    const uint64_t total = meta_bytes(info) + info->payload_bytes;
+    if (cap < total)
+        return RANS_AMD_E_SPACE;
+
+    uint8_t *out = static_cast<uint8_t *>(dst);
+    memset(out, 0, (size_t)meta_bytes(info));
+    Header h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, kMagic, 8);
+    h.version = kVersion;
+    h.format = info->format;
+    h.scale_bits = info->scale_bits;
+    h.nsyms = info->nsyms;
+    h.n_ways = info->n_ways;
+    h.chunk_syms = info->chunk_syms;
+    h.sym_bytes = info->sym_bytes;
+    h.n_symbols = info->n_symbols;
+    h.n_chunks = info->n_chunks;
+    h.payload_bytes = info->payload_bytes;
+    uint64_t ck = fnv1a(0xcbf29ce484222325ull, &h, sizeof(h));
+    ck = fnv1a(ck, norm_freqs, 4ull * info->nsyms);
+    ck = fnv1a(ck, lengths, 4ull * info->n_chunks);
+    h.checksum = ck;
+    memcpy(out, &h, sizeof(h));
+    memcpy(out + kHeaderBytes, norm_freqs, 4ull * info->nsyms);
+    if (info->n_chunks)
+        memcpy(out + kHeaderBytes + 4ull * info->nsyms, lengths, 4ull * info->n_chunks);
+    if (info->payload_bytes)
+        memcpy(out + meta_bytes(info), payload, (size_t)info->payload_bytes);
+    if (out_bytes)
+        *out_bytes = total;
+    return RANS_AMD_OK;
+}
+
+int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container_info *info, const uint32_t **freqs,
+                             const uint32_t **lengths, const void **payload)
+{
+    if (!src || !info)
+        return RANS_AMD_E_ARG;
+    if (bytes < kHeaderBytes)
+        return RANS_AMD_E_CORRUPT;
+    Header h;
+    memcpy(&h, src, sizeof(h));
+    if (memcmp(h.magic, kMagic, 8) != 0 || h.version != kVersion)
+        return RANS_AMD_E_CORRUPT;
+    rans_amd_container_info i;
+    i.format = h.format;
+    i.scale_bits = h.scale_bits;
+    i.nsyms = h.nsyms;
+    i.n_ways = h.n_ways;
+    i.chunk_syms = h.chunk_syms;
+    i.sym_bytes = h.sym_bytes;
+    i.n_symbols = h.n_symbols;
+    i.n_chunks = h.n_chunks;
+    i.payload_bytes = h.payload_bytes;
+    if (!info_sane(&i))
+        return RANS_AMD_E_CORRUPT;
+    const uint64_t meta = meta_bytes(&i);
+    if (meta > bytes || i.payload_bytes > bytes - meta)
+        return RANS_AMD_E_CORRUPT;
+    const uint8_t *p = static_cast<const uint8_t *>(src);
+    const uint32_t *f = reinterpret_cast<const uint32_t *>(p + kHeaderBytes);
+    const uint32_t *l = reinterpret_cast<const uint32_t *>(p + kHeaderBytes + 4ull * i.nsyms);
+    const uint64_t stored = h.checksum;
+    h.checksum = 0;
+    uint64_t ck = fnv1a(0xcbf29ce484222325ull, &h, sizeof(h));
+    ck = fnv1a(ck, f, 4ull * i.nsyms);
+    ck = fnv1a(ck, l, 4ull * i.n_chunks);
+    if (ck != stored)
+        return RANS_AMD_E_CORRUPT;
+    uint64_t at = 0;
+    for (uint64_t c = 0; c < i.n_chunks; ++c)
+        at = (c + 1 == i.n_chunks) ? at + l[c] : at + align16(l[c]);
+    if (at != i.payload_bytes)
+        return RANS_AMD_E_CORRUPT;
+    *info = i;
+    if (freqs)
+        *freqs = f;
+    if (lengths)
+        *lengths = l;
+    if (payload)
+        *payload = p + meta;
+    return RANS_AMD_OK;
+}
+
+} // extern "C"
