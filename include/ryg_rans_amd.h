@@ -157,7 +157,7 @@ uint64_t rans_amd_num_chunks(uint64_t n, uint32_t chunk_syms);
 uint64_t rans_amd_chunk_bound(int format, uint32_t chunk_syms, uint32_t n_ways);
 /* Worst-case bytes of the whole container for n symbols. */
 uint64_t rans_amd_encode_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms);
-/* 1 if (format, n_ways) has a GPU kernel: n_ways in 1..64 or a multiple of 64 up to 512. */
+/* 1 if (format, n_ways) has a GPU kernel: n_ways in 1..512 (64, 128, 256: fastest paths). */
 int rans_amd_ways_supported(int format, uint32_t n_ways);
 
 /* ---- bulk encode / decode on device-resident data ------------------------- */

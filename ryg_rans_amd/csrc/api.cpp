@@ -433,7 +433,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         return fail(RANS_AMD_E_ARG, "encode: model belongs to another context");
     const int format = model->host.format;
     if (!ways_supported(format, n_ways))
-        return fail(RANS_AMD_E_UNSUPPORTED, "encode: n_ways must be 1..64, 128, 256 or 512");
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode: n_ways must be in 1..512");
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0)
         return fail(RANS_AMD_E_ARG, "encode: d_out must be 16-byte aligned");
     const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
@@ -519,7 +519,7 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         return fail(RANS_AMD_E_ARG, "decode: model belongs to another context");
     const int format = model->host.format;
     if (!ways_supported(format, n_ways))
-        return fail(RANS_AMD_E_UNSUPPORTED, "decode: n_ways must be 1..64, 128, 256 or 512");
+        return fail(RANS_AMD_E_UNSUPPORTED, "decode: n_ways must be in 1..512");
     if ((reinterpret_cast<uintptr_t>(d_container) & 15u) != 0)
         return fail(RANS_AMD_E_ARG, "decode: d_container must be 16-byte aligned");
     const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);

@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x >> 6);
     const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t N = (K > 1) ? 64u * K : p.n_ways;
+    const uint32_t N = p.n_ways; // <= 64 * K; lanes idx >= N idle
 
     EncTables<FMT> T;
     T.recs = reinterpret_cast<const uint4 *>(smem);
@@ -1478,8 +1478,15 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
         return fast ? launch_decode_t<FMT, 8, OUT_FAST8>(p, num_cus, s, name)
                     : launch_decode_t<FMT, 8, OUT_SLOW>(p, num_cus, s, name);
     default:
+        // any other lane count: K = ceil(N / 64) states per lane, the unused tail lanes idle
         if (p.n_ways >= 1 && p.n_ways < 64)
             return launch_decode_t<FMT, 1, OUT_SLOW>(p, num_cus, s, name);
+        if (p.n_ways < 128)
+            return launch_decode_t<FMT, 2, OUT_SLOW>(p, num_cus, s, name);
+        if (p.n_ways < 256)
+            return launch_decode_t<FMT, 4, OUT_SLOW>(p, num_cus, s, name);
+        if (p.n_ways < 512)
+            return launch_decode_t<FMT, 8, OUT_SLOW>(p, num_cus, s, name);
         return hipErrorInvalidValue;
     }
 }
@@ -1538,15 +1545,16 @@ template <int FMT> hipError_t launch_encode_f(const EncParams &p, int num_cus, h
         default: break;
         }
     }
-    switch (p.n_ways) {
-    case 128: return launch_encode_t<FMT, 2>(p, num_cus, s);
-    case 256: return launch_encode_t<FMT, 4>(p, num_cus, s);
-    case 512: return launch_encode_t<FMT, 8>(p, num_cus, s);
-    default:
-        if (p.n_ways >= 1 && p.n_ways <= 64)
-            return launch_encode_t<FMT, 1>(p, num_cus, s);
-        return hipErrorInvalidValue;
-    }
+    // K = ceil(N / 64) states per lane; lane counts that are not a multiple of 64 leave lanes idle
+    if (p.n_ways >= 1 && p.n_ways <= 64)
+        return launch_encode_t<FMT, 1>(p, num_cus, s);
+    if (p.n_ways <= 128)
+        return launch_encode_t<FMT, 2>(p, num_cus, s);
+    if (p.n_ways <= 256)
+        return launch_encode_t<FMT, 4>(p, num_cus, s);
+    if (p.n_ways <= 512)
+        return launch_encode_t<FMT, 8>(p, num_cus, s);
+    return hipErrorInvalidValue;
 }
 
 } // namespace
@@ -1555,7 +1563,7 @@ bool ways_supported(int format, uint32_t n_ways)
 {
     if (format < 0 || format > 3)
         return false;
-    return (n_ways >= 1 && n_ways <= 64) || n_ways == 128 || n_ways == 256 || n_ways == 512;
+    return n_ways >= 1 && n_ways <= 512;
 }
 
 hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name)

@@ -173,7 +173,8 @@ def test_layout_arithmetic():
             assert b % 16 == 0 and b >= chunk * (4 if fmt == FMT_R64 else 2) + ways * (8 if fmt == FMT_R64 else 4)
         assert R.encode_bound(fmt, 10 * 4096 + 7, 64, 4096) == 10 * R.chunk_bound(fmt, 4096, 64) + R.chunk_bound(fmt, 7, 64)
     assert R.ways_supported(FMT_WORD, 64) and R.ways_supported(FMT_BYTE, 1) and R.ways_supported(FMT_R64, 512)
-    assert not R.ways_supported(FMT_WORD, 0) and not R.ways_supported(FMT_WORD, 100) and not R.ways_supported(FMT_WORD, 1024)
+    assert R.ways_supported(FMT_WORD, 100) and R.ways_supported(FMT_ALIAS, 300)
+    assert not R.ways_supported(FMT_WORD, 0) and not R.ways_supported(FMT_WORD, 513) and not R.ways_supported(FMT_WORD, 1024)
 
 
 def test_model_rejections():
