@@ -140,6 +140,13 @@ int rans_amd_normalize_freqs(uint32_t *freqs, uint32_t *cum_freqs, uint32_t nsym
 int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_freqs, uint32_t nsyms,
                           uint32_t scale_bits, rans_amd_model **out_model);
 int rans_amd_model_destroy(rans_amd_model *model);
+/* One call for what every reference main does before coding (main.cpp:139-162):
+ * count_freqs + normalize_freqs(1 << scale_bits) + table build.  syms is host memory when
+ * syms_on_device == 0, else device memory (histogram on the GPU; synchronises `stream`).
+ * norm_freqs_out (optional, nsyms entries) receives the normalised frequencies. */
+int rans_amd_build_model_o0(rans_amd_ctx *ctx, int format, const void *syms, uint64_t n, int syms_on_device,
+                            uint32_t nsyms, uint32_t scale_bits, uint32_t *norm_freqs_out,
+                            rans_amd_model **out_model, void *stream);
 int rans_amd_model_format(const rans_amd_model *model);
 uint32_t rans_amd_model_scale_bits(const rans_amd_model *model);
 uint32_t rans_amd_model_nsyms(const rans_amd_model *model);
@@ -159,6 +166,10 @@ uint64_t rans_amd_chunk_bound(int format, uint32_t chunk_syms, uint32_t n_ways);
 uint64_t rans_amd_encode_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms);
 /* 1 if (format, n_ways) has a GPU kernel: n_ways in 1..512 (64, 128, 256: fastest paths). */
 int rans_amd_ways_supported(int format, uint32_t n_ways);
+/* Device scratch rans_amd_encode needs for this shape (one worst-case slot per chunk).  The
+ * context allocates it on first use and keeps it (rans_amd_ctx_trim releases it); this query lets
+ * a caller budget HBM up front. */
+uint64_t rans_amd_encode_workspace_bytes(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms);
 
 /* ---- bulk encode / decode on device-resident data ------------------------- */
 

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "rans_amd_encode_host", "rans_amd_decode_host",
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel",
     "rans_amd_offsets_from_lengths", "rans_amd_container_bytes", "rans_amd_container_pack",
-    "rans_amd_container_parse",
+    "rans_amd_container_parse", "rans_amd_encode_workspace_bytes", "rans_amd_build_model_o0",
 ]
 
 
@@ -101,6 +101,8 @@ def _load():
         "rans_amd_set_timing": (i32, [vp, i32]),
         "rans_amd_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "rans_amd_last_decode_kernel": (C.c_char_p, [vp]),
+        "rans_amd_encode_workspace_bytes": (u64, [i32, u64, u32, u32]),
+        "rans_amd_build_model_o0": (i32, [vp, i32, vp, u64, i32, u32, u32, u32p, C.POINTER(vp), vp]),
         "rans_amd_offsets_from_lengths": (i32, [u32p, u64, u64p]),
         "rans_amd_container_bytes": (u64, [C.POINTER(ContainerInfo)]),
         "rans_amd_container_pack": (i32, [C.POINTER(ContainerInfo), u32p, u32p, vp, vp, u64, u64p]),

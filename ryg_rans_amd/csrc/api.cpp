@@ -421,6 +421,32 @@ uint64_t rans_amd_encode_bound(int format, uint64_t n, uint32_t n_ways, uint32_t
 
 int rans_amd_ways_supported(int format, uint32_t n_ways) { return ways_supported(format, n_ways) ? 1 : 0; }
 
+uint64_t rans_amd_encode_workspace_bytes(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
+{
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    const uint64_t slot = rans_amd_chunk_bound(format, (uint32_t)(n < chunk_syms ? n : chunk_syms), n_ways);
+    return nchunks * slot + 64;
+}
+
+int rans_amd_build_model_o0(rans_amd_ctx *ctx, int format, const void *syms, uint64_t n, int syms_on_device,
+                            uint32_t nsyms, uint32_t scale_bits, uint32_t *norm_freqs_out,
+                            rans_amd_model **out_model, void *stream)
+{
+    if (!out_model || nsyms == 0 || nsyms > 65536 || scale_bits == 0 || scale_bits > 31)
+        return fail(RANS_AMD_E_ARG, "build_model_o0: bad argument");
+    std::vector<uint32_t> freqs(nsyms), cum(nsyms + 1);
+    const int sym_bytes = nsyms <= 256 ? 1 : 2;
+    int rc = syms_on_device ? rans_amd_count_freqs(ctx, syms, n, sym_bytes, nsyms, freqs.data(), stream)
+                            : rans_amd_count_freqs_host(syms, n, sym_bytes, nsyms, freqs.data());
+    if (rc == RANS_AMD_OK)
+        rc = rans_amd_normalize_freqs(freqs.data(), cum.data(), nsyms, 1u << scale_bits);
+    if (rc == RANS_AMD_OK)
+        rc = rans_amd_model_create(ctx, format, freqs.data(), nsyms, scale_bits, out_model);
+    if (rc == RANS_AMD_OK && norm_freqs_out)
+        memcpy(norm_freqs_out, freqs.data(), sizeof(uint32_t) * nsyms);
+    return rc;
+}
+
 /* ---- encode ------------------------------------------------------------- */
 
 int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,

@@ -193,3 +193,19 @@ def test_model_rejections():
     assert e.value.status == R.E_UNSUPPORTED
     with pytest.raises(R.RansAmdError):
         R.Model(None, FMT_BYTE, f, 17)  # rans_byte.h:176
+
+
+def test_build_model_o0_host_only(oracle):
+    """count + normalise + tables in one call (host symbols, host-only model)."""
+    import ctypes as C
+    data = oracle.gen_zipf(40000, K=256, s=1.0, seed=11)
+    out = C.c_void_p()
+    freqs = np.zeros(256, np.uint32)
+    rc = R.lib().rans_amd_build_model_o0(None, FMT_BYTE, data.ctypes.data, data.size, 0, 256, 14,
+                                         freqs.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(out), None)
+    assert rc == R.OK and out.value
+    f_o, _ = oracle.normalize(oracle.count_freqs(data, 256), 1 << 14)
+    assert np.array_equal(freqs, f_o)
+    assert R.lib().rans_amd_model_format(out) == FMT_BYTE and R.lib().rans_amd_model_scale_bits(out) == 14
+    R.lib().rans_amd_model_destroy(out)
+    assert R.lib().rans_amd_encode_workspace_bytes(FMT_WORD, 10 * 4096, 64, 4096) == 10 * R.chunk_bound(FMT_WORD, 4096, 64) + 64
