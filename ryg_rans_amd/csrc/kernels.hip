@@ -1413,7 +1413,10 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
         attr_set = true;
     }
     const uint64_t want = (p.nchunks + 255) / 256;
-    const uint64_t cap = (uint64_t)num_cus * (lds * 4 <= 160 * 1024 ? 4 : (lds * 2 <= 160 * 1024 ? 2 : 1));
+    // 256-thread blocks: up to 8 per CU (32 waves) when the tables leave room in LDS; the kernel
+    // is latency-bound (per-lane scattered loads), so residency matters more than anything else
+    const size_t lds_room = lds ? (160 * 1024) / lds : 8;
+    const uint64_t cap = (uint64_t)num_cus * (lds_room >= 8 ? 8 : (lds_room >= 1 ? lds_room : 1));
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     if (name)
         *name = "k_decode_lanes";

@@ -79,6 +79,7 @@ def main():
     run(ctx, "byte sb16 64-way", R.FMT_BYTE, 16, 256, 1 << big, 64, 32768)
     run(ctx, "r64 sb14 64-way", R.FMT_R64, 14, 256, 1 << big, 64, 32768)
     run(ctx, "C2 r64 sb14 2-way 256 MiB", R.FMT_R64, 14, 256, 1 << 28, 2, 4096, reps=3)
+    run(ctx, "C2 r64 2-way, 256-symbol chunks", R.FMT_R64, 14, 256, 1 << 28, 2, 256, reps=3)
     run(ctx, "C2 r64 2-way, 512-symbol chunks", R.FMT_R64, 14, 256, 1 << 28, 2, 512, reps=3)
     run(ctx, "C2 r64 2-way, 1024-symbol chunks", R.FMT_R64, 14, 256, 1 << 28, 2, 1024, reps=3)
     run(ctx, "word 2-way, 1024-symbol chunks", R.FMT_WORD, 12, 256, 1 << 28, 2, 1024, reps=3)
