@@ -241,3 +241,66 @@ def test_native_cpp_example(gpu):
     for fmt, ways in (("word", "64"), ("byte", "64"), ("r64", "2"), ("alias", "256")):
         out = subprocess.run([exe, "-", fmt, ways], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "decode ok!" in out.stdout, (fmt, out.stdout, out.stderr)
+
+
+def test_unaligned_buffers_and_streams(gpu, oracle):
+    """Symbol buffers at odd addresses take the element-wise paths; containers must be 16-byte
+    aligned (E_ARG otherwise); work on a non-default HIP stream."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(200003, K=256, s=1.0, seed=12)
+    for fmt, sb in ((FMT_WORD, 12), (FMT_BYTE, 14)):
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        want, offs, lens = oracle.encode_chunked(fmt, om, data, 64, 8192, align=16)
+        backing = torch.zeros(data.size + 64, dtype=torch.uint8, device="cuda")
+        for shift in (1, 2, 3, 5):
+            d_syms = backing[shift:shift + data.size]
+            d_syms.copy_(torch.from_numpy(data))
+            assert d_syms.data_ptr() % 4 == shift % 4
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                cont, d_offs, d_lens, total = ctx.encode(gm, d_syms, 64, 8192)
+                assert total == want.size
+                assert np.array_equal(cont[:total].cpu().numpy()[int(offs[3]):int(offs[3]) + int(lens[3])],
+                                      want[int(offs[3]):int(offs[3]) + int(lens[3])])
+                out_backing = torch.zeros(data.size + 64, dtype=torch.uint8, device="cuda")
+                d_out = out_backing[shift:shift + data.size]
+                ctx.decode(gm, cont, total, d_offs, d_lens, data.size, 64, 8192, d_out=d_out)
+            side.synchronize()
+            assert np.array_equal(d_out.cpu().numpy(), data), (fmt, shift)
+            assert int(out_backing[:shift].sum()) == 0 and int(out_backing[shift + data.size:].sum()) == 0
+        # a container that does not start on a 16-byte boundary is refused, not mis-decoded
+        cont2 = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+        cont2[8:8 + total] = cont[:total]
+        with pytest.raises(R.RansAmdError) as e:
+            ctx.decode(gm, cont2[8:], total, d_offs, d_lens, data.size, 64, 8192)
+        assert e.value.status == R.E_ARG
+
+
+def test_random_corruption_never_crashes(gpu, oracle):
+    """Fuzz: random byte flips / truncations / index damage.  The decoder may return garbage
+    symbols but must flag or survive every case (all table and window indices are masked)."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(99)
+    data = oracle.gen_zipf(150000, K=256, s=1.0, seed=13)
+    for fmt, sb, n_ways, chunk in ((FMT_WORD, 12, 64, 4096), (FMT_BYTE, 14, 64, 4096), (FMT_R64, 14, 2, 512),
+                                   (FMT_ALIAS, 16, 128, 8192)):
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        cont, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+        d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+        for trial in range(12):
+            bad = cont.copy()
+            l2 = lens.copy()
+            kind = trial % 3
+            if kind == 0:
+                idx = rng.integers(0, bad.size, 40)
+                bad[idx] ^= rng.integers(1, 256, 40).astype(np.uint8)
+            elif kind == 1:
+                bad[rng.integers(0, bad.size):] = 0
+            else:
+                l2[rng.integers(0, l2.size, 3)] = rng.integers(0, 1 << 20, 3).astype(np.uint32)
+            d_cont = torch.from_numpy(np.concatenate([bad, np.zeros(64, np.uint8)])).cuda()
+            d_lens = torch.from_numpy(l2.astype(np.int32)).cuda()
+            out = ctx.decode(gm, d_cont, bad.size, d_offs, d_lens, data.size, n_ways, chunk, sync=False)
+            nbad = ctx.decode_errors()
+            same = np.array_equal(out.cpu().numpy(), data)
+            assert nbad > 0 or same, (fmt, trial)
