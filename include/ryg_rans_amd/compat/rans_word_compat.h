@@ -119,59 +119,83 @@ static inline void RansSimdDecInit(RansSimdDec *r, uint16_t **pptr)
     *pptr += 8; /* four states of two words each */
 }
 
-/* returns the four symbols, lane 0 in the low byte */
+/* returns the four symbols, lane 0 in the low byte.  The four table records are gathered
+ * with pextrd/pinsrd so nothing bounces through memory (a store of four scalars followed
+ * by a vector load would miss store forwarding). */
 static inline uint32_t RansSimdDecSym(RansSimdDec *r, RansWordTables const *tab)
 {
     const __m128i x = r->simd;
-    RansSimdDec slot;
-    slot.simd = _mm_and_si128(x, _mm_set1_epi32(RANS_WORD_M - 1));
-    uint32_t syms = 0;
-    uint32_t rec[4];
-    for (int i = 0; i < 4; i++) {
-        syms |= (uint32_t)tab->slot2sym[slot.lane[i]] << (8 * i);
-        rec[i] = tab->slots[slot.lane[i]].u32;
-    }
-    const __m128i fb = _mm_loadu_si128(reinterpret_cast<const __m128i *>(rec));
+    const __m128i slots = _mm_and_si128(x, _mm_set1_epi32(RANS_WORD_M - 1));
+    const uint32_t i0 = (uint32_t)_mm_cvtsi128_si32(slots);
+    const uint32_t i1 = (uint32_t)_mm_extract_epi32(slots, 1);
+    const uint32_t i2 = (uint32_t)_mm_extract_epi32(slots, 2);
+    const uint32_t i3 = (uint32_t)_mm_extract_epi32(slots, 3);
+    __m128i fb = _mm_cvtsi32_si128((int)tab->slots[i0].u32);
+    fb = _mm_insert_epi32(fb, (int)tab->slots[i1].u32, 1);
+    fb = _mm_insert_epi32(fb, (int)tab->slots[i2].u32, 2);
+    fb = _mm_insert_epi32(fb, (int)tab->slots[i3].u32, 3);
+    const uint32_t syms = (uint32_t)tab->slot2sym[i0] | ((uint32_t)tab->slot2sym[i1] << 8) |
+                          ((uint32_t)tab->slot2sym[i2] << 16) | ((uint32_t)tab->slot2sym[i3] << 24);
     const __m128i freq = _mm_and_si128(fb, _mm_set1_epi32(0xffff));
     const __m128i bias = _mm_srli_epi32(fb, 16);
+    /* freq < 2^12 and x >> 12 < 2^20: the low 32 bits of the product are exact */
     r->simd = _mm_add_epi32(_mm_mullo_epi32(_mm_srli_epi32(x, RANS_WORD_SCALE_BITS), freq), bias);
     return syms;
 }
-
-/* pshufb controls: lanes set in `mask` receive consecutive stream words in lane order */
-struct RansWordCompatShuffles {
-    int8_t ctl[16][16];
-    uint8_t words[16];
-    RansWordCompatShuffles()
-    {
-        for (int mask = 0; mask < 16; mask++) {
-            int next = 0;
-            memset(ctl[mask], -1, 16); /* -1 = write zero */
-            for (int lane = 0; lane < 4; lane++)
-                if (mask & (1 << lane)) {
-                    ctl[mask][4 * lane + 0] = (int8_t)(2 * next);
-                    ctl[mask][4 * lane + 1] = (int8_t)(2 * next + 1);
-                    next++;
-                }
-            words[mask] = (uint8_t)next;
-        }
-    }
-};
 
 /* NOTE: like the original API this reads 8 bytes at *pptr whatever the mask is; keep 8 bytes
  * of padding behind the stream (the GPU path has no such requirement). */
 static inline void RansSimdDecRenorm(RansSimdDec *r, uint16_t **pptr)
 {
-    static const RansWordCompatShuffles tbl;
+    /* pshufb controls: the lanes set in the mask receive consecutive stream words, in lane
+     * order, in their low half; -1 writes zero.  Literal so no initialisation guard runs. */
+    static const int8_t ctl_tab[16][16] __attribute__((aligned(16))) = {
+        {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, /* lanes 0000 */
+        { 0,  1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, /* lanes 0001 */
+        {-1, -1, -1, -1,  0,  1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, /* lanes 0010 */
+        { 0,  1, -1, -1,  2,  3, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, /* lanes 0011 */
+        {-1, -1, -1, -1, -1, -1, -1, -1,  0,  1, -1, -1, -1, -1, -1, -1}, /* lanes 0100 */
+        { 0,  1, -1, -1, -1, -1, -1, -1,  2,  3, -1, -1, -1, -1, -1, -1}, /* lanes 0101 */
+        {-1, -1, -1, -1,  0,  1, -1, -1,  2,  3, -1, -1, -1, -1, -1, -1}, /* lanes 0110 */
+        { 0,  1, -1, -1,  2,  3, -1, -1,  4,  5, -1, -1, -1, -1, -1, -1}, /* lanes 0111 */
+        {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,  0,  1, -1, -1}, /* lanes 1000 */
+        { 0,  1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,  2,  3, -1, -1}, /* lanes 1001 */
+        {-1, -1, -1, -1,  0,  1, -1, -1, -1, -1, -1, -1,  2,  3, -1, -1}, /* lanes 1010 */
+        { 0,  1, -1, -1,  2,  3, -1, -1, -1, -1, -1, -1,  4,  5, -1, -1}, /* lanes 1011 */
+        {-1, -1, -1, -1, -1, -1, -1, -1,  0,  1, -1, -1,  2,  3, -1, -1}, /* lanes 1100 */
+        { 0,  1, -1, -1, -1, -1, -1, -1,  2,  3, -1, -1,  4,  5, -1, -1}, /* lanes 1101 */
+        {-1, -1, -1, -1,  0,  1, -1, -1,  2,  3, -1, -1,  4,  5, -1, -1}, /* lanes 1110 */
+        { 0,  1, -1, -1,  2,  3, -1, -1,  4,  5, -1, -1,  6,  7, -1, -1}, /* lanes 1111 */
+    };
+    /* companion control applied to the states: a refilled lane moves its low half up */
+    static const int8_t shift_tab[16][16] __attribute__((aligned(16))) = {
+        { 0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 15}, /* lanes 0000 */
+        {-1, -1,  0,  1,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 15}, /* lanes 0001 */
+        { 0,  1,  2,  3, -1, -1,  4,  5,  8,  9, 10, 11, 12, 13, 14, 15}, /* lanes 0010 */
+        {-1, -1,  0,  1, -1, -1,  4,  5,  8,  9, 10, 11, 12, 13, 14, 15}, /* lanes 0011 */
+        { 0,  1,  2,  3,  4,  5,  6,  7, -1, -1,  8,  9, 12, 13, 14, 15}, /* lanes 0100 */
+        {-1, -1,  0,  1,  4,  5,  6,  7, -1, -1,  8,  9, 12, 13, 14, 15}, /* lanes 0101 */
+        { 0,  1,  2,  3, -1, -1,  4,  5, -1, -1,  8,  9, 12, 13, 14, 15}, /* lanes 0110 */
+        {-1, -1,  0,  1, -1, -1,  4,  5, -1, -1,  8,  9, 12, 13, 14, 15}, /* lanes 0111 */
+        { 0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, -1, -1, 12, 13}, /* lanes 1000 */
+        {-1, -1,  0,  1,  4,  5,  6,  7,  8,  9, 10, 11, -1, -1, 12, 13}, /* lanes 1001 */
+        { 0,  1,  2,  3, -1, -1,  4,  5,  8,  9, 10, 11, -1, -1, 12, 13}, /* lanes 1010 */
+        {-1, -1,  0,  1, -1, -1,  4,  5,  8,  9, 10, 11, -1, -1, 12, 13}, /* lanes 1011 */
+        { 0,  1,  2,  3,  4,  5,  6,  7, -1, -1,  8,  9, -1, -1, 12, 13}, /* lanes 1100 */
+        {-1, -1,  0,  1,  4,  5,  6,  7, -1, -1,  8,  9, -1, -1, 12, 13}, /* lanes 1101 */
+        { 0,  1,  2,  3, -1, -1,  4,  5, -1, -1,  8,  9, -1, -1, 12, 13}, /* lanes 1110 */
+        {-1, -1,  0,  1, -1, -1,  4,  5, -1, -1,  8,  9, -1, -1, 12, 13}, /* lanes 1111 */
+    };
+    static const uint8_t words_tab[16] = {0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4};
     const __m128i x = r->simd;
     /* x < 2^16  <=>  high half is zero */
     const __m128i low = _mm_cmpeq_epi32(_mm_srli_epi32(x, 16), _mm_setzero_si128());
     const int mask = _mm_movemask_ps(_mm_castsi128_ps(low));
     const __m128i next = _mm_loadl_epi64(reinterpret_cast<const __m128i *>(*pptr));
-    const __m128i ctl = _mm_loadu_si128(reinterpret_cast<const __m128i *>(tbl.ctl[mask]));
-    const __m128i refilled = _mm_or_si128(_mm_slli_epi32(x, 16), _mm_shuffle_epi8(next, ctl));
-    r->simd = _mm_blendv_epi8(x, refilled, low);
-    *pptr += tbl.words[mask];
+    const __m128i ctl = _mm_load_si128(reinterpret_cast<const __m128i *>(ctl_tab[mask]));
+    const __m128i shf = _mm_load_si128(reinterpret_cast<const __m128i *>(shift_tab[mask]));
+    r->simd = _mm_or_si128(_mm_shuffle_epi8(x, shf), _mm_shuffle_epi8(next, ctl));
+    *pptr += words_tab[mask];
 }
 
 #endif /* RANS_WORD_COMPAT_SIMD */
