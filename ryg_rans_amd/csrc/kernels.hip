@@ -1312,11 +1312,84 @@ __global__ void __launch_bounds__(256) k_compact(const CompactParams p)
 }
 
 // ---------------------------------------------------------------------------
-// Histogram (count_freqs, main.cpp:59-66): per-block LDS histogram, merged
-// with global atomics.
+// Histogram (count_freqs, main.cpp:59-66).  1 byte of HBM traffic per symbol, so the LDS
+// atomic rate is what has to keep up: a skewed source (Zipf: the top symbol is 16 % of
+// the input) sends ~10 lanes of every wave to the same counter, and same-bank atomics
+// serialise.  u8 path: every wave owns kHistCopies private copies of the 256 counters, a
+// lane uses copy (lane & 7), and the copies start 8 banks apart, so the lanes that hit
+// one symbol spread over eight banks; counters of symbols >= nsyms are simply counted and
+// flagged at the end (no per-symbol range check).  u16 path (alphabets up to 4096): one
+// table per block.
 // ---------------------------------------------------------------------------
-template <int SYM_BYTES> __global__ void __launch_bounds__(256) k_histogram(const void *syms, uint64_t n, uint32_t nsyms,
-                                                                             uint32_t *hist, uint32_t *flags)
+constexpr uint32_t kHistCopies = 8;
+constexpr uint32_t kHistCopyStride = 256 + 8; // dwords: copy c starts in bank 8 * c
+
+__global__ void __launch_bounds__(256) k_histogram_u8(const void *syms, uint64_t n, uint32_t nsyms, uint32_t *hist,
+                                                      uint32_t *flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *all = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t waves = blockDim.x >> 6;
+    const uint32_t total = waves * kHistCopies * kHistCopyStride;
+    for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
+        all[i] = 0;
+    __syncthreads();
+    uint32_t *h = all + ((threadIdx.x >> 6) * kHistCopies + (threadIdx.x & (kHistCopies - 1))) * kHistCopyStride;
+
+    const uint8_t *p = static_cast<const uint8_t *>(syms);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 16-byte loads from the first aligned address on; the ragged head and tail go bytewise
+    const uint64_t head = (16u - (reinterpret_cast<uintptr_t>(p) & 15u)) & 15u;
+    const uint64_t nhead = head < n ? head : n;
+    const uint64_t nvec = (n - nhead) / 16;
+    gvec_cptr pv = reinterpret_cast<gvec_cptr>(reinterpret_cast<uintptr_t>(p + nhead));
+    auto count4 = [&](uint32_t w) {
+        atomicAdd(&h[w & 0xffu], 1u);
+        atomicAdd(&h[(w >> 8) & 0xffu], 1u);
+        atomicAdd(&h[(w >> 16) & 0xffu], 1u);
+        atomicAdd(&h[w >> 24], 1u);
+    };
+    uint64_t i = tid;
+    if (i < nvec) {
+        u32x4 v = __builtin_nontemporal_load(pv + i);
+        for (i += stride; i < nvec; i += stride) { // next load in flight while this one is counted
+            const u32x4 nv = __builtin_nontemporal_load(pv + i);
+            count4(v.x);
+            count4(v.y);
+            count4(v.z);
+            count4(v.w);
+            v = nv;
+        }
+        count4(v.x);
+        count4(v.y);
+        count4(v.z);
+        count4(v.w);
+    }
+    for (uint64_t j = tid; j < nhead; j += stride)
+        atomicAdd(&h[p[j]], 1u);
+    for (uint64_t j = nhead + nvec * 16 + tid; j < n; j += stride)
+        atomicAdd(&h[p[j]], 1u);
+    __syncthreads();
+
+    bool bad = false;
+    for (uint32_t b = threadIdx.x; b < 256u; b += blockDim.x) {
+        uint32_t sum = 0;
+        for (uint32_t c = 0; c < waves * kHistCopies; ++c)
+            sum += all[c * kHistCopyStride + b];
+        if (sum) {
+            if (b < nsyms)
+                atomicAdd(&hist[b], sum);
+            else
+                bad = true;
+        }
+    }
+    if (bad)
+        atomicOr(flags, 1u);
+}
+
+__global__ void __launch_bounds__(256) k_histogram_u16(const void *syms, uint64_t n, uint32_t nsyms, uint32_t *hist,
+                                                       uint32_t *flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
@@ -1325,41 +1398,32 @@ template <int SYM_BYTES> __global__ void __launch_bounds__(256) k_histogram(cons
     __syncthreads();
     bool bad = false;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    if constexpr (SYM_BYTES == 1) {
-        const uint8_t *p = static_cast<const uint8_t *>(syms);
-        const uint64_t nvec = (reinterpret_cast<uintptr_t>(p) & 15u) ? 0 : n / 16;
-        const uint4 *pv = reinterpret_cast<const uint4 *>(p);
-        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-            const uint4 v = pv[i];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint16_t *p = static_cast<const uint16_t *>(syms);
+    auto count1 = [&](uint32_t sym) {
+        if (sym < nsyms)
+            atomicAdd(&h[sym], 1u);
+        else
+            bad = true;
+    };
+    // 16-byte loads (8 symbols) from the first aligned address on
+    const uint64_t head = ((16u - (reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) / 2;
+    const uint64_t nhead = head < n ? head : n;
+    const uint64_t nvec = (n - nhead) / 8;
+    gvec_cptr pv = reinterpret_cast<gvec_cptr>(reinterpret_cast<uintptr_t>(p + nhead));
+    for (uint64_t i = tid; i < nvec; i += stride) {
+        const u32x4 v = __builtin_nontemporal_load(pv + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const uint32_t s = (w[a] >> (8 * b)) & 0xffu;
-                    if (s < nsyms)
-                        atomicAdd(&h[s], 1u);
-                    else
-                        bad = true;
-                }
-        }
-        for (uint64_t i = nvec * 16 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-            const uint32_t s = p[i];
-            if (s < nsyms)
-                atomicAdd(&h[s], 1u);
-            else
-                bad = true;
-        }
-    } else {
-        const uint16_t *p = static_cast<const uint16_t *>(syms);
-        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-            const uint32_t s = p[i];
-            if (s < nsyms)
-                atomicAdd(&h[s], 1u);
-            else
-                bad = true;
+        for (int a = 0; a < 4; ++a) {
+            count1(w[a] & 0xffffu);
+            count1(w[a] >> 16);
         }
     }
+    for (uint64_t j = tid; j < nhead; j += stride)
+        count1(p[j]);
+    for (uint64_t j = nhead + nvec * 8 + tid; j < n; j += stride)
+        count1(p[j]);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nsyms; i += blockDim.x)
         if (h[i])
@@ -1609,12 +1673,14 @@ hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t strea
 hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
                             uint32_t *d_flags, int num_cus, hipStream_t stream)
 {
-    const size_t lds = (size_t)nsyms * 4;
     const uint32_t grid = (uint32_t)num_cus * 4;
-    if (sym_bytes == 1)
-        hipLaunchKernelGGL(k_histogram<1>, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
-    else
-        hipLaunchKernelGGL(k_histogram<2>, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+    if (sym_bytes == 1) {
+        const size_t lds = (size_t)(256 / 64) * kHistCopies * kHistCopyStride * 4;
+        hipLaunchKernelGGL(k_histogram_u8, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+    } else {
+        const size_t lds = (size_t)nsyms * 4;
+        hipLaunchKernelGGL(k_histogram_u16, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+    }
     return hipGetLastError();
 }
 
