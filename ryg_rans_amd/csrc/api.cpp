@@ -100,6 +100,7 @@ struct rans_amd_model {
     void *d_table0 = nullptr;
     void *d_table1 = nullptr;
     void *d_enc = nullptr;
+    void *d_word_enc = nullptr;
     void *d_remap = nullptr;
     uint32_t table0_bytes = 0, table1_bytes = 0;
 };
@@ -342,6 +343,8 @@ int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_fr
     }
     if (rc == RANS_AMD_OK)
         rc = upload(h.enc_recs.data(), h.enc_recs.size() * sizeof(EncRec), &m->d_enc);
+    if (rc == RANS_AMD_OK && !h.word_enc_recs.empty())
+        rc = upload(h.word_enc_recs.data(), h.word_enc_recs.size() * sizeof(WordEncRec), &m->d_word_enc);
     if (rc == RANS_AMD_OK) {
         const size_t lds = (size_t)((m->table0_bytes + 15u) & ~15u) + ((m->table1_bytes + 15u) & ~15u) +
                            (size_t)(kDecBlockThreads / 64) * kRingStride;
@@ -362,7 +365,7 @@ int rans_amd_model_destroy(rans_amd_model *m)
         return RANS_AMD_OK;
     if (m->ctx) {
         DeviceGuard guard(m->ctx->device);
-        for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_remap})
+        for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_word_enc, m->d_remap})
             if (p)
                 (void)hipFree(p);
     }
@@ -488,6 +491,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         ep.slot_bytes = slot;
         ep.lengths = d_lengths;
         ep.enc_recs = model->d_enc;
+        ep.word_enc_recs = model->d_word_enc;
         ep.alias_remap = static_cast<const uint32_t *>(model->d_remap);
         ep.nsyms = model->host.nsyms;
         ep.scale_bits = model->host.scale_bits;

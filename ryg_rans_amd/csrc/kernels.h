@@ -53,6 +53,7 @@ struct EncParams {
     uint64_t slot_bytes;  // multiple of 16
     uint32_t *lengths;    // out: stream bytes per chunk
     const void *enc_recs; // EncRec[nsyms]
+    const void *word_enc_recs; // WordEncRec[256] (FMT_WORD only, else NULL)
     const uint32_t *alias_remap;
     uint32_t nsyms;
     uint32_t scale_bits;

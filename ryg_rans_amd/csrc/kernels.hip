@@ -752,6 +752,48 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
     }
 }
 
+// Hand-written encoder sub-step of the word format for a FULL wave (64 active lanes, symbols
+// already turned into LDS addresses of their WordEncRec): rans_word_sse41.h:81-93 for 64 lanes.
+//   v_add_co    carry of x + (cmpl << 20)  <=>  x >= freq << 20: the lanes that emit a word
+//   s_bcnt1 ..  words emitted -> the wave's write offset moves down (these SALU ops are also the
+//               wait states a VALU write of vcc needs before v_mbcnt may read it)
+//   v_mbcnt x2  rank among the emitting lanes = word index (ascending lane = ascending address)
+//   global_store_short + v_lshrrev under the emit mask, then exec back to all ones
+//   x / freq    round-up reciprocal (model.h, WordEncRec): one v_mul_hi_u32 and four cheap ops,
+//               exact, so no compare/select; x' = x + bias + q * cmpl in one v_mad_u32_u24 + add
+// 15 VALU, no v_cndmask, no branch.  `wp` is the byte offset of the lowest word written so far.
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x3 &rec, uint32_t &wp,
+                                              const uint8_t RANS_GLOBAL *slot, uint32_t &worst)
+{
+    uint32_t t, q, sh, cnt;
+    asm volatile("v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
+                 "v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                 "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
+                 "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                 "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
+                 "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
+                 "s_mov_b64 exec, vcc\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
+                 "global_store_short %[t], %[x], %[base]\n\t"
+                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                 "s_mov_b64 exec, -1\n\t"
+                 "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
+                 "v_lshrrev_b32_e32 %[sh], 24, %[w]\n\t"
+                 "v_sub_u32_e32 %[t], %[x], %[q]\n\t"
+                 "v_lshrrev_b32_e32 %[t], 1, %[t]\n\t"
+                 "v_add_u32_e32 %[q], %[q], %[t]\n\t"
+                 "v_lshrrev_b32_e32 %[q], %[sh], %[q]\n\t"
+                 "v_mad_u32_u24 %[q], %[q], %[w], %[x]\n\t"
+                 "v_add_u32_e32 %[x], %[q], %[bias]"
+                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [sh] "=&v"(sh),
+                   [cnt] "=&s"(cnt)
+                 : [m] "v"(rec.x), [w] "v"(rec.y), [bias] "v"(rec.z), [base] "s"(slot)
+                 : "vcc", "scc", "memory");
+}
+
 template <int FMT, int K>
 __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
 {
@@ -759,9 +801,18 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
     using state_t = typename Tr::state_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
+    // word format: the 256 WordEncRec of the full-wave path come first (LDS address = sym << 4),
+    // the per-symbol EncRec table of the general path behind them
+    constexpr uint32_t kWordRecBytes = FMT == FMT_WORD ? 256u * (uint32_t)sizeof(WordEncRec) : 0u;
+    if constexpr (FMT == FMT_WORD) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.word_enc_recs);
+        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x)
+            l[i] = g[i];
+    }
     {
         const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
-        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        uint4 *l = reinterpret_cast<uint4 *>(smem + kWordRecBytes);
         for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
             l[i] = g[i];
     }
@@ -773,7 +824,7 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
     const uint32_t N = p.n_ways; // <= 64 * K; lanes idx >= N idle
 
     EncTables<FMT> T;
-    T.recs = reinterpret_cast<const uint4 *>(smem);
+    T.recs = reinterpret_cast<const uint4 *>(smem + kWordRecBytes);
     T.alias_remap = p.alias_remap;
     T.scale_bits = p.scale_bits;
     T.nsyms = p.nsyms;
@@ -806,7 +857,9 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
         // one super-group (16 rounds) ahead of the arithmetic.
         const bool fast_in = p.sym_bytes == 1 && N == p.n_ways && (N & 63u) == 0 &&
                              ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 3u) == 0;
-        const uint32_t fast_rounds = fast_in ? (rounds & ~15u) : 0u;
+        // (the word path addresses its record table by raw LDS address: dynamic LDS must start at 0)
+        const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem == 0u;
+        const uint32_t fast_rounds = (fast_in && (FMT != FMT_WORD || lds_at_zero)) ? (rounds & ~15u) : 0u;
 
         // rounds from last to first; round `rounds` is the partial one
         for (uint32_t rr = rounds + 1; rr-- > fast_rounds;) {
@@ -830,7 +883,10 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
             }
         }
 
+        uint32_t worst = 0; // word fast path: max of cmpl_sh, > 0x0fffffff iff a symbol has no record
         if (fast_rounds) {
+            uint32_t rec_mask = 0xff0u;
+            asm volatile("" : "+v"(rec_mask)); // keep the mask in a VGPR (a literal operand costs a slower VALU form)
             uint32_t cur[4][K], nxt[4][K];
             auto load_super = [&](uint32_t (&dstq)[4][K], uint32_t sg) {
 #pragma unroll
@@ -851,11 +907,30 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
 #pragma unroll
                     for (int k = 0; k < K; ++k)
                         t[k] = quad_transpose(cur[j][k], sel1, sel2);
+                if constexpr (FMT == FMT_WORD) {
+                    // symbol byte J -> LDS address of its record, (sym << 4) + table offset; the record
+                    // of the next sub-step is read before the current one is worked on (the asm block is
+                    // a scheduling barrier for the compiler)
+                    auto rec_at = [&](int step) { // step 0 = (J 3, k K-1), descending
+                        const int J = 3 - step / K, k = K - 1 - step % K;
+                        const uint32_t at = (J == 0 ? (t[k] << 4) : (t[k] >> (8 * J - 4))) & rec_mask;
+                        return *reinterpret_cast<const __attribute__((address_space(3))) u32x3 *>((uintptr_t)at); // table at LDS address 0
+                    };
+                    u32x3 rec = rec_at(0);
+#pragma unroll
+                    for (int step = 0; step < 4 * K; ++step) {
+                        const u32x3 now = rec;
+                        if (step + 1 < 4 * K)
+                            rec = rec_at(step + 1);
+                        enc_word_full(x[K - 1 - step % K], now, wp, slot, worst);
+                    }
+                } else {
 #pragma unroll
                     for (int J = 3; J >= 0; --J)
 #pragma unroll
                         for (int k = K - 1; k >= 0; --k)
                             enc_substep<FMT>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
+                }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -865,6 +940,8 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
             }
         }
 
+        if (worst > 0x0fffffffu)
+            bad = true;
         // flush: lane N-1 first, i.e. lane 0's state ends up first in memory
         // (main.cpp:244-245, main_simd.cpp:298-299)
         wp -= N * Tr::kStateBytes;
@@ -1561,8 +1638,8 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
 template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num_cus, hipStream_t stream)
 {
     const uint32_t waves = kEncBlockThreads / 64;
-    const size_t lds = (size_t)p.nsyms * sizeof(EncRec);
-    if (lds > 128 * 1024)
+    const size_t lds = (size_t)p.nsyms * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
+    if (lds > 128 * 1024 || (FMT == FMT_WORD && !p.word_enc_recs))
         return hipErrorInvalidValue;
     auto kern = k_encode<FMT, K>;
     static bool attr_set = false;

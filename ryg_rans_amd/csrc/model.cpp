@@ -202,6 +202,19 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
             uint32_t s = cum2sym[slot];
             word_slots[slot] = WordSlot{freqs[s] | (s << 24), slot - cum[s]};
         }
+        word_enc_recs.assign(256, WordEncRec{0u, 0xffffffffu, 0u, 0u});
+        for (uint32_t s = 0; s < ns; ++s) {
+            const uint32_t f = freqs[s];
+            if (f == 0)
+                continue;
+            if (f == 1) {
+                word_enc_recs[s] = WordEncRec{0xffffffffu, M - 1, cum[s] + M - 1, 0u};
+                continue;
+            }
+            const uint32_t l = ceil_log2(f);
+            const uint64_t mprime = (((uint64_t)1 << 32) * (((uint64_t)1 << l) - f)) / f + 1;
+            word_enc_recs[s] = WordEncRec{(uint32_t)mprime, (M - f) | ((l - 1) << 24), cum[s], 0u};
+        }
     }
     if (fmt == RANS_AMD_FMT_ALIAS) {
         int rc = build_alias();

@@ -69,6 +69,24 @@ struct EncRec {
     // FMT_R64 reuses the slots as {freq | rshift << 24, start, rcp64 lo, rcp64 hi} (model.cpp)
 };
 
+// WordEncRec: encoder record of the word format for the full-wave kernel path (always 256 of them;
+// symbols outside the model carry cmpl_sh = 0xffffffff, which the kernel tracks with one v_max).
+// 12 bytes of payload on a 16-byte stride: the kernel reads them with one ds_read_b96 -- the LDS
+// pipe (bank conflicts between different symbols' records) is the encoder's bottleneck.
+// x / freq comes from the round-up method of Granlund & Montgomery for 32-bit dividends:
+//   t = mulhi(x, mprime); q = (t + ((x - t) >> 1)) >> sh      (exact for every 32-bit x, freq >= 2)
+// and the state update is x + bias + q * cmpl with cmpl = 4096 - freq, which equals
+// (q << 12) + x % freq + start (rans_word_sse41.h:92).  freq == 1 uses mprime = 2^32 - 1, sh = 0
+// (q = x - 1) with bias = start + 4095, cmpl = 4095 -- the same identity rans_byte.h:186-199 uses.
+// The renormalisation test x >= freq << 20 (rans_word_sse41.h:85) is the carry of
+// x + (cmpl << 20): (4096 - freq) << 20 = 2^32 - (freq << 20).
+struct WordEncRec {
+    uint32_t mprime;
+    uint32_t cmpl_sh; // cmpl (bits 0..23, feeds v_mad_u32_u24 directly) | sh << 24
+    uint32_t bias;
+    uint32_t pad;
+};
+
 int count_freqs_host(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *freqs);
 int normalize_freqs(uint32_t *freqs, uint32_t *cum, uint32_t nsyms, uint32_t target_total);
 
@@ -91,6 +109,7 @@ struct HostModel {
     std::vector<SymRec> sym_recs;       // [nsyms]          FMT_BYTE / FMT_R64
     std::vector<AliasHalf> alias_halves; // [2*nsyms]        FMT_ALIAS
     std::vector<EncRec> enc_recs;       // [nsyms]          all formats
+    std::vector<WordEncRec> word_enc_recs; // [256]         FMT_WORD
 
     // Returns a rans_amd_status.
     int build(int format, const uint32_t *norm_freqs, uint32_t nsyms, uint32_t scale_bits);

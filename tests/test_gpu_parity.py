@@ -199,6 +199,26 @@ def test_device_histogram(gpu, oracle):
     data16 = oracle.gen_zipf(300001, K=4096, s=1.0, seed=4)
     got = ctx.count_freqs_device(torch.from_numpy(data16.view(np.int16)).cuda(), 4096)
     assert np.array_equal(got, oracle.count_freqs(data16, 4096))
+    # ragged head / tail around the 16-byte vector body, tiny and empty inputs
+    d8 = torch.from_numpy(data).cuda()
+    d16 = torch.from_numpy(data16.view(np.int16)).cuda()
+    for lo, hi in ((1, 1 << 20), (3, 70001), (15, 16), (5, 5), (7, 38), (16, 1 << 19)):
+        assert np.array_equal(ctx.count_freqs_device(d8[lo:hi], 256), oracle.count_freqs(data[lo:hi], 256)), (lo, hi)
+    for lo, hi in ((1, 300001), (3, 4), (7, 7), (5, 20), (8, 300000)):
+        assert np.array_equal(ctx.count_freqs_device(d16[lo:hi], 4096),
+                              oracle.count_freqs(data16[lo:hi], 4096)), (lo, hi)
+    # a symbol outside the declared alphabet is an error, not a silent drop (both widths)
+    small = (data & 63).copy()
+    small[12345] = 64
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.count_freqs_device(torch.from_numpy(small).cuda(), 64)
+    assert e.value.status == R.E_ARG
+    small[12345] = 63
+    assert np.array_equal(ctx.count_freqs_device(torch.from_numpy(small).cuda(), 64), oracle.count_freqs(small, 64))
+    bad16 = data16.copy()
+    bad16[77] = 4096
+    with pytest.raises(R.RansAmdError):
+        ctx.count_freqs_device(torch.from_numpy(bad16.view(np.int16)).cuda(), 4096)
 
 
 def test_full_size_roundtrip_properties(gpu):
@@ -304,3 +324,50 @@ def test_random_corruption_never_crashes(gpu, oracle):
             nbad = ctx.decode_errors()
             same = np.array_equal(out.cpu().numpy(), data)
             assert nbad > 0 or same, (fmt, trial)
+
+
+def test_word_encoder_full_wave_path_extremes(gpu, oracle):
+    """The hand-written word encoder sub-step (full waves, >= 16 rounds): every frequency class
+    of its division-free update -- freq 1 (q = x - 1 identity), powers of two, the largest
+    frequencies (dividend >= 2^31), a 4095/1 split -- against the oracle byte for byte, for 64-,
+    128- and 256-way, and a symbol without a record anywhere in a chunk is E_MODEL."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(21)
+    n = 1 << 17
+    cases = []
+    f = np.zeros(256, np.uint32); f[0] = 4095; f[200] = 1
+    cases.append(("4095/1", f, rng.choice([0, 200], n, p=[0.999, 0.001]).astype(np.uint8)))
+    f = np.zeros(256, np.uint32); f[:16] = [2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4, 2, 1, 1, 0, 0, 0]; f[15] = 0
+    f[13] = 0; f[14] = 0
+    assert f.sum() == 4096
+    cases.append(("powers of two", f, rng.choice(13, n, p=f[:13] / 4096.0).astype(np.uint8)))
+    f = np.ones(256, np.uint32); f[3] = 4096 - 255
+    cases.append(("3841 + 255 x 1", f, rng.choice(256, n, p=f / 4096.0).astype(np.uint8)))
+    f = np.zeros(256, np.uint32); f[10] = 2049; f[11] = 2047
+    cases.append(("2049/2047", f, rng.integers(10, 12, n).astype(np.uint8)))
+    f = np.zeros(256, np.uint32); f[:5] = [3, 5, 7, 4081 - 1365, 1365]
+    cases.append(("odd", f, rng.choice(5, n, p=f[:5] / 4096.0).astype(np.uint8)))
+    for name, f, data in cases:
+        om = oracle.model(f, 12)
+        gm = ctx.model(FMT_WORD, f, 12)
+        d = torch.from_numpy(data).cuda()
+        for n_ways, chunk in ((64, 8192), (128, 16384), (256, 32768), (64, n)):
+            want, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, n_ways, chunk, align=16)
+            cont, d_offs, d_lens, total = ctx.encode(gm, d, n_ways, chunk)
+            assert total == want.size, (name, n_ways)
+            assert np.array_equal(d_lens.cpu().numpy().astype(np.int64), lens.astype(np.int64)), (name, n_ways)
+            got = cont[:total].cpu().numpy()
+            for c in range(len(lens)):
+                o, ln = int(offs[c]), int(lens[c])
+                assert np.array_equal(got[o:o + ln], want[o:o + ln]), (name, n_ways, c)
+            out = ctx.decode(gm, cont, total, d_offs, d_lens, n, n_ways, chunk)
+            assert np.array_equal(out.cpu().numpy(), data), (name, n_ways)
+    # a symbol the model has no record for, deep inside the full-wave part of a chunk
+    name, f, data = cases[1]
+    gm = ctx.model(FMT_WORD, f, 12)
+    for bad_sym in (13, 255):
+        bad = data.copy()
+        bad[5 * 8192 + 4321] = bad_sym
+        with pytest.raises(R.RansAmdError) as e:
+            ctx.encode(gm, torch.from_numpy(bad).cuda(), 64, 8192)
+        assert e.value.status == R.E_MODEL
