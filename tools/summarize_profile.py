@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short_name(name):
-    m = re.search(r"(k_[a-z_]+(<[^>]*>)?)", name)
+    m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", name)
     return m.group(1) if m else name[:40]
 
 
