@@ -82,6 +82,7 @@ struct rans_amd_ctx {
     DeviceBuffer scratch;   // encode slots
     DeviceBuffer lengths;   // encode lengths when the caller passes none
     DeviceBuffer hist;
+    DeviceBuffer layout_sums; // per-block totals of the offset scan (many-chunk containers)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // dec start/stop, enc start/stop
     bool timing = false;
     bool dec_timed = false, enc_timed = false;
@@ -220,6 +221,7 @@ int rans_amd_ctx_destroy(rans_amd_ctx *ctx)
     ctx->scratch.release();
     ctx->lengths.release();
     ctx->hist.release();
+    ctx->layout_sums.release();
     if (ctx->d_words)
         (void)hipFree(ctx->d_words);
     for (int i = 0; i < 4; ++i)
@@ -238,6 +240,7 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx)
     ctx->scratch.release();
     ctx->lengths.release();
     ctx->hist.release();
+    ctx->layout_sums.release();
     return RANS_AMD_OK;
 }
 
@@ -505,6 +508,13 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     lp.nchunks = nchunks;
     lp.out_cap = out_cap;
     lp.flags = ctx->d_enc_flags();
+    lp.block_sums = nullptr;
+    if (layout_blocks(nchunks) > 1) {
+        int rc = ctx->layout_sums.reserve((size_t)layout_blocks(nchunks) * 8);
+        if (rc)
+            return rc;
+        lp.block_sums = static_cast<uint64_t *>(ctx->layout_sums.ptr);
+    }
     HIP_TRY(launch_layout(lp, s));
     if (nchunks) {
         CompactParams cp;

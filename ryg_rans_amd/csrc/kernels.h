@@ -67,6 +67,7 @@ struct LayoutParams {
     uint64_t nchunks;
     uint64_t out_cap;
     uint32_t *flags;   // bit1: container does not fit out_cap
+    uint64_t *block_sums; // [layout_blocks(nchunks)] scratch, needed when that is > 1
 };
 
 struct CompactParams {
@@ -83,6 +84,7 @@ struct CompactParams {
 hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name);
 hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream);
 hipError_t launch_layout(const LayoutParams &p, hipStream_t stream);
+uint32_t layout_blocks(uint64_t nchunks); // blocks (and block_sums entries) launch_layout uses
 hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t stream);
 hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
                             uint32_t *d_flags, int num_cus, hipStream_t stream);

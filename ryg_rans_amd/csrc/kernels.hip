@@ -1300,59 +1300,86 @@ __global__ void __launch_bounds__(256) k_encode_lanes16(const EncParams p)
 
 // ---------------------------------------------------------------------------
 // Layout: offsets[c] = sum_{i<c} align16(lengths[i]); offsets[nchunks] = end of
-// the last stream.  One block; nchunks is small (n / chunk_syms).
+// the last stream.  Every block scans kLayoutChunksPerBlock chunks; with more than one
+// block (narrow interleaves produce 10^5..10^6 chunks) k_layout_sums first leaves every
+// block's total in block_sums[] and k_layout adds the totals of the blocks before it.
 // ---------------------------------------------------------------------------
+constexpr int kLayoutPer = 8; // consecutive chunks per thread
+constexpr uint32_t kLayoutChunksPerBlock = 1024 * kLayoutPer;
+
+__device__ __forceinline__ uint64_t block_sum_1024(uint64_t v, uint64_t *wave_sum)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d, 64);
+    if (lane_id() == 0)
+        wave_sum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint64_t t = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w)
+        t += wave_sum[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ void __launch_bounds__(1024) k_layout_sums(const LayoutParams p)
+{
+    __shared__ uint64_t wave_sum[16];
+    const uint64_t c0 = (uint64_t)blockIdx.x * kLayoutChunksPerBlock + (uint64_t)threadIdx.x * kLayoutPer;
+    uint64_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < kLayoutPer; ++i)
+        mine += c0 + i < p.nchunks ? (((uint64_t)p.lengths[c0 + i] + 15u) & ~uint64_t(15)) : 0;
+    const uint64_t total = block_sum_1024(mine, wave_sum);
+    if (threadIdx.x == 0)
+        p.block_sums[blockIdx.x] = total;
+}
+
 __global__ void __launch_bounds__(1024) k_layout(const LayoutParams p)
 {
-    constexpr int kPer = 8; // consecutive chunks per thread -> 8192 chunks per block pass
     __shared__ uint64_t wave_sum[16];
-    __shared__ uint64_t carry;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0)
-        carry = 0;
+    uint64_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += blockDim.x)
+        part += p.block_sums[b];
+    const uint64_t carry = blockIdx.x ? block_sum_1024(part, wave_sum) : 0;
+
+    const uint64_t c0 = (uint64_t)blockIdx.x * kLayoutChunksPerBlock + (uint64_t)threadIdx.x * kLayoutPer;
+    uint64_t sz[kLayoutPer];
+    uint64_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < kLayoutPer; ++i) {
+        sz[i] = c0 + i < p.nchunks ? (((uint64_t)p.lengths[c0 + i] + 15u) & ~uint64_t(15)) : 0;
+        mine += sz[i];
+    }
+    // inclusive scan of the per-thread sums inside the wave
+    uint64_t v = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_up(v, d, 64);
+        if ((int)lane >= d)
+            v += o;
+    }
+    if (lane == 63)
+        wave_sum[wave] = v;
     __syncthreads();
-    for (uint64_t base = 0; base < p.nchunks; base += (uint64_t)blockDim.x * kPer) {
-        const uint64_t c0 = base + (uint64_t)threadIdx.x * kPer;
-        uint64_t sz[kPer];
-        uint64_t mine = 0;
+    uint64_t before = carry;
+    for (uint32_t w = 0; w < wave; ++w)
+        before += wave_sum[w];
+    uint64_t at = before + v - mine;
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            sz[i] = c0 + i < p.nchunks ? (((uint64_t)p.lengths[c0 + i] + 15u) & ~uint64_t(15)) : 0;
-            mine += sz[i];
-        }
-        // inclusive scan of the per-thread sums inside the wave
-        uint64_t v = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t o = __shfl_up(v, d, 64);
-            if ((int)lane >= d)
-                v += o;
-        }
-        if (lane == 63)
-            wave_sum[wave] = v;
-        __syncthreads();
-        uint64_t before = carry;
-        for (uint32_t w = 0; w < wave; ++w)
-            before += wave_sum[w];
-        uint64_t at = before + v - mine;
-#pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            const uint64_t c = c0 + i;
-            if (c < p.nchunks) {
-                p.offsets[c] = at;
-                if (c == p.nchunks - 1) {
-                    p.offsets[p.nchunks] = at + p.lengths[c];
-                    if (at + sz[i] > p.out_cap)
-                        atomicOr(p.flags, 2u);
-                }
+    for (int i = 0; i < kLayoutPer; ++i) {
+        const uint64_t c = c0 + i;
+        if (c < p.nchunks) {
+            p.offsets[c] = at;
+            if (c == p.nchunks - 1) {
+                p.offsets[p.nchunks] = at + p.lengths[c];
+                if (at + sz[i] > p.out_cap)
+                    atomicOr(p.flags, 2u);
             }
-            at += sz[i];
         }
-        __syncthreads();
-        if (threadIdx.x == blockDim.x - 1)
-            carry = before + v;
-        __syncthreads();
+        at += sz[i];
     }
     if (p.nchunks == 0 && threadIdx.x == 0)
         p.offsets[0] = 0;
@@ -1703,6 +1730,12 @@ template <int FMT> hipError_t launch_encode_f(const EncParams &p, int num_cus, h
 
 } // namespace
 
+uint32_t layout_blocks(uint64_t nchunks)
+{
+    const uint64_t b = (nchunks + kLayoutChunksPerBlock - 1) / kLayoutChunksPerBlock;
+    return (uint32_t)(b ? b : 1);
+}
+
 bool ways_supported(int format, uint32_t n_ways)
 {
     if (format < 0 || format > 3)
@@ -1734,7 +1767,13 @@ hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_
 
 hipError_t launch_layout(const LayoutParams &p, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, stream, p);
+    const uint32_t blocks = layout_blocks(p.nchunks);
+    if (blocks > 1) {
+        if (!p.block_sums)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_layout_sums, dim3(blocks), dim3(1024), 0, stream, p);
+    }
+    hipLaunchKernelGGL(k_layout, dim3(blocks), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
 

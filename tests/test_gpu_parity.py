@@ -371,3 +371,23 @@ def test_word_encoder_full_wave_path_extremes(gpu, oracle):
         with pytest.raises(R.RansAmdError) as e:
             ctx.encode(gm, torch.from_numpy(bad).cuda(), 64, 8192)
         assert e.value.status == R.E_MODEL
+
+
+def test_many_chunks_layout(gpu, oracle):
+    """More than 8192 chunks: the offset scan runs on several blocks (k_layout_sums + k_layout)."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf((1 << 21) + 77, K=256, s=1.0, seed=5)
+    for fmt, sb, n_ways, chunk in ((FMT_R64, 14, 2, 128), (FMT_WORD, 12, 64, 64), (FMT_BYTE, 14, 1, 96)):
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        want, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+        assert len(lens) > 2 * 8192
+        cont, d_offs, d_lens, total = ctx.encode(gm, torch.from_numpy(data).cuda(), n_ways, chunk)
+        assert total == want.size
+        assert np.array_equal(d_offs.cpu().numpy().astype(np.uint64), offs)
+        assert np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens)
+        got = cont[:total].cpu().numpy()
+        for c in (0, 1, 8191, 8192, 8193, 16383, 16384, len(lens) - 2, len(lens) - 1):
+            o, ln = int(offs[c]), int(lens[c])
+            assert np.array_equal(got[o:o + ln], want[o:o + ln]), (fmt, c)
+        out = ctx.decode(gm, cont, total, d_offs, d_lens, data.size, n_ways, chunk)
+        assert np.array_equal(out.cpu().numpy(), data)
