@@ -205,6 +205,26 @@ template <int FMT> struct DecTables {
     uint32_t mask;
     uint32_t bucket_shift; // alias: scale_bits - log2(nsyms)
     uint32_t mask12v;      // 0xfff held in a VGPR (a literal operand makes v_and a 3.5-cycle op)
+    // VGPR copies of mask / scale_bits / bucket_shift: a VALU and/shift with an SGPR operand issues in
+    // 4.7 cycles, with VGPR operands in 2.7 (profiles/r01_ubench.log)
+    uint32_t maskv, sbv, bshiftv;
+
+    __device__ __forceinline__ void init(const uint8_t *table0, const uint8_t *table1, uint32_t sb, uint32_t log2nsyms)
+    {
+        t0 = table0;
+        t1 = table1;
+        scale_bits = sb;
+        mask = (1u << sb) - 1u;
+        bucket_shift = sb - log2nsyms;
+        mask12v = 0xfffu;
+        maskv = mask;
+        sbv = sb;
+        bshiftv = bucket_shift;
+        asm volatile("v_mov_b32 %0, %0" : "+v"(mask12v)); // opaque: keep them in VGPRs
+        asm volatile("v_mov_b32 %0, %0" : "+v"(maskv));
+        asm volatile("v_mov_b32 %0, %0" : "+v"(sbv));
+        asm volatile("v_mov_b32 %0, %0" : "+v"(bshiftv));
+    }
 };
 
 template <int FMT>
@@ -219,11 +239,11 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         return e.x;
     } else if constexpr (FMT == FMT_BYTE) {
         // rans_byte.h:125-128 (get), :291-298 (step)
-        const uint32_t cf = x & T.mask;
+        const uint32_t cf = x & T.maskv;
         const uint32_t s = T.t0[cf];
         const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s]; // {freq, start}
         // freq <= 2^16 and x >> scale_bits < 2^23 (scale_bits >= 8): 24-bit multiply is exact
-        x = (r.x & 0xffffffu) * ((x >> T.scale_bits) & 0xffffffu) + cf - r.y;
+        x = (r.x & 0xffffffu) * ((x >> T.sbv) & 0xffffffu) + cf - r.y;
         return s;
     } else if constexpr (FMT == FMT_R64) {
         // rans64.h:118-121 (get), :286-292 (step)
@@ -234,12 +254,15 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         return s;
     } else {
         // main_alias.cpp:252-267; the subtraction wraps in 32 bits on purpose
-        const uint32_t xm = x & T.mask;
-        const uint32_t bucket = xm >> T.bucket_shift;
+        const uint32_t xm = x & T.maskv;
+        const uint32_t bucket = xm >> T.bshiftv;
         const uint32_t div = reinterpret_cast<const uint32_t *>(T.t1)[bucket];
-        const uint32_t half = 2u * bucket + (xm < div ? 1u : 0u);
+        // xm < div as the sign bit of the difference (both < 2^17): a compare + v_cndmask costs
+        // ~27 issue cycles on gfx950, sub + shift 5.5
+        const uint32_t below = (xm - div) >> 31;
+        const uint32_t half = 2u * bucket + below;
         const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[half]; // {freq | sym << 16, adjust}
-        x = (e.x & 0xffffu) * ((x >> T.scale_bits) & 0xffffffu) + xm - e.y;
+        x = (e.x & 0xffffu) * ((x >> T.sbv) & 0xffffffu) + xm - e.y;
         return e.x >> 16;
     }
 }
@@ -411,13 +434,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     const uint32_t waves_per_block = blockDim.x >> 6;
 
     DecTables<FMT> T;
-    T.t0 = smem;
-    T.t1 = smem + t0_bytes;
-    T.scale_bits = p.scale_bits;
-    T.mask = (1u << p.scale_bits) - 1u;
-    T.bucket_shift = p.scale_bits - p.log2nsyms;
-    T.mask12v = 0xfffu;
-    asm volatile("v_mov_b32 %0, %0" : "+v"(T.mask12v)); // opaque: keep it in a VGPR
+    T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
 
     uint8_t *ring = smem + t0_bytes + t1_bytes + wave * kRingStride;
     uint8_t *tile = smem + t0_bytes + t1_bytes + waves_per_block * kRingStride + wave * kOutTileBytes; // OUT_FAST8_LDS
@@ -1065,13 +1082,7 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
     __syncthreads();
 
     DecTables<FMT> T;
-    T.t0 = smem;
-    T.t1 = smem + t0_bytes;
-    T.scale_bits = p.scale_bits;
-    T.mask = (1u << p.scale_bits) - 1u;
-    T.bucket_shift = p.scale_bits - p.log2nsyms;
-    T.mask12v = 0xfffu;
-    asm volatile("v_mov_b32 %0, %0" : "+v"(T.mask12v)); // opaque: keep it in a VGPR
+    T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
 
     if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
         p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
