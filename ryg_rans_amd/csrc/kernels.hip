@@ -1000,46 +1000,68 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
 // Per-lane stream window for the lane-per-stream decoder: 16 bytes of the lane's own stream
 // in registers plus the next 16 prefetched, so that a lane touches global memory once per
 // 16 stream bytes (a dword-per-unit walk would issue 4-16x as many scattered accesses).
+// The window is consumed from its low end and shifted down after every unit -- positional
+// indexing would be a chain of v_cndmask (~22 issue cycles each on gfx950) -- and the refill
+// loads straight into `pre` under the lanes' exec mask, so the load issued at one refill is only
+// waited for at the next one.
 struct LaneWindow {
     u32x4 win, pre;
     uint64_t next;  // global address of the 16 bytes after `pre`
     uint64_t limit; // 16-byte aligned end of the readable container
-    uint32_t pos;   // byte position inside win (0..15)
+    uint32_t left;  // bytes left in win (1..16)
     uint32_t used;  // stream bytes consumed so far
 
-    __device__ __forceinline__ u32x4 fetch(uint64_t a)
+    template <int UNIT> __device__ __forceinline__ void shift()
     {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (a < limit)
-            v = *reinterpret_cast<const u32x4 RANS_GLOBAL *>(a);
-        return v;
+        if constexpr (UNIT == 4) {
+            win.x = win.y;
+            win.y = win.z;
+            win.z = win.w;
+        } else {
+            win.x = __builtin_amdgcn_alignbit(win.y, win.x, 8 * UNIT);
+            win.y = __builtin_amdgcn_alignbit(win.z, win.y, 8 * UNIT);
+            win.z = __builtin_amdgcn_alignbit(win.w, win.z, 8 * UNIT);
+            win.w >>= 8 * UNIT;
+        }
     }
-    __device__ __forceinline__ void open(uint64_t addr, uint64_t lim)
+    __device__ __forceinline__ void refill()
+    {
+        win = pre;
+        left = 16;
+        if (next < limit) // past the container: `pre` keeps stale bytes, which only a corrupt chunk consumes
+            pre = *reinterpret_cast<const u32x4 RANS_GLOBAL *>(next);
+        next += 16;
+    }
+    template <int UNIT> __device__ __forceinline__ void open(uint64_t addr, uint64_t lim)
     {
         limit = lim;
         const uint64_t base = addr & ~uint64_t(15);
-        pos = (uint32_t)(addr & 15u);
         used = 0;
-        win = fetch(base);
-        pre = fetch(base + 16);
+        win = u32x4{0u, 0u, 0u, 0u};
+        pre = win;
+        if (base < limit)
+            win = *reinterpret_cast<const u32x4 RANS_GLOBAL *>(base);
+        if (base + 16 < limit)
+            pre = *reinterpret_cast<const u32x4 RANS_GLOBAL *>(base + 16);
         next = base + 32;
+        left = 16;
+        for (uint32_t skip = (uint32_t)(addr & 15u); skip != 0; skip -= UNIT) { // once per chunk
+            shift<UNIT>();
+            left -= UNIT;
+        }
     }
     template <int UNIT> __device__ __forceinline__ uint32_t take()
     {
-        const uint32_t d = pos >> 2;
-        uint32_t w = d == 0 ? win.x : d == 1 ? win.y : d == 2 ? win.z : win.w;
+        uint32_t w = win.x;
         if constexpr (UNIT == 2)
-            w = (w >> ((pos & 2u) * 8u)) & 0xffffu;
+            w &= 0xffffu;
         else if constexpr (UNIT == 1)
-            w = (w >> ((pos & 3u) * 8u)) & 0xffu;
-        pos += UNIT;
+            w &= 0xffu;
+        shift<UNIT>();
         used += UNIT;
-        if (pos == 16u) {
-            win = pre;
-            pre = fetch(next);
-            next += 16;
-            pos = 0;
-        }
+        left -= UNIT;
+        if (left == 0)
+            refill();
         return w;
     }
 };
@@ -1114,7 +1136,7 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
             }
         }
         LaneWindow W;
-        W.open(reinterpret_cast<uint64_t>(p.container) + off + NW * Tr::kStateBytes, glimit);
+        W.open<(int)Tr::kUnit>(reinterpret_cast<uint64_t>(p.container) + off + NW * Tr::kStateBytes, glimit);
         bool bad = false;
 
         const uint32_t rounds = nsym / NW;
