@@ -247,10 +247,16 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         return s;
     } else if constexpr (FMT == FMT_R64) {
         // rans64.h:118-121 (get), :286-292 (step)
-        const uint32_t cf = (uint32_t)x & T.mask;
+        const uint32_t cf = (uint32_t)x & T.maskv;
         const uint32_t s = T.t0[cf];
         const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s];
-        x = (uint64_t)r.x * (x >> T.scale_bits) + cf - r.y;
+        // freq * (x >> sb) + (cf - start) with x < 2^63: cf - start is in [0, freq), so it is a plain
+        // 32-bit value; the high word of x >> sb is < 2^17 and freq <= 2^16, so its product is one
+        // 24-bit multiply added to the high word -- one v_mad_u64_u32 instead of two plus a 64-bit
+        // subtract-with-borrow
+        const uint64_t xs = x >> T.scale_bits;
+        const uint32_t bias = cf - r.y;
+        x = (uint64_t)r.x * (uint32_t)xs + bias + ((uint64_t)__umul24(r.x, (uint32_t)(xs >> 32)) << 32);
         return s;
     } else {
         // main_alias.cpp:252-267; the subtraction wraps in 32 bits on purpose
@@ -1083,6 +1089,214 @@ __device__ __forceinline__ void lane_renorm(typename FmtTraits<FMT>::state_t &x,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Staged lane-per-stream decoder.  Per-lane 16-byte loads pull a whole memory line for every
+// 16 bytes used, and the line is long evicted when the lane comes back for its next 16 bytes
+// (measured: >= 4x over-fetch, the kernel sat on the fabric at ~3.3 TB/s); and a lane that
+// refills on its own stalls its whole wave.  Here the WAVE refills for all of its 64 chunks at
+// once, every 16 symbols: a lane's stream lives in a 128-byte ring in LDS (two 64-byte lines),
+// lanes publish which line they need next, and 4 lanes fetch one chunk's line with coalesced
+// 16-byte loads (4 load instructions cover 64 chunks x 64 B).  16 symbols consume at most one
+// line (rans64: <= 4 B per symbol), so "at least 64 bytes ahead" before every group is all the
+// invariant there is.  Ring rows are 136 bytes apart: equal positions of the 64 lanes spread over
+// 32 banks.  Positions are 32-bit offsets from the line of the wave's first chunk.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kLaneLine = 64;
+constexpr uint32_t kLaneRingStride = 2 * kLaneLine + 8;
+constexpr uint32_t kLaneWaveLds = 64 * kLaneRingStride + 64 * 4; // rings + one request word per lane
+
+template <int FMT> struct LaneRing {
+    const uint8_t *row; // this lane's ring in LDS
+    uint32_t cur;       // read position (offset from the wave's region base)
+    uint32_t used;      // stream bytes consumed
+
+    template <int UNIT> __device__ __forceinline__ uint32_t take()
+    {
+        const uint8_t *at = row + (cur & (2 * kLaneLine - 1));
+        cur += UNIT;
+        used += UNIT;
+        if constexpr (UNIT == 4)
+            return *reinterpret_cast<const uint32_t *>(at);
+        else if constexpr (UNIT == 2)
+            return *reinterpret_cast<const uint16_t *>(at);
+        else
+            return *at;
+    }
+    __device__ __forceinline__ void renorm(typename FmtTraits<FMT>::state_t &x, bool active)
+    {
+        // the branch bodies hold an LDS read, so they stay exec-masked branches (no v_cndmask)
+        if constexpr (FMT == FMT_WORD) {
+            if (active && x < (1u << 16)) // rans_word_sse41.h:134-141
+                x = (x << 16) | take<2>();
+        } else if constexpr (FMT == FMT_R64) {
+            if (active && x < (1ull << 31)) // rans64.h:305-316
+                x = (x << 32) | take<4>();
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) // rans_byte.h:307-318, at most two bytes for scale_bits <= 16
+                if (active && x < (1u << 23))
+                    x = (x << 8) | take<1>();
+        }
+    }
+};
+
+template <int FMT, int NW>
+__global__ void __launch_bounds__(256) k_decode_lanes_staged(const DecParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1_bytes = (p.table1_bytes + 15u) & ~15u;
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+        const uint4 *g1 = reinterpret_cast<const uint4 *>(p.table1);
+        uint4 *l1 = reinterpret_cast<uint4 *>(smem + t0_bytes);
+        for (uint32_t i = threadIdx.x; i < t1_bytes / 16u; i += blockDim.x)
+            l1[i] = g1[i];
+    }
+    __syncthreads();
+
+    DecTables<FMT> T;
+    T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    uint8_t *rings = smem + t0_bytes + t1_bytes + wave * kLaneWaveLds;
+    uint32_t *req = reinterpret_cast<uint32_t *>(rings + 64u * kLaneRingStride);
+    const uint32_t part = lane & 3u, grp = lane >> 2;
+
+    const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
+    const uint64_t glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
+    const bool wide_out = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 15u) == 0;
+    uint32_t nbad = 0;
+    const uint64_t nbatches = (p.nchunks + 63u) / 64u;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += total_waves) {
+        const uint64_t batch = uniform64(batch_v);
+        const uint64_t chunk = batch * 64u + lane;
+        bool valid = chunk < p.nchunks;
+        const uint64_t off = valid ? p.offsets[chunk] : 0;
+        const uint32_t len = valid ? p.lengths[chunk] : 0;
+        const uint64_t first = chunk * p.chunk_syms;
+        // region base: the line of the batch's first chunk (lane 0 always holds a chunk)
+        const uint64_t rb = uniform64(off) & ~uint64_t(kLaneLine - 1);
+        if (valid && ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off + len > p.container_bytes || off < rb ||
+                      off - rb >= (1u << 30))) {
+            nbad++;
+            valid = false;
+        }
+        const uint32_t nsym = valid ? (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms) : 0u;
+        uint8_t RANS_GLOBAL *dst = (uint8_t RANS_GLOBAL *)p.out + first * p.sym_bytes;
+
+        state_t x[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l) { // RansDecInit order: lane 0's state first
+            x[l] = Tr::kL;
+            if (valid) {
+                const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.container + off;
+                if constexpr (FMT == FMT_R64) {
+                    const u32x2 v = reinterpret_cast<const u32x2 RANS_GLOBAL *>(src)[l];
+                    x[l] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                } else {
+                    x[l] = reinterpret_cast<const uint32_t RANS_GLOBAL *>(src)[l];
+                }
+            }
+        }
+        LaneRing<FMT> W;
+        W.row = rings + lane * kLaneRingStride;
+        W.cur = (uint32_t)(off - rb) + NW * Tr::kStateBytes;
+        W.used = 0;
+        uint32_t ld = W.cur & ~(kLaneLine - 1u); // next line this lane has not staged yet
+
+        // the whole wave takes part (also lanes without a chunk): lane -> which line its chunk needs,
+        // then lane (4 g + part) moves 16 bytes of chunk (16 j + g)'s line, j = 0..3
+        auto refill = [&]() {
+            const bool need = valid && (int32_t)(ld - W.cur) < (int32_t)kLaneLine;
+            req[lane] = need ? (ld | 1u) : 0u;
+            if (need)
+                ld += kLaneLine;
+            uint32_t r[4];
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[j] = req[16 * j + grp]; // LDS ops of one wave execute in order: sees the writes above
+                v[j] = u32x4{0u, 0u, 0u, 0u};
+                const uint64_t a = cbase + rb + (r[j] & ~(kLaneLine - 1u)) + part * 16u;
+                if ((r[j] & 1u) && a < glimit)
+                    v[j] = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(a));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r[j] & 1u) {
+                    uint8_t *at = rings + (16u * j + grp) * kLaneRingStride + (r[j] & kLaneLine) + part * 16u;
+                    reinterpret_cast<u32x2 *>(at)[0] = u32x2{v[j].x, v[j].y}; // rows are 8-byte aligned
+                    reinterpret_cast<u32x2 *>(at)[1] = u32x2{v[j].z, v[j].w};
+                }
+        };
+
+        refill(); // two lines ahead to start with
+        for (uint32_t i0 = 0; __builtin_amdgcn_ballot_w64(i0 < nsym) != 0; i0 += 16u) {
+            refill();
+            if (i0 >= nsym)
+                continue;
+            const uint32_t cnt = nsym - i0 < 16u ? nsym - i0 : 16u;
+            if (cnt == 16u && wide_out) {
+                // 16 symbols per 16-byte store: 16/NW rounds
+                u32x4 pack = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int rr = 0; rr < 16 / NW; ++rr) {
+#pragma unroll
+                    for (int l = 0; l < NW; ++l) {
+                        uint32_t sy = dec_step<FMT>(T, x[l]);
+                        if constexpr (Tr::kSymByte == 3)
+                            sy >>= 24;
+                        const int pos = rr * NW + l;
+                        pack[pos / 4] |= (sy & 0xffu) << (8 * (pos % 4));
+                    }
+#pragma unroll
+                    for (int l = 0; l < NW; ++l)
+                        W.renorm(x[l], true);
+                }
+                *reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i0) = pack;
+            } else {
+                // ragged group or unaligned / 16-bit output: element stores
+                for (uint32_t i = 0; i < cnt; i += NW) {
+                    const uint32_t c = cnt - i < (uint32_t)NW ? cnt - i : (uint32_t)NW;
+#pragma unroll
+                    for (int l = 0; l < NW; ++l)
+                        if ((uint32_t)l < c) {
+                            uint32_t sy = dec_step<FMT>(T, x[l]);
+                            if constexpr (Tr::kSymByte == 3)
+                                sy >>= 24;
+                            if (p.sym_bytes == 1)
+                                dst[i0 + i + l] = (uint8_t)sy;
+                            else
+                                reinterpret_cast<uint16_t RANS_GLOBAL *>(dst)[i0 + i + l] = (uint16_t)sy;
+                        }
+#pragma unroll
+                    for (int l = 0; l < NW; ++l)
+                        W.renorm(x[l], (uint32_t)l < c);
+                }
+            }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int l = 0; l < NW; ++l)
+            bad = bad || (x[l] != Tr::kL);
+        if (valid && (bad || W.used + NW * Tr::kStateBytes != len))
+            nbad++;
+    }
+    if (nbad)
+        atomicAdd(p.err_count, (unsigned long long)nbad);
+}
+
 template <int FMT, int NW>
 __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
 {
@@ -1603,15 +1817,20 @@ template <int FMT, int NW>
 hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
     const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
-    const size_t lds = (size_t)t0 + t1;
-    auto kern = k_decode_lanes<FMT, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // A/B knob: the per-lane register window this kernel replaced (>= 4x over-fetch)
+    static const bool reg_window = getenv("RANS_AMD_LANES_REGWIN") != nullptr;
+    const size_t staged_lds = (size_t)t0 + t1 + (256 / 64) * (size_t)kLaneWaveLds;
+    // 64 chunks of one wave must lie within 2^30 bytes (32-bit ring positions): any sane chunk size
+    const bool staged = !reg_window && staged_lds <= 160 * 1024 && (uint64_t)p.chunk_syms * 8u < (1u << 22);
+    const size_t lds = staged ? staged_lds : (size_t)t0 + t1;
+    auto kern = staged ? k_decode_lanes_staged<FMT, NW> : k_decode_lanes<FMT, NW>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[staged]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess)
             return e;
-        attr_set = true;
+        attr_set[staged] = true;
     }
     const uint64_t want = (p.nchunks + 255) / 256;
     // 256-thread blocks: up to 8 per CU (32 waves) when the tables leave room in LDS; the kernel
@@ -1620,7 +1839,7 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
     const uint64_t cap = (uint64_t)num_cus * (lds_room >= 8 ? 8 : (lds_room >= 1 ? lds_room : 1));
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     if (name)
-        *name = "k_decode_lanes";
+        *name = staged ? "k_decode_lanes_staged" : "k_decode_lanes";
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
