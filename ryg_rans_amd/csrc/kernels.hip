@@ -1241,48 +1241,83 @@ __global__ void __launch_bounds__(256) k_decode_lanes_staged(const DecParams p)
                 }
         };
 
-        refill(); // two lines ahead to start with
-        for (uint32_t i0 = 0; __builtin_amdgcn_ballot_w64(i0 < nsym) != 0; i0 += 16u) {
-            refill();
-            if (i0 >= nsym)
-                continue;
-            const uint32_t cnt = nsym - i0 < 16u ? nsym - i0 : 16u;
-            if (cnt == 16u && wide_out) {
-                // 16 symbols per 16-byte store: 16/NW rounds
-                u32x4 pack = {0u, 0u, 0u, 0u};
+        // 16 symbols into four dwords: 16/NW rounds of NW steps + renormalisations
+        auto decode16 = [&]() -> u32x4 {
+            uint32_t pk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int rr = 0; rr < 16 / NW; ++rr) {
+            for (int rr = 0; rr < 16 / NW; ++rr) {
 #pragma unroll
-                    for (int l = 0; l < NW; ++l) {
-                        uint32_t sy = dec_step<FMT>(T, x[l]);
-                        if constexpr (Tr::kSymByte == 3)
-                            sy >>= 24;
-                        const int pos = rr * NW + l;
-                        pack[pos / 4] |= (sy & 0xffu) << (8 * (pos % 4));
-                    }
-#pragma unroll
-                    for (int l = 0; l < NW; ++l)
-                        W.renorm(x[l], true);
+                for (int l = 0; l < NW; ++l) {
+                    uint32_t sy = dec_step<FMT>(T, x[l]);
+                    if constexpr (Tr::kSymByte == 3)
+                        sy >>= 24;
+                    const int pos = rr * NW + l;
+                    pk[pos / 4] |= (sy & 0xffu) << (8 * (pos % 4));
                 }
-                *reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i0) = pack;
-            } else {
-                // ragged group or unaligned / 16-bit output: element stores
-                for (uint32_t i = 0; i < cnt; i += NW) {
-                    const uint32_t c = cnt - i < (uint32_t)NW ? cnt - i : (uint32_t)NW;
 #pragma unroll
-                    for (int l = 0; l < NW; ++l)
-                        if ((uint32_t)l < c) {
-                            uint32_t sy = dec_step<FMT>(T, x[l]);
-                            if constexpr (Tr::kSymByte == 3)
-                                sy >>= 24;
-                            if (p.sym_bytes == 1)
-                                dst[i0 + i + l] = (uint8_t)sy;
-                            else
-                                reinterpret_cast<uint16_t RANS_GLOBAL *>(dst)[i0 + i + l] = (uint16_t)sy;
-                        }
+                for (int l = 0; l < NW; ++l)
+                    W.renorm(x[l], true);
+            }
+            return u32x4{pk[0], pk[1], pk[2], pk[3]};
+        };
+
+        refill(); // two lines ahead to start with
+        // 64 symbols per trip: four groups of 16 (a refill before each), then the lane writes its 64
+        // bytes with four back-to-back 16-byte stores.  One 16-byte store per group left every line
+        // dirty in L2 for four groups -- long enough to be evicted half-written: 3.2x the bytes on
+        // the write side (WRITE_SIZE 0.87 GB for 0.27 GB of symbols).
+        for (uint32_t i0 = 0; __builtin_amdgcn_ballot_w64(i0 < nsym) != 0; i0 += 64u) {
+            const uint32_t left = i0 < nsym ? nsym - i0 : 0u;
+            if (__builtin_amdgcn_ballot_w64(!(left >= 64u && wide_out) && valid) == 0) { // wave-uniform
+                u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
+                refill();
+                if (left)
+                    q0 = decode16();
+                refill();
+                if (left)
+                    q1 = decode16();
+                refill();
+                if (left)
+                    q2 = decode16();
+                refill();
+                if (left) {
+                    q3 = decode16();
+                    u32x4 RANS_GLOBAL *o = reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i0);
+                    o[0] = q0;
+                    o[1] = q1;
+                    o[2] = q2;
+                    o[3] = q3;
+                }
+                continue;
+            }
+            // ragged end of a chunk, unaligned or 16-bit output: 16 symbols at a time
+            for (uint32_t g = 0; g < 4u; ++g) {
+                refill();
+                const uint32_t j0 = i0 + 16u * g;
+                if (j0 >= nsym)
+                    continue;
+                const uint32_t cnt = nsym - j0 < 16u ? nsym - j0 : 16u;
+                if (cnt == 16u && wide_out) {
+                    const u32x4 q = decode16();
+                    *reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + j0) = q;
+                } else {
+                    for (uint32_t i = 0; i < cnt; i += NW) {
+                        const uint32_t c = cnt - i < (uint32_t)NW ? cnt - i : (uint32_t)NW;
 #pragma unroll
-                    for (int l = 0; l < NW; ++l)
-                        W.renorm(x[l], (uint32_t)l < c);
+                        for (int l = 0; l < NW; ++l)
+                            if ((uint32_t)l < c) {
+                                uint32_t sy = dec_step<FMT>(T, x[l]);
+                                if constexpr (Tr::kSymByte == 3)
+                                    sy >>= 24;
+                                if (p.sym_bytes == 1)
+                                    dst[j0 + i + l] = (uint8_t)sy;
+                                else
+                                    reinterpret_cast<uint16_t RANS_GLOBAL *>(dst)[j0 + i + l] = (uint16_t)sy;
+                            }
+#pragma unroll
+                        for (int l = 0; l < NW; ++l)
+                            W.renorm(x[l], (uint32_t)l < c);
+                    }
                 }
             }
         }
