@@ -1141,7 +1141,7 @@ template <int FMT> struct LaneRing {
 };
 
 template <int FMT, int NW>
-__global__ void __launch_bounds__(256) k_decode_lanes_staged(const DecParams p)
+__global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
 {
     using Tr = FmtTraits<FMT>;
     using state_t = typename Tr::state_t;
@@ -1854,10 +1854,30 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
     const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
     // A/B knob: the per-lane register window this kernel replaced (>= 4x over-fetch)
     static const bool reg_window = getenv("RANS_AMD_LANES_REGWIN") != nullptr;
-    const size_t staged_lds = (size_t)t0 + t1 + (256 / 64) * (size_t)kLaneWaveLds;
+    // staged kernel: the tables are shared by the block, every wave adds kLaneWaveLds of rings, so one
+    // large block per CU keeps the most waves resident (rans64, 14 bits: 15 waves; 4-wave blocks: 12)
+    const size_t table_lds = (size_t)t0 + t1;
+    uint32_t sw = table_lds + kLaneWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - table_lds) / kLaneWaveLds) : 0;
+    sw = sw > 16 ? 16 : sw;
+    if (const char *e = getenv("RANS_AMD_LANES_WAVES")) { // experiment knob: waves per block
+        const uint32_t v = (uint32_t)atoi(e);
+        if (v >= 1 && v < sw)
+            sw = v;
+    }
     // 64 chunks of one wave must lie within 2^30 bytes (32-bit ring positions): any sane chunk size
-    const bool staged = !reg_window && staged_lds <= 160 * 1024 && (uint64_t)p.chunk_syms * 8u < (1u << 22);
-    const size_t lds = staged ? staged_lds : (size_t)t0 + t1;
+    const bool staged = !reg_window && sw >= 1 && (uint64_t)p.chunk_syms * 8u < (1u << 22);
+    {   // One batch (64 chunks) is a long latency-bound job, so a last round with a few waves per CU
+        // costs as much as a full one: take the fewest rounds the LDS allows and split the batches
+        // evenly over them (16 batches per CU: 16 waves x 1 round, or 8 x 2 -- never 14 + 2).
+        const uint64_t batches = (p.nchunks + 63) / 64;
+        const uint64_t per_cu = (batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
+        if (sw >= 1) {
+            const uint64_t rounds = (per_cu + sw - 1) / sw;
+            const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
+            sw = (uint32_t)(even ? even : 1);
+        }
+    }
+    const size_t lds = staged ? table_lds + (size_t)sw * kLaneWaveLds : table_lds;
     auto kern = staged ? k_decode_lanes_staged<FMT, NW> : k_decode_lanes<FMT, NW>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[staged]) {
@@ -1867,6 +1887,15 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
             return e;
         attr_set[staged] = true;
     }
+    if (staged) {
+        const uint64_t batches = (p.nchunks + 63) / 64;
+        const uint64_t want_blocks = (batches + sw - 1) / sw;
+        const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
+        if (name)
+            *name = "k_decode_lanes_staged";
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * sw), lds, stream, p);
+        return hipGetLastError();
+    }
     const uint64_t want = (p.nchunks + 255) / 256;
     // 256-thread blocks: up to 8 per CU (32 waves) when the tables leave room in LDS; the kernel
     // is latency-bound (per-lane scattered loads), so residency matters more than anything else
@@ -1874,7 +1903,7 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
     const uint64_t cap = (uint64_t)num_cus * (lds_room >= 8 ? 8 : (lds_room >= 1 ? lds_room : 1));
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     if (name)
-        *name = staged ? "k_decode_lanes_staged" : "k_decode_lanes";
+        *name = "k_decode_lanes";
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
