@@ -427,10 +427,18 @@ uint64_t rans_amd_encode_bound(int format, uint64_t n, uint32_t n_ways, uint32_t
 
 int rans_amd_ways_supported(int format, uint32_t n_ways) { return ways_supported(format, n_ways) ? 1 : 0; }
 
+// scratch slot of one chunk: worst-case stream, a whole number of 64-byte lines (the staged lane
+// encoder flushes its output ring line by line)
+static uint64_t encode_slot_bytes(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
+{
+    const uint64_t b = rans_amd_chunk_bound(format, (uint32_t)(n < chunk_syms ? n : chunk_syms), n_ways);
+    return (b + 63) & ~uint64_t(63);
+}
+
 uint64_t rans_amd_encode_workspace_bytes(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
 {
     const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
-    const uint64_t slot = rans_amd_chunk_bound(format, (uint32_t)(n < chunk_syms ? n : chunk_syms), n_ways);
+    const uint64_t slot = encode_slot_bytes(format, n, n_ways, chunk_syms);
     return nchunks * slot + 64;
 }
 
@@ -473,7 +481,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     std::lock_guard<std::mutex> lock(ctx->mu);
     hipStream_t s = static_cast<hipStream_t>(stream);
 
-    const uint64_t slot = rans_amd_chunk_bound(format, (uint32_t)(n < chunk_syms ? n : chunk_syms), n_ways);
+    const uint64_t slot = encode_slot_bytes(format, n, n_ways, chunk_syms);
     if (slot > 0xfffffff0ull) // chunk stream lengths and in-slot cursors are 32-bit
         return fail(RANS_AMD_E_UNSUPPORTED, "encode: chunk_syms too large (a chunk's stream must stay below 4 GiB)");
     int rc = ctx->scratch.reserve((size_t)(nchunks * slot + 64));

@@ -1498,6 +1498,232 @@ __device__ __forceinline__ void lane_put(typename FmtTraits<FMT>::state_t &x, ui
     }
 }
 
+// ---------------------------------------------------------------------------
+// Staged lane-per-stream encoder: the mirror image of k_decode_lanes_staged.  Per-lane stores of
+// every emitted unit reached HBM as partial lines (measured 6.4x the stream bytes on the write
+// side) and per-lane 16-byte symbol loads pulled whole lines (3.6x).  Here
+//   * symbols: the wave loads one 64-byte block of each of its 64 chunks with coalesced 16-byte
+//     loads (4 lanes per chunk) into per-lane rows in LDS; every lane then walks its row from
+//     the top, 16 symbols per ds_read_b128;
+//   * stream: units go into a 128-byte ring per lane (two 64-byte lines, written downwards); after
+//     every 16 symbols (at most 64 bytes emitted) a line that has filled up is written out by 4
+//     lanes with 16-byte stores -- whole 64-byte lines, each written once.
+// Slots are whole lines (api.cpp, encode_slot_bytes); what lies below the stream start inside the
+// lowest line is never read.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kEncRowStride = 80; // 64 symbol bytes, rows 16-byte aligned, 20 dwords apart
+constexpr uint32_t kEncWaveLds = 64 * kEncRowStride + 64 * kLaneRingStride + 64 * 4;
+
+template <int FMT> struct LaneOut {
+    uint8_t *row;  // this lane's output ring in LDS
+    uint32_t w;    // write offset inside the chunk's slot, moves down
+    template <int UNIT> __device__ __forceinline__ void emit(uint32_t v)
+    {
+        w -= UNIT;
+        uint8_t *at = row + (w & (2 * kLaneLine - 1));
+        if constexpr (UNIT == 4)
+            *reinterpret_cast<uint32_t *>(at) = v;
+        else if constexpr (UNIT == 2)
+            *reinterpret_cast<uint16_t *>(at) = (uint16_t)v;
+        else
+            *at = (uint8_t)v;
+    }
+};
+
+// one symbol of the sequential reference encoder for a lane-private state, emitting into the ring
+template <int FMT>
+__device__ __forceinline__ void lane_put_staged(typename FmtTraits<FMT>::state_t &x, uint32_t sym, const uint4 *recs,
+                                                const EncParams &p, LaneOut<FMT> &O, bool &bad)
+{
+    const bool known = sym < p.nsyms;
+    const uint4 rec = recs[known ? sym : 0u];
+    const uint32_t freq = (FMT == FMT_R64) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
+    if (!known || freq == 0) {
+        bad = true;
+        return;
+    }
+    if constexpr (FMT == FMT_WORD) {
+        uint32_t y = x;
+        if (y >= (freq << 20)) { // rans_word_sse41.h:85-89
+            O.template emit<2>(y);
+            y >>= 16;
+        }
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        x = (q << 12) + rem + start;
+    } else if constexpr (FMT == FMT_R64) {
+        uint64_t y = x;
+        if (y >= (((uint64_t)freq) << (63u - p.scale_bits))) { // rans64.h:83-88
+            O.template emit<4>((uint32_t)y);
+            y >>= 32;
+        }
+        uint64_t q, rem;
+        divmod_rcp64(y, freq, rec, q, rem);
+        x = (q << p.scale_bits) + rem + start;
+    } else {
+        uint32_t y = x;
+        const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq; // rans_byte.h:64-70
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (y >= x_max) {
+                O.template emit<1>(y);
+                y >>= 8;
+            }
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        if constexpr (FMT == FMT_ALIAS)
+            x = (q << p.scale_bits) + p.alias_remap[rem + start];
+        else
+            x = (q << p.scale_bits) + rem + start;
+    }
+}
+
+template <int FMT, int NW>
+__global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
+        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
+            l[i] = g[i];
+    }
+    __syncthreads();
+    const uint4 *recs = reinterpret_cast<const uint4 *>(smem);
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    uint8_t *rows = smem + p.nsyms * (uint32_t)sizeof(EncRec) + wave * kEncWaveLds;
+    uint8_t *rings = rows + 64u * kEncRowStride;
+    uint32_t *req = reinterpret_cast<uint32_t *>(rings + 64u * kLaneRingStride);
+    const uint32_t part = lane & 3u, grp = lane >> 2;
+    const uint32_t slot_lines = (uint32_t)(p.slot_bytes / kLaneLine);
+
+    bool bad = false;
+    const uint64_t nbatches = (p.nchunks + 63u) / 64u;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += total_waves) {
+        const uint64_t chunk0 = uniform64(batch_v) * 64u;
+        const uint64_t chunk = chunk0 + lane;
+        const bool valid = chunk < p.nchunks;
+        auto syms_of = [&](uint64_t c) -> uint32_t { // symbols in chunk c (0 past the end)
+            if (c >= p.nchunks)
+                return 0u;
+            const uint64_t first = c * p.chunk_syms;
+            return (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        };
+        const uint32_t nsym = syms_of(chunk);
+        const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + chunk * (uint64_t)p.chunk_syms;
+        uint8_t RANS_GLOBAL *slots0 = (uint8_t RANS_GLOBAL *)p.scratch + chunk0 * p.slot_bytes; // wave-uniform
+
+        state_t x[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l)
+            x[l] = Tr::kL;
+        LaneOut<FMT> O;
+        O.row = rings + lane * kLaneRingStride;
+        O.w = (uint32_t)p.slot_bytes;
+        uint32_t flushed = slot_lines; // lines [flushed, slot_lines) are in memory
+
+        // the whole wave takes part: lanes publish the line they have filled (or, at the end, the lines
+        // that hold anything), lane (4 g + part) writes 16 bytes of chunk (16 j + g)'s line
+        auto flush = [&](bool final) {
+            const bool need = valid && flushed != 0u &&
+                              (final ? O.w < flushed * kLaneLine : O.w <= (flushed - 1u) * kLaneLine);
+            req[lane] = need ? (((flushed - 1u) << 1) | 1u) : 0u;
+            if (need)
+                flushed -= 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = 16u * j + grp;
+                const uint32_t r = req[q]; // LDS ops of one wave execute in order
+                if (r & 1u) {
+                    const uint32_t line = r >> 1;
+                    const uint8_t *at = rings + q * kLaneRingStride + (line & 1u) * kLaneLine + part * 16u;
+                    const u32x2 a = reinterpret_cast<const u32x2 *>(at)[0], b = reinterpret_cast<const u32x2 *>(at)[1];
+                    u32x4 RANS_GLOBAL *o = reinterpret_cast<u32x4 RANS_GLOBAL *>(
+                        slots0 + (uint64_t)q * p.slot_bytes + (uint64_t)line * kLaneLine + part * 16u);
+                    *o = u32x4{a.x, a.y, b.x, b.y};
+                }
+            }
+        };
+
+        // symbol i belongs to state i mod NW; visit i = nsym-1 .. 0 (main.cpp:233-243).  The top
+        // nsym % 16 symbols come one by one from memory, the rest through the staged rows.
+        const uint32_t nsym16 = nsym & ~15u;
+        for (uint32_t i = nsym; i > nsym16; --i) {
+            const uint32_t sym = (uint32_t)src[i - 1];
+            const uint32_t l = (i - 1) % NW;
+#pragma unroll
+            for (int ll = 0; ll < NW; ++ll) // static register indexing
+                if ((uint32_t)ll == l)
+                    lane_put_staged<FMT>(x[ll], sym, recs, p, O, bad);
+        }
+        flush(false);
+
+        const uint32_t my_blocks = (nsym16 + 63u) >> 6;
+        uint32_t max_blocks = my_blocks;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)max_blocks, d, 64);
+            max_blocks = o > max_blocks ? o : max_blocks;
+        }
+        max_blocks = uniform(max_blocks);
+        for (uint32_t k = max_blocks; k-- > 0;) {
+            // stage block k of every chunk: 16 bytes per lane, 4 instructions for 64 chunks
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = 16u * j + grp;
+                const uint32_t qsyms16 = syms_of(chunk0 + q) & ~15u;
+                const uint32_t at = 64u * k + 16u * part;
+                if (at + 16u <= qsyms16) {
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(
+                        reinterpret_cast<uint64_t>(p.syms) + (chunk0 + q) * (uint64_t)p.chunk_syms + at));
+                    *reinterpret_cast<u32x4 *>(rows + q * kEncRowStride + 16u * part) = v;
+                }
+            }
+            const uint8_t *row = rows + lane * kEncRowStride;
+#pragma unroll
+            for (int g = 3; g >= 0; --g) {
+                if (64u * k + 16u * g + 16u <= nsym16) {
+                    const u32x4 cur = *reinterpret_cast<const u32x4 *>(row + 16 * g);
+#pragma unroll
+                    for (int j = 15; j >= 0; --j) {
+                        const uint32_t sym = (cur[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                        lane_put_staged<FMT>(x[j % NW], sym, recs, p, O, bad);
+                    }
+                }
+                flush(false);
+            }
+        }
+        // flush states NW-1 .. 0 (lane 0's first in memory), then whatever the ring still holds
+        if (valid) {
+#pragma unroll
+            for (int l = NW - 1; l >= 0; --l) {
+                if constexpr (FMT == FMT_R64) {
+                    O.template emit<4>((uint32_t)(x[l] >> 32));
+                    O.template emit<4>((uint32_t)x[l]);
+                } else if constexpr (FMT == FMT_WORD) {
+                    O.template emit<2>(x[l] >> 16);
+                    O.template emit<2>(x[l]);
+                } else {
+                    O.template emit<1>(x[l] >> 24);
+                    O.template emit<1>(x[l] >> 16);
+                    O.template emit<1>(x[l] >> 8);
+                    O.template emit<1>(x[l]);
+                }
+            }
+            p.lengths[chunk] = (uint32_t)p.slot_bytes - O.w;
+        }
+        flush(true);
+        flush(true);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
+        atomicOr(p.flags, 1u);
+}
+
 // Lane-per-stream encoder, second generation: symbols arrive as 16-byte per-lane loads
 // (one scattered access per 16 symbols instead of per symbol), one group prefetched.
 template <int FMT, int NW>
@@ -2002,9 +2228,41 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
 
 template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, int num_cus, hipStream_t stream)
 {
-    const size_t lds = (size_t)p.nsyms * sizeof(EncRec);
-    if (lds > 128 * 1024)
+    const size_t table_lds = (size_t)p.nsyms * sizeof(EncRec);
+    if (table_lds > 128 * 1024)
         return hipErrorInvalidValue;
+    // staged kernel (coalesced symbol loads, whole-line stream stores): u8 symbols in 16-byte aligned
+    // chunks, slots made of whole lines; RANS_AMD_LANES_REGWIN keeps the per-lane kernel for A/B runs
+    static const bool reg_window = getenv("RANS_AMD_LANES_REGWIN") != nullptr;
+    uint32_t sw = table_lds + kEncWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - table_lds) / kEncWaveLds) : 0;
+    sw = sw > 16 ? 16 : sw;
+    const bool staged = !reg_window && sw >= 1 && p.sym_bytes == 1 && (p.slot_bytes % kLaneLine) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 15u) == 0 &&
+                        (reinterpret_cast<uintptr_t>(p.scratch) & 15u) == 0 &&
+                        (p.nchunks + 63) / 64 >= (uint64_t)num_cus * 6; // fewer, longer batches: the per-lane kernel's
+                                                                        // many small blocks hide latency better (measured)
+    if (staged) {
+        // same split as the staged decoder: fewest rounds, batches spread evenly over them
+        const uint64_t batches = (p.nchunks + 63) / 64;
+        const uint64_t per_cu = (batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
+        const uint64_t rounds = (per_cu + sw - 1) / sw;
+        const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
+        sw = (uint32_t)(even ? even : 1);
+        auto kern = k_encode_lanes_staged<FMT, NW>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess)
+                return e;
+            attr_set = true;
+        }
+        const uint64_t want_blocks = (batches + sw - 1) / sw;
+        const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * sw), table_lds + (size_t)sw * kEncWaveLds, stream, p);
+        return hipGetLastError();
+    }
+    const size_t lds = table_lds;
     auto kern = k_encode_lanes16<FMT, NW>;
     static bool attr_set = false;
     if (!attr_set) {
