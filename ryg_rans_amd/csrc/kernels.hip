@@ -2074,12 +2074,23 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     return hipGetLastError();
 }
 
+// RANS_AMD_LANES=staged | regwin: pin the lane-per-stream kernel generation (tests, A/B runs); read at
+// every launch so one process can exercise both
+static int lanes_force()
+{
+    const char *e = getenv("RANS_AMD_LANES");
+    if (!e)
+        return 0;
+    return e[0] == 's' ? 1 : (e[0] == 'r' ? -1 : 0);
+}
+
 template <int FMT, int NW>
 hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
     const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
-    // A/B knob: the per-lane register window this kernel replaced (>= 4x over-fetch)
-    static const bool reg_window = getenv("RANS_AMD_LANES_REGWIN") != nullptr;
+    // RANS_AMD_LANES=regwin: the per-lane register window this kernel replaced (>= 4x over-fetch)
+    const int force = lanes_force();
+    const bool reg_window = force < 0;
     // staged kernel: the tables are shared by the block, every wave adds kLaneWaveLds of rings, so one
     // large block per CU keeps the most waves resident (rans64, 14 bits: 15 waves; 4-wave blocks: 12)
     const size_t table_lds = (size_t)t0 + t1;
@@ -2232,15 +2243,17 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, 
     if (table_lds > 128 * 1024)
         return hipErrorInvalidValue;
     // staged kernel (coalesced symbol loads, whole-line stream stores): u8 symbols in 16-byte aligned
-    // chunks, slots made of whole lines; RANS_AMD_LANES_REGWIN keeps the per-lane kernel for A/B runs
-    static const bool reg_window = getenv("RANS_AMD_LANES_REGWIN") != nullptr;
+    // chunks, slots made of whole lines; RANS_AMD_LANES=regwin keeps the per-lane kernel (A/B runs), =staged forces
+    // this one whatever the batch count (tests)
+    const int force = lanes_force();
+    const bool reg_window = force < 0;
     uint32_t sw = table_lds + kEncWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - table_lds) / kEncWaveLds) : 0;
     sw = sw > 16 ? 16 : sw;
     const bool staged = !reg_window && sw >= 1 && p.sym_bytes == 1 && (p.slot_bytes % kLaneLine) == 0 &&
                         ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 15u) == 0 &&
                         (reinterpret_cast<uintptr_t>(p.scratch) & 15u) == 0 &&
-                        (p.nchunks + 63) / 64 >= (uint64_t)num_cus * 6; // fewer, longer batches: the per-lane kernel's
-                                                                        // many small blocks hide latency better (measured)
+                        // fewer, longer batches: the per-lane kernel's many small blocks hide latency better
+                        (force > 0 || (p.nchunks + 63) / 64 >= (uint64_t)num_cus * 6);
     if (staged) {
         // same split as the staged decoder: fewest rounds, batches spread evenly over them
         const uint64_t batches = (p.nchunks + 63) / 64;

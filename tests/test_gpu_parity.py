@@ -391,3 +391,40 @@ def test_many_chunks_layout(gpu, oracle):
             assert np.array_equal(got[o:o + ln], want[o:o + ln]), (fmt, c)
         out = ctx.decode(gm, cont, total, d_offs, d_lens, data.size, n_ways, chunk)
         assert np.array_equal(out.cpu().numpy(), data)
+
+
+@pytest.mark.parametrize("generation", ["staged", "regwin"])
+def test_lane_kernels_both_generations(gpu, oracle, generation, monkeypatch):
+    """Narrow interleaves (N = 1, 2, 4, 8): the wave-cooperative staged kernels and the per-lane
+    register-window kernels they replaced, pinned through RANS_AMD_LANES, every format, ragged last
+    chunk, chunk sizes that are and are not multiples of 16 / 64, against the oracle byte for byte."""
+    R, ctx, torch = gpu
+    monkeypatch.setenv("RANS_AMD_LANES", generation)
+    data = oracle.gen_zipf(200000 + 37, K=256, s=1.0, seed=17)
+    d_syms = torch.from_numpy(data).cuda()
+    for fmt, sb in FORMATS:
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        for n_ways, chunk in ((2, 512), (1, 256), (4, 1024), (8, 2048), (2, 80), (2, 1000), (1, 48), (8, 64)):
+            want, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+            cont, d_offs, d_lens, total = ctx.encode(gm, d_syms, n_ways, chunk)
+            assert total == want.size, (fmt, n_ways, chunk)
+            assert np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens), (fmt, n_ways, chunk)
+            got = cont[:total].cpu().numpy()
+            for c in (0, 1, len(lens) // 2, len(lens) - 2, len(lens) - 1):
+                o, ln = int(offs[c]), int(lens[c])
+                assert np.array_equal(got[o:o + ln], want[o:o + ln]), (fmt, n_ways, chunk, c)
+            # decode the ORACLE's container (independent of the GPU encoder) and the GPU's own
+            d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
+            out = ctx.decode(gm, d_cont, want.size, torch.from_numpy(offs.astype(np.int64)).cuda(),
+                             torch.from_numpy(lens.astype(np.int32)).cuda(), data.size, n_ways, chunk)
+            assert np.array_equal(out.cpu().numpy(), data), (fmt, n_ways, chunk)
+            out = ctx.decode(gm, cont, total, d_offs, d_lens, data.size, n_ways, chunk)
+            assert np.array_equal(out.cpu().numpy(), data), (fmt, n_ways, chunk)
+    # unaligned symbol buffers fall back inside the library, whatever is pinned
+    om, gm = _models(R, ctx, oracle, FMT_R64, 14, data)
+    backing = torch.zeros(data.size + 16, dtype=torch.uint8, device="cuda")
+    backing[3:3 + data.size] = d_syms
+    cont, d_offs, d_lens, total = ctx.encode(gm, backing[3:3 + data.size], 2, 512)
+    out_b = torch.zeros(data.size + 16, dtype=torch.uint8, device="cuda")
+    ctx.decode(gm, cont, total, d_offs, d_lens, data.size, 2, 512, d_out=out_b[5:5 + data.size])
+    assert np.array_equal(out_b[5:5 + data.size].cpu().numpy(), data)
