@@ -1,7 +1,7 @@
 // api.cpp -- the extern "C" boundary declared in include/ryg_rans_amd.h.
 //
 // Host-side plumbing only: argument checking, device memory for tables and
-// workspaces, kernel launches (kernels.hip).  There is no CPU implementation of
+// workspaces, kernel launches (the .hip files).  There is no CPU implementation of
 // encode/decode behind these entry points: without a usable GPU every call
 // fails with RANS_AMD_E_HIP.
 #include "../../include/ryg_rans_amd.h"

@@ -1,0 +1,292 @@
+// container_kernels.hip -- offset scan, compaction and histogram kernels around the coders.
+
+#include "device_common.hpp"
+#include "launchers.hpp"
+
+namespace rans_amd {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Layout: offsets[c] = sum_{i<c} align16(lengths[i]); offsets[nchunks] = end of
+// the last stream.  Every block scans kLayoutChunksPerBlock chunks; with more than one
+// block (narrow interleaves produce 10^5..10^6 chunks) k_layout_sums first leaves every
+// block's total in block_sums[] and k_layout adds the totals of the blocks before it.
+// ---------------------------------------------------------------------------
+constexpr int kLayoutPer = 8; // consecutive chunks per thread
+constexpr uint32_t kLayoutChunksPerBlock = 1024 * kLayoutPer;
+
+__device__ __forceinline__ uint64_t block_sum_1024(uint64_t v, uint64_t *wave_sum)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d, 64);
+    if (lane_id() == 0)
+        wave_sum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint64_t t = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w)
+        t += wave_sum[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ void __launch_bounds__(1024) k_layout_sums(const LayoutParams p)
+{
+    __shared__ uint64_t wave_sum[16];
+    const uint64_t c0 = (uint64_t)blockIdx.x * kLayoutChunksPerBlock + (uint64_t)threadIdx.x * kLayoutPer;
+    uint64_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < kLayoutPer; ++i)
+        mine += c0 + i < p.nchunks ? (((uint64_t)p.lengths[c0 + i] + 15u) & ~uint64_t(15)) : 0;
+    const uint64_t total = block_sum_1024(mine, wave_sum);
+    if (threadIdx.x == 0)
+        p.block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) k_layout(const LayoutParams p)
+{
+    __shared__ uint64_t wave_sum[16];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint64_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += blockDim.x)
+        part += p.block_sums[b];
+    const uint64_t carry = blockIdx.x ? block_sum_1024(part, wave_sum) : 0;
+
+    const uint64_t c0 = (uint64_t)blockIdx.x * kLayoutChunksPerBlock + (uint64_t)threadIdx.x * kLayoutPer;
+    uint64_t sz[kLayoutPer];
+    uint64_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < kLayoutPer; ++i) {
+        sz[i] = c0 + i < p.nchunks ? (((uint64_t)p.lengths[c0 + i] + 15u) & ~uint64_t(15)) : 0;
+        mine += sz[i];
+    }
+    // inclusive scan of the per-thread sums inside the wave
+    uint64_t v = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_up(v, d, 64);
+        if ((int)lane >= d)
+            v += o;
+    }
+    if (lane == 63)
+        wave_sum[wave] = v;
+    __syncthreads();
+    uint64_t before = carry;
+    for (uint32_t w = 0; w < wave; ++w)
+        before += wave_sum[w];
+    uint64_t at = before + v - mine;
+#pragma unroll
+    for (int i = 0; i < kLayoutPer; ++i) {
+        const uint64_t c = c0 + i;
+        if (c < p.nchunks) {
+            p.offsets[c] = at;
+            if (c == p.nchunks - 1) {
+                p.offsets[p.nchunks] = at + p.lengths[c];
+                if (at + sz[i] > p.out_cap)
+                    atomicOr(p.flags, 2u);
+            }
+        }
+        at += sz[i];
+    }
+    if (p.nchunks == 0 && threadIdx.x == 0)
+        p.offsets[0] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// Compaction: chunk c's stream sits at the END of its scratch slot (arbitrary
+// alignment); copy it to out + offsets[c] (16-byte aligned).  One wave per
+// chunk, dword granularity; source dwords are realigned with v_alignbyte_b32.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_compact(const CompactParams p)
+{
+    if (*p.flags & 2u)
+        return;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * waves_per_block + wave; chunk < p.nchunks; chunk += total_waves) {
+        const uint32_t len = p.lengths[chunk];
+        const uint8_t *src = p.scratch + (chunk + 1) * p.slot_bytes - len;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(p.out + p.offsets[chunk]);
+        const uintptr_t sa = reinterpret_cast<uintptr_t>(src);
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(sa & ~uintptr_t(3));
+        const uint32_t shift = (uint32_t)(sa & 3u);
+        const uint32_t ndw = (len + 3u) >> 2;
+        for (uint32_t i = lane; i < ndw; i += 64u) {
+            const uint32_t lo = s4[i];
+            // the dword after the slot end is never needed when shift == 0
+            const uint32_t hi = shift ? s4[i + 1] : 0u;
+            dst[i] = __builtin_amdgcn_alignbyte(hi, lo, shift);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Histogram (count_freqs, main.cpp:59-66).  1 byte of HBM traffic per symbol, so the LDS
+// atomic rate is what has to keep up: a skewed source (Zipf: the top symbol is 16 % of
+// the input) sends ~10 lanes of every wave to the same counter, and same-bank atomics
+// serialise.  u8 path: every wave owns kHistCopies private copies of the 256 counters, a
+// lane uses copy (lane & 7), and the copies start 8 banks apart, so the lanes that hit
+// one symbol spread over eight banks; counters of symbols >= nsyms are simply counted and
+// flagged at the end (no per-symbol range check).  u16 path (alphabets up to 4096): one
+// table per block.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kHistCopies = 8;
+constexpr uint32_t kHistCopyStride = 256 + 8; // dwords: copy c starts in bank 8 * c
+
+__global__ void __launch_bounds__(256) k_histogram_u8(const void *syms, uint64_t n, uint32_t nsyms, uint32_t *hist,
+                                                      uint32_t *flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *all = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t waves = blockDim.x >> 6;
+    const uint32_t total = waves * kHistCopies * kHistCopyStride;
+    for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
+        all[i] = 0;
+    __syncthreads();
+    uint32_t *h = all + ((threadIdx.x >> 6) * kHistCopies + (threadIdx.x & (kHistCopies - 1))) * kHistCopyStride;
+
+    const uint8_t *p = static_cast<const uint8_t *>(syms);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 16-byte loads from the first aligned address on; the ragged head and tail go bytewise
+    const uint64_t head = (16u - (reinterpret_cast<uintptr_t>(p) & 15u)) & 15u;
+    const uint64_t nhead = head < n ? head : n;
+    const uint64_t nvec = (n - nhead) / 16;
+    gvec_cptr pv = reinterpret_cast<gvec_cptr>(reinterpret_cast<uintptr_t>(p + nhead));
+    auto count4 = [&](uint32_t w) {
+        atomicAdd(&h[w & 0xffu], 1u);
+        atomicAdd(&h[(w >> 8) & 0xffu], 1u);
+        atomicAdd(&h[(w >> 16) & 0xffu], 1u);
+        atomicAdd(&h[w >> 24], 1u);
+    };
+    uint64_t i = tid;
+    if (i < nvec) {
+        u32x4 v = __builtin_nontemporal_load(pv + i);
+        for (i += stride; i < nvec; i += stride) { // next load in flight while this one is counted
+            const u32x4 nv = __builtin_nontemporal_load(pv + i);
+            count4(v.x);
+            count4(v.y);
+            count4(v.z);
+            count4(v.w);
+            v = nv;
+        }
+        count4(v.x);
+        count4(v.y);
+        count4(v.z);
+        count4(v.w);
+    }
+    for (uint64_t j = tid; j < nhead; j += stride)
+        atomicAdd(&h[p[j]], 1u);
+    for (uint64_t j = nhead + nvec * 16 + tid; j < n; j += stride)
+        atomicAdd(&h[p[j]], 1u);
+    __syncthreads();
+
+    bool bad = false;
+    for (uint32_t b = threadIdx.x; b < 256u; b += blockDim.x) {
+        uint32_t sum = 0;
+        for (uint32_t c = 0; c < waves * kHistCopies; ++c)
+            sum += all[c * kHistCopyStride + b];
+        if (sum) {
+            if (b < nsyms)
+                atomicAdd(&hist[b], sum);
+            else
+                bad = true;
+        }
+    }
+    if (bad)
+        atomicOr(flags, 1u);
+}
+
+__global__ void __launch_bounds__(256) k_histogram_u16(const void *syms, uint64_t n, uint32_t nsyms, uint32_t *hist,
+                                                       uint32_t *flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+    for (uint32_t i = threadIdx.x; i < nsyms; i += blockDim.x)
+        h[i] = 0;
+    __syncthreads();
+    bool bad = false;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint16_t *p = static_cast<const uint16_t *>(syms);
+    auto count1 = [&](uint32_t sym) {
+        if (sym < nsyms)
+            atomicAdd(&h[sym], 1u);
+        else
+            bad = true;
+    };
+    // 16-byte loads (8 symbols) from the first aligned address on
+    const uint64_t head = ((16u - (reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) / 2;
+    const uint64_t nhead = head < n ? head : n;
+    const uint64_t nvec = (n - nhead) / 8;
+    gvec_cptr pv = reinterpret_cast<gvec_cptr>(reinterpret_cast<uintptr_t>(p + nhead));
+    for (uint64_t i = tid; i < nvec; i += stride) {
+        const u32x4 v = __builtin_nontemporal_load(pv + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            count1(w[a] & 0xffffu);
+            count1(w[a] >> 16);
+        }
+    }
+    for (uint64_t j = tid; j < nhead; j += stride)
+        count1(p[j]);
+    for (uint64_t j = nhead + nvec * 8 + tid; j < n; j += stride)
+        count1(p[j]);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nsyms; i += blockDim.x)
+        if (h[i])
+            atomicAdd(&hist[i], h[i]);
+    if (bad)
+        atomicOr(flags, 1u);
+}
+
+
+} // namespace
+
+uint32_t layout_blocks(uint64_t nchunks)
+{
+    const uint64_t b = (nchunks + kLayoutChunksPerBlock - 1) / kLayoutChunksPerBlock;
+    return (uint32_t)(b ? b : 1);
+}
+
+hipError_t launch_layout(const LayoutParams &p, hipStream_t stream)
+{
+    const uint32_t blocks = layout_blocks(p.nchunks);
+    if (blocks > 1) {
+        if (!p.block_sums)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_layout_sums, dim3(blocks), dim3(1024), 0, stream, p);
+    }
+    hipLaunchKernelGGL(k_layout, dim3(blocks), dim3(1024), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t stream)
+{
+    uint64_t want = (p.nchunks + 3) / 4;
+    uint64_t cap = (uint64_t)num_cus * 8;
+    const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
+                            uint32_t *d_flags, int num_cus, hipStream_t stream)
+{
+    const uint32_t grid = (uint32_t)num_cus * 4;
+    if (sym_bytes == 1) {
+        const size_t lds = (size_t)(256 / 64) * kHistCopies * kHistCopyStride * 4;
+        hipLaunchKernelGGL(k_histogram_u8, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+    } else {
+        const size_t lds = (size_t)nsyms * 4;
+        hipLaunchKernelGGL(k_histogram_u16, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+    }
+    return hipGetLastError();
+}
+
+} // namespace rans_amd

@@ -1,0 +1,597 @@
+// decode_wave.hip -- the wave-per-chunk decoder (the headline kernel) of the hand-written gfx950
+// (CDNA4, wave64) kernels for interleaved rANS; encode_wave.hip, lanes.hip and container_kernels.hip
+// hold the rest.
+//
+// Mapping of the reference's hot loops onto the GPU
+// --------------------------------------------------
+// The reference decodes an N-way interleaved stream with N rANS states that take
+// turns: every "round" each state decodes one symbol (table lookup + one
+// multiply-add, no stream access), then the states, in ascending lane order,
+// pull the renormalisation units they need from ONE shared cursor
+// (main.cpp:259-280, main_simd.cpp:313-332).  The SSE4.1 decoder does this for
+// 4 lanes with movemask + pshufb (rans_word_sse41.h:182-227).  Here:
+//
+//   * one wavefront owns one chunk (an independent N-way stream), N = 64*K:
+//     lane l holds states l, l+64, ..., i.e. K states per lane;
+//   * the symbol lookup table lives in LDS, shared by the 16 waves of a block;
+//   * "which lanes renormalise" is a 64-bit ballot; a lane's position in the
+//     stream is popcount(ballot & lanes_below) (v_mbcnt), so the wave consumes
+//     popcount(ballot) consecutive units per sub-step: stream I/O is dense and
+//     in order by construction;
+//   * the compressed stream is pulled through a per-wave LDS window ("ring")
+//     in aligned 1 KiB blocks (16 B per lane, one global_load_dwordx4 per
+//     block), prefetched one block ahead in registers;
+//   * decoded bytes are transposed in registers across 4 rounds (v_perm_b32 +
+//     quad DPP) so a store instruction writes 256 contiguous bytes per wave.
+//
+// No MFMA: the work is integer, table-driven and serial per state.
+// The encoder is the exact mirror (symbols visited last to first, units pushed
+// downwards); it writes every chunk into a worst-case scratch slot, then a
+// layout pass (prefix sum of sizes) and a compaction pass build the container.
+//
+// Bit-exactness: the arithmetic below is the reference's (file:line cited at
+// each step); only its *scheduling* across lanes is new.
+
+#include "device_common.hpp"
+#include "launchers.hpp"
+
+namespace rans_amd {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Stream window: a 2 KiB ring per wave in LDS, filled in aligned 1 KiB blocks
+// (one global_load_dwordx4 per lane), the next block prefetched in registers.
+//
+//   rd    ring offset of the read cursor at the last checkpoint (< 2048)
+//   adv   bytes consumed since that checkpoint
+//   avail valid bytes ahead of rd at the checkpoint
+//   wr    ring offset of the block that is written next (0 or 1024)
+//
+// checkpoint() folds adv into rd/avail and, when a block is free (avail <=
+// 1024), writes the prefetched block and issues the next fetch.  Between two
+// checkpoints the decoder consumes at most kMaxAdvance bytes and reads at most
+// one more sub-step beyond that, so addresses never wrap between checkpoints:
+// the first kRingMirror bytes of the ring are mirrored behind its end.
+// Everything here is wave-uniform (SGPRs); the refill branch is a scalar branch.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kMaxAdvance = 512;
+static_assert(kRingMirror >= kMaxAdvance + 256, "mirror must cover one checkpoint interval plus one sub-step");
+
+struct StreamWindow {
+    uint8_t *ring;      // LDS, wave-private
+    uint32_t ring_addr; // the same as a raw LDS byte address (for the asm path)
+    uint64_t gnext;     // global address of the next 1 KiB block to fetch
+    uint64_t glimit;    // 16-byte aligned end of what may be fetched for this chunk
+    uint32_t rd, adv, avail, wr;
+    u32x4 pre; // prefetched block (16 B per lane)
+
+    __device__ __forceinline__ u32x4 fetch(uint32_t lane)
+    {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (gnext + kRingBlock <= glimit) { // whole block readable: wave-uniform fast path
+            gvec_cptr g = reinterpret_cast<gvec_cptr>(gnext);
+            v = __builtin_nontemporal_load(g + lane);
+        } else if (gnext + lane * 16u < glimit) {
+            gvec_cptr g = reinterpret_cast<gvec_cptr>(gnext);
+            v = __builtin_nontemporal_load(g + lane);
+        }
+        gnext += kRingBlock;
+        return v;
+    }
+    __device__ __forceinline__ void put(uint32_t lane, uint32_t at, const u32x4 &v)
+    {
+        *reinterpret_cast<u32x4 *>(ring + at + lane * 16u) = v;
+        if (at == 0 && lane < kRingMirror / 16u)
+            *reinterpret_cast<u32x4 *>(ring + kRingBytes + lane * 16u) = v;
+    }
+    __device__ __forceinline__ void open(uint8_t *lds, uint64_t gaddr, uint64_t limit, uint32_t lane)
+    {
+        ring = lds;
+        ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
+        glimit = limit;
+        gnext = gaddr & ~uint64_t(15);
+        rd = (uint32_t)(gaddr & 15u);
+        adv = 0;
+        u32x4 b0 = fetch(lane);
+        u32x4 b1 = fetch(lane);
+        pre = fetch(lane);
+        put(lane, 0, b0);
+        put(lane, kRingBlock, b1);
+        wr = 0;
+        avail = kRingBytes - rd;
+    }
+    __device__ __forceinline__ void checkpoint(uint32_t lane)
+    {
+        rd = (rd + adv) & (kRingBytes - 1);
+        avail -= adv;
+        adv = 0;
+        if (avail <= kRingBlock) {
+            put(lane, wr, pre);
+            wr ^= kRingBlock;
+            avail += kRingBlock;
+            pre = fetch(lane);
+        }
+    }
+    // ring offset / LDS address of the read cursor (no wrap between checkpoints)
+    __device__ __forceinline__ uint32_t cursor() const { return rd + adv; }
+    __device__ __forceinline__ uint32_t cursor_addr() const { return ring_addr + rd + adv; }
+    __device__ __forceinline__ void consume(uint32_t bytes) { adv += bytes; }
+};
+
+// ---------------------------------------------------------------------------
+// Renormalisation of one sub-step (64 lanes, ascending lane order == ascending
+// stream address).  `active` masks lanes that have no symbol in this round.
+// Returns the bytes consumed (wave-uniform).
+// ---------------------------------------------------------------------------
+template <int FMT>
+__device__ __forceinline__ uint32_t dec_renorm(const StreamWindow &W, typename FmtTraits<FMT>::state_t &x,
+                                               bool active)
+{
+    if constexpr (FMT == FMT_WORD) {
+        // rans_word_sse41.h:134-141 / :182-227
+        const bool need = active && x < (1u << 16);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(need);
+        const uint32_t at = W.cursor() + 2u * rank_below(m);
+        const uint32_t w = *reinterpret_cast<const uint16_t *>(W.ring + at);
+        x = need ? ((x << 16) | w) : x;
+        return 2u * (uint32_t)__builtin_popcountll(m);
+    } else if constexpr (FMT == FMT_R64) {
+        // rans64.h:305-316
+        const bool need = active && x < (1ull << 31);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(need);
+        const uint32_t at = W.cursor() + 4u * rank_below(m);
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(W.ring + at);
+        x = need ? ((x << 32) | w) : x;
+        return 4u * (uint32_t)__builtin_popcountll(m);
+    } else {
+        // rans_byte.h:307-318.  With scale_bits <= 16 a lane needs 0, 1 or 2
+        // bytes: x >= 2^7 after D, and a second byte is needed iff x < 2^15.
+        // The first byte read is the more significant one.
+        const bool n1 = active && x < (1u << 23);
+        const bool n2 = active && x < (1u << 15);
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(n1);
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(n2);
+        const uint32_t at = W.cursor() + rank_below(m1) + rank_below(m2);
+        const uint32_t b0 = W.ring[at];
+        const uint32_t b1 = W.ring[at + 1];
+        const uint32_t x1 = (x << 8) | b0;
+        const uint32_t x2 = (x1 << 8) | b1;
+        x = n2 ? x2 : (n1 ? x1 : x);
+        return (uint32_t)__builtin_popcountll(m1) + (uint32_t)__builtin_popcountll(m2);
+    }
+}
+
+// Hand-written renormalisation sub-step of the word format for a FULL wave (all 64
+// lanes hold a state and are active): rans_word_sse41.h:134-141 for 64 lanes at once.
+//   v_cmpx      lanes with x < 2^16 stay enabled; vcc = the same mask
+//   v_mbcnt x2  rank of the lane among the enabled ones = its word index in the stream
+//   ds_read_u16 only the enabled lanes read; v_perm merges (x << 16) | word
+//   s_bcnt1     words consumed by the wave (returned)
+// 5 VALU + 1 LDS + 2 SALU, no branch, no v_cndmask.  exec is restored to all ones,
+// which is what it was (the caller runs this only in wave-uniform full-wave code).
+__device__ __forceinline__ uint32_t renorm_word_full(uint32_t &x, uint32_t cursor_addr, uint32_t k65536)
+{
+    uint32_t t, w, cnt;
+    // gfx940+ hazard: a VALU write of an SGPR/VCC needs 2 wait states before a VALU reads it
+    // as an operand (LLVM GCNHazardRecognizer, VALUWriteSGPRVALURead); hipcc does not pad
+    // inside an asm statement, hence the s_nop 1.
+    asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[x]\n\t"
+                 "s_nop 1\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "v_lshl_add_u32 %[t], %[t], 1, %[cur]\n\t"
+                 "ds_read_u16 %[w], %[t]\n\t"
+                 "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_perm_b32 %[x], %[x], %[w], %[sel]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [x] "+v"(x), [t] "=&v"(t), [w] "=&v"(w), [cnt] "=&s"(cnt)
+                 : [lim] "v"(k65536), [cur] "s"(cursor_addr), [sel] "s"(0x05040100u)
+                 : "vcc", "scc", "memory");
+    return cnt;
+}
+
+// Same for the byte formats (rans_byte.h:307-318): a lane needs 0, 1 or 2 bytes
+// (x < 2^23, x < 2^15); its offset in the stream is the sum of both masks' ranks; the
+// first byte is the more significant one.  9 VALU + 2 LDS, no branch.  Returns bytes consumed.
+__device__ __forceinline__ uint32_t renorm_byte_full(uint32_t &x, uint32_t cursor_addr, uint32_t k2p23, uint32_t k2p15)
+{
+    uint32_t t, b0, b1, c1, c2;
+    uint64_t m1;
+    asm volatile("v_cmp_gt_u32_e32 vcc, %[l23], %[x]\n\t"
+                 "s_nop 1\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "s_mov_b64 %[m1], vcc\n\t"
+                 "s_bcnt1_i32_b64 %[c1], vcc\n\t"
+                 "v_cmp_gt_u32_e32 vcc, %[l15], %[x]\n\t"
+                 "v_add_u32_e32 %[t], %[cur], %[t]\n\t"
+                 "s_nop 0\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, %[t]\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "s_bcnt1_i32_b64 %[c2], vcc\n\t"
+                 "s_mov_b64 exec, %[m1]\n\t"
+                 "ds_read_u8 %[b0], %[t]\n\t"
+                 "s_mov_b64 exec, vcc\n\t"
+                 "ds_read_u8 %[b1], %[t] offset:1\n\t"
+                 "s_mov_b64 exec, %[m1]\n\t"
+                 "s_waitcnt lgkmcnt(1)\n\t"
+                 "v_lshl_or_b32 %[x], %[x], 8, %[b0]\n\t"
+                 "s_mov_b64 exec, vcc\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_lshl_or_b32 %[x], %[x], 8, %[b1]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [x] "+v"(x), [t] "=&v"(t), [b0] "=&v"(b0), [b1] "=&v"(b1), [c1] "=&s"(c1), [c2] "=&s"(c2),
+                   [m1] "=&s"(m1)
+                 : [l23] "v"(k2p23), [l15] "v"(k2p15), [cur] "s"(cursor_addr)
+                 : "vcc", "scc", "memory");
+    return c1 + c2;
+}
+
+// byte `kSymByte` of `raw` goes to byte J of acc, the other bytes of acc stay
+template <int SYMBYTE, int J> __device__ __forceinline__ uint32_t acc_symbol(uint32_t raw, uint32_t acc)
+{
+    if constexpr (J == 0) {
+        return raw; // fixed up by J == 1
+    } else if constexpr (J == 1) {
+        // byte0 <- acc[SYMBYTE] (round 0's symbol), byte1 <- raw[SYMBYTE]
+        constexpr uint32_t sel = (uint32_t)SYMBYTE | ((4u + SYMBYTE) << 8) | 0x03020000u;
+        return __builtin_amdgcn_perm(raw, acc, sel);
+    } else {
+        constexpr uint32_t ident = 0x03020100u;
+        constexpr uint32_t sel = (ident & ~(0xffu << (8 * J))) | ((4u + SYMBYTE) << (8 * J));
+        return __builtin_amdgcn_perm(raw, acc, sel);
+    }
+}
+
+template <int FMT, int K, int OUT>
+__global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(const DecParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
+
+    // ---- stage the tables into LDS (once per block) ----------------------
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1_bytes = (p.table1_bytes + 15u) & ~15u;
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+        const uint4 *g1 = reinterpret_cast<const uint4 *>(p.table1);
+        uint4 *l1 = reinterpret_cast<uint4 *>(smem + t0_bytes);
+        for (uint32_t i = threadIdx.x; i < t1_bytes / 16u; i += blockDim.x)
+            l1[i] = g1[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+
+    DecTables<FMT> T;
+    T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+
+    uint8_t *ring = smem + t0_bytes + t1_bytes + wave * kRingStride;
+    uint8_t *tile = smem + t0_bytes + t1_bytes + waves_per_block * kRingStride + wave * kOutTileBytes; // OUT_FAST8_LDS
+    static_assert(OUT != OUT_FAST8_LDS || K == 1, "the LDS output tile holds 4 rounds of 64 symbols");
+    const uint32_t N = (OUT != OUT_SLOW) ? 64u * K : p.n_ways;
+    const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
+    const uint64_t glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
+
+    // per-lane constants of the output transpose
+    const uint32_t sel1 = (lane & 1u) ? 0x03070105u : 0x06020400u;
+    const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
+    const uint32_t out_lane_off = (lane & 3u) * N + (lane & ~3u);
+
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u;
+    // Chunks are handed out dynamically.  The SIMD arbitrates VALU issue by wave age, so the
+    // waves of the older of a CU's two workgroups run ~20 % faster than the younger ones
+    // (measured: 314 vs 372 us for the same work); with a static split the kernel lasts as long
+    // as the slowest wave while the SIMDs drain.  One atomic per chunk on a single word tops
+    // out near 88 claims/us, so there are kWorkPools counters on separate cache lines; pool =
+    // blockIdx % 8 (= the XCD, as dispatched today; only speed depends on that) owns the chunks
+    // c with c % 8 == pool.
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint32_t npools = gridDim.x < kWorkPools ? gridDim.x : kWorkPools;
+    const uint32_t pool = blockIdx.x % npools;
+    for (;;) {
+        if (p.work_counter) {
+            uint32_t got = 0;
+            if (lane == 0)
+                got = atomicAdd(p.work_counter + pool * kWorkPoolStride, 1u);
+            chunk_v = (uint64_t)uniform(got) * npools + pool;
+        }
+        if (chunk_v >= p.nchunks)
+            break;
+        // everything derived from the chunk index is wave-uniform; say so explicitly
+        // so it lives in SGPRs and the loop control below is scalar
+        const uint64_t chunk = uniform64(chunk_v);
+        chunk_v += total_waves; // static stride when there is no counter
+        const uint64_t off = uniform64(p.offsets[chunk]);
+        const uint32_t len = uniform(p.lengths[chunk]);
+        const uint64_t first = chunk * p.chunk_syms;
+        const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        const uint64_t src = cbase + off;
+        uint8_t RANS_GLOBAL *dst = reinterpret_cast<uint8_t RANS_GLOBAL *>(
+            reinterpret_cast<uint64_t>(p.out) + first * p.sym_bytes);
+
+        bool ok = ((off & 15u) == 0) && (len >= N * Tr::kStateBytes) && (off + len <= p.container_bytes);
+        if (!ok) { // wave-uniform
+            if (lane == 0)
+                atomicAdd(p.err_count, 1ull);
+            continue;
+        }
+
+        // ---- initial states: lane 0's first (RansDecInit order, main.cpp:261-262)
+        state_t x[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t idx = k * 64u + lane;
+            x[k] = Tr::kL;
+            if (idx < N) {
+                if constexpr (FMT == FMT_R64) {
+                    const u32x2 v = *(reinterpret_cast<const u32x2 RANS_GLOBAL *>(src) + idx);
+                    x[k] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                } else {
+                    x[k] = *(reinterpret_cast<const uint32_t RANS_GLOBAL *>(src) + idx);
+                }
+            }
+        }
+
+        StreamWindow W;
+        // fetch nothing beyond this chunk's own stream (rounded up to the 16-byte granule)
+        const uint64_t climit = (src + len + 15u) & ~uint64_t(15);
+        W.open(ring, src + N * Tr::kStateBytes, climit < glimit ? climit : glimit, lane);
+        uint32_t consumed = N * Tr::kStateBytes;
+
+        const uint32_t rounds = uniform(nsym / N);
+        const uint32_t tail = uniform(nsym - rounds * N);
+        uint32_t r = 0;
+        // sub-steps between two window checkpoints: at most kMaxAdvance bytes are consumed
+        constexpr int kCheckEvery = (FMT == FMT_R64) ? 2 : 4;
+
+        if constexpr (OUT == OUT_FAST16) {
+            // ---- pairs of full rounds, u16 symbols: lane 2i ends up with round r's symbols of
+            // lanes 2i,2i+1 and lane 2i+1 with round r+1's: one dword store per lane and pair
+            const uint32_t pairs = rounds >> 1;
+            uint8_t RANS_GLOBAL *gdst = dst;
+            const uint32_t sel16 = (lane & 1u) ? 0x03020706u : 0x05040100u;
+            const uint32_t lane_off16 = ((lane & 1u) * N + (lane & ~1u)) * 2u;
+            const uint32_t k2p23 = (1u << 23) + (lane >> 6), k2p15 = (1u << 15) + (lane >> 6);
+            for (uint32_t g = 0; g < pairs; ++g) {
+                uint32_t acc[K];
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint32_t s16 = dec_step<FMT>(T, x[k]) & 0xffffu;
+                        acc[k] = J == 0 ? s16 : (acc[k] | (s16 << 16));
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if ((J * K + k) % kCheckEvery == 0)
+                            W.checkpoint(lane);
+                        uint32_t c;
+                        if constexpr (FMT == FMT_BYTE || FMT == FMT_ALIAS)
+                            c = renorm_byte_full(x[k], W.cursor_addr(), k2p23, k2p15);
+                        else
+                            c = dec_renorm<FMT>(W, x[k], true);
+                        W.consume(c);
+                        consumed += c;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t o = quad_perm<1, 0, 3, 2>(acc[k]);
+                    const uint32_t v = __builtin_amdgcn_perm(o, acc[k], sel16);
+                    *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + (lane_off16 + k * 128u)) = v;
+                }
+                gdst += 4u * N;
+            }
+            r = pairs << 1;
+        } else
+        if constexpr (OUT != OUT_SLOW) {
+            // ---- groups of 4 full rounds, symbols transposed in registers ----
+            const uint32_t groups = rounds >> 2;
+            uint8_t RANS_GLOBAL *gdst = dst;
+            const uint32_t k65536 = 0x10000u + (lane >> 6); // VGPRs holding the renorm limits (lane < 64)
+            const uint32_t k2p23 = (1u << 23) + (lane >> 6), k2p15 = (1u << 15) + (lane >> 6);
+            for (uint32_t g = 0; g < groups; ++g) {
+                uint32_t acc[K];
+#define RANS_ROUND(J)                                                              \
+    _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
+        const uint32_t raw = dec_step<FMT>(T, x[k]);                               \
+        if constexpr (OUT == OUT_FAST8_LDS)                                        \
+            tile[J * 64 + lane] = (uint8_t)(raw >> (8 * Tr::kSymByte));            \
+        else if constexpr (OUT == OUT_FAST8_BYTE)                                  \
+            gdst[J * N + k * 64 + lane] = (uint8_t)(raw >> (8 * Tr::kSymByte));    \
+        else                                                                       \
+            acc[k] = acc_symbol<Tr::kSymByte, J>(raw, acc[k]);                     \
+    }                                                                              \
+    _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
+        if ((J * K + k) % kCheckEvery == 0)                                        \
+            W.checkpoint(lane);                                                    \
+        uint32_t c;                                                                \
+        if constexpr (FMT == FMT_WORD && (OUT == OUT_FAST8 || OUT == OUT_FAST8_LDS || OUT == OUT_FAST8_BYTE)) \
+            c = 2u * renorm_word_full(x[k], W.cursor_addr(), k65536);              \
+        else if constexpr ((FMT == FMT_BYTE || FMT == FMT_ALIAS) && (OUT == OUT_FAST8 || OUT == OUT_FAST8_BYTE)) \
+            c = renorm_byte_full(x[k], W.cursor_addr(), k2p23, k2p15);             \
+        else                                                                       \
+            c = dec_renorm<FMT>(W, x[k], true);                                    \
+        W.consume(c);                                                              \
+        consumed += c;                                                             \
+    }
+                RANS_ROUND(0)
+                RANS_ROUND(1)
+                RANS_ROUND(2)
+                RANS_ROUND(3)
+#undef RANS_ROUND
+                if constexpr (OUT == OUT_FAST8_LDS) {
+                    // LDS ops of one wave execute in order: the read sees the four writes
+                    const uint32_t v = reinterpret_cast<const uint32_t *>(tile)[lane];
+                    *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + lane * 4u) = v;
+                } else if constexpr (OUT != OUT_FAST8_BYTE) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint32_t v = quad_transpose(acc[k], sel1, sel2);
+                        *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + (out_lane_off + k * 64u)) = v;
+                    }
+                }
+                gdst += 4u * N;
+            }
+            r = groups << 2;
+        }
+
+        // ---- remaining full rounds and the partial tail round: element stores
+        for (; r <= rounds; ++r) {
+            const uint32_t cnt = (r < rounds) ? N : tail;
+            if (cnt == 0)
+                break;
+            uint8_t RANS_GLOBAL *rdst = dst + (uint64_t)r * N * p.sym_bytes;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t idx = k * 64u + lane;
+                if (idx < cnt) {
+                    uint32_t s = dec_step<FMT>(T, x[k]);
+                    if constexpr (Tr::kSymByte == 3)
+                        s >>= 24;
+                    if (p.sym_bytes == 1)
+                        rdst[idx] = (uint8_t)s;
+                    else
+                        reinterpret_cast<uint16_t RANS_GLOBAL *>(rdst)[idx] = (uint16_t)s;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t idx = k * 64u + lane;
+                W.checkpoint(lane);
+                const uint32_t c = dec_renorm<FMT>(W, x[k], idx < cnt);
+                W.consume(c);
+                consumed += c;
+            }
+        }
+
+        // ---- integrity: every state back at L, cursor exactly at the end ----
+        bool good = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            good = good && (x[k] == Tr::kL);
+        const bool all_good = __builtin_amdgcn_ballot_w64(!good) == 0 && consumed == len;
+        if (!all_good && lane == 0)
+            atomicAdd(p.err_count, 1ull);
+    }
+    if (p.trace && lane == 0) { // debug timeline: when did this wave start and stop, on which XCD
+        unsigned long long *t = p.trace + 3ull * ((uint64_t)blockIdx.x * waves_per_block + wave);
+        t[0] = t_start;
+        t[1] = wall_clock64();
+        t[2] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11));
+    }
+}
+
+template <int FMT, int K, int OUT>
+hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
+{
+    const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
+    const uint32_t waves = kDecBlockThreads / 64;
+    const size_t lds = (size_t)t0 + t1 + (size_t)waves * kRingStride + (OUT == OUT_FAST8_LDS ? waves * kOutTileBytes : 0);
+    if (lds > 160 * 1024)
+        return hipErrorInvalidValue;
+    auto kern = k_decode<FMT, K, OUT>;
+    static bool attr_set = false; // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_set = true;
+    }
+    const int blocks_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+    uint64_t want = (p.nchunks + waves - 1) / waves;
+    uint64_t cap = (uint64_t)num_cus * blocks_per_cu;
+    const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    if (name)
+        *name = FMT == FMT_WORD ? "k_decode<word>" : FMT == FMT_BYTE ? "k_decode<byte>"
+                : FMT == FMT_R64 ? "k_decode<r64>" : "k_decode<alias>";
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, hipStream_t s, const char **name)
+{
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)p.chunk_syms) & 3u) == 0;
+    const bool fast = aligned && p.sym_bytes == 1;
+    if (aligned && p.sym_bytes == 2) {
+        switch (p.n_ways) {
+        case 64: return launch_decode_t<FMT, 1, OUT_FAST16>(p, num_cus, s, name);
+        case 128: return launch_decode_t<FMT, 2, OUT_FAST16>(p, num_cus, s, name);
+        case 256: return launch_decode_t<FMT, 4, OUT_FAST16>(p, num_cus, s, name);
+        default: break;
+        }
+    }
+    // A/B knobs (word format, 64-way only): alternatives that were measured and lost, kept so the
+    // measurements in DESIGN.md can be repeated.
+    static const bool no_asm = getenv("RANS_AMD_NO_ASM") != nullptr;   // compiler-scheduled renorm: -2 %
+    static const bool lds_out = getenv("RANS_AMD_LDS_OUT") != nullptr;  // output via an LDS tile: -7 %
+    static const bool byte_out = getenv("RANS_AMD_BYTE_OUT") != nullptr; // per-round byte stores: -5 %
+    if constexpr (FMT == FMT_WORD) {
+        if (fast && lds_out && p.n_ways == 64)
+            return launch_decode_t<FMT_WORD, 1, OUT_FAST8_LDS>(p, num_cus, s, name);
+        if (fast && byte_out && p.n_ways == 64)
+            return launch_decode_t<FMT_WORD, 1, OUT_FAST8_BYTE>(p, num_cus, s, name);
+    }
+    if (FMT == FMT_WORD && fast && no_asm) {
+        switch (p.n_ways) {
+        case 64: return launch_decode_t<FMT_WORD, 1, OUT_FAST8_NOASM>(p, num_cus, s, name);
+        case 128: return launch_decode_t<FMT_WORD, 2, OUT_FAST8_NOASM>(p, num_cus, s, name);
+        case 256: return launch_decode_t<FMT_WORD, 4, OUT_FAST8_NOASM>(p, num_cus, s, name);
+        default: break;
+        }
+    }
+    switch (p.n_ways) {
+    case 64:
+        return fast ? launch_decode_t<FMT, 1, OUT_FAST8>(p, num_cus, s, name)
+                    : launch_decode_t<FMT, 1, OUT_SLOW>(p, num_cus, s, name);
+    case 128:
+        return fast ? launch_decode_t<FMT, 2, OUT_FAST8>(p, num_cus, s, name)
+                    : launch_decode_t<FMT, 2, OUT_SLOW>(p, num_cus, s, name);
+    case 256:
+        return fast ? launch_decode_t<FMT, 4, OUT_FAST8>(p, num_cus, s, name)
+                    : launch_decode_t<FMT, 4, OUT_SLOW>(p, num_cus, s, name);
+    case 512:
+        return fast ? launch_decode_t<FMT, 8, OUT_FAST8>(p, num_cus, s, name)
+                    : launch_decode_t<FMT, 8, OUT_SLOW>(p, num_cus, s, name);
+    default:
+        // any other lane count: K = ceil(N / 64) states per lane, the unused tail lanes idle
+        if (p.n_ways >= 1 && p.n_ways < 64)
+            return launch_decode_t<FMT, 1, OUT_SLOW>(p, num_cus, s, name);
+        if (p.n_ways < 128)
+            return launch_decode_t<FMT, 2, OUT_SLOW>(p, num_cus, s, name);
+        if (p.n_ways < 256)
+            return launch_decode_t<FMT, 4, OUT_SLOW>(p, num_cus, s, name);
+        if (p.n_ways < 512)
+            return launch_decode_t<FMT, 8, OUT_SLOW>(p, num_cus, s, name);
+        return hipErrorInvalidValue;
+    }
+}
+
+
+} // namespace
+
+hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name)
+{
+    switch (format) {
+    case FMT_WORD: return launch_decode_f<FMT_WORD>(p, num_cus, stream, name);
+    case FMT_BYTE: return launch_decode_f<FMT_BYTE>(p, num_cus, stream, name);
+    case FMT_R64: return launch_decode_f<FMT_R64>(p, num_cus, stream, name);
+    case FMT_ALIAS: return launch_decode_f<FMT_ALIAS>(p, num_cus, stream, name);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace rans_amd

@@ -1,0 +1,212 @@
+// device_common.hpp -- device-side helpers shared by the kernel translation units (formats, lane
+// utilities, the D step of every format, the exact divisions of the encoders).  Included inside
+// each .hip file; everything lives in an anonymous namespace.
+#pragma once
+
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/ryg_rans_amd.h"
+#include "model.h"
+
+namespace rans_amd {
+
+namespace {
+
+constexpr int FMT_BYTE = RANS_AMD_FMT_BYTE;
+constexpr int FMT_WORD = RANS_AMD_FMT_WORD;
+constexpr int FMT_R64 = RANS_AMD_FMT_R64;
+constexpr int FMT_ALIAS = RANS_AMD_FMT_ALIAS;
+
+// OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
+// symbols transposed in registers.  OUT_FAST8_NOASM: same with the compiler-scheduled renorm
+// (A/B knob).  OUT_FAST8_LDS: symbols staged through a 256-byte LDS tile per wave
+// (ds_write_b8 per round, one ds_read_b32 + global_store_dword per 4 rounds; K == 1 only).
+// OUT_FAST16: u16 symbols, 2 rounds packed per dword and swapped between lane pairs.
+// OUT_FAST8_BYTE: one global_store_byte per lane and round (64 contiguous bytes per wave), no transpose.
+enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST8_NOASM = 2, OUT_FAST8_LDS = 3, OUT_FAST16 = 4, OUT_FAST8_BYTE = 5 };
+constexpr uint32_t kOutTileBytes = 256;
+
+template <int FMT> struct FmtTraits;
+template <> struct FmtTraits<FMT_WORD> {
+    using state_t = uint32_t;
+    static constexpr uint32_t kUnit = 2, kStateBytes = 4;
+    static constexpr uint32_t kL = 1u << 16; // rans_word_sse41.h:35
+    static constexpr int kSymByte = 3;        // WordSlot.lo keeps the symbol in its top byte
+};
+template <> struct FmtTraits<FMT_BYTE> {
+    using state_t = uint32_t;
+    static constexpr uint32_t kUnit = 1, kStateBytes = 4;
+    static constexpr uint32_t kL = 1u << 23; // rans_byte.h:50
+    static constexpr int kSymByte = 0;
+};
+template <> struct FmtTraits<FMT_ALIAS> {
+    using state_t = uint32_t;
+    static constexpr uint32_t kUnit = 1, kStateBytes = 4;
+    static constexpr uint32_t kL = 1u << 23;
+    static constexpr int kSymByte = 0;
+};
+template <> struct FmtTraits<FMT_R64> {
+    using state_t = uint64_t;
+    static constexpr uint32_t kUnit = 4, kStateBytes = 8;
+    static constexpr uint64_t kL = 1ull << 31; // rans64.h:59
+    static constexpr int kSymByte = 0;
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t lane_id()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// number of set bits of m strictly below this lane
+__device__ __forceinline__ uint32_t rank_below(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return (uint64_t)uniform((uint32_t)v) | ((uint64_t)uniform((uint32_t)(v >> 32)) << 32);
+}
+
+// explicit global address space: keeps loads/stores as global_* (not flat_*)
+#define RANS_GLOBAL __attribute__((address_space(1)))
+typedef const u32x4 RANS_GLOBAL *gvec_cptr;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// quad_perm DPP: lane i of each quad reads lane P[i]
+template <int P0, int P1, int P2, int P3> __device__ __forceinline__ uint32_t quad_perm(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
+}
+
+// ---------------------------------------------------------------------------
+// D step: symbol lookup + state update, no stream access.
+// Returns a word whose byte FmtTraits::kSymByte (u8 alphabets) or low 16 bits
+// hold the symbol.
+// ---------------------------------------------------------------------------
+template <int FMT> struct DecTables {
+    const uint8_t *t0; // LDS
+    const uint8_t *t1; // LDS
+    uint32_t scale_bits;
+    uint32_t mask;
+    uint32_t bucket_shift; // alias: scale_bits - log2(nsyms)
+    uint32_t mask12v;      // 0xfff held in a VGPR (a literal operand makes v_and a 3.5-cycle op)
+    // VGPR copies of mask / scale_bits / bucket_shift: a VALU and/shift with an SGPR operand issues in
+    // 4.7 cycles, with VGPR operands in 2.7 (profiles/r01_ubench.log)
+    uint32_t maskv, sbv, bshiftv;
+
+    __device__ __forceinline__ void init(const uint8_t *table0, const uint8_t *table1, uint32_t sb, uint32_t log2nsyms)
+    {
+        t0 = table0;
+        t1 = table1;
+        scale_bits = sb;
+        mask = (1u << sb) - 1u;
+        bucket_shift = sb - log2nsyms;
+        mask12v = 0xfffu;
+        maskv = mask;
+        sbv = sb;
+        bshiftv = bucket_shift;
+        asm volatile("v_mov_b32 %0, %0" : "+v"(mask12v)); // opaque: keep them in VGPRs
+        asm volatile("v_mov_b32 %0, %0" : "+v"(maskv));
+        asm volatile("v_mov_b32 %0, %0" : "+v"(sbv));
+        asm volatile("v_mov_b32 %0, %0" : "+v"(bshiftv));
+    }
+};
+
+template <int FMT>
+__device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename FmtTraits<FMT>::state_t &x)
+{
+    if constexpr (FMT == FMT_WORD) {
+        // rans_word_sse41.h:123-131 / :151-179: slot = x & 4095;
+        // x = freq * (x >> 12) + bias.  freq < 2^12 and x >> 12 < 2^20, so the
+        // 24-bit multiply-add is exact.
+        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[x & T.mask12v];
+        x = (e.x & 0xffffffu) * (x >> 12) + e.y;
+        return e.x;
+    } else if constexpr (FMT == FMT_BYTE) {
+        // rans_byte.h:125-128 (get), :291-298 (step)
+        const uint32_t cf = x & T.maskv;
+        const uint32_t s = T.t0[cf];
+        const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s]; // {freq, start}
+        // freq <= 2^16 and x >> scale_bits < 2^23 (scale_bits >= 8): 24-bit multiply is exact
+        x = (r.x & 0xffffffu) * ((x >> T.sbv) & 0xffffffu) + cf - r.y;
+        return s;
+    } else if constexpr (FMT == FMT_R64) {
+        // rans64.h:118-121 (get), :286-292 (step)
+        const uint32_t cf = (uint32_t)x & T.maskv;
+        const uint32_t s = T.t0[cf];
+        const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s];
+        // freq * (x >> sb) + (cf - start) with x < 2^63: cf - start is in [0, freq), so it is a plain
+        // 32-bit value; the high word of x >> sb is < 2^17 and freq <= 2^16, so its product is one
+        // 24-bit multiply added to the high word -- one v_mad_u64_u32 instead of two plus a 64-bit
+        // subtract-with-borrow
+        const uint64_t xs = x >> T.scale_bits;
+        const uint32_t bias = cf - r.y;
+        x = (uint64_t)r.x * (uint32_t)xs + bias + ((uint64_t)__umul24(r.x, (uint32_t)(xs >> 32)) << 32);
+        return s;
+    } else {
+        // main_alias.cpp:252-267; the subtraction wraps in 32 bits on purpose
+        const uint32_t xm = x & T.maskv;
+        const uint32_t bucket = xm >> T.bshiftv;
+        const uint32_t div = reinterpret_cast<const uint32_t *>(T.t1)[bucket];
+        // xm < div as the sign bit of the difference (both < 2^17): a compare + v_cndmask costs
+        // ~27 issue cycles on gfx950, sub + shift 5.5
+        const uint32_t below = (xm - div) >> 31;
+        const uint32_t half = 2u * bucket + below;
+        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[half]; // {freq | sym << 16, adjust}
+        x = (e.x & 0xffffu) * ((x >> T.sbv) & 0xffffffu) + xm - e.y;
+        return e.x >> 16;
+    }
+}
+
+// 4x4 byte transpose inside each quad of lanes.  In: lane q of a quad holds the
+// bytes of column (4j+q) for rows 0..3.  Out: lane q holds row q, columns
+// 4j..4j+3, i.e. four consecutive output bytes.
+__device__ __forceinline__ uint32_t quad_transpose(uint32_t v, uint32_t sel1, uint32_t sel2)
+{
+    // (the same shuffles through the LDS crossbar, ds_swizzle, measured 2 % slower: the LDS pipe is
+    // the co-bottleneck of the decoder)
+    uint32_t o = quad_perm<1, 0, 3, 2>(v);
+    v = __builtin_amdgcn_perm(o, v, sel1);
+    o = quad_perm<2, 3, 0, 1>(v);
+    return __builtin_amdgcn_perm(o, v, sel2);
+}
+
+// exact x / freq and x % freq from the 32-bit reciprocal floor(2^32 / freq):
+// the estimate is never too large and at most 1 too small.
+__device__ __forceinline__ void divmod_rcp(uint32_t x, uint32_t freq, uint32_t rcp, uint32_t &q, uint32_t &rem)
+{
+    q = __umulhi(x, rcp);
+    // after renormalisation x < 2^(31-scale_bits) * freq (byte, scale_bits >= 8) or 2^20 * freq
+    // (word), so q < 2^23 and freq <= 2^16: the 24-bit multiply (full rate) is exact
+    rem = x - __umul24(q, freq);
+    if (rem >= freq) {
+        q += 1;
+        rem -= freq;
+    }
+}
+
+// 64-bit variant for rans64 (state < 2^63): Alverson reciprocal, exact for freq >= 2; freq == 1
+// (rcp = 2^64 - 1, q = x - 1) is fixed by the correction step.  rec = {freq | rshift << 24, start,
+// rcp lo, rcp hi} (model.cpp).
+__device__ __forceinline__ void divmod_rcp64(uint64_t x, uint32_t freq, const uint4 &rec, uint64_t &q, uint64_t &rem)
+{
+    const uint64_t rcp = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
+    q = __umul64hi(x, rcp) >> (rec.x >> 24);
+    rem = x - q * freq;
+    if (rem >= freq) {
+        q += 1;
+        rem -= freq;
+    }
+}
+
+} // namespace
+
+} // namespace rans_amd

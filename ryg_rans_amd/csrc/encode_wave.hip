@@ -1,0 +1,366 @@
+// encode_wave.hip -- the wave-per-chunk encoder (see decode_wave.hip for the mapping of the
+// reference's loops onto a wavefront).
+
+#include "device_common.hpp"
+#include "launchers.hpp"
+
+namespace rans_amd {
+
+namespace {
+
+// ===========================================================================
+// Encoder: mirror image of the decoder.  One wave per chunk, symbols visited
+// last round first; within a sub-step the lanes that must emit compact their
+// units below the write cursor in ascending lane order (the decoder will read
+// them back in exactly that order).
+// ===========================================================================
+
+template <int FMT> struct EncTables {
+    const uint4 *recs; // LDS: EncRec {freq, start, rcp, remap}
+    const uint32_t *alias_remap; // global
+    uint32_t scale_bits;
+    uint32_t nsyms;
+};
+
+// One encoder sub-step for 64 lanes.  `wp` = write cursor (byte offset inside the
+// slot, moves down, wave-uniform).
+template <int FMT>
+__device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename FmtTraits<FMT>::state_t &x,
+                                            uint32_t sym, bool active, uint8_t RANS_GLOBAL *slot, uint32_t &wp,
+                                            bool &bad)
+{
+    const bool in_alphabet = sym < T.nsyms;
+    const uint4 rec = T.recs[in_alphabet ? sym : 0u];
+    const uint32_t freq = (FMT == FMT_R64) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
+    if (active && (!in_alphabet || freq == 0)) {
+        bad = true;
+        active = false;
+    }
+
+    if constexpr (FMT == FMT_WORD) {
+        // rans_word_sse41.h:81-93
+        const bool emit = active && x >= (freq << 20);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(emit);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        wp -= 2u * cnt;
+        if (emit)
+            *reinterpret_cast<uint16_t RANS_GLOBAL *>(slot + wp + 2u * rank_below(m)) = (uint16_t)(x & 0xffffu);
+        uint32_t y = emit ? (x >> 16) : x;
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        const uint32_t xn = (q << 12) + rem + start;
+        x = active ? xn : x;
+    } else if constexpr (FMT == FMT_R64) {
+        // rans64.h:77-93
+        const uint64_t x_max = ((uint64_t)freq) << (63u - T.scale_bits); // ((L >> sb) << 32) * freq
+        const bool emit = active && x >= x_max;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(emit);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        wp -= 4u * cnt;
+        if (emit)
+            *reinterpret_cast<uint32_t RANS_GLOBAL *>(slot + wp + 4u * rank_below(m)) = (uint32_t)x;
+        uint64_t y = emit ? (x >> 32) : x;
+        uint64_t q, rem;
+        divmod_rcp64(y, freq, rec, q, rem);
+        const uint64_t xn = (q << T.scale_bits) + rem + start;
+        x = active ? xn : x;
+    } else {
+        // rans_byte.h:62-74 (renorm: 0, 1 or 2 bytes for scale_bits <= 16), :83-90 (put),
+        // main_alias.cpp:241-250 (alias put).  The low byte is emitted first, i.e.
+        // ends up at the higher address.
+        const uint32_t x_max = ((1u << 23 >> T.scale_bits) << 8) * freq;
+        const bool e1 = active && x >= x_max;
+        const bool e2 = e1 && (x >> 8) >= x_max;
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(e1);
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(e2);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m1) + (uint32_t)__builtin_popcountll(m2);
+        wp -= cnt;
+        const uint32_t at = wp + rank_below(m1) + rank_below(m2);
+        if (e2) {
+            slot[at] = (uint8_t)(x >> 8);
+            slot[at + 1] = (uint8_t)x;
+        } else if (e1) {
+            slot[at] = (uint8_t)x;
+        }
+        uint32_t y = e2 ? (x >> 16) : (e1 ? (x >> 8) : x);
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        uint32_t xn;
+        if constexpr (FMT == FMT_ALIAS)
+            xn = (q << T.scale_bits) + (active ? T.alias_remap[rem + start] : 0u);
+        else
+            xn = (q << T.scale_bits) + rem + start;
+        x = active ? xn : x;
+    }
+}
+
+// Hand-written encoder sub-step of the word format for a FULL wave (64 active lanes, symbols
+// already turned into LDS addresses of their WordEncRec): rans_word_sse41.h:81-93 for 64 lanes.
+//   v_add_co    carry of x + (cmpl << 20)  <=>  x >= freq << 20: the lanes that emit a word
+//   s_bcnt1 ..  words emitted -> the wave's write offset moves down (these SALU ops are also the
+//               wait states a VALU write of vcc needs before v_mbcnt may read it)
+//   v_mbcnt x2  rank among the emitting lanes = word index (ascending lane = ascending address)
+//   global_store_short + v_lshrrev under the emit mask, then exec back to all ones
+//   x / freq    round-up reciprocal (model.h, WordEncRec): one v_mul_hi_u32 and four cheap ops,
+//               exact, so no compare/select; x' = x + bias + q * cmpl in one v_mad_u32_u24 + add
+// 15 VALU, no v_cndmask, no branch.  `wp` is the byte offset of the lowest word written so far.
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x3 &rec, uint32_t &wp,
+                                              const uint8_t RANS_GLOBAL *slot, uint32_t &worst)
+{
+    uint32_t t, q, sh, cnt;
+    asm volatile("v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
+                 "v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                 "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
+                 "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                 "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
+                 "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
+                 "s_mov_b64 exec, vcc\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
+                 "global_store_short %[t], %[x], %[base]\n\t"
+                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                 "s_mov_b64 exec, -1\n\t"
+                 "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
+                 "v_lshrrev_b32_e32 %[sh], 24, %[w]\n\t"
+                 "v_sub_u32_e32 %[t], %[x], %[q]\n\t"
+                 "v_lshrrev_b32_e32 %[t], 1, %[t]\n\t"
+                 "v_add_u32_e32 %[q], %[q], %[t]\n\t"
+                 "v_lshrrev_b32_e32 %[q], %[sh], %[q]\n\t"
+                 "v_mad_u32_u24 %[q], %[q], %[w], %[x]\n\t"
+                 "v_add_u32_e32 %[x], %[q], %[bias]"
+                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [sh] "=&v"(sh),
+                   [cnt] "=&s"(cnt)
+                 : [m] "v"(rec.x), [w] "v"(rec.y), [bias] "v"(rec.z), [base] "s"(slot)
+                 : "vcc", "scc", "memory");
+}
+
+template <int FMT, int K>
+__global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    // word format: the 256 WordEncRec of the full-wave path come first (LDS address = sym << 4),
+    // the per-symbol EncRec table of the general path behind them
+    constexpr uint32_t kWordRecBytes = FMT == FMT_WORD ? 256u * (uint32_t)sizeof(WordEncRec) : 0u;
+    if constexpr (FMT == FMT_WORD) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.word_enc_recs);
+        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x)
+            l[i] = g[i];
+    }
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
+        uint4 *l = reinterpret_cast<uint4 *>(smem + kWordRecBytes);
+        for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
+            l[i] = g[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t N = p.n_ways; // <= 64 * K; lanes idx >= N idle
+
+    EncTables<FMT> T;
+    T.recs = reinterpret_cast<const uint4 *>(smem + kWordRecBytes);
+    T.alias_remap = p.alias_remap;
+    T.scale_bits = p.scale_bits;
+    T.nsyms = p.nsyms;
+
+    bool bad = false;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    // per-lane constants of the 4x4 byte transpose (same lane mapping as the decoder's stores)
+    const uint32_t sel1 = (lane & 1u) ? 0x03070105u : 0x06020400u;
+    const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
+    const uint32_t in_lane_off = (lane & 3u) * N + (lane & ~3u);
+
+    for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave; chunk_v < p.nchunks;
+         chunk_v += total_waves) {
+        const uint64_t chunk = uniform64(chunk_v);
+        const uint64_t first = chunk * p.chunk_syms;
+        const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + first * p.sym_bytes;
+        uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + chunk * p.slot_bytes;
+        uint32_t wp = (uint32_t)p.slot_bytes;
+
+        state_t x[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            x[k] = Tr::kL; // RansEncInit / RansWordEncInit / Rans64EncInit
+
+        const uint32_t rounds = uniform(nsym / N);
+        const uint32_t tail = uniform(nsym - rounds * N);
+        // Fast input path: full waves, u8 symbols, dword-aligned rows -> symbols of 4 rounds
+        // arrive as one coalesced dword per lane and are transposed in registers; loads run
+        // one super-group (16 rounds) ahead of the arithmetic.
+        const bool fast_in = p.sym_bytes == 1 && N == p.n_ways && (N & 63u) == 0 &&
+                             ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 3u) == 0;
+        // (the word path addresses its record table by raw LDS address: dynamic LDS must start at 0)
+        const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem == 0u;
+        const uint32_t fast_rounds = (fast_in && (FMT != FMT_WORD || lds_at_zero)) ? (rounds & ~15u) : 0u;
+
+        // rounds from last to first; round `rounds` is the partial one
+        for (uint32_t rr = rounds + 1; rr-- > fast_rounds;) {
+            const uint32_t cnt = (rr < rounds) ? N : tail;
+            if (cnt == 0)
+                continue;
+            const uint8_t RANS_GLOBAL *rsrc = src + (uint64_t)rr * N * p.sym_bytes;
+            uint32_t sym[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t idx = k * 64u + lane;
+                sym[k] = 0;
+                if (idx < cnt)
+                    sym[k] = p.sym_bytes == 1 ? (uint32_t)rsrc[idx]
+                                              : (uint32_t) reinterpret_cast<const uint16_t RANS_GLOBAL *>(rsrc)[idx];
+            }
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                const uint32_t idx = k * 64u + lane;
+                enc_substep<FMT>(T, x[k], sym[k], idx < cnt, slot, wp, bad);
+            }
+        }
+
+        uint32_t worst = 0; // word fast path: max of cmpl_sh, > 0x0fffffff iff a symbol has no record
+        if (fast_rounds) {
+            uint32_t rec_mask = 0xff0u;
+            asm volatile("" : "+v"(rec_mask)); // keep the mask in a VGPR (a literal operand costs a slower VALU form)
+            uint32_t cur[4][K], nxt[4][K];
+            auto load_super = [&](uint32_t (&dstq)[4][K], uint32_t sg) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        dstq[j][k] = *reinterpret_cast<const uint32_t RANS_GLOBAL *>(
+                            src + (uint64_t)(sg * 16u + j * 4u) * N + in_lane_off + k * 64u);
+            };
+            uint32_t sg = fast_rounds >> 4;
+            load_super(cur, sg - 1);
+            while (sg-- > 0) {
+                if (sg > 0)
+                    load_super(nxt, sg - 1);
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    uint32_t t[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        t[k] = quad_transpose(cur[j][k], sel1, sel2);
+                if constexpr (FMT == FMT_WORD) {
+                    // symbol byte J -> LDS address of its record, (sym << 4) + table offset; the record
+                    // of the next sub-step is read before the current one is worked on (the asm block is
+                    // a scheduling barrier for the compiler)
+                    auto rec_at = [&](int step) { // step 0 = (J 3, k K-1), descending
+                        const int J = 3 - step / K, k = K - 1 - step % K;
+                        const uint32_t at = (J == 0 ? (t[k] << 4) : (t[k] >> (8 * J - 4))) & rec_mask;
+                        return *reinterpret_cast<const __attribute__((address_space(3))) u32x3 *>((uintptr_t)at); // table at LDS address 0
+                    };
+                    u32x3 rec = rec_at(0);
+#pragma unroll
+                    for (int step = 0; step < 4 * K; ++step) {
+                        const u32x3 now = rec;
+                        if (step + 1 < 4 * K)
+                            rec = rec_at(step + 1);
+                        enc_word_full(x[K - 1 - step % K], now, wp, slot, worst);
+                    }
+                } else {
+#pragma unroll
+                    for (int J = 3; J >= 0; --J)
+#pragma unroll
+                        for (int k = K - 1; k >= 0; --k)
+                            enc_substep<FMT>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
+                }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        cur[j][k] = nxt[j][k];
+            }
+        }
+
+        if (worst > 0x0fffffffu)
+            bad = true;
+        // flush: lane N-1 first, i.e. lane 0's state ends up first in memory
+        // (main.cpp:244-245, main_simd.cpp:298-299)
+        wp -= N * Tr::kStateBytes;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t idx = k * 64u + lane;
+            if (idx < N) {
+                uint8_t RANS_GLOBAL *at = slot + wp + idx * Tr::kStateBytes;
+                if constexpr (FMT == FMT_R64) {
+                    reinterpret_cast<uint32_t RANS_GLOBAL *>(at)[0] = (uint32_t)x[k];
+                    reinterpret_cast<uint32_t RANS_GLOBAL *>(at)[1] = (uint32_t)(x[k] >> 32);
+                } else if constexpr (FMT == FMT_WORD) {
+                    reinterpret_cast<uint16_t RANS_GLOBAL *>(at)[0] = (uint16_t)x[k];
+                    reinterpret_cast<uint16_t RANS_GLOBAL *>(at)[1] = (uint16_t)(x[k] >> 16);
+                } else {
+                    at[0] = (uint8_t)x[k];
+                    at[1] = (uint8_t)(x[k] >> 8);
+                    at[2] = (uint8_t)(x[k] >> 16);
+                    at[3] = (uint8_t)(x[k] >> 24);
+                }
+            }
+        }
+        if (lane == 0)
+            p.lengths[chunk] = (uint32_t)p.slot_bytes - wp;
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
+        atomicOr(p.flags, 1u);
+}
+
+template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num_cus, hipStream_t stream)
+{
+    const uint32_t waves = kEncBlockThreads / 64;
+    const size_t lds = (size_t)p.nsyms * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
+    if (lds > 128 * 1024 || (FMT == FMT_WORD && !p.word_enc_recs))
+        return hipErrorInvalidValue;
+    auto kern = k_encode<FMT, K>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_set = true;
+    }
+    uint64_t want = (p.nchunks + waves - 1) / waves;
+    uint64_t cap = (uint64_t)num_cus * 8;
+    const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kEncBlockThreads), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int FMT> hipError_t launch_encode_f(const EncParams &p, int num_cus, hipStream_t s)
+{
+    // K = ceil(N / 64) states per lane; lane counts that are not a multiple of 64 leave lanes idle
+    if (p.n_ways >= 1 && p.n_ways <= 64)
+        return launch_encode_t<FMT, 1>(p, num_cus, s);
+    if (p.n_ways <= 128)
+        return launch_encode_t<FMT, 2>(p, num_cus, s);
+    if (p.n_ways <= 256)
+        return launch_encode_t<FMT, 4>(p, num_cus, s);
+    if (p.n_ways <= 512)
+        return launch_encode_t<FMT, 8>(p, num_cus, s);
+    return hipErrorInvalidValue;
+}
+
+
+} // namespace
+
+hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipStream_t stream)
+{
+    switch (format) {
+    case FMT_WORD: return launch_encode_f<FMT_WORD>(p, num_cus, stream);
+    case FMT_BYTE: return launch_encode_f<FMT_BYTE>(p, num_cus, stream);
+    case FMT_R64: return launch_encode_f<FMT_R64>(p, num_cus, stream);
+    case FMT_ALIAS: return launch_encode_f<FMT_ALIAS>(p, num_cus, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace rans_amd

@@ -1,5 +1,5 @@
 // kernels.h -- launch interface between the C-ABI layer (api.cpp) and the HIP
-// kernels (kernels.hip).  Internal; not installed.
+// kernels (decode_wave.hip, encode_wave.hip, lanes.hip, container_kernels.hip).  Internal; not installed.
 #pragma once
 
 #include <cstdint>
@@ -8,7 +8,7 @@
 
 namespace rans_amd {
 
-// Per-wave LDS stream window (see kernels.hip "stream window").
+// Per-wave LDS stream window (see decode_wave.hip "stream window").
 constexpr uint32_t kRingBytes = 2048;   // two 1 KiB blocks
 constexpr uint32_t kRingBlock = 1024;   // 64 lanes x 16 B
 constexpr uint32_t kRingMirror = 768;   // copy of ring[0..768) after the end: no wrap between checkpoints

@@ -1,0 +1,994 @@
+// lanes.hip -- lane-per-stream kernels for narrow interleaves (N = 1, 2, 4, 8), both generations.
+
+#include "device_common.hpp"
+#include "launchers.hpp"
+
+namespace rans_amd {
+
+namespace {
+
+// ===========================================================================
+// Lane-per-stream kernels for narrow interleaves (N = 1, 2, 4, 8; BASELINE config 2 is
+// the reference's 2-way rans64 loop, main64.cpp:224-287).  An N-way stream with N << 64
+// cannot feed a wavefront, so here every LANE owns a whole chunk: its N states live in
+// registers, it walks its own stream with its own pointer (the renormalisation order
+// inside a chunk is the sequential reference order, no cross-lane work at all), and a
+// wave decodes 64 chunks at once.  Tables are shared through LDS as before.
+// ===========================================================================
+
+// Per-lane stream window for the lane-per-stream decoder: 16 bytes of the lane's own stream
+// in registers plus the next 16 prefetched, so that a lane touches global memory once per
+// 16 stream bytes (a dword-per-unit walk would issue 4-16x as many scattered accesses).
+// The window is consumed from its low end and shifted down after every unit -- positional
+// indexing would be a chain of v_cndmask (~22 issue cycles each on gfx950) -- and the refill
+// loads straight into `pre` under the lanes' exec mask, so the load issued at one refill is only
+// waited for at the next one.
+struct LaneWindow {
+    u32x4 win, pre;
+    uint64_t next;  // global address of the 16 bytes after `pre`
+    uint64_t limit; // 16-byte aligned end of the readable container
+    uint32_t left;  // bytes left in win (1..16)
+    uint32_t used;  // stream bytes consumed so far
+
+    template <int UNIT> __device__ __forceinline__ void shift()
+    {
+        if constexpr (UNIT == 4) {
+            win.x = win.y;
+            win.y = win.z;
+            win.z = win.w;
+        } else {
+            win.x = __builtin_amdgcn_alignbit(win.y, win.x, 8 * UNIT);
+            win.y = __builtin_amdgcn_alignbit(win.z, win.y, 8 * UNIT);
+            win.z = __builtin_amdgcn_alignbit(win.w, win.z, 8 * UNIT);
+            win.w >>= 8 * UNIT;
+        }
+    }
+    __device__ __forceinline__ void refill()
+    {
+        win = pre;
+        left = 16;
+        if (next < limit) // past the container: `pre` keeps stale bytes, which only a corrupt chunk consumes
+            pre = *reinterpret_cast<const u32x4 RANS_GLOBAL *>(next);
+        next += 16;
+    }
+    template <int UNIT> __device__ __forceinline__ void open(uint64_t addr, uint64_t lim)
+    {
+        limit = lim;
+        const uint64_t base = addr & ~uint64_t(15);
+        used = 0;
+        win = u32x4{0u, 0u, 0u, 0u};
+        pre = win;
+        if (base < limit)
+            win = *reinterpret_cast<const u32x4 RANS_GLOBAL *>(base);
+        if (base + 16 < limit)
+            pre = *reinterpret_cast<const u32x4 RANS_GLOBAL *>(base + 16);
+        next = base + 32;
+        left = 16;
+        for (uint32_t skip = (uint32_t)(addr & 15u); skip != 0; skip -= UNIT) { // once per chunk
+            shift<UNIT>();
+            left -= UNIT;
+        }
+    }
+    template <int UNIT> __device__ __forceinline__ uint32_t take()
+    {
+        uint32_t w = win.x;
+        if constexpr (UNIT == 2)
+            w &= 0xffffu;
+        else if constexpr (UNIT == 1)
+            w &= 0xffu;
+        shift<UNIT>();
+        used += UNIT;
+        left -= UNIT;
+        if (left == 0)
+            refill();
+        return w;
+    }
+};
+
+template <int FMT>
+__device__ __forceinline__ void lane_renorm(typename FmtTraits<FMT>::state_t &x, LaneWindow &W, bool active)
+{
+    if constexpr (FMT == FMT_WORD) {
+        if (active && x < (1u << 16)) // rans_word_sse41.h:134-141
+            x = (x << 16) | W.take<2>();
+    } else if constexpr (FMT == FMT_R64) {
+        if (active && x < (1ull << 31)) // rans64.h:305-316
+            x = (x << 32) | W.take<4>();
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) // rans_byte.h:307-318, at most two bytes for scale_bits <= 16
+            if (active && x < (1u << 23))
+                x = (x << 8) | W.take<1>();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Staged lane-per-stream decoder.  Per-lane 16-byte loads pull a whole memory line for every
+// 16 bytes used, and the line is long evicted when the lane comes back for its next 16 bytes
+// (measured: >= 4x over-fetch, the kernel sat on the fabric at ~3.3 TB/s); and a lane that
+// refills on its own stalls its whole wave.  Here the WAVE refills for all of its 64 chunks at
+// once, every 16 symbols: a lane's stream lives in a 128-byte ring in LDS (two 64-byte lines),
+// lanes publish which line they need next, and 4 lanes fetch one chunk's line with coalesced
+// 16-byte loads (4 load instructions cover 64 chunks x 64 B).  16 symbols consume at most one
+// line (rans64: <= 4 B per symbol), so "at least 64 bytes ahead" before every group is all the
+// invariant there is.  Ring rows are 136 bytes apart: equal positions of the 64 lanes spread over
+// 32 banks.  Positions are 32-bit offsets from the line of the wave's first chunk.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kLaneLine = 64;
+constexpr uint32_t kLaneRingStride = 2 * kLaneLine + 8;
+constexpr uint32_t kLaneWaveLds = 64 * kLaneRingStride + 64 * 4; // rings + one request word per lane
+
+template <int FMT> struct LaneRing {
+    const uint8_t *row; // this lane's ring in LDS
+    uint32_t cur;       // read position (offset from the wave's region base)
+    uint32_t used;      // stream bytes consumed
+
+    template <int UNIT> __device__ __forceinline__ uint32_t take()
+    {
+        const uint8_t *at = row + (cur & (2 * kLaneLine - 1));
+        cur += UNIT;
+        used += UNIT;
+        if constexpr (UNIT == 4)
+            return *reinterpret_cast<const uint32_t *>(at);
+        else if constexpr (UNIT == 2)
+            return *reinterpret_cast<const uint16_t *>(at);
+        else
+            return *at;
+    }
+    __device__ __forceinline__ void renorm(typename FmtTraits<FMT>::state_t &x, bool active)
+    {
+        // the branch bodies hold an LDS read, so they stay exec-masked branches (no v_cndmask)
+        if constexpr (FMT == FMT_WORD) {
+            if (active && x < (1u << 16)) // rans_word_sse41.h:134-141
+                x = (x << 16) | take<2>();
+        } else if constexpr (FMT == FMT_R64) {
+            if (active && x < (1ull << 31)) // rans64.h:305-316
+                x = (x << 32) | take<4>();
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) // rans_byte.h:307-318, at most two bytes for scale_bits <= 16
+                if (active && x < (1u << 23))
+                    x = (x << 8) | take<1>();
+        }
+    }
+};
+
+template <int FMT, int NW>
+__global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1_bytes = (p.table1_bytes + 15u) & ~15u;
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+        const uint4 *g1 = reinterpret_cast<const uint4 *>(p.table1);
+        uint4 *l1 = reinterpret_cast<uint4 *>(smem + t0_bytes);
+        for (uint32_t i = threadIdx.x; i < t1_bytes / 16u; i += blockDim.x)
+            l1[i] = g1[i];
+    }
+    __syncthreads();
+
+    DecTables<FMT> T;
+    T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    uint8_t *rings = smem + t0_bytes + t1_bytes + wave * kLaneWaveLds;
+    uint32_t *req = reinterpret_cast<uint32_t *>(rings + 64u * kLaneRingStride);
+    const uint32_t part = lane & 3u, grp = lane >> 2;
+
+    const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
+    const uint64_t glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
+    const bool wide_out = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 15u) == 0;
+    uint32_t nbad = 0;
+    const uint64_t nbatches = (p.nchunks + 63u) / 64u;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += total_waves) {
+        const uint64_t batch = uniform64(batch_v);
+        const uint64_t chunk = batch * 64u + lane;
+        bool valid = chunk < p.nchunks;
+        const uint64_t off = valid ? p.offsets[chunk] : 0;
+        const uint32_t len = valid ? p.lengths[chunk] : 0;
+        const uint64_t first = chunk * p.chunk_syms;
+        // region base: the line of the batch's first chunk (lane 0 always holds a chunk)
+        const uint64_t rb = uniform64(off) & ~uint64_t(kLaneLine - 1);
+        if (valid && ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off + len > p.container_bytes || off < rb ||
+                      off - rb >= (1u << 30))) {
+            nbad++;
+            valid = false;
+        }
+        const uint32_t nsym = valid ? (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms) : 0u;
+        uint8_t RANS_GLOBAL *dst = (uint8_t RANS_GLOBAL *)p.out + first * p.sym_bytes;
+
+        state_t x[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l) { // RansDecInit order: lane 0's state first
+            x[l] = Tr::kL;
+            if (valid) {
+                const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.container + off;
+                if constexpr (FMT == FMT_R64) {
+                    const u32x2 v = reinterpret_cast<const u32x2 RANS_GLOBAL *>(src)[l];
+                    x[l] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                } else {
+                    x[l] = reinterpret_cast<const uint32_t RANS_GLOBAL *>(src)[l];
+                }
+            }
+        }
+        LaneRing<FMT> W;
+        W.row = rings + lane * kLaneRingStride;
+        W.cur = (uint32_t)(off - rb) + NW * Tr::kStateBytes;
+        W.used = 0;
+        uint32_t ld = W.cur & ~(kLaneLine - 1u); // next line this lane has not staged yet
+
+        // the whole wave takes part (also lanes without a chunk): lane -> which line its chunk needs,
+        // then lane (4 g + part) moves 16 bytes of chunk (16 j + g)'s line, j = 0..3
+        auto refill = [&]() {
+            const bool need = valid && (int32_t)(ld - W.cur) < (int32_t)kLaneLine;
+            req[lane] = need ? (ld | 1u) : 0u;
+            if (need)
+                ld += kLaneLine;
+            uint32_t r[4];
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[j] = req[16 * j + grp]; // LDS ops of one wave execute in order: sees the writes above
+                v[j] = u32x4{0u, 0u, 0u, 0u};
+                const uint64_t a = cbase + rb + (r[j] & ~(kLaneLine - 1u)) + part * 16u;
+                if ((r[j] & 1u) && a < glimit)
+                    v[j] = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(a));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r[j] & 1u) {
+                    uint8_t *at = rings + (16u * j + grp) * kLaneRingStride + (r[j] & kLaneLine) + part * 16u;
+                    reinterpret_cast<u32x2 *>(at)[0] = u32x2{v[j].x, v[j].y}; // rows are 8-byte aligned
+                    reinterpret_cast<u32x2 *>(at)[1] = u32x2{v[j].z, v[j].w};
+                }
+        };
+
+        // 16 symbols into four dwords: 16/NW rounds of NW steps + renormalisations
+        auto decode16 = [&]() -> u32x4 {
+            uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int rr = 0; rr < 16 / NW; ++rr) {
+#pragma unroll
+                for (int l = 0; l < NW; ++l) {
+                    uint32_t sy = dec_step<FMT>(T, x[l]);
+                    if constexpr (Tr::kSymByte == 3)
+                        sy >>= 24;
+                    const int pos = rr * NW + l;
+                    pk[pos / 4] |= (sy & 0xffu) << (8 * (pos % 4));
+                }
+#pragma unroll
+                for (int l = 0; l < NW; ++l)
+                    W.renorm(x[l], true);
+            }
+            return u32x4{pk[0], pk[1], pk[2], pk[3]};
+        };
+
+        refill(); // two lines ahead to start with
+        // 64 symbols per trip: four groups of 16 (a refill before each), then the lane writes its 64
+        // bytes with four back-to-back 16-byte stores.  One 16-byte store per group left every line
+        // dirty in L2 for four groups -- long enough to be evicted half-written: 3.2x the bytes on
+        // the write side (WRITE_SIZE 0.87 GB for 0.27 GB of symbols).
+        for (uint32_t i0 = 0; __builtin_amdgcn_ballot_w64(i0 < nsym) != 0; i0 += 64u) {
+            const uint32_t left = i0 < nsym ? nsym - i0 : 0u;
+            if (__builtin_amdgcn_ballot_w64(!(left >= 64u && wide_out) && valid) == 0) { // wave-uniform
+                u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
+                refill();
+                if (left)
+                    q0 = decode16();
+                refill();
+                if (left)
+                    q1 = decode16();
+                refill();
+                if (left)
+                    q2 = decode16();
+                refill();
+                if (left) {
+                    q3 = decode16();
+                    u32x4 RANS_GLOBAL *o = reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i0);
+                    o[0] = q0;
+                    o[1] = q1;
+                    o[2] = q2;
+                    o[3] = q3;
+                }
+                continue;
+            }
+            // ragged end of a chunk, unaligned or 16-bit output: 16 symbols at a time
+            for (uint32_t g = 0; g < 4u; ++g) {
+                refill();
+                const uint32_t j0 = i0 + 16u * g;
+                if (j0 >= nsym)
+                    continue;
+                const uint32_t cnt = nsym - j0 < 16u ? nsym - j0 : 16u;
+                if (cnt == 16u && wide_out) {
+                    const u32x4 q = decode16();
+                    *reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + j0) = q;
+                } else {
+                    for (uint32_t i = 0; i < cnt; i += NW) {
+                        const uint32_t c = cnt - i < (uint32_t)NW ? cnt - i : (uint32_t)NW;
+#pragma unroll
+                        for (int l = 0; l < NW; ++l)
+                            if ((uint32_t)l < c) {
+                                uint32_t sy = dec_step<FMT>(T, x[l]);
+                                if constexpr (Tr::kSymByte == 3)
+                                    sy >>= 24;
+                                if (p.sym_bytes == 1)
+                                    dst[j0 + i + l] = (uint8_t)sy;
+                                else
+                                    reinterpret_cast<uint16_t RANS_GLOBAL *>(dst)[j0 + i + l] = (uint16_t)sy;
+                            }
+#pragma unroll
+                        for (int l = 0; l < NW; ++l)
+                            W.renorm(x[l], (uint32_t)l < c);
+                    }
+                }
+            }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int l = 0; l < NW; ++l)
+            bad = bad || (x[l] != Tr::kL);
+        if (valid && (bad || W.used + NW * Tr::kStateBytes != len))
+            nbad++;
+    }
+    if (nbad)
+        atomicAdd(p.err_count, (unsigned long long)nbad);
+}
+
+template <int FMT, int NW>
+__global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1_bytes = (p.table1_bytes + 15u) & ~15u;
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+        const uint4 *g1 = reinterpret_cast<const uint4 *>(p.table1);
+        uint4 *l1 = reinterpret_cast<uint4 *>(smem + t0_bytes);
+        for (uint32_t i = threadIdx.x; i < t1_bytes / 16u; i += blockDim.x)
+            l1[i] = g1[i];
+    }
+    __syncthreads();
+
+    DecTables<FMT> T;
+    T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
+    const uint8_t RANS_GLOBAL *cbase = (const uint8_t RANS_GLOBAL *)p.container;
+    const uint64_t glimit = (reinterpret_cast<uint64_t>(p.container) + p.container_bytes + 15u) & ~uint64_t(15);
+    const bool wide_out = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 15u) == 0;
+    uint32_t nbad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; chunk < p.nchunks; chunk += stride) {
+        const uint64_t off = p.offsets[chunk];
+        const uint32_t len = p.lengths[chunk];
+        const uint64_t first = chunk * p.chunk_syms;
+        const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        if ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off + len > p.container_bytes) {
+            nbad++;
+            continue;
+        }
+        const uint8_t RANS_GLOBAL *src = cbase + off;
+        uint8_t RANS_GLOBAL *dst = (uint8_t RANS_GLOBAL *)p.out + first * p.sym_bytes;
+
+        state_t x[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l) { // RansDecInit order: lane 0's state first
+            if constexpr (FMT == FMT_R64) {
+                const u32x2 v = reinterpret_cast<const u32x2 RANS_GLOBAL *>(src)[l];
+                x[l] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            } else {
+                x[l] = reinterpret_cast<const uint32_t RANS_GLOBAL *>(src)[l];
+            }
+        }
+        LaneWindow W;
+        W.open<(int)Tr::kUnit>(reinterpret_cast<uint64_t>(p.container) + off + NW * Tr::kStateBytes, glimit);
+        bool bad = false;
+
+        const uint32_t rounds = nsym / NW;
+        const uint32_t tail = nsym - rounds * NW;
+        uint32_t i = 0; // symbol index inside the chunk
+        if (wide_out) {
+            // 16 symbols per 16-byte store: 16/NW rounds per group
+            constexpr int kRoundsPerGroup = 16 / NW;
+            const uint32_t groups = rounds / kRoundsPerGroup;
+            for (uint32_t g = 0; g < groups; ++g) {
+                u32x4 pack = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int rr = 0; rr < kRoundsPerGroup; ++rr) {
+#pragma unroll
+                    for (int l = 0; l < NW; ++l) {
+                        uint32_t sy = dec_step<FMT>(T, x[l]);
+                        if constexpr (Tr::kSymByte == 3)
+                            sy >>= 24;
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int pos = rr * NW + l;
+                        pack[pos / 4] |= (sy & 0xffu) << (8 * (pos % 4));
+                    }
+#pragma unroll
+                    for (int l = 0; l < NW; ++l)
+                        lane_renorm<FMT>(x[l], W, true);
+                }
+                *reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i) = pack;
+                i += 16;
+            }
+        }
+        // remaining rounds + tail: element stores
+        while (i < nsym) {
+            const uint32_t cnt = nsym - i < (uint32_t)NW ? nsym - i : (uint32_t)NW;
+#pragma unroll
+            for (int l = 0; l < NW; ++l)
+                if ((uint32_t)l < cnt) {
+                    uint32_t sy = dec_step<FMT>(T, x[l]);
+                    if constexpr (Tr::kSymByte == 3)
+                        sy >>= 24;
+                    if (p.sym_bytes == 1)
+                        dst[i + l] = (uint8_t)sy;
+                    else
+                        reinterpret_cast<uint16_t RANS_GLOBAL *>(dst)[i + l] = (uint16_t)sy;
+                }
+#pragma unroll
+            for (int l = 0; l < NW; ++l)
+                lane_renorm<FMT>(x[l], W, (uint32_t)l < cnt);
+            i += cnt;
+        }
+        (void)tail;
+#pragma unroll
+        for (int l = 0; l < NW; ++l)
+            bad = bad || (x[l] != Tr::kL);
+        if (bad || W.used + NW * Tr::kStateBytes != len)
+            nbad++;
+    }
+    if (nbad)
+        atomicAdd(p.err_count, (unsigned long long)nbad);
+}
+
+// one symbol of the sequential reference encoder (RansEncPut / RansWordEncPut / Rans64EncPut /
+// RansEncPutAlias) for a lane-private state and write pointer
+template <int FMT>
+__device__ __forceinline__ void lane_put(typename FmtTraits<FMT>::state_t &x, uint32_t sym, const uint4 *recs,
+                                         const EncParams &p, uint8_t RANS_GLOBAL *&wp, bool &bad)
+{
+    const bool known = sym < p.nsyms;
+    const uint4 rec = recs[known ? sym : 0u];
+    const uint32_t freq = (FMT == FMT_R64) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
+    if (!known || freq == 0) {
+        bad = true;
+        return;
+    }
+    if constexpr (FMT == FMT_WORD) {
+        uint32_t y = x;
+        if (y >= (freq << 20)) {
+            wp -= 2;
+            *reinterpret_cast<uint16_t RANS_GLOBAL *>(wp) = (uint16_t)y;
+            y >>= 16;
+        }
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        x = (q << 12) + rem + start;
+    } else if constexpr (FMT == FMT_R64) {
+        uint64_t y = x;
+        if (y >= (((uint64_t)freq) << (63u - p.scale_bits))) {
+            wp -= 4;
+            *reinterpret_cast<uint32_t RANS_GLOBAL *>(wp) = (uint32_t)y;
+            y >>= 32;
+        }
+        uint64_t q, rem;
+        divmod_rcp64(y, freq, rec, q, rem);
+        x = (q << p.scale_bits) + rem + start;
+    } else {
+        uint32_t y = x;
+        const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (y >= x_max) {
+                *--wp = (uint8_t)y;
+                y >>= 8;
+            }
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        if constexpr (FMT == FMT_ALIAS)
+            x = (q << p.scale_bits) + p.alias_remap[rem + start];
+        else
+            x = (q << p.scale_bits) + rem + start;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Staged lane-per-stream encoder: the mirror image of k_decode_lanes_staged.  Per-lane stores of
+// every emitted unit reached HBM as partial lines (measured 6.4x the stream bytes on the write
+// side) and per-lane 16-byte symbol loads pulled whole lines (3.6x).  Here
+//   * symbols: the wave loads one 64-byte block of each of its 64 chunks with coalesced 16-byte
+//     loads (4 lanes per chunk) into per-lane rows in LDS; every lane then walks its row from
+//     the top, 16 symbols per ds_read_b128;
+//   * stream: units go into a 128-byte ring per lane (two 64-byte lines, written downwards); after
+//     every 16 symbols (at most 64 bytes emitted) a line that has filled up is written out by 4
+//     lanes with 16-byte stores -- whole 64-byte lines, each written once.
+// Slots are whole lines (api.cpp, encode_slot_bytes); what lies below the stream start inside the
+// lowest line is never read.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kEncRowStride = 80; // 64 symbol bytes, rows 16-byte aligned, 20 dwords apart
+constexpr uint32_t kEncWaveLds = 64 * kEncRowStride + 64 * kLaneRingStride + 64 * 4;
+
+template <int FMT> struct LaneOut {
+    uint8_t *row;  // this lane's output ring in LDS
+    uint32_t w;    // write offset inside the chunk's slot, moves down
+    template <int UNIT> __device__ __forceinline__ void emit(uint32_t v)
+    {
+        w -= UNIT;
+        uint8_t *at = row + (w & (2 * kLaneLine - 1));
+        if constexpr (UNIT == 4)
+            *reinterpret_cast<uint32_t *>(at) = v;
+        else if constexpr (UNIT == 2)
+            *reinterpret_cast<uint16_t *>(at) = (uint16_t)v;
+        else
+            *at = (uint8_t)v;
+    }
+};
+
+// one symbol of the sequential reference encoder for a lane-private state, emitting into the ring
+template <int FMT>
+__device__ __forceinline__ void lane_put_staged(typename FmtTraits<FMT>::state_t &x, uint32_t sym, const uint4 *recs,
+                                                const EncParams &p, LaneOut<FMT> &O, bool &bad)
+{
+    const bool known = sym < p.nsyms;
+    const uint4 rec = recs[known ? sym : 0u];
+    const uint32_t freq = (FMT == FMT_R64) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
+    if (!known || freq == 0) {
+        bad = true;
+        return;
+    }
+    if constexpr (FMT == FMT_WORD) {
+        uint32_t y = x;
+        if (y >= (freq << 20)) { // rans_word_sse41.h:85-89
+            O.template emit<2>(y);
+            y >>= 16;
+        }
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        x = (q << 12) + rem + start;
+    } else if constexpr (FMT == FMT_R64) {
+        uint64_t y = x;
+        if (y >= (((uint64_t)freq) << (63u - p.scale_bits))) { // rans64.h:83-88
+            O.template emit<4>((uint32_t)y);
+            y >>= 32;
+        }
+        uint64_t q, rem;
+        divmod_rcp64(y, freq, rec, q, rem);
+        x = (q << p.scale_bits) + rem + start;
+    } else {
+        uint32_t y = x;
+        const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq; // rans_byte.h:64-70
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (y >= x_max) {
+                O.template emit<1>(y);
+                y >>= 8;
+            }
+        uint32_t q, rem;
+        divmod_rcp(y, freq, rcp, q, rem);
+        if constexpr (FMT == FMT_ALIAS)
+            x = (q << p.scale_bits) + p.alias_remap[rem + start];
+        else
+            x = (q << p.scale_bits) + rem + start;
+    }
+}
+
+template <int FMT, int NW>
+__global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
+        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
+            l[i] = g[i];
+    }
+    __syncthreads();
+    const uint4 *recs = reinterpret_cast<const uint4 *>(smem);
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    uint8_t *rows = smem + p.nsyms * (uint32_t)sizeof(EncRec) + wave * kEncWaveLds;
+    uint8_t *rings = rows + 64u * kEncRowStride;
+    uint32_t *req = reinterpret_cast<uint32_t *>(rings + 64u * kLaneRingStride);
+    const uint32_t part = lane & 3u, grp = lane >> 2;
+    const uint32_t slot_lines = (uint32_t)(p.slot_bytes / kLaneLine);
+
+    bool bad = false;
+    const uint64_t nbatches = (p.nchunks + 63u) / 64u;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += total_waves) {
+        const uint64_t chunk0 = uniform64(batch_v) * 64u;
+        const uint64_t chunk = chunk0 + lane;
+        const bool valid = chunk < p.nchunks;
+        auto syms_of = [&](uint64_t c) -> uint32_t { // symbols in chunk c (0 past the end)
+            if (c >= p.nchunks)
+                return 0u;
+            const uint64_t first = c * p.chunk_syms;
+            return (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        };
+        const uint32_t nsym = syms_of(chunk);
+        const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + chunk * (uint64_t)p.chunk_syms;
+        uint8_t RANS_GLOBAL *slots0 = (uint8_t RANS_GLOBAL *)p.scratch + chunk0 * p.slot_bytes; // wave-uniform
+
+        state_t x[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l)
+            x[l] = Tr::kL;
+        LaneOut<FMT> O;
+        O.row = rings + lane * kLaneRingStride;
+        O.w = (uint32_t)p.slot_bytes;
+        uint32_t flushed = slot_lines; // lines [flushed, slot_lines) are in memory
+
+        // the whole wave takes part: lanes publish the line they have filled (or, at the end, the lines
+        // that hold anything), lane (4 g + part) writes 16 bytes of chunk (16 j + g)'s line
+        auto flush = [&](bool final) {
+            const bool need = valid && flushed != 0u &&
+                              (final ? O.w < flushed * kLaneLine : O.w <= (flushed - 1u) * kLaneLine);
+            req[lane] = need ? (((flushed - 1u) << 1) | 1u) : 0u;
+            if (need)
+                flushed -= 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = 16u * j + grp;
+                const uint32_t r = req[q]; // LDS ops of one wave execute in order
+                if (r & 1u) {
+                    const uint32_t line = r >> 1;
+                    const uint8_t *at = rings + q * kLaneRingStride + (line & 1u) * kLaneLine + part * 16u;
+                    const u32x2 a = reinterpret_cast<const u32x2 *>(at)[0], b = reinterpret_cast<const u32x2 *>(at)[1];
+                    u32x4 RANS_GLOBAL *o = reinterpret_cast<u32x4 RANS_GLOBAL *>(
+                        slots0 + (uint64_t)q * p.slot_bytes + (uint64_t)line * kLaneLine + part * 16u);
+                    *o = u32x4{a.x, a.y, b.x, b.y};
+                }
+            }
+        };
+
+        // symbol i belongs to state i mod NW; visit i = nsym-1 .. 0 (main.cpp:233-243).  The top
+        // nsym % 16 symbols come one by one from memory, the rest through the staged rows.
+        const uint32_t nsym16 = nsym & ~15u;
+        for (uint32_t i = nsym; i > nsym16; --i) {
+            const uint32_t sym = (uint32_t)src[i - 1];
+            const uint32_t l = (i - 1) % NW;
+#pragma unroll
+            for (int ll = 0; ll < NW; ++ll) // static register indexing
+                if ((uint32_t)ll == l)
+                    lane_put_staged<FMT>(x[ll], sym, recs, p, O, bad);
+        }
+        flush(false);
+
+        const uint32_t my_blocks = (nsym16 + 63u) >> 6;
+        uint32_t max_blocks = my_blocks;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)max_blocks, d, 64);
+            max_blocks = o > max_blocks ? o : max_blocks;
+        }
+        max_blocks = uniform(max_blocks);
+        for (uint32_t k = max_blocks; k-- > 0;) {
+            // stage block k of every chunk: 16 bytes per lane, 4 instructions for 64 chunks
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = 16u * j + grp;
+                const uint32_t qsyms16 = syms_of(chunk0 + q) & ~15u;
+                const uint32_t at = 64u * k + 16u * part;
+                if (at + 16u <= qsyms16) {
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(
+                        reinterpret_cast<uint64_t>(p.syms) + (chunk0 + q) * (uint64_t)p.chunk_syms + at));
+                    *reinterpret_cast<u32x4 *>(rows + q * kEncRowStride + 16u * part) = v;
+                }
+            }
+            const uint8_t *row = rows + lane * kEncRowStride;
+#pragma unroll
+            for (int g = 3; g >= 0; --g) {
+                if (64u * k + 16u * g + 16u <= nsym16) {
+                    const u32x4 cur = *reinterpret_cast<const u32x4 *>(row + 16 * g);
+#pragma unroll
+                    for (int j = 15; j >= 0; --j) {
+                        const uint32_t sym = (cur[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                        lane_put_staged<FMT>(x[j % NW], sym, recs, p, O, bad);
+                    }
+                }
+                flush(false);
+            }
+        }
+        // flush states NW-1 .. 0 (lane 0's first in memory), then whatever the ring still holds
+        if (valid) {
+#pragma unroll
+            for (int l = NW - 1; l >= 0; --l) {
+                if constexpr (FMT == FMT_R64) {
+                    O.template emit<4>((uint32_t)(x[l] >> 32));
+                    O.template emit<4>((uint32_t)x[l]);
+                } else if constexpr (FMT == FMT_WORD) {
+                    O.template emit<2>(x[l] >> 16);
+                    O.template emit<2>(x[l]);
+                } else {
+                    O.template emit<1>(x[l] >> 24);
+                    O.template emit<1>(x[l] >> 16);
+                    O.template emit<1>(x[l] >> 8);
+                    O.template emit<1>(x[l]);
+                }
+            }
+            p.lengths[chunk] = (uint32_t)p.slot_bytes - O.w;
+        }
+        flush(true);
+        flush(true);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
+        atomicOr(p.flags, 1u);
+}
+
+// Lane-per-stream encoder, second generation: symbols arrive as 16-byte per-lane loads
+// (one scattered access per 16 symbols instead of per symbol), one group prefetched.
+template <int FMT, int NW>
+__global__ void __launch_bounds__(256) k_encode_lanes16(const EncParams p)
+{
+    using Tr = FmtTraits<FMT>;
+    using state_t = typename Tr::state_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
+        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
+            l[i] = g[i];
+    }
+    __syncthreads();
+    const uint4 *recs = reinterpret_cast<const uint4 *>(smem);
+    const bool wide_in = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 15u) == 0;
+
+    bool bad = false;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; chunk < p.nchunks; chunk += stride) {
+        const uint64_t first = chunk * p.chunk_syms;
+        const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
+        const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + first * p.sym_bytes;
+        uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + chunk * p.slot_bytes;
+        uint8_t RANS_GLOBAL *wp = slot + p.slot_bytes;
+
+        state_t x[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l)
+            x[l] = Tr::kL;
+
+        // symbol i belongs to state i mod NW; visit i = nsym-1 .. 0 (main.cpp:233-243).
+        // [0, fast_end) is walked in 16-symbol groups; the ragged top part one by one.
+        const uint32_t fast_end = wide_in ? (nsym & ~15u) : 0u;
+        for (uint32_t i = nsym; i > fast_end; --i) {
+            const uint32_t sym = p.sym_bytes == 1 ? (uint32_t)src[i - 1]
+                                                  : (uint32_t) reinterpret_cast<const uint16_t RANS_GLOBAL *>(src)[i - 1];
+            const uint32_t l = (i - 1) % NW;
+#pragma unroll
+            for (int ll = 0; ll < NW; ++ll) // static register indexing
+                if ((uint32_t)ll == l)
+                    lane_put<FMT>(x[ll], sym, recs, p, wp, bad);
+        }
+        if (fast_end) {
+            const u32x4 RANS_GLOBAL *g16 = reinterpret_cast<const u32x4 RANS_GLOBAL *>(src);
+            uint32_t g = fast_end >> 4;
+            u32x4 cur = g16[g - 1], nxt = cur;
+            while (g-- > 0) {
+                if (g > 0)
+                    nxt = g16[g - 1];
+#pragma unroll
+                for (int j = 15; j >= 0; --j) {
+                    const uint32_t sym = (cur[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    lane_put<FMT>(x[j % NW], sym, recs, p, wp, bad);
+                }
+                cur = nxt;
+            }
+        }
+        // flush states NW-1 .. 0 (lane 0's first in memory)
+#pragma unroll
+        for (int l = NW - 1; l >= 0; --l) {
+            wp -= Tr::kStateBytes;
+            if constexpr (FMT == FMT_R64) {
+                reinterpret_cast<uint32_t RANS_GLOBAL *>(wp)[0] = (uint32_t)x[l];
+                reinterpret_cast<uint32_t RANS_GLOBAL *>(wp)[1] = (uint32_t)(x[l] >> 32);
+            } else if constexpr (FMT == FMT_WORD) {
+                reinterpret_cast<uint16_t RANS_GLOBAL *>(wp)[0] = (uint16_t)x[l];
+                reinterpret_cast<uint16_t RANS_GLOBAL *>(wp)[1] = (uint16_t)(x[l] >> 16);
+            } else {
+                wp[0] = (uint8_t)x[l];
+                wp[1] = (uint8_t)(x[l] >> 8);
+                wp[2] = (uint8_t)(x[l] >> 16);
+                wp[3] = (uint8_t)(x[l] >> 24);
+            }
+        }
+        p.lengths[chunk] = (uint32_t)((slot + p.slot_bytes) - wp);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane_id() == 0)
+        atomicOr(p.flags, 1u);
+}
+
+// RANS_AMD_LANES=staged | regwin: pin the lane-per-stream kernel generation (tests, A/B runs); read at
+// every launch so one process can exercise both
+static int lanes_force()
+{
+    const char *e = getenv("RANS_AMD_LANES");
+    if (!e)
+        return 0;
+    return e[0] == 's' ? 1 : (e[0] == 'r' ? -1 : 0);
+}
+
+template <int FMT, int NW>
+hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
+{
+    const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
+    // RANS_AMD_LANES=regwin: the per-lane register window this kernel replaced (>= 4x over-fetch)
+    const int force = lanes_force();
+    const bool reg_window = force < 0;
+    // staged kernel: the tables are shared by the block, every wave adds kLaneWaveLds of rings, so one
+    // large block per CU keeps the most waves resident (rans64, 14 bits: 15 waves; 4-wave blocks: 12)
+    const size_t table_lds = (size_t)t0 + t1;
+    uint32_t sw = table_lds + kLaneWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - table_lds) / kLaneWaveLds) : 0;
+    sw = sw > 16 ? 16 : sw;
+    if (const char *e = getenv("RANS_AMD_LANES_WAVES")) { // experiment knob: waves per block
+        const uint32_t v = (uint32_t)atoi(e);
+        if (v >= 1 && v < sw)
+            sw = v;
+    }
+    // 64 chunks of one wave must lie within 2^30 bytes (32-bit ring positions): any sane chunk size
+    const bool staged = !reg_window && sw >= 1 && (uint64_t)p.chunk_syms * 8u < (1u << 22);
+    {   // One batch (64 chunks) is a long latency-bound job, so a last round with a few waves per CU
+        // costs as much as a full one: take the fewest rounds the LDS allows and split the batches
+        // evenly over them (16 batches per CU: 16 waves x 1 round, or 8 x 2 -- never 14 + 2).
+        const uint64_t batches = (p.nchunks + 63) / 64;
+        const uint64_t per_cu = (batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
+        if (sw >= 1) {
+            const uint64_t rounds = (per_cu + sw - 1) / sw;
+            const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
+            sw = (uint32_t)(even ? even : 1);
+        }
+    }
+    const size_t lds = staged ? table_lds + (size_t)sw * kLaneWaveLds : table_lds;
+    auto kern = staged ? k_decode_lanes_staged<FMT, NW> : k_decode_lanes<FMT, NW>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[staged]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_set[staged] = true;
+    }
+    if (staged) {
+        const uint64_t batches = (p.nchunks + 63) / 64;
+        const uint64_t want_blocks = (batches + sw - 1) / sw;
+        const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
+        if (name)
+            *name = "k_decode_lanes_staged";
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * sw), lds, stream, p);
+        return hipGetLastError();
+    }
+    const uint64_t want = (p.nchunks + 255) / 256;
+    // 256-thread blocks: up to 8 per CU (32 waves) when the tables leave room in LDS; the kernel
+    // is latency-bound (per-lane scattered loads), so residency matters more than anything else
+    const size_t lds_room = lds ? (160 * 1024) / lds : 8;
+    const uint64_t cap = (uint64_t)num_cus * (lds_room >= 8 ? 8 : (lds_room >= 1 ? lds_room : 1));
+    const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    if (name)
+        *name = "k_decode_lanes";
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, int num_cus, hipStream_t stream)
+{
+    const size_t table_lds = (size_t)p.nsyms * sizeof(EncRec);
+    if (table_lds > 128 * 1024)
+        return hipErrorInvalidValue;
+    // staged kernel (coalesced symbol loads, whole-line stream stores): u8 symbols in 16-byte aligned
+    // chunks, slots made of whole lines; RANS_AMD_LANES=regwin keeps the per-lane kernel (A/B runs), =staged forces
+    // this one whatever the batch count (tests)
+    const int force = lanes_force();
+    const bool reg_window = force < 0;
+    uint32_t sw = table_lds + kEncWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - table_lds) / kEncWaveLds) : 0;
+    sw = sw > 16 ? 16 : sw;
+    const bool staged = !reg_window && sw >= 1 && p.sym_bytes == 1 && (p.slot_bytes % kLaneLine) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 15u) == 0 &&
+                        (reinterpret_cast<uintptr_t>(p.scratch) & 15u) == 0 &&
+                        // fewer, longer batches: the per-lane kernel's many small blocks hide latency better
+                        (force > 0 || (p.nchunks + 63) / 64 >= (uint64_t)num_cus * 6);
+    if (staged) {
+        // same split as the staged decoder: fewest rounds, batches spread evenly over them
+        const uint64_t batches = (p.nchunks + 63) / 64;
+        const uint64_t per_cu = (batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
+        const uint64_t rounds = (per_cu + sw - 1) / sw;
+        const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
+        sw = (uint32_t)(even ? even : 1);
+        auto kern = k_encode_lanes_staged<FMT, NW>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess)
+                return e;
+            attr_set = true;
+        }
+        const uint64_t want_blocks = (batches + sw - 1) / sw;
+        const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * sw), table_lds + (size_t)sw * kEncWaveLds, stream, p);
+        return hipGetLastError();
+    }
+    const size_t lds = table_lds;
+    auto kern = k_encode_lanes16<FMT, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_set = true;
+    }
+    const uint64_t want = (p.nchunks + 255) / 256;
+    const uint64_t cap = (uint64_t)num_cus * 8;
+    const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int FMT> hipError_t launch_decode_lanes_f(const DecParams &p, int num_cus, hipStream_t s, const char **name)
+{
+    switch (p.n_ways) {
+    case 1: return launch_decode_lanes_t<FMT, 1>(p, num_cus, s, name);
+    case 2: return launch_decode_lanes_t<FMT, 2>(p, num_cus, s, name);
+    case 4: return launch_decode_lanes_t<FMT, 4>(p, num_cus, s, name);
+    case 8: return launch_decode_lanes_t<FMT, 8>(p, num_cus, s, name);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int FMT> hipError_t launch_encode_lanes_f(const EncParams &p, int num_cus, hipStream_t s)
+{
+    switch (p.n_ways) {
+    case 1: return launch_encode_lanes_t<FMT, 1>(p, num_cus, s);
+    case 2: return launch_encode_lanes_t<FMT, 2>(p, num_cus, s);
+    case 4: return launch_encode_lanes_t<FMT, 4>(p, num_cus, s);
+    case 8: return launch_encode_lanes_t<FMT, 8>(p, num_cus, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace
+
+hipError_t launch_decode_lanes(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name)
+{
+    switch (format) {
+    case FMT_WORD: return launch_decode_lanes_f<FMT_WORD>(p, num_cus, stream, name);
+    case FMT_BYTE: return launch_decode_lanes_f<FMT_BYTE>(p, num_cus, stream, name);
+    case FMT_R64: return launch_decode_lanes_f<FMT_R64>(p, num_cus, stream, name);
+    case FMT_ALIAS: return launch_decode_lanes_f<FMT_ALIAS>(p, num_cus, stream, name);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_encode_lanes(int format, const EncParams &p, int num_cus, hipStream_t stream)
+{
+    switch (format) {
+    case FMT_WORD: return launch_encode_lanes_f<FMT_WORD>(p, num_cus, stream);
+    case FMT_BYTE: return launch_encode_lanes_f<FMT_BYTE>(p, num_cus, stream);
+    case FMT_R64: return launch_encode_lanes_f<FMT_R64>(p, num_cus, stream);
+    case FMT_ALIAS: return launch_encode_lanes_f<FMT_ALIAS>(p, num_cus, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace rans_amd

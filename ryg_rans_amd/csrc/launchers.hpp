@@ -1,0 +1,22 @@
+// launchers.hpp -- entry points of the kernel translation units (internal; the public launchers of
+// kernels.h are assembled from these in dispatch.cpp).
+#pragma once
+
+#include "kernels.h"
+
+namespace rans_amd {
+
+// wave-per-chunk kernels (N-way streams with N = 64 K lanes): decode_wave.hip, encode_wave.hip
+hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name);
+hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipStream_t stream);
+
+// lane-per-stream kernels (N = 1, 2, 4, 8 with at least kLaneKernelMinChunks chunks): lanes.hip
+constexpr uint64_t kLaneKernelMinChunks = 64;
+inline bool lanes_applicable(uint64_t nchunks, uint32_t n_ways)
+{
+    return nchunks >= kLaneKernelMinChunks && (n_ways == 1 || n_ways == 2 || n_ways == 4 || n_ways == 8);
+}
+hipError_t launch_decode_lanes(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name);
+hipError_t launch_encode_lanes(int format, const EncParams &p, int num_cus, hipStream_t stream);
+
+} // namespace rans_amd

@@ -60,7 +60,7 @@ struct AliasHalf {
     uint32_t adjust;
 };
 // EncRec: per-symbol encoder record.  q = x / freq is recovered exactly from
-// mulhi(x, rcp) with one correction step; see kernels.hip.
+// mulhi(x, rcp) with one correction step; see device_common.hpp.
 struct EncRec {
     uint32_t freq;
     uint32_t start;

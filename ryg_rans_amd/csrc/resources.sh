@@ -1,7 +1,9 @@
 #!/bin/bash
 # Per-kernel register / occupancy summary from hipcc's kernel-resource-usage remarks.
 cd "$(dirname "$0")"
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage -c kernels.hip -o /dev/null 2>&1 |
+for f in decode_wave.hip encode_wave.hip lanes.hip container_kernels.hip; do
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage -c $f -o /dev/null 2>&1
+done |
 python3 -c '
 import sys,re,subprocess
 cur=None; rows=[]
