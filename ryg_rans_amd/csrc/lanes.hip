@@ -841,11 +841,6 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
     const size_t table_lds = (size_t)t0 + t1;
     uint32_t sw = table_lds + kLaneWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - table_lds) / kLaneWaveLds) : 0;
     sw = sw > 16 ? 16 : sw;
-    if (const char *e = getenv("RANS_AMD_LANES_WAVES")) { // experiment knob: waves per block
-        const uint32_t v = (uint32_t)atoi(e);
-        if (v >= 1 && v < sw)
-            sw = v;
-    }
     // 64 chunks of one wave must lie within 2^30 bytes (32-bit ring positions): any sane chunk size
     const bool staged = !reg_window && sw >= 1 && (uint64_t)p.chunk_syms * 8u < (1u << 22);
     {   // One batch (64 chunks) is a long latency-bound job, so a last round with a few waves per CU
