@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
         // Fast input path: full waves, u8 symbols, dword-aligned rows -> symbols of 4 rounds
         // arrive as one coalesced dword per lane and are transposed in registers; loads run
         // one super-group (16 rounds) ahead of the arithmetic.
-        const bool fast_in = p.sym_bytes == 1 && N == p.n_ways && (N & 63u) == 0 &&
+        // (N == 64 K exactly: with N = 192 on the K = 4 kernel the fourth sub-step has no lanes)
+        const bool fast_in = p.sym_bytes == 1 && N == 64u * K &&
                              ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 3u) == 0;
         // (the word path addresses its record table by raw LDS address: dynamic LDS must start at 0)
         const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem == 0u;

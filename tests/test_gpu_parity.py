@@ -57,7 +57,7 @@ def _models(R, ctx, oracle, fmt, sb, data, nsyms=256):
 
 
 @pytest.mark.parametrize("fmt,sb", FORMATS)
-@pytest.mark.parametrize("n_ways", [64, 256, 1, 2, 8, 33, 128, 512, 100, 200, 300, 511])
+@pytest.mark.parametrize("n_ways", [64, 256, 1, 2, 8, 33, 128, 512, 100, 200, 300, 511, 192, 320, 384, 448])
 def test_single_stream_matches_oracle(gpu, oracle, fmt, sb, n_ways):
     """chunk_syms >= n: the container is the raw reference-format stream."""
     R, ctx, torch = gpu

@@ -1,0 +1,20 @@
+"""Randomised GPU-vs-oracle parity sweep (tools/stress.py) as part of the GPU suite: random format,
+scale_bits, source skew, n, N (any value in 1..512), chunk size, buffer misalignment and lane-kernel
+generation; GPU encode must equal the oracle's bytes and both containers must decode to the input.
+(The sweep found the N = 192/320/384/448 encoder bug that the hand-picked cases had missed.)"""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_parity_sweep(seed, oracle):
+    import torch
+    assert torch.cuda.is_available()
+    import stress
+    assert stress.run(400, seed, oracle=oracle) == 0

@@ -1,0 +1,106 @@
+"""Randomised GPU-vs-oracle parity sweep (run on the GPU box): random format, scale_bits, alphabet
+skew, n, N, chunk size, buffer misalignment and lane-kernel generation; every case checks
+  * GPU encode == oracle encode (lengths, offsets, every chunk's bytes),
+  * GPU decode of the ORACLE container == input, GPU decode of its own container == input.
+    python tools/stress.py [--cases 300] [--seed 1]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ryg_rans_amd as R  # noqa: E402
+from _oracle import FMT_ALIAS, FMT_BYTE, FMT_R64, FMT_WORD, Oracle  # noqa: E402
+
+
+def run(cases, seed, ctx=None, oracle=None):
+    """Returns the number of failing cases (details are printed)."""
+    rng = np.random.default_rng(seed)
+    oracle = oracle or Oracle()
+    ctx = ctx or R.Context(0)
+    fails = 0
+    saved = os.environ.get("RANS_AMD_LANES")
+    for case in range(cases):
+        fmt = int(rng.choice([FMT_WORD, FMT_BYTE, FMT_R64, FMT_ALIAS]))
+        sb = {FMT_WORD: 12, FMT_BYTE: int(rng.integers(8, 17)), FMT_R64: int(rng.integers(8, 17)),
+              FMT_ALIAS: int(rng.integers(8, 17))}[fmt]
+        n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 70000), rng.integers(70000, 400000)]))
+        n_ways = int(rng.choice([1, 2, 4, 8, 64, 128, 256, 512, int(rng.integers(1, 513))]))
+        chunk = int(rng.choice([n + 5, 16 * int(rng.integers(1, 300)), int(rng.integers(1, 5000)), 64 * int(rng.integers(1, 64))]))
+        kind = int(rng.integers(0, 4))
+        K = 256
+        if kind == 0:
+            data = oracle.gen_zipf(n, K=K, s=float(rng.uniform(0.3, 2.5)), seed=int(rng.integers(1, 1 << 30)))
+        elif kind == 1:
+            data = rng.integers(0, K, n).astype(np.uint8)
+        elif kind == 2:
+            data = np.minimum(rng.geometric(float(rng.uniform(0.02, 0.7)), n) - 1, K - 1).astype(np.uint8)
+        else:
+            data = (rng.integers(0, 2, n) * int(rng.integers(1, 256))).astype(np.uint8)
+        if len(np.unique(data)) < 2:
+            continue
+        os.environ["RANS_AMD_LANES"] = str(rng.choice(["staged", "regwin", ""]))
+        desc = dict(case=case, fmt=fmt, sb=sb, n=n, n_ways=n_ways, chunk=chunk, kind=kind, lanes=os.environ["RANS_AMD_LANES"])
+        try:
+            counts = oracle.count_freqs(data, K)
+            f, _ = oracle.normalize(counts, 1 << sb)
+            if fmt == FMT_ALIAS and (1 << sb) < K:
+                continue
+            om = oracle.model(f, sb, with_alias=(fmt == FMT_ALIAS))
+            gm = ctx.model(fmt, f, sb)
+            want, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+            shift = int(rng.choice([0, 0, 1, 4, 16]))
+            backing = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+            d_syms = backing[shift:shift + n]
+            d_syms.copy_(torch.from_numpy(data))
+            cont, d_offs, d_lens, total = ctx.encode(gm, d_syms, n_ways, chunk)
+            ok = total == want.size and np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens) and \
+                np.array_equal(d_offs.cpu().numpy().astype(np.uint64), offs)
+            if ok:
+                got = cont[:total].cpu().numpy()
+                for c in range(len(lens)):
+                    o, ln = int(offs[c]), int(lens[c])
+                    if not np.array_equal(got[o:o + ln], want[o:o + ln]):
+                        ok = False
+                        desc["bad_chunk"] = c
+                        break
+            d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
+            ob = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+            oshift = int(rng.choice([0, 0, 1, 4, 16]))
+            out = ctx.decode(gm, d_cont, want.size, torch.from_numpy(offs.astype(np.int64)).cuda(),
+                             torch.from_numpy(lens.astype(np.int32)).cuda(), n, n_ways, chunk, d_out=ob[oshift:oshift + n])
+            ok_dec = np.array_equal(ob[oshift:oshift + n].cpu().numpy(), data) and ctx.decode_errors() == 0
+            ok_dec = ok_dec and int(ob[:oshift].sum()) == 0 and int(ob[oshift + n:].sum()) == 0
+            if ok:
+                out2 = ctx.decode(gm, cont, total, d_offs, d_lens, n, n_ways, chunk)
+                ok_dec = ok_dec and np.array_equal(out2.cpu().numpy(), data)
+            if not (ok and ok_dec):
+                fails += 1
+                print("FAIL", desc, "encode_ok", ok, "decode_ok", ok_dec, flush=True)
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print("EXC", desc, repr(e), flush=True)
+    if saved is None:
+        os.environ.pop("RANS_AMD_LANES", None)
+    else:
+        os.environ["RANS_AMD_LANES"] = saved
+    return fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    fails = run(a.cases, a.seed)
+    print("cases %d, failures %d" % (a.cases, fails))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
