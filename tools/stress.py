@@ -33,31 +33,43 @@ def run(cases, seed, ctx=None, oracle=None):
         n_ways = int(rng.choice([1, 2, 4, 8, 64, 128, 256, 512, int(rng.integers(1, 513))]))
         chunk = int(rng.choice([n + 5, 16 * int(rng.integers(1, 300)), int(rng.integers(1, 5000)), 64 * int(rng.integers(1, 64))]))
         kind = int(rng.integers(0, 4))
+        # alphabet: mostly 256 byte symbols; sometimes smaller, for alias a power of two, and
+        # occasionally the 4096-symbol u16 alphabet of BASELINE config 4
         K = 256
+        pick = int(rng.integers(0, 10))
+        if fmt == FMT_ALIAS:
+            if pick == 0 and sb >= 12:
+                K = 4096
+            elif pick <= 3:
+                K = 1 << int(rng.integers(1, min(sb, 8) + 1))
+        elif pick <= 2:
+            K = int(rng.integers(2, 257))
+        dt = np.uint8 if K <= 256 else np.uint16
         if kind == 0:
-            data = oracle.gen_zipf(n, K=K, s=float(rng.uniform(0.3, 2.5)), seed=int(rng.integers(1, 1 << 30)))
+            data = oracle.gen_zipf(n, K=K, s=float(rng.uniform(0.3, 2.5)), seed=int(rng.integers(1, 1 << 30))).astype(dt)
         elif kind == 1:
-            data = rng.integers(0, K, n).astype(np.uint8)
+            data = rng.integers(0, K, n).astype(dt)
         elif kind == 2:
-            data = np.minimum(rng.geometric(float(rng.uniform(0.02, 0.7)), n) - 1, K - 1).astype(np.uint8)
+            data = np.minimum(rng.geometric(float(rng.uniform(0.02, 0.7)), n) - 1, K - 1).astype(dt)
         else:
-            data = (rng.integers(0, 2, n) * int(rng.integers(1, 256))).astype(np.uint8)
+            data = (rng.integers(0, 2, n) * int(rng.integers(1, K))).astype(dt)
         if len(np.unique(data)) < 2:
             continue
         os.environ["RANS_AMD_LANES"] = str(rng.choice(["staged", "regwin", ""]))
-        desc = dict(case=case, fmt=fmt, sb=sb, n=n, n_ways=n_ways, chunk=chunk, kind=kind, lanes=os.environ["RANS_AMD_LANES"])
+        desc = dict(case=case, fmt=fmt, sb=sb, K=K, n=n, n_ways=n_ways, chunk=chunk, kind=kind, lanes=os.environ["RANS_AMD_LANES"])
         try:
             counts = oracle.count_freqs(data, K)
             f, _ = oracle.normalize(counts, 1 << sb)
-            if fmt == FMT_ALIAS and (1 << sb) < K:
+            if (1 << sb) < K:
                 continue
             om = oracle.model(f, sb, with_alias=(fmt == FMT_ALIAS))
             gm = ctx.model(fmt, f, sb)
             want, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
             shift = int(rng.choice([0, 0, 1, 4, 16]))
-            backing = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+            tdt = torch.uint8 if K <= 256 else torch.int16
+            backing = torch.zeros(n + 64, dtype=tdt, device="cuda")
             d_syms = backing[shift:shift + n]
-            d_syms.copy_(torch.from_numpy(data))
+            d_syms.copy_(torch.from_numpy(data if K <= 256 else data.view(np.int16)))
             cont, d_offs, d_lens, total = ctx.encode(gm, d_syms, n_ways, chunk)
             ok = total == want.size and np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens) and \
                 np.array_equal(d_offs.cpu().numpy().astype(np.uint64), offs)
@@ -70,15 +82,15 @@ def run(cases, seed, ctx=None, oracle=None):
                         desc["bad_chunk"] = c
                         break
             d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
-            ob = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+            ob = torch.zeros(n + 64, dtype=tdt, device="cuda")
             oshift = int(rng.choice([0, 0, 1, 4, 16]))
             out = ctx.decode(gm, d_cont, want.size, torch.from_numpy(offs.astype(np.int64)).cuda(),
                              torch.from_numpy(lens.astype(np.int32)).cuda(), n, n_ways, chunk, d_out=ob[oshift:oshift + n])
-            ok_dec = np.array_equal(ob[oshift:oshift + n].cpu().numpy(), data) and ctx.decode_errors() == 0
-            ok_dec = ok_dec and int(ob[:oshift].sum()) == 0 and int(ob[oshift + n:].sum()) == 0
+            ok_dec = np.array_equal(ob[oshift:oshift + n].cpu().numpy().view(dt), data) and ctx.decode_errors() == 0
+            ok_dec = ok_dec and int(ob[:oshift].to(torch.int64).sum()) == 0 and int(ob[oshift + n:].to(torch.int64).sum()) == 0
             if ok:
                 out2 = ctx.decode(gm, cont, total, d_offs, d_lens, n, n_ways, chunk)
-                ok_dec = ok_dec and np.array_equal(out2.cpu().numpy(), data)
+                ok_dec = ok_dec and np.array_equal(out2.cpu().numpy().view(dt), data)
             if not (ok and ok_dec):
                 fails += 1
                 print("FAIL", desc, "encode_ok", ok, "decode_ok", ok_dec, flush=True)
