@@ -193,18 +193,19 @@ __device__ __forceinline__ void divmod_rcp(uint32_t x, uint32_t freq, uint32_t r
     }
 }
 
-// 64-bit variant for rans64 (state < 2^63): Alverson reciprocal, exact for freq >= 2; freq == 1
-// (rcp = 2^64 - 1, q = x - 1) is fixed by the correction step.  rec = {freq | rshift << 24, start,
-// rcp lo, rcp hi} (model.cpp).
-__device__ __forceinline__ void divmod_rcp64(uint64_t x, uint32_t freq, const uint4 &rec, uint64_t &q, uint64_t &rem)
+// rans64 encoder update C(s, y) for a renormalised state y < 2^63, in the form the reference uses
+// (Rans64EncPutSymbol, rans64.h:262-278): q = mulhi64(y, rcp) >> rshift is floor(y / freq) exactly for
+// freq >= 2 (Alverson reciprocal, rans64.h:167-247) and y - 1 for freq == 1 (rcp = 2^64 - 1), and
+//   y + bias + q * (M - freq)   ==   (floor(y / freq) << scale_bits) + y % freq + start
+// with bias = start (freq >= 2) or start + M - 1 (freq == 1): no remainder, no correction step, no
+// selects.  rec = {freq | rshift << 24, bias, rcp lo, rcp hi} (model.cpp).  q < 2^49 and
+// M - freq < 2^16: the high word of q needs only a 24-bit multiply.
+__device__ __forceinline__ uint64_t enc_update_r64(uint64_t y, const uint4 &rec, uint32_t scale_bits)
 {
     const uint64_t rcp = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
-    q = __umul64hi(x, rcp) >> (rec.x >> 24);
-    rem = x - q * freq;
-    if (rem >= freq) {
-        q += 1;
-        rem -= freq;
-    }
+    const uint64_t q = __umul64hi(y, rcp) >> (rec.x >> 24);
+    const uint32_t cmpl = (1u << scale_bits) - (rec.x & 0xffffffu);
+    return y + rec.y + (uint64_t)(uint32_t)q * cmpl + ((uint64_t)__umul24((uint32_t)(q >> 32), cmpl) << 32);
 }
 
 } // namespace

@@ -60,9 +60,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         if (emit)
             *reinterpret_cast<uint32_t RANS_GLOBAL *>(slot + wp + 4u * rank_below(m)) = (uint32_t)x;
         uint64_t y = emit ? (x >> 32) : x;
-        uint64_t q, rem;
-        divmod_rcp64(y, freq, rec, q, rem);
-        const uint64_t xn = (q << T.scale_bits) + rem + start;
+        const uint64_t xn = enc_update_r64(y, rec, T.scale_bits);
         x = active ? xn : x;
     } else {
         // rans_byte.h:62-74 (renorm: 0, 1 or 2 bytes for scale_bits <= 16), :83-90 (put),

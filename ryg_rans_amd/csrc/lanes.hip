@@ -490,9 +490,7 @@ __device__ __forceinline__ void lane_put(typename FmtTraits<FMT>::state_t &x, ui
             *reinterpret_cast<uint32_t RANS_GLOBAL *>(wp) = (uint32_t)y;
             y >>= 32;
         }
-        uint64_t q, rem;
-        divmod_rcp64(y, freq, rec, q, rem);
-        x = (q << p.scale_bits) + rem + start;
+        x = enc_update_r64(y, rec, p.scale_bits);
     } else {
         uint32_t y = x;
         const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq;
@@ -570,9 +568,7 @@ __device__ __forceinline__ void lane_put_staged(typename FmtTraits<FMT>::state_t
             O.template emit<4>((uint32_t)y);
             y >>= 32;
         }
-        uint64_t q, rem;
-        divmod_rcp64(y, freq, rec, q, rem);
-        x = (q << p.scale_bits) + rem + start;
+        x = enc_update_r64(y, rec, p.scale_bits);
     } else {
         uint32_t y = x;
         const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq; // rans_byte.h:64-70

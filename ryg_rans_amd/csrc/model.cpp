@@ -177,18 +177,21 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
         sym_recs[s] = SymRec{freqs[s], cum[s]};
         uint32_t f = freqs[s];
         if (fmt == RANS_AMD_FMT_R64) {
-            // 64-bit Alverson reciprocal (exact quotients for x < 2^63): q = mulhi64(x, rcp) >> rshift.
-            // Record layout: {freq | rshift << 24, start, rcp_lo, rcp_hi}.  freq == 1 uses rcp = 2^64 - 1
-            // (q = x - 1) and relies on the kernel's single correction step.
+            // 64-bit Alverson reciprocal (exact quotients for x < 2^63, rans64.h:167-247):
+            // q = mulhi64(x, rcp) >> rshift.  Record layout: {freq | rshift << 24, bias, rcp_lo, rcp_hi}.
+            // freq == 1: rcp = 2^64 - 1 gives q = x - 1 and bias = start + M - 1 makes
+            // x + bias + q * (M - 1) come out as x * M + start (rans64.h:216-221).
             uint64_t rcp64 = ~0ull;
             uint32_t rshift = 0;
+            uint32_t bias = cum[s] + M - 1;
             if (f >= 2) {
                 uint32_t sh = ceil_log2(f);
                 unsigned __int128 num = ((unsigned __int128)1 << (sh + 63)) + (f - 1);
                 rcp64 = (uint64_t)(num / f);
                 rshift = sh - 1;
+                bias = cum[s];
             }
-            enc_recs[s] = EncRec{f | (rshift << 24), cum[s], (uint32_t)rcp64, (uint32_t)(rcp64 >> 32)};
+            enc_recs[s] = EncRec{f | (rshift << 24), bias, (uint32_t)rcp64, (uint32_t)(rcp64 >> 32)};
             continue;
         }
         uint32_t rcp = f <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / f);

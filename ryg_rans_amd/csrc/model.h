@@ -66,7 +66,7 @@ struct EncRec {
     uint32_t start;
     uint32_t rcp;   // floor(2^32 / freq), 0xffffffff for freq == 1
     uint32_t remap; // alias only: offset of this symbol's run in alias_remap (== start)
-    // FMT_R64 reuses the slots as {freq | rshift << 24, start, rcp64 lo, rcp64 hi} (model.cpp)
+    // FMT_R64 reuses the slots as {freq | rshift << 24, bias, rcp64 lo, rcp64 hi} (model.cpp)
 };
 
 // WordEncRec: encoder record of the word format for the full-wave kernel path (always 256 of them;
