@@ -193,6 +193,18 @@ __device__ __forceinline__ void divmod_rcp(uint32_t x, uint32_t freq, uint32_t r
     }
 }
 
+// Byte-format encoder update for a renormalised state y < 2^31, the reference's form
+// (RansEncPutSymbol, rans_byte.h:258-280): q = mulhi(y, rcp) >> rshift is floor(y / freq) exactly for
+// freq >= 2 (Alverson, rans_byte.h:201-243) and y - 1 for freq == 1; y + bias + q * (M - freq) then
+// equals (floor(y / freq) << scale_bits) + y % freq + start.  rec = {freq | rshift << 24, bias, rcp, -}.
+// q < 2^(31 - scale_bits) <= 2^23 and M - freq <= 2^16: one 24-bit multiply.
+__device__ __forceinline__ uint32_t enc_update_byte(uint32_t y, const uint4 &rec, uint32_t scale_bits)
+{
+    const uint32_t q = __umulhi(y, rec.z) >> (rec.x >> 24);
+    const uint32_t cmpl = (1u << scale_bits) - (rec.x & 0xffffffu);
+    return y + rec.y + __umul24(q, cmpl);
+}
+
 // rans64 encoder update C(s, y) for a renormalised state y < 2^63, in the form the reference uses
 // (Rans64EncPutSymbol, rans64.h:262-278): q = mulhi64(y, rcp) >> rshift is floor(y / freq) exactly for
 // freq >= 2 (Alverson reciprocal, rans64.h:167-247) and y - 1 for freq == 1 (rcp = 2^64 - 1), and

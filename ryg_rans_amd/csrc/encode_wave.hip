@@ -31,7 +31,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 {
     const bool in_alphabet = sym < T.nsyms;
     const uint4 rec = T.recs[in_alphabet ? sym : 0u];
-    const uint32_t freq = (FMT == FMT_R64) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
+    const uint32_t freq = (FMT == FMT_R64 || FMT == FMT_BYTE) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
     if (active && (!in_alphabet || freq == 0)) {
         bad = true;
         active = false;
@@ -66,7 +66,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         // rans_byte.h:62-74 (renorm: 0, 1 or 2 bytes for scale_bits <= 16), :83-90 (put),
         // main_alias.cpp:241-250 (alias put).  The low byte is emitted first, i.e.
         // ends up at the higher address.
-        const uint32_t x_max = ((1u << 23 >> T.scale_bits) << 8) * freq;
+        const uint32_t x_max = freq << (31u - T.scale_bits);
         const bool e1 = active && x >= x_max;
         const bool e2 = e1 && (x >> 8) >= x_max;
         const uint64_t m1 = __builtin_amdgcn_ballot_w64(e1);
@@ -81,13 +81,14 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
             slot[at] = (uint8_t)x;
         }
         uint32_t y = e2 ? (x >> 16) : (e1 ? (x >> 8) : x);
-        uint32_t q, rem;
-        divmod_rcp(y, freq, rcp, q, rem);
         uint32_t xn;
-        if constexpr (FMT == FMT_ALIAS)
+        if constexpr (FMT == FMT_ALIAS) {
+            uint32_t q, rem;
+            divmod_rcp(y, freq, rcp, q, rem);
             xn = (q << T.scale_bits) + (active ? T.alias_remap[rem + start] : 0u);
-        else
-            xn = (q << T.scale_bits) + rem + start;
+        } else {
+            xn = enc_update_byte(y, rec, T.scale_bits);
+        }
         x = active ? xn : x;
     }
 }

@@ -468,7 +468,7 @@ __device__ __forceinline__ void lane_put(typename FmtTraits<FMT>::state_t &x, ui
 {
     const bool known = sym < p.nsyms;
     const uint4 rec = recs[known ? sym : 0u];
-    const uint32_t freq = (FMT == FMT_R64) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
+    const uint32_t freq = (FMT == FMT_R64 || FMT == FMT_BYTE) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
     if (!known || freq == 0) {
         bad = true;
         return;
@@ -493,19 +493,20 @@ __device__ __forceinline__ void lane_put(typename FmtTraits<FMT>::state_t &x, ui
         x = enc_update_r64(y, rec, p.scale_bits);
     } else {
         uint32_t y = x;
-        const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq;
+        const uint32_t x_max = freq << (31u - p.scale_bits);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
             if (y >= x_max) {
                 *--wp = (uint8_t)y;
                 y >>= 8;
             }
-        uint32_t q, rem;
-        divmod_rcp(y, freq, rcp, q, rem);
-        if constexpr (FMT == FMT_ALIAS)
+        if constexpr (FMT == FMT_ALIAS) {
+            uint32_t q, rem;
+            divmod_rcp(y, freq, rcp, q, rem);
             x = (q << p.scale_bits) + p.alias_remap[rem + start];
-        else
-            x = (q << p.scale_bits) + rem + start;
+        } else {
+            x = enc_update_byte(y, rec, p.scale_bits);
+        }
     }
 }
 
@@ -548,7 +549,7 @@ __device__ __forceinline__ void lane_put_staged(typename FmtTraits<FMT>::state_t
 {
     const bool known = sym < p.nsyms;
     const uint4 rec = recs[known ? sym : 0u];
-    const uint32_t freq = (FMT == FMT_R64) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
+    const uint32_t freq = (FMT == FMT_R64 || FMT == FMT_BYTE) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
     if (!known || freq == 0) {
         bad = true;
         return;
@@ -571,19 +572,20 @@ __device__ __forceinline__ void lane_put_staged(typename FmtTraits<FMT>::state_t
         x = enc_update_r64(y, rec, p.scale_bits);
     } else {
         uint32_t y = x;
-        const uint32_t x_max = ((1u << 23 >> p.scale_bits) << 8) * freq; // rans_byte.h:64-70
+        const uint32_t x_max = freq << (31u - p.scale_bits); // rans_byte.h:64-70
 #pragma unroll
         for (int b = 0; b < 2; ++b)
             if (y >= x_max) {
                 O.template emit<1>(y);
                 y >>= 8;
             }
-        uint32_t q, rem;
-        divmod_rcp(y, freq, rcp, q, rem);
-        if constexpr (FMT == FMT_ALIAS)
+        if constexpr (FMT == FMT_ALIAS) {
+            uint32_t q, rem;
+            divmod_rcp(y, freq, rcp, q, rem);
             x = (q << p.scale_bits) + p.alias_remap[rem + start];
-        else
-            x = (q << p.scale_bits) + rem + start;
+        } else {
+            x = enc_update_byte(y, rec, p.scale_bits);
+        }
     }
 }
 

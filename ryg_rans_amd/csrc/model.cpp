@@ -194,6 +194,19 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
             enc_recs[s] = EncRec{f | (rshift << 24), bias, (uint32_t)rcp64, (uint32_t)(rcp64 >> 32)};
             continue;
         }
+        if (fmt == RANS_AMD_FMT_BYTE) {
+            // 32-bit Alverson reciprocal of RansEncSymbolInit (rans_byte.h:201-243), exact for x < 2^31:
+            // {freq | rshift << 24, bias, rcp, -}; freq < 2: rcp = ~0, bias = start + M - 1.
+            uint32_t rcp = 0xffffffffu, rshift = 0, bias = cum[s] + M - 1;
+            if (f >= 2) {
+                const uint32_t sh = ceil_log2(f);
+                rcp = (uint32_t)(((1ull << (sh + 31)) + f - 1) / f);
+                rshift = sh - 1;
+                bias = cum[s];
+            }
+            enc_recs[s] = EncRec{f | (rshift << 24), bias, rcp, 0u};
+            continue;
+        }
         uint32_t rcp = f <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / f);
         enc_recs[s] = EncRec{f, cum[s], rcp, cum[s]};
     }
