@@ -193,6 +193,18 @@ __device__ __forceinline__ void divmod_rcp(uint32_t x, uint32_t freq, uint32_t r
     }
 }
 
+// Word-format encoder update for a renormalised state y (any 32-bit value: y < 2^20 * freq reaches 2^32
+// for freq > 2048, beyond the 31-bit range of the Alverson reciprocal): round-up method of Granlund &
+// Montgomery, t = mulhi(y, m'); q = (t + ((y - t) >> 1)) >> sh, exact for freq >= 2, q = y - 1 for
+// freq == 1 (m' = 2^32 - 1, sh = 0); y + bias + q * (4096 - freq) == (y / freq << 12) + y % freq + start
+// (rans_word_sse41.h:92).  rec = {freq, bias, m', cmpl | sh << 24} (model.cpp).
+__device__ __forceinline__ uint32_t enc_update_word(uint32_t y, const uint4 &rec)
+{
+    const uint32_t t = __umulhi(y, rec.z);
+    const uint32_t q = (t + ((y - t) >> 1)) >> (rec.w >> 24);
+    return y + rec.y + __umul24(q, rec.w);
+}
+
 // Byte-format encoder update for a renormalised state y < 2^31, the reference's form
 // (RansEncPutSymbol, rans_byte.h:258-280): q = mulhi(y, rcp) >> rshift is floor(y / freq) exactly for
 // freq >= 2 (Alverson, rans_byte.h:201-243) and y - 1 for freq == 1; y + bias + q * (M - freq) then

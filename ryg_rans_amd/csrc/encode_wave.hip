@@ -46,9 +46,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         if (emit)
             *reinterpret_cast<uint16_t RANS_GLOBAL *>(slot + wp + 2u * rank_below(m)) = (uint16_t)(x & 0xffffu);
         uint32_t y = emit ? (x >> 16) : x;
-        uint32_t q, rem;
-        divmod_rcp(y, freq, rcp, q, rem);
-        const uint32_t xn = (q << 12) + rem + start;
+        const uint32_t xn = enc_update_word(y, rec);
         x = active ? xn : x;
     } else if constexpr (FMT == FMT_R64) {
         // rans64.h:77-93

@@ -480,9 +480,7 @@ __device__ __forceinline__ void lane_put(typename FmtTraits<FMT>::state_t &x, ui
             *reinterpret_cast<uint16_t RANS_GLOBAL *>(wp) = (uint16_t)y;
             y >>= 16;
         }
-        uint32_t q, rem;
-        divmod_rcp(y, freq, rcp, q, rem);
-        x = (q << 12) + rem + start;
+        x = enc_update_word(y, rec);
     } else if constexpr (FMT == FMT_R64) {
         uint64_t y = x;
         if (y >= (((uint64_t)freq) << (63u - p.scale_bits))) {
@@ -560,9 +558,7 @@ __device__ __forceinline__ void lane_put_staged(typename FmtTraits<FMT>::state_t
             O.template emit<2>(y);
             y >>= 16;
         }
-        uint32_t q, rem;
-        divmod_rcp(y, freq, rcp, q, rem);
-        x = (q << 12) + rem + start;
+        x = enc_update_word(y, rec);
     } else if constexpr (FMT == FMT_R64) {
         uint64_t y = x;
         if (y >= (((uint64_t)freq) << (63u - p.scale_bits))) { // rans64.h:83-88

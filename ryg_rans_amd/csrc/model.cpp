@@ -207,6 +207,19 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
             enc_recs[s] = EncRec{f | (rshift << 24), bias, rcp, 0u};
             continue;
         }
+        if (fmt == RANS_AMD_FMT_WORD) {
+            // round-up reciprocal for 32-bit dividends (see WordEncRec in model.h; same numbers):
+            // {freq, bias, m', cmpl | sh << 24}
+            if (f <= 1) {
+                enc_recs[s] = EncRec{f, cum[s] + M - 1, 0xffffffffu, M - 1};
+            } else {
+                const uint32_t l = ceil_log2(f);
+                const uint64_t mprime = (((uint64_t)1 << 32) * (((uint64_t)1 << l) - f)) / f + 1;
+                enc_recs[s] = EncRec{f, cum[s], (uint32_t)mprime, (M - f) | ((l - 1) << 24)};
+            }
+            continue;
+        }
+        // alias: remainder needed for the remap lookup -> floor(2^32 / freq) and one correction step
         uint32_t rcp = f <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / f);
         enc_recs[s] = EncRec{f, cum[s], rcp, cum[s]};
     }

@@ -59,14 +59,17 @@ struct AliasHalf {
     uint32_t lo;
     uint32_t adjust;
 };
-// EncRec: per-symbol encoder record.  q = x / freq is recovered exactly from
-// mulhi(x, rcp) with one correction step; see device_common.hpp.
+// EncRec: per-symbol encoder record of the general (any N, lane-per-stream) paths; the four slots
+// depend on the format (model.cpp):
+//   alias  {freq, start, floor(2^32 / freq), remap base}   q from mulhi + one correction, remainder kept
+//   byte   {freq | rshift << 24, bias, rcp, -}             Alverson, x + bias + q * (M - freq)
+//   word   {freq, bias, m', cmpl | sh << 24}               round-up method (see WordEncRec)
+//   rans64 {freq | rshift << 24, bias, rcp lo, rcp hi}     64-bit Alverson
 struct EncRec {
-    uint32_t freq;
-    uint32_t start;
-    uint32_t rcp;   // floor(2^32 / freq), 0xffffffff for freq == 1
-    uint32_t remap; // alias only: offset of this symbol's run in alias_remap (== start)
-    // FMT_R64 reuses the slots as {freq | rshift << 24, bias, rcp64 lo, rcp64 hi} (model.cpp)
+    uint32_t freq;  // (byte, rans64: | rshift << 24)
+    uint32_t start; // alias: start; the other formats: bias
+    uint32_t rcp;   // reciprocal (rans64: low half)
+    uint32_t remap; // alias: offset of this symbol's run in alias_remap; word: cmpl | sh << 24; rans64: rcp high half
 };
 
 // WordEncRec: encoder record of the word format for the full-wave kernel path (always 256 of them;
