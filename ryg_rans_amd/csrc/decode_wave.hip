@@ -274,6 +274,11 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 
     DecTables<FMT> T;
     T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+    if (!lds_starts_at_zero(smem)) { // cannot happen without static LDS; never decode on a wrong assumption
+        if (threadIdx.x == 0)
+            atomicAdd(p.err_count, 1ull << 32);
+        return;
+    }
 
     uint8_t *ring = smem + t0_bytes + t1_bytes + wave * kRingStride;
     uint8_t *tile = smem + t0_bytes + t1_bytes + waves_per_block * kRingStride + wave * kOutTileBytes; // OUT_FAST8_LDS

@@ -80,6 +80,20 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 typedef const u32x4 RANS_GLOBAL *gvec_cptr;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// Raw LDS addressing.  Every kernel here uses dynamic LDS only, which therefore starts at LDS address
+// 0; the tables that sit first are addressed by their byte offset alone, which saves the VALU add of a
+// link-time base the compiler cannot fold (`v_add_u32 v, 0, v`).  lds_starts_at_zero() is checked
+// once per kernel; a kernel that ever failed the check reports an error instead of decoding.
+#define RANS_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ bool lds_starts_at_zero(const uint8_t *smem)
+{
+    return (uint32_t)(uintptr_t)(RANS_LDS const uint8_t *)smem == 0u;
+}
+__device__ __forceinline__ uint32_t lds0_u8(uint32_t byte_offset)
+{
+    return *reinterpret_cast<RANS_LDS const uint8_t *>((uintptr_t)byte_offset);
+}
+
 // quad_perm DPP: lane i of each quad reads lane P[i]
 template <int P0, int P1, int P2, int P3> __device__ __forceinline__ uint32_t quad_perm(uint32_t v)
 {
@@ -133,7 +147,7 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
     } else if constexpr (FMT == FMT_BYTE) {
         // rans_byte.h:125-128 (get), :291-298 (step)
         const uint32_t cf = x & T.maskv;
-        const uint32_t s = T.t0[cf];
+        const uint32_t s = lds0_u8(cf); // cum2sym is the first table in LDS (t0 == LDS address 0)
         const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s]; // {freq, start}
         // freq <= 2^16 and x >> scale_bits < 2^23 (scale_bits >= 8): 24-bit multiply is exact
         x = (r.x & 0xffffffu) * ((x >> T.sbv) & 0xffffffu) + cf - r.y;
@@ -141,7 +155,7 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
     } else if constexpr (FMT == FMT_R64) {
         // rans64.h:118-121 (get), :286-292 (step)
         const uint32_t cf = (uint32_t)x & T.maskv;
-        const uint32_t s = T.t0[cf];
+        const uint32_t s = lds0_u8(cf); // cum2sym is the first table in LDS (t0 == LDS address 0)
         const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s];
         // freq * (x >> sb) + (cf - start) with x < 2^63: cf - start is in [0, freq), so it is a plain
         // 32-bit value; the high word of x >> sb is < 2^17 and freq <= 2^16, so its product is one

@@ -175,6 +175,11 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
 
     DecTables<FMT> T;
     T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+    if (!lds_starts_at_zero(smem)) { // cannot happen without static LDS; never decode on a wrong assumption
+        if (threadIdx.x == 0)
+            atomicAdd(p.err_count, 1ull << 32);
+        return;
+    }
 
     if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
         p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
@@ -367,6 +372,11 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
 
     DecTables<FMT> T;
     T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+    if (!lds_starts_at_zero(smem)) { // cannot happen without static LDS; never decode on a wrong assumption
+        if (threadIdx.x == 0)
+            atomicAdd(p.err_count, 1ull << 32);
+        return;
+    }
 
     if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
         p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
