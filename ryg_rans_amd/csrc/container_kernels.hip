@@ -96,9 +96,24 @@ __global__ void __launch_bounds__(1024) k_layout(const LayoutParams p)
 
 // ---------------------------------------------------------------------------
 // Compaction: chunk c's stream sits at the END of its scratch slot (arbitrary
-// alignment); copy it to out + offsets[c] (16-byte aligned).  One wave per
-// chunk, dword granularity; source dwords are realigned with v_alignbyte_b32.
+// alignment); copy it to out + offsets[c] (16-byte aligned).  One wave per chunk, 16 bytes per
+// lane and trip: two aligned 16-byte loads (the second is the next lane's first, an L1 hit), a
+// funnel shift by the source misalignment -- wave-uniform, so the dword part of the shift is a
+// scalar branch and the byte part four v_alignbyte_b32 -- and one 16-byte store.  The last store of a
+// chunk may spill up to 15 bytes into the alignment padding behind it; the scratch buffer carries
+// 64 bytes of slack for the loads past the last slot.
 // ---------------------------------------------------------------------------
+template <int DSH> __device__ __forceinline__ u32x4 funnel16(const u32x4 &a, const u32x4 &b, uint32_t bsh)
+{
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    u32x4 r;
+    r.x = __builtin_amdgcn_alignbyte(w[DSH + 1], w[DSH + 0], bsh);
+    r.y = __builtin_amdgcn_alignbyte(w[DSH + 2], w[DSH + 1], bsh);
+    r.z = __builtin_amdgcn_alignbyte(w[DSH + 3], w[DSH + 2], bsh);
+    r.w = __builtin_amdgcn_alignbyte(w[DSH + 4], w[DSH + 3], bsh);
+    return r;
+}
+
 __global__ void __launch_bounds__(256) k_compact(const CompactParams p)
 {
     if (*p.flags & 2u)
@@ -107,19 +122,25 @@ __global__ void __launch_bounds__(256) k_compact(const CompactParams p)
     const uint32_t wave = uniform(threadIdx.x >> 6);
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
-    for (uint64_t chunk = (uint64_t)blockIdx.x * waves_per_block + wave; chunk < p.nchunks; chunk += total_waves) {
-        const uint32_t len = p.lengths[chunk];
-        const uint8_t *src = p.scratch + (chunk + 1) * p.slot_bytes - len;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(p.out + p.offsets[chunk]);
-        const uintptr_t sa = reinterpret_cast<uintptr_t>(src);
-        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(sa & ~uintptr_t(3));
-        const uint32_t shift = (uint32_t)(sa & 3u);
-        const uint32_t ndw = (len + 3u) >> 2;
-        for (uint32_t i = lane; i < ndw; i += 64u) {
-            const uint32_t lo = s4[i];
-            // the dword after the slot end is never needed when shift == 0
-            const uint32_t hi = shift ? s4[i + 1] : 0u;
-            dst[i] = __builtin_amdgcn_alignbyte(hi, lo, shift);
+    for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave; chunk_v < p.nchunks; chunk_v += total_waves) {
+        const uint64_t chunk = uniform64(chunk_v);
+        const uint32_t len = uniform(p.lengths[chunk]);
+        const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1) * p.slot_bytes - len;
+        gvec_cptr src = reinterpret_cast<gvec_cptr>(sa & ~uint64_t(15));
+        u32x4 RANS_GLOBAL *dst = reinterpret_cast<u32x4 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + p.offsets[chunk]);
+        const uint32_t dsh = uniform((uint32_t)(sa & 15u) >> 2), bsh = uniform((uint32_t)(sa & 3u));
+        const uint32_t n16 = (len + 15u) >> 4;
+        for (uint32_t i = lane; i < n16; i += 64u) {
+            const u32x4 a = __builtin_nontemporal_load(src + i);
+            const u32x4 b = __builtin_nontemporal_load(src + i + 1);
+            u32x4 r;
+            switch (dsh) { // wave-uniform
+            case 0: r = funnel16<0>(a, b, bsh); break;
+            case 1: r = funnel16<1>(a, b, bsh); break;
+            case 2: r = funnel16<2>(a, b, bsh); break;
+            default: r = funnel16<3>(a, b, bsh); break;
+            }
+            dst[i] = r;
         }
     }
 }
