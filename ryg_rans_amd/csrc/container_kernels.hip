@@ -145,6 +145,26 @@ __global__ void __launch_bounds__(256) k_compact(const CompactParams p)
     }
 }
 
+// Small chunks (narrow interleaves: a few hundred bytes each): 16 lanes per chunk, four chunks per
+// wave trip, and the source read with UNALIGNED 16-byte global loads (gfx950 runs global memory in
+// unaligned-access mode; the funnel shift above would need per-lane selects here).
+__global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
+{
+    if (*p.flags & 2u)
+        return;
+    const uint32_t lane = lane_id();
+    const uint32_t sub = lane & 15u;
+    const uint64_t groups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; chunk < p.nchunks; chunk += groups) {
+        const uint32_t len = p.lengths[chunk];
+        const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1) * p.slot_bytes - len;
+        u32x4 RANS_GLOBAL *dst = reinterpret_cast<u32x4 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + p.offsets[chunk]);
+        const uint32_t n16 = (len + 15u) >> 4;
+        for (uint32_t i = sub; i < n16; i += 16u)
+            dst[i] = *reinterpret_cast<gvec_cptr>(sa + 16ull * i);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Histogram (count_freqs, main.cpp:59-66).  1 byte of HBM traffic per symbol, so the LDS
 // atomic rate is what has to keep up: a skewed source (Zipf: the top symbol is 16 % of
@@ -289,8 +309,14 @@ hipError_t launch_layout(const LayoutParams &p, hipStream_t stream)
 
 hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t stream)
 {
-    uint64_t want = (p.nchunks + 3) / 4;
-    uint64_t cap = (uint64_t)num_cus * 8;
+    const uint64_t cap = (uint64_t)num_cus * 8;
+    if (p.slot_bytes <= 8192) { // small chunks: 16 lanes each
+        const uint64_t want = (p.nchunks + 15) / 16;
+        const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+        hipLaunchKernelGGL(k_compact_small, dim3(grid), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
+    const uint64_t want = (p.nchunks + 3) / 4;
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
     hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
