@@ -412,7 +412,6 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
         bool bad = false;
 
         const uint32_t rounds = nsym / NW;
-        const uint32_t tail = nsym - rounds * NW;
         uint32_t i = 0; // symbol index inside the chunk
         if (wide_out) {
             // 16 symbols per 16-byte store: 16/NW rounds per group
@@ -427,8 +426,6 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
                         uint32_t sy = dec_step<FMT>(T, x[l]);
                         if constexpr (Tr::kSymByte == 3)
                             sy >>= 24;
-                        constexpr int dummy = 0;
-                        (void)dummy;
                         const int pos = rr * NW + l;
                         pack[pos / 4] |= (sy & 0xffu) << (8 * (pos % 4));
                     }
@@ -459,7 +456,6 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
                 lane_renorm<FMT>(x[l], W, (uint32_t)l < cnt);
             i += cnt;
         }
-        (void)tail;
 #pragma unroll
         for (int l = 0; l < NW; ++l)
             bad = bad || (x[l] != Tr::kL);
