@@ -96,7 +96,8 @@ struct rans_amd_ctx {
 };
 
 struct rans_amd_model {
-    rans_amd_ctx *ctx = nullptr;
+    rans_amd_ctx *ctx = nullptr; // identity only (encode/decode check it); never dereferenced by the model
+    int device = -1;             // device that owns the d_* buffers (the context may be gone at destroy time)
     HostModel host;
     void *d_table0 = nullptr;
     void *d_table1 = nullptr;
@@ -293,6 +294,7 @@ int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_fr
     if (!m)
         return fail(RANS_AMD_E_NOMEM, "model");
     m->ctx = ctx;
+    m->device = ctx ? ctx->device : -1;
     int rc = m->host.build(format, norm_freqs, nsyms, scale_bits);
     if (rc) {
         delete m;
@@ -366,8 +368,8 @@ int rans_amd_model_destroy(rans_amd_model *m)
 {
     if (!m)
         return RANS_AMD_OK;
-    if (m->ctx) {
-        DeviceGuard guard(m->ctx->device);
+    if (m->device >= 0) { // not m->ctx->device: a model may outlive its context
+        DeviceGuard guard(m->device);
         for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_word_enc, m->d_remap})
             if (p)
                 (void)hipFree(p);

@@ -301,9 +301,9 @@ hipError_t launch_layout(const LayoutParams &p, hipStream_t stream)
     if (blocks > 1) {
         if (!p.block_sums)
             return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_layout_sums, dim3(blocks), dim3(1024), 0, stream, p);
+        RANS_LAUNCH(k_layout_sums, dim3(blocks), dim3(1024), 0, stream, p);
     }
-    hipLaunchKernelGGL(k_layout, dim3(blocks), dim3(1024), 0, stream, p);
+    RANS_LAUNCH(k_layout, dim3(blocks), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -313,12 +313,12 @@ hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t strea
     if (p.slot_bytes <= 8192) { // small chunks: 16 lanes each
         const uint64_t want = (p.nchunks + 15) / 16;
         const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
-        hipLaunchKernelGGL(k_compact_small, dim3(grid), dim3(256), 0, stream, p);
+        RANS_LAUNCH(k_compact_small, dim3(grid), dim3(256), 0, stream, p);
         return hipGetLastError();
     }
     const uint64_t want = (p.nchunks + 3) / 4;
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, stream, p);
+    RANS_LAUNCH(k_compact, dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -328,10 +328,10 @@ hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_
     const uint32_t grid = (uint32_t)num_cus * 4;
     if (sym_bytes == 1) {
         const size_t lds = (size_t)(256 / 64) * kHistCopies * kHistCopyStride * 4;
-        hipLaunchKernelGGL(k_histogram_u8, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+        RANS_LAUNCH(k_histogram_u8, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
     } else {
         const size_t lds = (size_t)nsyms * 4;
-        hipLaunchKernelGGL(k_histogram_u16, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+        RANS_LAUNCH(k_histogram_u16, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
     }
     return hipGetLastError();
 }

@@ -523,7 +523,7 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     if (name)
         *name = FMT == FMT_WORD ? "k_decode<word>" : FMT == FMT_BYTE ? "k_decode<byte>"
                 : FMT == FMT_R64 ? "k_decode<r64>" : "k_decode<alias>";
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
+    RANS_LAUNCH(kern, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -329,7 +329,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     uint64_t want = (p.nchunks + waves - 1) / waves;
     uint64_t cap = (uint64_t)num_cus * 8;
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kEncBlockThreads), lds, stream, p);
+    RANS_LAUNCH(kern, dim3(grid), dim3(kEncBlockThreads), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -870,7 +870,7 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
         const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
         if (name)
             *name = "k_decode_lanes_staged";
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * sw), lds, stream, p);
+        RANS_LAUNCH(kern, dim3(grid), dim3(64 * sw), lds, stream, p);
         return hipGetLastError();
     }
     const uint64_t want = (p.nchunks + 255) / 256;
@@ -881,7 +881,7 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     if (name)
         *name = "k_decode_lanes";
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    RANS_LAUNCH(kern, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -920,7 +920,7 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, 
         }
         const uint64_t want_blocks = (batches + sw - 1) / sw;
         const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * sw), table_lds + (size_t)sw * kEncWaveLds, stream, p);
+        RANS_LAUNCH(kern, dim3(grid), dim3(64 * sw), table_lds + (size_t)sw * kEncWaveLds, stream, p);
         return hipGetLastError();
     }
     const size_t lds = table_lds;
@@ -936,7 +936,7 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, 
     const uint64_t want = (p.nchunks + 255) / 256;
     const uint64_t cap = (uint64_t)num_cus * 8;
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    RANS_LAUNCH(kern, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -4,6 +4,14 @@
 
 #include "kernels.h"
 
+// Launch and report THIS launch's status: hipGetLastError() is per thread and sticky, so an error left
+// behind by other code in the process (PyTorch probing a device, say) would otherwise be blamed on us.
+#define RANS_LAUNCH(kern, grid, block, lds, stream, ...)                         \
+    do {                                                                         \
+        (void)hipGetLastError();                                                 \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);         \
+    } while (0)
+
 namespace rans_amd {
 
 // wave-per-chunk kernels (N-way streams with N = 64 K lanes): decode_wave.hip, encode_wave.hip

@@ -428,3 +428,19 @@ def test_lane_kernels_both_generations(gpu, oracle, generation, monkeypatch):
     out_b = torch.zeros(data.size + 16, dtype=torch.uint8, device="cuda")
     ctx.decode(gm, cont, total, d_offs, d_lens, data.size, 2, 512, d_out=out_b[5:5 + data.size])
     assert np.array_equal(out_b[5:5 + data.size].cpu().numpy(), data)
+
+
+def test_model_may_outlive_its_context(gpu, oracle):
+    """Destroying a context before its models (Python GC order does that) must be harmless: the
+    model frees its device tables on its own device, and no sticky HIP error is left behind for the
+    next launch to trip over."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(70000, K=256, s=1.0, seed=23)
+    ctx2 = R.Context(0)
+    om, gm2 = _models(R, ctx2, oracle, FMT_WORD, 12, data)
+    ctx2.close()
+    gm2.close()
+    om, gm = _models(R, ctx, oracle, FMT_WORD, 12, data)
+    cont, offs, lens, total = ctx.encode(gm, torch.from_numpy(data).cuda(), 64, 4096)
+    out = ctx.decode(gm, cont, total, offs, lens, data.size, 64, 4096)
+    assert np.array_equal(out.cpu().numpy(), data)
