@@ -508,14 +508,9 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
     auto kern = k_decode<FMT, K, OUT>;
-    static bool attr_set = false; // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess)
-            return e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 160 * 1024, lds_ok); e != hipSuccess)
+        return e;
     const int blocks_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
     uint64_t want = (p.nchunks + waves - 1) / waves;
     uint64_t cap = (uint64_t)num_cus * blocks_per_cu;

@@ -318,14 +318,9 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     if (lds > 128 * 1024 || (FMT == FMT_WORD && !p.word_enc_recs))
         return hipErrorInvalidValue;
     auto kern = k_encode<FMT, K>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess)
-            return e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 128 * 1024, lds_ok); e != hipSuccess)
+        return e;
     uint64_t want = (p.nchunks + waves - 1) / waves;
     uint64_t cap = (uint64_t)num_cus * 8;
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);

@@ -856,14 +856,9 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
     }
     const size_t lds = staged ? table_lds + (size_t)sw * kLaneWaveLds : table_lds;
     auto kern = staged ? k_decode_lanes_staged<FMT, NW> : k_decode_lanes<FMT, NW>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[staged]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess)
-            return e;
-        attr_set[staged] = true;
-    }
+    static std::atomic<uint64_t> lds_ok[2] = {{0}, {0}}; // per kernel generation, one bit per device
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 160 * 1024, lds_ok[staged]); e != hipSuccess)
+        return e;
     if (staged) {
         const uint64_t batches = (p.nchunks + 63) / 64;
         const uint64_t want_blocks = (batches + sw - 1) / sw;
@@ -910,14 +905,9 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, 
         const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
         sw = (uint32_t)(even ? even : 1);
         auto kern = k_encode_lanes_staged<FMT, NW>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess)
-                return e;
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
+        if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 160 * 1024, lds_ok); e != hipSuccess)
+            return e;
         const uint64_t want_blocks = (batches + sw - 1) / sw;
         const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
         RANS_LAUNCH(kern, dim3(grid), dim3(64 * sw), table_lds + (size_t)sw * kEncWaveLds, stream, p);
@@ -925,14 +915,9 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, 
     }
     const size_t lds = table_lds;
     auto kern = k_encode_lanes16<FMT, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess)
-            return e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 128 * 1024, lds_ok); e != hipSuccess)
+        return e;
     const uint64_t want = (p.nchunks + 255) / 256;
     const uint64_t cap = (uint64_t)num_cus * 8;
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);

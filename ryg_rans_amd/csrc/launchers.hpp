@@ -12,7 +12,26 @@
         hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);         \
     } while (0)
 
+#include <atomic>
+
 namespace rans_amd {
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): function attributes are per device, and
+// one process may hold contexts on several GPUs.  `done` is a per-kernel bit set indexed by device.
+inline hipError_t allow_large_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit)
+        return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess)
+        done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // wave-per-chunk kernels (N-way streams with N = 64 K lanes): decode_wave.hip, encode_wave.hip
 hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name);
