@@ -91,8 +91,12 @@ typedef enum rans_amd_table {
     RANS_AMD_TAB_DEC_SYMBOLS = 10  /* RansDecSymbol[nsyms] (4 B) or Rans64DecSymbol[nsyms] (8 B) */
 } rans_amd_table;
 
-typedef struct rans_amd_ctx rans_amd_ctx;     /* one per (process, GPU); thread-compatible */
-typedef struct rans_amd_model rans_amd_model; /* immutable after creation; shareable across streams */
+/* A context owns ONE encode workspace, error counter and work-counter ring: host calls on it are
+ * serialised by a mutex, and its asynchronous work must stay on ONE stream at a time (synchronise
+ * before switching streams).  Concurrent streams want one context each.  Models are immutable, may be
+ * used from any stream, and may be destroyed after the context they were created with. */
+typedef struct rans_amd_ctx rans_amd_ctx;     /* one per (process, GPU) and per concurrent stream */
+typedef struct rans_amd_model rans_amd_model; /* immutable after creation */
 
 /* ---- library / context ------------------------------------------------- */
 
