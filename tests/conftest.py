@@ -12,6 +12,13 @@ for p in (HERE, ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A fresh checkout has no binaries (they are git-ignored): build the product library and the
+    # checkers once, exactly as __graft_entry__.build() does.  Nothing is rebuilt when they exist.
+    need = [os.path.join(ROOT, "ryg_rans_amd", "lib", "libryg_rans_amd.so"),
+            os.path.join(ROOT, "oracle", "librans_oracle.so")]
+    if not all(os.path.exists(f) for f in need):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
