@@ -85,3 +85,39 @@ def test_reference_mains_build_unchanged_against_compat_headers(book1):
         for line in lines:
             assert line in out, (name, line)
         assert out.count("decode ok!") == len(lines) and "ERROR" not in out
+
+
+def _avx2_driver():
+    if "avx2" not in open("/proc/cpuinfo").read():
+        pytest.skip("host CPU has no AVX2")
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "libcompat_avx2_driver.so")
+    subprocess.run(["g++", "-O3", "-mavx2", "-shared", "-fPIC", "-I", COMPAT, "-o", so,
+                    os.path.join(HERE, "compat_avx2_driver.cpp")], check=True)
+    lib = C.CDLL(so)
+    u8p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+    lib.compat_decode_avx2.argtypes = [u32p, u32p, u8p, C.c_size_t, C.c_size_t, u8p]
+    lib.compat_time_word8.argtypes = [C.c_int, u32p, u32p, u8p, C.c_size_t, C.c_size_t, u8p, C.c_int]
+    lib.compat_time_word8.restype = C.c_double
+    return lib
+
+
+def test_avx2_word_decoder_extension(oracle):
+    """rans_word_avx2.h (8 lanes in one vector) decodes the reference's 8-way word streams: every
+    tail length, skewed / flat / two-symbol sources, and the cursor ends exactly on the stream end."""
+    lib = _avx2_driver()
+    rng = np.random.default_rng(5)
+    sources = [oracle.gen_zipf(100003, K=256, s=1.0, seed=6), rng.integers(0, 256, 4099, dtype=np.uint8),
+               (rng.integers(0, 2, 30001) * 200).astype(np.uint8),
+               np.minimum(rng.geometric(0.3, 50000) - 1, 255).astype(np.uint8)]
+    for data in sources:
+        f, cum = oracle.normalize(oracle.count_freqs(data, 256), 1 << 12)
+        model = oracle.model(f, 12)
+        for n in (data.size, data.size - 1, data.size - 5, 8, 9, 15, 16, 1):
+            d = data[:n]
+            want = oracle.encode(FMT_WORD, model, d, 8)
+            padded = np.concatenate([want, np.zeros(32, np.uint8)])
+            out = np.zeros(n, np.uint8)
+            assert lib.compat_decode_avx2(_p(f, C.c_uint32), _p(cum, C.c_uint32), _p(padded, C.c_uint8), want.size,
+                                          n, _p(out, C.c_uint8)) == 0, n
+            assert np.array_equal(out, d), n
