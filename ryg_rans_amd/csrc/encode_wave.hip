@@ -24,13 +24,15 @@ template <int FMT> struct EncTables {
 
 // One encoder sub-step for 64 lanes.  `wp` = write cursor (byte offset inside the
 // slot, moves down, wave-uniform).
-template <int FMT>
+// PADDED: the record table holds 256 entries (zero records behind nsyms) and `sym` is a byte, so it
+// indexes the table as it is -- no range select (a v_cndmask costs ~22 issue cycles on gfx950).
+template <int FMT, bool PADDED = false>
 __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename FmtTraits<FMT>::state_t &x,
                                             uint32_t sym, bool active, uint8_t RANS_GLOBAL *slot, uint32_t &wp,
                                             bool &bad)
 {
-    const bool in_alphabet = sym < T.nsyms;
-    const uint4 rec = T.recs[in_alphabet ? sym : 0u];
+    const bool in_alphabet = PADDED || sym < T.nsyms;
+    const uint4 rec = T.recs[PADDED ? sym : (in_alphabet ? sym : 0u)];
     const uint32_t freq = (FMT == FMT_R64 || FMT == FMT_BYTE) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
     if (active && (!in_alphabet || freq == 0)) {
         bad = true;
@@ -78,7 +80,10 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         } else if (e1) {
             slot[at] = (uint8_t)x;
         }
-        uint32_t y = e2 ? (x >> 16) : (e1 ? (x >> 8) : x);
+        // bytes emitted = [x >= x_max] + [x >> 8 >= x_max] as sign bits (x, x_max < 2^31), then one shift:
+        // no selects.  Inactive or invalid lanes may shift by garbage; their result is discarded below.
+        const uint32_t nb = ((x_max - 1u - x) >> 31) + ((x_max - 1u - (x >> 8)) >> 31);
+        const uint32_t y = x >> (nb << 3);
         uint32_t xn;
         if constexpr (FMT == FMT_ALIAS) {
             uint32_t q, rem;
@@ -154,6 +159,8 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
         uint4 *l = reinterpret_cast<uint4 *>(smem + kWordRecBytes);
         for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
             l[i] = g[i];
+        for (uint32_t i = p.nsyms + threadIdx.x; i < 256u; i += blockDim.x) // byte alphabets: 256 entries,
+            l[i] = uint4{0u, 0u, 0u, 0u};                                    // freq 0 behind nsyms
     }
     __syncthreads();
 
@@ -269,7 +276,7 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
                     for (int J = 3; J >= 0; --J)
 #pragma unroll
                         for (int k = K - 1; k >= 0; --k)
-                            enc_substep<FMT>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
+                            enc_substep<FMT, true>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
                 }
                 }
 #pragma unroll
@@ -314,7 +321,7 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
 template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num_cus, hipStream_t stream)
 {
     const uint32_t waves = kEncBlockThreads / 64;
-    const size_t lds = (size_t)p.nsyms * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
+    const size_t lds = (size_t)(p.nsyms < 256 ? 256 : p.nsyms) * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
     if (lds > 128 * 1024 || (FMT == FMT_WORD && !p.word_enc_recs))
         return hipErrorInvalidValue;
     auto kern = k_encode<FMT, K>;
