@@ -18,7 +18,7 @@ import ryg_rans_amd as R  # noqa: E402
 from _oracle import FMT_ALIAS, FMT_BYTE, FMT_R64, FMT_WORD, Oracle  # noqa: E402
 
 
-def run(cases, seed, ctx=None, oracle=None):
+def run(cases, seed, ctx=None, oracle=None, big=False):
     """Returns the number of failing cases (details are printed)."""
     rng = np.random.default_rng(seed)
     oracle = oracle or Oracle()
@@ -30,6 +30,8 @@ def run(cases, seed, ctx=None, oracle=None):
         sb = {FMT_WORD: 12, FMT_BYTE: int(rng.integers(8, 17)), FMT_R64: int(rng.integers(8, 17)),
               FMT_ALIAS: int(rng.integers(8, 17))}[fmt]
         n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 70000), rng.integers(70000, 400000)]))
+        if big and rng.integers(0, 8) == 0:  # now and then: enough chunks for several rounds of every persistent grid
+            n = int(rng.integers(3_000_000, 7_000_000))
         n_ways = int(rng.choice([1, 2, 4, 8, 64, 128, 256, 512, int(rng.integers(1, 513))]))
         chunk = int(rng.choice([n + 5, 16 * int(rng.integers(1, 300)), int(rng.integers(1, 5000)), 64 * int(rng.integers(1, 64))]))
         kind = int(rng.integers(0, 4))
@@ -108,8 +110,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="mix in inputs of 3-7 M symbols")
     a = ap.parse_args()
-    fails = run(a.cases, a.seed)
+    fails = run(a.cases, a.seed, big=a.big)
     print("cases %d, failures %d" % (a.cases, fails))
     sys.exit(1 if fails else 0)
 
