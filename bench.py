@@ -8,19 +8,26 @@ synthetic order-0 byte streams, one 1 GiB shard per GPU (BASELINE.json configs[2
 
 A "step" = one pass of the decode hot path over the whole shard (device-resident
 container -> device-resident symbols).  Per rank: generate Zipf(256, s=1) bytes on
-the GPU (seed = rank+1), build the order-0 model (GPU histogram + exact
-normalize_freqs), encode with the GPU encoder (setup, untimed), then W warm-up and K
-timed decodes.  Shards are independent: no collective on the data path; RCCL only
-carries the barriers and the 64-byte per-rank result record (weak scaling).
+the GPU (SURVEY 8(d) generator: splitmix64 + inverse CDF, seed = rank+1 -- the same
+bytes tests/_oracle.py's gen_zipf makes on the CPU), build the order-0 model (GPU
+histogram + exact normalize_freqs), encode with the GPU encoder (setup, untimed), then
+W warm-up and K timed decodes.  Shards are independent: no collective on the data
+path; RCCL only carries the barriers and the 40-byte per-rank result record (weak scaling).
 
 Rank 0 prints ONE JSON line.  `value` = decoded (uncompressed) GB/s of the whole job.
 `roofline` = algorithmic bytes (compressed stream read + symbols written) of one decode
 launch / its average duration measured with HIP events on the launch stream, vs the
-8 TB/s HBM peak.  `cpu_baseline` = the reference's own fastest decoder (SSE4.1 8-way,
-oracle/_ref) on this box's host cores over a bounded sample of the same data.
+8 TB/s HBM peak.  `clocks` = shader clock and per-wave clocks per 64-symbol round measured
+by the kernel itself in one extra instrumented launch.  `configs` (N=1 only) = the other
+BASELINE configurations and the encoders, each timed over back-to-back launches in this same
+run.  `cpu_baseline` (N=1 only) = the reference's own fastest decoder (SSE4.1 8-way,
+oracle/_ref) on this box's host cores over a bounded sample of the same data; the same CPU
+leg re-encodes sampled chunks of every container with the oracle and compares the bytes.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -31,6 +38,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0  # measured float4 streaming copy (same guide)
 MAX_CLOCK_HZ = 2.4e9
+WAVES_PER_SIMD = 8      # resident waves per SIMD of the wave-per-chunk decoder (2 blocks x 16 waves per CU)
 
 
 def parse_args():
@@ -42,32 +50,155 @@ def parse_args():
     ap.add_argument("--ways", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=32768, help="symbols per independent chunk stream")
     ap.add_argument("--format", default="word", choices=["word", "byte", "r64", "alias"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (reference timing + oracle checks)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
+    ap.add_argument("--config-steps", type=int, default=20, help="back-to-back launches per `configs` entry")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="dry-run aid: every rank uses this GPU (needs --backend gloo)")
-    ap.add_argument("--cpu-shard-log2", type=int, default=25, help="CPU baseline: symbols per host thread")
     return ap.parse_args()
 
 
-def gen_zipf_bytes(torch, n, seed, device):
-    """Zipf(K=256, s=1) bytes by inverse CDF on the GPU (SURVEY.md 8(d) distribution)."""
-    w = 1.0 / torch.arange(1, 257, dtype=torch.float64, device=device)
-    cdf = torch.cumsum(w / w.sum(), 0).float()
-    out = torch.empty(n, dtype=torch.uint8, device=device)
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    step = min(n, 1 << 26)
+# ---- synthetic input: SURVEY.md 8(d) ---------------------------------------------------------
+
+def zipf_cdf(K, s):
+    """Running sums of 1/(k+1)^s in double precision, summed in index order (oracle/rans_oracle.c:580-587)."""
+    run, cdf = 0.0, []
+    for k in range(K):
+        run += 1.0 / math.pow(float(k + 1), s)
+        cdf.append(run)
+    return cdf, run
+
+
+def gen_zipf(torch, n, K, s, seed, device):
+    """Zipf(K, s) symbols, bit-identical to tests/_oracle.py Oracle.gen_zipf(n, K, s, seed): splitmix64 is
+    counter based (state_i = seed + (i + 1) * golden), u = (z >> 11) * 2^-53 * Z, symbol = first k with
+    cdf[k] > u.  uint8 for K <= 256, else int16 holding the u16 symbol."""
+    cdf_list, run = zipf_cdf(K, s)
+    cdf = torch.tensor(cdf_list, dtype=torch.float64, device=device)
+    out = torch.empty(n, dtype=torch.uint8 if K <= 256 else torch.int16, device=device)
+
+    def as_i64(v):  # 64-bit constant as the signed value torch.int64 holds
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    golden, c1, c2 = as_i64(0x9E3779B97F4A7C15), as_i64(0xBF58476D1CE4E5B9), as_i64(0x94D049BB133111EB)
+
+    def lsr(z, k):  # logical shift right of an int64 tensor
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    step = min(n, 1 << 25)
     for i in range(0, n, step):
         m = min(step, n - i)
-        u = torch.rand(m, device=device, generator=g)
-        out[i:i + m] = torch.searchsorted(cdf, u).clamp_(max=255).to(torch.uint8)
+        idx = torch.arange(i + 1, i + 1 + m, dtype=torch.int64, device=device)
+        z = idx * golden + as_i64(seed & ((1 << 64) - 1))  # wraps modulo 2^64 like the C code
+        z = (z ^ lsr(z, 30)) * c1
+        z = (z ^ lsr(z, 27)) * c2
+        z = z ^ lsr(z, 31)
+        u = lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0) * run
+        sym = torch.searchsorted(cdf, u, right=True).clamp_(max=K - 1)
+        out[i:i + m] = sym.to(out.dtype)
     return out
 
 
-def cpu_baseline(d_syms, freqs, n, shard_log2):
-    """Reference CPU path on this box (rank 0, N=1 only).  TEST/BASELINE leg: the only
-    place bench.py touches oracle/."""
+# ---- timing helpers ----------------------------------------------------------------------------
+
+def timed_launches(torch, fn, steps, warmup):
+    """Mean / min milliseconds of `steps` back-to-back launches of fn (HIP events on the launch stream)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    for k in range(steps):
+        ev0[k].record()
+        fn()
+        ev1[k].record()
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    return sum(ms) / len(ms), min(ms)
+
+
+def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, steps, device, d_syms=None):
+    """One `configs` entry: decode and encode of a BASELINE configuration, `steps` back-to-back launches each,
+    round trip verified.  Returns (entry, artefacts for the CPU-side oracle check)."""
+    n = 1 << log2n
+    sym_bytes = 1 if K <= 256 else 2
+    if d_syms is None:
+        d_syms = gen_zipf(torch, n, K, 1.0, seed, device)
+    counts = ctx.count_freqs_device(d_syms, K)
+    freqs, _ = R.normalize_freqs(counts, 1 << sb)
+    model = ctx.model(fmt, freqs, sb)
+    cont, offs, lens, total = ctx.encode(model, d_syms, ways, chunk)
+    out = torch.empty_like(d_syms)
+    dec_ms, dec_min = timed_launches(
+        torch, lambda: ctx.decode(model, cont, total, offs, lens, n, ways, chunk, d_out=out, sync=False), steps, 2)
+    bad = ctx.decode_errors()
+    exact = bool(torch.equal(out, d_syms)) and bad == 0
+    kernel = ctx.last_decode_kernel()
+    cont2, offs2, lens2 = torch.empty_like(cont), torch.empty_like(offs), torch.empty_like(lens)
+    enc_ms, enc_min = timed_launches(
+        torch, lambda: ctx.encode(model, d_syms, ways, chunk, d_out=cont2, sync=False, d_offsets=offs2, d_lengths=lens2),
+        steps, 2)
+    # (bytes between chunks are alignment padding nobody writes: compare index and sizes, not the raw buffers)
+    same_container = bool(torch.equal(offs2, offs)) and bool(torch.equal(lens2, lens))
+    alg = n * sym_bytes + total
+    entry = {
+        "name": name, "format": R.FORMAT_NAMES[fmt], "scale_bits": sb, "alphabet": K, "n_ways": ways, "chunk_syms": chunk,
+        "symbols": n, "decoded_bytes": n * sym_bytes, "stream_bytes": total,
+        "algorithmic_bytes_per_launch": alg,
+        "decode": {"kernel": kernel, "ms_mean": round(dec_ms, 4), "ms_min": round(dec_min, 4), "launches": steps,
+                   "decoded_GBps": round(n * sym_bytes / dec_ms / 1e6, 1),
+                   "achieved_GBps": round(alg / dec_ms / 1e6, 1), "frac": round(alg / dec_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+        "encode": {"kernels": "k_encode* + k_layout + k_compact*", "ms_mean": round(enc_ms, 4), "ms_min": round(enc_min, 4),
+                   "launches": steps, "input_GBps": round(n * sym_bytes / enc_ms / 1e6, 1),
+                   "achieved_GBps": round(alg / enc_ms / 1e6, 1), "frac": round(alg / enc_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+        "bit_exact_roundtrip": exact and same_container,
+    }
+    art = {"fmt": fmt, "sb": sb, "K": K, "ways": ways, "chunk": chunk, "n": n, "freqs": freqs, "d_syms": d_syms,
+           "cont": cont, "offs": offs, "lens": lens, "total": total, "entry": entry}
+    return entry, art
+
+
+# ---- CPU leg (rank 0, N = 1): the only place bench.py touches oracle/ ---------------------------------
+
+def oracle_check_chunks(art, want=64):
+    """Re-encode sampled chunks of a GPU-made container with the CPU oracle and compare the bytes; check the
+    whole index (offsets = prefix sums of 16-byte aligned lengths).  Returns the number of chunks compared."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from _oracle import FMT_ALIAS, Oracle
+    orc = Oracle()
+    fmt, n, chunk, ways = art["fmt"], art["n"], art["chunk"], art["ways"]
+    lens = art["lens"].cpu().numpy().astype(np.uint32).astype(np.uint64)
+    offs = art["offs"].cpu().numpy().astype(np.uint64)
+    nchunks = lens.size
+    aligned = (lens + np.uint64(15)) & ~np.uint64(15)
+    want_offs = np.zeros(nchunks + 1, dtype=np.uint64)
+    want_offs[1:] = np.cumsum(aligned)
+    want_offs[nchunks] = want_offs[nchunks - 1] + lens[nchunks - 1]
+    assert np.array_equal(offs, want_offs), "chunk index differs from the prefix sums of its lengths"
+    assert int(offs[nchunks]) == art["total"]
+    rng = np.random.default_rng(2024)
+    picks = {0, 1, nchunks - 1, nchunks - 2, nchunks // 2}
+    picks |= {c for c in (8191, 8192, 8193, 16383, 16384) if c < nchunks}
+    picks |= set(int(c) for c in rng.integers(0, nchunks, want))
+    picks = sorted(c for c in picks if 0 <= c < nchunks)
+    om = orc.model(art["freqs"], art["sb"], with_alias=(fmt == FMT_ALIAS))
+    syms, cont = art["d_syms"], art["cont"]
+    for c in picks:
+        lo, hi = c * chunk, min(n, (c + 1) * chunk)
+        h_syms = syms[lo:hi].cpu().numpy()
+        if h_syms.dtype == np.int16:
+            h_syms = h_syms.view(np.uint16)
+        ref = orc.encode(fmt, om, h_syms, ways)
+        a, ln = int(offs[c]), int(lens[c])
+        got = cont[a:a + ln].cpu().numpy()
+        assert ref.size == ln and np.array_equal(got, ref), "chunk %d differs from the oracle's stream" % c
+    return len(picks)
+
+
+def cpu_baseline(d_syms, freqs, n):
+    """Reference CPU path on this box: the reference's SSE4.1 8-way decoder over independent shards."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
@@ -157,6 +288,16 @@ def cpu_baseline(d_syms, freqs, n, shard_log2):
             "host_cpus": cores, "usable_cpus": usable}
 
 
+def kernel_source_tag():
+    """sha256 (first 16 hex digits) of the sources the decode kernel is built from: a committed PMC traffic
+    measurement is quoted only when it was taken on this very kernel."""
+    h = hashlib.sha256()
+    for f in ("decode_wave.hip", "device_common.hpp", "kernels.h"):
+        with open(os.path.join(ROOT, "ryg_rans_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     args = parse_args()
     import torch
@@ -187,7 +328,7 @@ def main():
 
     # ---- setup (untimed): data, model, GPU encode ------------------------------
     ctx = R.Context(gpu_index)
-    d_syms = gen_zipf_bytes(torch, n, seed=rank + 1, device=device)
+    d_syms = gen_zipf(torch, n, 256, 1.0, rank + 1, device)
     counts = ctx.count_freqs_device(d_syms, 256)
     freqs, _ = R.normalize_freqs(counts, 1 << sb)
     model = ctx.model(fmt, freqs, sb)
@@ -240,7 +381,7 @@ def main():
             "metric": "decode GB/s (uncompressed), 64-way interleaved rANS (word format)",
             "value": round(value, 2),
             "unit": "GB/s",
-            "n_gpus": world,
+            "n_gpus": agg["n_ranks"],  # counted from the records the all-gather delivered, not from the environment
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
@@ -255,9 +396,13 @@ def main():
                             % (args.format, args.ways, n >> 20, args.chunk, 2 if world == 1 else 4),
                 "format": args.format, "n_ways": args.ways, "chunk_syms": args.chunk, "scale_bits": sb,
                 "symbols_per_gpu": n, "compressed_bytes_per_symbol": round(total / n, 5),
+                "generator": "splitmix64 + inverse CDF (SURVEY 8(d)), seed = rank + 1",
                 "sharding": "one independent shard per GPU, no data-path collective",
             },
             "bit_exact_roundtrip": all_ok,
+            "per_rank": {"kernel_ms": [round(r.kernel_ms, 4) for r in records],
+                         "elapsed_ms_per_step": [round(r.elapsed_s / args.steps * 1e3, 4) for r in records],
+                         "stream_bytes": [int(r.stream_bytes) for r in records]},
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -265,33 +410,91 @@ def main():
                 "algorithmic_bytes_per_launch": n + total,
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
             },
-            "clocks_per_symbol": {
-                "gpu_aggregate_at_2.4GHz": round(k_s * MAX_CLOCK_HZ / n, 6),
-                "per_wave_round_of_64": round(k_s * MAX_CLOCK_HZ / n * 64 * 8192, 1),
-            },
         }
+        # per-wave clocks, measured by the kernel in one extra (untimed, instrumented) launch
+        try:
+            ctx.set_timing(2)
+            step()
+            wc = ctx.last_wave_clocks()
+            ctx.set_timing(0)
+            per_wave_round = wc["shader_cycles"] / max(1, wc["rounds"])
+            result["clocks"] = {
+                "sclk_hz_measured": round(wc["sclk_hz"]),
+                "per_wave_clocks_per_round_of_64": round(per_wave_round, 1),
+                "per_simd_clocks_per_round_of_64": round(per_wave_round / WAVES_PER_SIMD, 2),
+                "clocks_per_symbol_per_simd": round(per_wave_round / WAVES_PER_SIMD / 64.0, 4),
+                "gpu_aggregate_clocks_per_symbol": round(k_s * wc["sclk_hz"] / n, 6),
+                "waves": wc["waves"], "rounds": wc["rounds"],
+                "instrumented_launch_ms": round(wc["kernel_ticks_ms"], 4),
+                "method": "s_memtime / wall_clock64 bracket around each wave's work (rans_amd_set_timing(ctx, 2)), "
+                          "one extra launch after the timed region; the reference's analogue is the __rdtsc "
+                          "bracket of main.cpp:171,184-186",
+            }
+        except Exception as e:  # noqa: BLE001
+            result["clocks"] = {"error": repr(e)}
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this very command
-        # (tools/profile.sh -> tools/summarize_profile.py -> profiles/<tag>_traffic.json); PMC passes
-        # cannot share a process with the timed run, so the committed measurement is quoted when it
-        # was taken on the same workload, else null.
-        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r01_traffic.json"))
+        # (tools/profile.sh -> tools/summarize_profile.py -> profiles/<tag>_traffic.json); PMC passes cannot
+        # share a process with the timed run, so a committed measurement is quoted only when it was taken on
+        # this workload AND on the kernel sources of this checkout (its `kernel_source_tag`), else null.
+        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r02_traffic.json"))
         default_workload = (args.format == "word" and args.ways == 64 and args.chunk == 32768 and args.log2n == 30)
         if os.path.exists(tj) and default_workload:
             try:
                 t = json.load(open(tj))
-                result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-                result["roofline"]["traffic_source"] = os.path.relpath(tj, ROOT) + \
-                    " (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes)"
+                if t.get("kernel_source_tag") == kernel_source_tag():
+                    result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+                    result["roofline"]["traffic_source"] = os.path.relpath(tj, ROOT) + \
+                        " (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes, same kernel sources)"
             except (OSError, ValueError):
                 pass
+        arts = [{"fmt": fmt, "sb": sb, "K": 256, "ways": args.ways, "chunk": args.chunk, "n": n, "freqs": freqs,
+                 "d_syms": d_syms, "cont": cont, "offs": offs, "lens": lens, "total": total, "entry": None}]
+        if world == 1 and not args.no_configs:
+            cfgs = []
+            try:
+                ks = args.config_steps
+                # the headline configuration's encoder
+                e, a = measure_config(torch, R, ctx, "C3 word 64-way 1 GiB (encoder of the headline config)", R.FMT_WORD, 12,
+                                      256, args.ways, args.chunk, args.log2n, 1, ks, device, d_syms=d_syms)
+                cfgs.append(e)
+                e, a = measure_config(torch, R, ctx, "C2 rans64 2-way 256 MiB Zipf(256)", R.FMT_R64, 14, 256, 2, 512, 28, 1,
+                                      ks, device)
+                cfgs.append(e)
+                arts.append(a)
+                e, a = measure_config(torch, R, ctx, "C4 alias 4096 symbols 64-way 512 Mi u16 symbols", R.FMT_ALIAS, 16,
+                                      4096, 64, 32768, 29, 1, ks, device)
+                cfgs.append(e)
+                arts.append(a)
+                e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256)", R.FMT_BYTE, 14, 256, 64, 32768,
+                                      30, 1, ks, device, d_syms=d_syms)
+                cfgs.append(e)
+                arts.append(a)
+            except Exception as e:  # noqa: BLE001
+                cfgs.append({"error": repr(e)})
+            result["configs"] = cfgs
+            if any(not c.get("bit_exact_roundtrip", False) for c in cfgs):
+                all_ok = False
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(d_syms, freqs, n, args.cpu_shard_log2)
+                checked = {}
+                for a in arts:
+                    key = "%s/%d-way/%d" % (R.FORMAT_NAMES[a["fmt"]], a["ways"], a["chunk"])
+                    checked[key] = oracle_check_chunks(a)
+                    if a["entry"] is not None:
+                        a["entry"]["oracle_chunks_checked"] = checked[key]
+                result["oracle_chunks_checked"] = checked["%s/%d-way/%d" % (args.format, args.ways, args.chunk)]
+                result["oracle_chunks_checked_all"] = checked
+            except Exception as e:  # noqa: BLE001
+                result["oracle_chunks_checked"] = 0
+                result["oracle_check_error"] = repr(e)
+                all_ok = False
+            try:
+                result["cpu_baseline"] = cpu_baseline(d_syms, freqs, n)
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "reference",
                                           "sample": "failed: %r" % (e,)}
         if not all_ok:
-            result["error"] = "round trip mismatch or corrupt chunk reported"
+            result["error"] = "round trip mismatch, corrupt chunk reported, or a chunk differs from the oracle"
         print(json.dumps(result), flush=True)
         if not all_ok:
             sys.exit(1)

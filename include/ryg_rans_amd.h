@@ -259,6 +259,19 @@ int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container
  * was launched with timing enabled (HIP events recorded on the launch stream).
  * Synchronises those events. */
 int rans_amd_set_timing(rans_amd_ctx *ctx, int enabled);
+/* enabled == 2 additionally makes every wave of the next wave-per-chunk decode launches record its own
+ * clocks (the GPU-side analogue of the __rdtsc bracket of main.cpp:171,184-186); those launches synchronise
+ * `stream` and are a few percent slower, so measure throughput with enabled <= 1. */
+typedef struct rans_amd_wave_clocks {
+    uint64_t waves;         /* wavefronts that ran */
+    uint64_t rounds;        /* 64-symbol rounds they decoded, all together (full rounds only) */
+    uint64_t shader_cycles; /* sum over waves of the shader cycles (s_memtime) between a wave's start and end */
+    double sclk_hz;         /* shader clock during the kernel: cycles / 100 MHz ticks of the longest-running wave */
+    double kernel_ticks_ms; /* first wave start to last wave end on the constant 100 MHz clock */
+} rans_amd_wave_clocks;
+/* shader_cycles / rounds = clocks one wave spends per round of 64 symbols (waiting included); divide by the
+ * waves resident per SIMD (8) for the issue cycles a SIMD spends per round. */
+int rans_amd_last_wave_clocks(rans_amd_ctx *ctx, rans_amd_wave_clocks *out);
 int rans_amd_last_kernel_ms(rans_amd_ctx *ctx, float *decode_ms, float *encode_ms);
 /* Name of the dominant device kernel the last decode used (for profile matching). */
 const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx);

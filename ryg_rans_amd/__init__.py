@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "rans_amd_num_chunks", "rans_amd_chunk_bound", "rans_amd_encode_bound", "rans_amd_ways_supported",
     "rans_amd_encode", "rans_amd_decode", "rans_amd_decode_errors",
     "rans_amd_encode_host", "rans_amd_decode_host",
-    "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel",
+    "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_wave_clocks",
     "rans_amd_offsets_from_lengths", "rans_amd_container_bytes", "rans_amd_container_pack",
     "rans_amd_container_parse", "rans_amd_encode_workspace_bytes", "rans_amd_build_model_o0",
 ]
@@ -47,6 +47,12 @@ class ContainerInfo(C.Structure):
     _fields_ = [("format", C.c_uint32), ("scale_bits", C.c_uint32), ("nsyms", C.c_uint32), ("n_ways", C.c_uint32),
                 ("chunk_syms", C.c_uint32), ("sym_bytes", C.c_uint32), ("n_symbols", C.c_uint64),
                 ("n_chunks", C.c_uint64), ("payload_bytes", C.c_uint64)]
+
+
+class WaveClocks(C.Structure):
+    """rans_amd_wave_clocks"""
+    _fields_ = [("waves", C.c_uint64), ("rounds", C.c_uint64), ("shader_cycles", C.c_uint64),
+                ("sclk_hz", C.c_double), ("kernel_ticks_ms", C.c_double)]
 
 
 class RansAmdError(RuntimeError):
@@ -101,6 +107,7 @@ def _load():
         "rans_amd_set_timing": (i32, [vp, i32]),
         "rans_amd_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "rans_amd_last_decode_kernel": (C.c_char_p, [vp]),
+        "rans_amd_last_wave_clocks": (i32, [vp, C.POINTER(WaveClocks)]),
         "rans_amd_encode_workspace_bytes": (u64, [i32, u64, u32, u32]),
         "rans_amd_build_model_o0": (i32, [vp, i32, vp, u64, i32, u32, u32, u32p, C.POINTER(vp), vp]),
         "rans_amd_offsets_from_lengths": (i32, [u32p, u64, u64p]),
@@ -110,6 +117,8 @@ def _load():
                                          C.POINTER(vp)]),
     }
     for name, (res, args) in sig.items():
+        if not hasattr(lib, name) and os.environ.get("RANS_AMD_LIB"):
+            continue  # an older experimental build (A/B runs) may lack the newest entry points
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -194,7 +203,15 @@ class Context:
 
     # -- measurement
     def set_timing(self, on=True):
+        """True/1: HIP events around every launch; 2: per-wave clocks as well (slower, synchronising)."""
         _check(_lib.rans_amd_set_timing(self._h, int(on)), "set_timing")
+
+    def last_wave_clocks(self):
+        """Per-wave clocks of the last decode launched under set_timing(2), as a dict."""
+        wc = WaveClocks()
+        _check(_lib.rans_amd_last_wave_clocks(self._h, C.byref(wc)), "last_wave_clocks")
+        return {"waves": wc.waves, "rounds": wc.rounds, "shader_cycles": wc.shader_cycles, "sclk_hz": wc.sclk_hz,
+                "kernel_ticks_ms": wc.kernel_ticks_ms}
 
     def last_kernel_ms(self):
         d, e = C.c_float(-1), C.c_float(-1)
@@ -242,8 +259,9 @@ class Context:
         return out, rc
 
     # -- bulk, device-resident (torch tensors)
-    def encode(self, model, d_syms, n_ways, chunk_syms, d_out=None, sync=True):
-        """Returns (d_container, d_offsets, d_lengths, total_bytes)."""
+    def encode(self, model, d_syms, n_ways, chunk_syms, d_out=None, sync=True, d_offsets=None, d_lengths=None):
+        """Returns (d_container, d_offsets, d_lengths, total_bytes).  d_out / d_offsets / d_lengths may be
+        passed in (timed loops: no allocation between launches)."""
         import torch
         n = d_syms.numel()
         nchunks = num_chunks(n, chunk_syms)
@@ -251,8 +269,10 @@ class Context:
         dev = d_syms.device
         if d_out is None:
             d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-        d_offsets = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
-        d_lengths = torch.zeros(max(nchunks, 1), dtype=torch.int32, device=dev)
+        if d_offsets is None:
+            d_offsets = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
+        if d_lengths is None:
+            d_lengths = torch.zeros(max(nchunks, 1), dtype=torch.int32, device=dev)
         total = C.c_uint64(0)
         _check(_lib.rans_amd_encode(self._h, model._h, d_syms.data_ptr(), n, n_ways, chunk_syms, d_out.data_ptr(),
                                     d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),

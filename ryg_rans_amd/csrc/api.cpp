@@ -83,6 +83,9 @@ struct rans_amd_ctx {
     DeviceBuffer lengths;   // encode lengths when the caller passes none
     DeviceBuffer hist;
     DeviceBuffer layout_sums; // per-block totals of the offset scan (many-chunk containers)
+    DeviceBuffer trace;       // per-wave clock records (rans_amd_set_timing(ctx, 2) / RANS_AMD_TRACE)
+    rans_amd_wave_clocks wave_clocks = {0, 0, 0, 0.0, 0.0};
+    bool wave_clocks_on = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // dec start/stop, enc start/stop
     bool timing = false;
     bool dec_timed = false, enc_timed = false;
@@ -223,6 +226,7 @@ int rans_amd_ctx_destroy(rans_amd_ctx *ctx)
     ctx->lengths.release();
     ctx->hist.release();
     ctx->layout_sums.release();
+    ctx->trace.release();
     if (ctx->d_words)
         (void)hipFree(ctx->d_words);
     for (int i = 0; i < 4; ++i)
@@ -242,6 +246,7 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx)
     ctx->lengths.release();
     ctx->hist.release();
     ctx->layout_sums.release();
+    ctx->trace.release();
     return RANS_AMD_OK;
 }
 
@@ -609,35 +614,64 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
             const uint32_t per_slot = kWorkPools * kWorkPoolStride;
             dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * per_slot;
             dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * per_slot;
-            ctx->launch_seq++;
         }
-        // debug timeline (RANS_AMD_TRACE=<file>): per-wave start/end ticks and XCD, written after a sync
+        // wave clocks (rans_amd_set_timing(ctx, 2)) and the debug timeline (RANS_AMD_TRACE=<file>): per-wave
+        // start/end ticks, XCD, shader cycles and rounds, read back after a sync
         static const char *trace_path = getenv("RANS_AMD_TRACE");
-        const size_t trace_words = 3u * 2u * 16u * (size_t)ctx->num_cus;
+        const bool want_trace = trace_path || ctx->wave_clocks_on;
+        const size_t trace_words = (size_t)kTraceWords * 2u * 16u * (size_t)ctx->num_cus;
         dp.trace = nullptr;
-        if (trace_path) {
-            int trc = ctx->hist.reserve(trace_words * 8 + (size_t)65536 * 4);
+        if (want_trace) {
+            int trc = ctx->trace.reserve(trace_words * 8);
             if (trc)
                 return trc;
-            dp.trace = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(ctx->hist.ptr) + 65536 * 4);
+            dp.trace = static_cast<unsigned long long *>(ctx->trace.ptr);
             HIP_TRY(hipMemsetAsync(dp.trace, 0, trace_words * 8, s));
         }
         if (ctx->timing)
             HIP_TRY(hipEventRecord(ctx->ev[0], s));
         HIP_TRY(launch_decode(format, dp, ctx->num_cus, s, &ctx->last_kernel));
+        // the launch that uses slot i zeroes slot i + 32: move on only once it really is in the stream,
+        // or a later launch would start from a counter nobody reset
+        if (dp.work_counter)
+            ctx->launch_seq++;
         if (ctx->timing) {
             HIP_TRY(hipEventRecord(ctx->ev[1], s));
             ctx->dec_timed = true;
         }
-        if (trace_path) {
+        if (want_trace) {
             std::vector<unsigned long long> host(trace_words);
             HIP_TRY(hipMemcpyAsync(host.data(), dp.trace, trace_words * 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            if (FILE *f = fopen(trace_path, "w")) {
-                for (size_t w = 0; w < trace_words / 3; ++w)
-                    if (host[3 * w + 1])
-                        fprintf(f, "%zu %llu %llu %llu\n", w, host[3 * w], host[3 * w + 1], host[3 * w + 2]);
-                fclose(f);
+            rans_amd_wave_clocks wc = {0, 0, 0, 0.0, 0.0};
+            unsigned long long t_first = ~0ull, t_last = 0, longest_ticks = 0, longest_cycles = 0;
+            for (size_t w = 0; w < trace_words / kTraceWords; ++w) {
+                const unsigned long long *t = &host[kTraceWords * w];
+                if (!t[1])
+                    continue; // this slot's wave never ran (grid smaller than the buffer) or is not instrumented
+                wc.waves++;
+                wc.shader_cycles += t[3];
+                wc.rounds += t[4];
+                t_first = t[0] < t_first ? t[0] : t_first;
+                t_last = t[1] > t_last ? t[1] : t_last;
+                if (t[1] - t[0] > longest_ticks) {
+                    longest_ticks = t[1] - t[0];
+                    longest_cycles = t[3];
+                }
+            }
+            if (wc.waves && longest_ticks) {
+                wc.sclk_hz = (double)longest_cycles / ((double)longest_ticks * 1e-8); // wall_clock64 ticks at 100 MHz
+                wc.kernel_ticks_ms = (double)(t_last - t_first) * 1e-5;
+            }
+            ctx->wave_clocks = wc;
+            if (trace_path) {
+                if (FILE *f = fopen(trace_path, "w")) {
+                    for (size_t w = 0; w < trace_words / kTraceWords; ++w)
+                        if (host[kTraceWords * w + 1])
+                            fprintf(f, "%zu %llu %llu %llu %llu %llu\n", w, host[kTraceWords * w], host[kTraceWords * w + 1],
+                                    host[kTraceWords * w + 2], host[kTraceWords * w + 3], host[kTraceWords * w + 4]);
+                    fclose(f);
+                }
             }
         }
     }
@@ -761,6 +795,7 @@ int rans_amd_set_timing(rans_amd_ctx *ctx, int enabled)
     if (!ctx)
         return fail(RANS_AMD_E_ARG, "ctx is NULL");
     ctx->timing = enabled != 0;
+    ctx->wave_clocks_on = enabled == 2;
     return RANS_AMD_OK;
 }
 
@@ -787,5 +822,13 @@ int rans_amd_last_kernel_ms(rans_amd_ctx *ctx, float *decode_ms, float *encode_m
 }
 
 const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+int rans_amd_last_wave_clocks(rans_amd_ctx *ctx, rans_amd_wave_clocks *out)
+{
+    if (!ctx || !out)
+        return fail(RANS_AMD_E_ARG, "last_wave_clocks: NULL argument");
+    *out = ctx->wave_clocks;
+    return out->waves ? RANS_AMD_OK : fail(RANS_AMD_E_ARG, "last_wave_clocks: no instrumented decode has run");
+}
 
 } // extern "C"

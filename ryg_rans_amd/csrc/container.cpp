@@ -48,7 +48,9 @@ bool info_sane(const rans_amd_container_info *i)
     if (!i || i->format > RANS_AMD_FMT_ALIAS || i->nsyms == 0 || i->nsyms > 65536 || i->scale_bits == 0 ||
         i->scale_bits > 31 || i->chunk_syms == 0 || i->n_ways == 0 || (i->sym_bytes != 1 && i->sym_bytes != 2))
         return false;
-    const uint64_t want_chunks = (i->n_symbols + i->chunk_syms - 1) / i->chunk_syms;
+    // no n_symbols + chunk_syms - 1: that wraps for n_symbols near 2^64 and would let a forged header
+    // (FNV is no protection) claim a huge symbol count with zero chunks
+    const uint64_t want_chunks = i->n_symbols / i->chunk_syms + (i->n_symbols % i->chunk_syms != 0);
     return want_chunks == i->n_chunks && i->n_chunks < (1ull << 40);
 }
 

@@ -41,41 +41,45 @@ namespace {
 
 // ---------------------------------------------------------------------------
 // Stream window: a 2 KiB ring per wave in LDS, filled in aligned 1 KiB blocks
-// (one global_load_dwordx4 per lane), the next block prefetched in registers.
+// (one buffer_load_dwordx4 per lane), the next block prefetched in registers.
 //
-//   rd    ring offset of the read cursor at the last checkpoint (< 2048)
-//   adv   bytes consumed since that checkpoint
-//   avail valid bytes ahead of rd at the checkpoint
-//   wr    ring offset of the block that is written next (0 or 1024)
+//   cur   raw LDS byte address of the read cursor (wave-uniform, an SGPR)
+//   mark  the cursor value at which the next refill is due: ring + 1024 while the cursor
+//         walks the first half, ring + 2048 while it walks the second
 //
-// checkpoint() folds adv into rd/avail and, when a block is free (avail <=
-// 1024), writes the prefetched block and issues the next fetch.  Between two
-// checkpoints the decoder consumes at most kMaxAdvance bytes and reads at most
-// one more sub-step beyond that, so addresses never wrap between checkpoints:
-// the first kRingMirror bytes of the ring are mirrored behind its end.
-// Everything here is wave-uniform (SGPRs); the refill branch is a scalar branch.
+// The ring holds the block under the cursor and the one after it.  When the cursor enters
+// the second half, the first half is dead: the prefetched block goes there (and its first
+// kRingMirror bytes are mirrored behind the ring's end, so reads never wrap), the next
+// fetch is issued.  When the cursor runs past the ring's end (into the mirror) it is wrapped
+// by -2048 and the second half is refilled.  A checkpoint is therefore one scalar compare +
+// branch; between two checkpoints the decoder consumes at most kMaxAdvance bytes and reads
+// at most one more sub-step beyond that.
+//
+// Fetches go through a buffer descriptor of the chunk's own stream (base = chunk start,
+// num_records = its 16-byte aligned length): the hardware returns zeros beyond the end, so
+// nothing outside the chunk's granules is ever read and the refill needs no address compare.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kMaxAdvance = 512;
 static_assert(kRingMirror >= kMaxAdvance + 256, "mirror must cover one checkpoint interval plus one sub-step");
+constexpr uint32_t kRsrcFlags = 0x00020000u; // raw buffer, 32-bit data format (gfx9 family)
+constexpr int kAuxNt = 2;                    // non-temporal: every stream byte is read exactly once
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 struct StreamWindow {
     uint8_t *ring;      // LDS, wave-private
-    uint32_t ring_addr; // the same as a raw LDS byte address (for the asm path)
-    uint64_t gnext;     // global address of the next 1 KiB block to fetch
-    uint64_t glimit;    // 16-byte aligned end of what may be fetched for this chunk
-    uint32_t rd, adv, avail, wr;
-    u32x4 pre; // prefetched block (16 B per lane)
+    uint32_t ring_addr; // the same as a raw LDS byte address
+    uint32_t cur, mark;
+    uint32_t lapped;    // stream bytes that lie before ring offset 0 of the current lap
+    uint32_t gnext;     // byte offset (within the chunk) of the next 1 KiB block to fetch
+    rsrc_t rsrc;
+    u32x4 pre;          // prefetched block (16 B per lane)
 
     __device__ __forceinline__ u32x4 fetch(uint32_t lane)
     {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (gnext + kRingBlock <= glimit) { // whole block readable: wave-uniform fast path
-            gvec_cptr g = reinterpret_cast<gvec_cptr>(gnext);
-            v = __builtin_nontemporal_load(g + lane);
-        } else if (gnext + lane * 16u < glimit) {
-            gvec_cptr g = reinterpret_cast<gvec_cptr>(gnext);
-            v = __builtin_nontemporal_load(g + lane);
-        }
+        // the whole offset travels in voffset: the range check then is simply offset >= num_records
+        // (with an soffset part it is offset >= num_records - soffset, which wraps once soffset is beyond the end)
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gnext + lane * 16u, 0, kAuxNt);
         gnext += kRingBlock;
         return v;
     }
@@ -85,38 +89,44 @@ struct StreamWindow {
         if (at == 0 && lane < kRingMirror / 16u)
             *reinterpret_cast<u32x4 *>(ring + kRingBytes + lane * 16u) = v;
     }
-    __device__ __forceinline__ void open(uint8_t *lds, uint64_t gaddr, uint64_t limit, uint32_t lane)
+    // chunk_base: 16-byte aligned global address of the chunk; first: offset of the first renormalisation
+    // unit in it (behind the initial states); fetchable: 16-byte aligned number of bytes that may be read
+    __device__ __forceinline__ void open(uint8_t *lds, uint64_t chunk_base, uint32_t first, uint32_t fetchable,
+                                         uint32_t lane)
     {
         ring = lds;
         ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
-        glimit = limit;
-        gnext = gaddr & ~uint64_t(15);
-        rd = (uint32_t)(gaddr & 15u);
-        adv = 0;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(chunk_base), 0, fetchable, kRsrcFlags);
+        gnext = first & ~15u;
+        lapped = gnext;
+        cur = ring_addr + (first & 15u);
+        mark = ring_addr + kRingBlock;
         u32x4 b0 = fetch(lane);
         u32x4 b1 = fetch(lane);
         pre = fetch(lane);
         put(lane, 0, b0);
         put(lane, kRingBlock, b1);
-        wr = 0;
-        avail = kRingBytes - rd;
     }
     __device__ __forceinline__ void checkpoint(uint32_t lane)
     {
-        rd = (rd + adv) & (kRingBytes - 1);
-        avail -= adv;
-        adv = 0;
-        if (avail <= kRingBlock) {
-            put(lane, wr, pre);
-            wr ^= kRingBlock;
-            avail += kRingBlock;
+        if (cur >= mark) { // wave-uniform: a scalar compare + branch
+            if (mark == ring_addr + kRingBlock) {
+                put(lane, 0, pre);
+                mark = ring_addr + kRingBytes;
+            } else {
+                cur -= kRingBytes;
+                lapped += kRingBytes;
+                put(lane, kRingBlock, pre);
+                mark = ring_addr + kRingBlock;
+            }
             pre = fetch(lane);
         }
     }
-    // ring offset / LDS address of the read cursor (no wrap between checkpoints)
-    __device__ __forceinline__ uint32_t cursor() const { return rd + adv; }
-    __device__ __forceinline__ uint32_t cursor_addr() const { return ring_addr + rd + adv; }
-    __device__ __forceinline__ void consume(uint32_t bytes) { adv += bytes; }
+    // ring offset of the read cursor (no wrap between checkpoints)
+    __device__ __forceinline__ uint32_t cursor() const { return cur - ring_addr; }
+    __device__ __forceinline__ void consume(uint32_t bytes) { cur += bytes; }
+    // offset within the chunk of the next unread byte
+    __device__ __forceinline__ uint32_t position() const { return lapped + (cur - ring_addr); }
 };
 
 // ---------------------------------------------------------------------------
@@ -165,37 +175,39 @@ __device__ __forceinline__ uint32_t dec_renorm(const StreamWindow &W, typename F
 // Hand-written renormalisation sub-step of the word format for a FULL wave (all 64
 // lanes hold a state and are active): rans_word_sse41.h:134-141 for 64 lanes at once.
 //   v_cmpx      lanes with x < 2^16 stay enabled; vcc = the same mask
+//   s_bcnt1     words the wave consumes in this sub-step
 //   v_mbcnt x2  rank of the lane among the enabled ones = its word index in the stream
 //   ds_read_u16 only the enabled lanes read; v_perm merges (x << 16) | word
-//   s_bcnt1     words consumed by the wave (returned)
-// 5 VALU + 1 LDS + 2 SALU, no branch, no v_cndmask.  exec is restored to all ones,
+//   s_lshl1_add the window cursor moves on by 2 bytes per word (cur is updated in place)
+// 5 VALU + 1 LDS + 5 SALU, no branch, no v_cndmask.  exec is restored to all ones,
 // which is what it was (the caller runs this only in wave-uniform full-wave code).
-__device__ __forceinline__ uint32_t renorm_word_full(uint32_t &x, uint32_t cursor_addr, uint32_t k65536)
+__device__ __forceinline__ void renorm_word_full(uint32_t &x, uint32_t &cur, uint32_t k65536)
 {
     uint32_t t, w, cnt;
     // gfx940+ hazard: a VALU write of an SGPR/VCC needs 2 wait states before a VALU reads it
     // as an operand (LLVM GCNHazardRecognizer, VALUWriteSGPRVALURead); hipcc does not pad
-    // inside an asm statement, hence the s_nop 1.
+    // inside an asm statement: s_bcnt1 is one of the two, s_nop 0 the other.
     asm volatile("v_cmpx_gt_u32_e32 vcc, %[lim], %[x]\n\t"
-                 "s_nop 1\n\t"
+                 "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                 "s_nop 0\n\t"
                  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
                  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
                  "v_lshl_add_u32 %[t], %[t], 1, %[cur]\n\t"
                  "ds_read_u16 %[w], %[t]\n\t"
-                 "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                 "s_lshl1_add_u32 %[cur], %[cnt], %[cur]\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "v_perm_b32 %[x], %[x], %[w], %[sel]\n\t"
                  "s_mov_b64 exec, -1"
-                 : [x] "+v"(x), [t] "=&v"(t), [w] "=&v"(w), [cnt] "=&s"(cnt)
-                 : [lim] "v"(k65536), [cur] "s"(cursor_addr), [sel] "s"(0x05040100u)
+                 : [x] "+v"(x), [t] "=&v"(t), [w] "=&v"(w), [cnt] "=&s"(cnt), [cur] "+s"(cur)
+                 : [lim] "v"(k65536), [sel] "s"(0x05040100u)
                  : "vcc", "scc", "memory");
-    return cnt;
 }
 
 // Same for the byte formats (rans_byte.h:307-318): a lane needs 0, 1 or 2 bytes
 // (x < 2^23, x < 2^15); its offset in the stream is the sum of both masks' ranks; the
-// first byte is the more significant one.  9 VALU + 2 LDS, no branch.  Returns bytes consumed.
-__device__ __forceinline__ uint32_t renorm_byte_full(uint32_t &x, uint32_t cursor_addr, uint32_t k2p23, uint32_t k2p15)
+// first byte is the more significant one.  9 VALU + 2 LDS, no branch; cur moves on by the
+// bytes consumed.
+__device__ __forceinline__ void renorm_byte_full(uint32_t &x, uint32_t &cur, uint32_t k2p23, uint32_t k2p15)
 {
     uint32_t t, b0, b1, c1, c2;
     uint64_t m1;
@@ -207,7 +219,7 @@ __device__ __forceinline__ uint32_t renorm_byte_full(uint32_t &x, uint32_t curso
                  "s_bcnt1_i32_b64 %[c1], vcc\n\t"
                  "v_cmp_gt_u32_e32 vcc, %[l15], %[x]\n\t"
                  "v_add_u32_e32 %[t], %[cur], %[t]\n\t"
-                 "s_nop 0\n\t"
+                 "s_add_i32 %[cur], %[cur], %[c1]\n\t"
                  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, %[t]\n\t"
                  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
                  "s_bcnt1_i32_b64 %[c2], vcc\n\t"
@@ -216,6 +228,7 @@ __device__ __forceinline__ uint32_t renorm_byte_full(uint32_t &x, uint32_t curso
                  "s_mov_b64 exec, vcc\n\t"
                  "ds_read_u8 %[b1], %[t] offset:1\n\t"
                  "s_mov_b64 exec, %[m1]\n\t"
+                 "s_add_i32 %[cur], %[cur], %[c2]\n\t"
                  "s_waitcnt lgkmcnt(1)\n\t"
                  "v_lshl_or_b32 %[x], %[x], 8, %[b0]\n\t"
                  "s_mov_b64 exec, vcc\n\t"
@@ -223,11 +236,115 @@ __device__ __forceinline__ uint32_t renorm_byte_full(uint32_t &x, uint32_t curso
                  "v_lshl_or_b32 %[x], %[x], 8, %[b1]\n\t"
                  "s_mov_b64 exec, -1"
                  : [x] "+v"(x), [t] "=&v"(t), [b0] "=&v"(b0), [b1] "=&v"(b1), [c1] "=&s"(c1), [c2] "=&s"(c2),
-                   [m1] "=&s"(m1)
-                 : [l23] "v"(k2p23), [l15] "v"(k2p15), [cur] "s"(cursor_addr)
+                   [m1] "=&s"(m1), [cur] "+s"(cur)
+                 : [l23] "v"(k2p23), [l15] "v"(k2p15)
                  : "vcc", "scc", "memory");
-    return c1 + c2;
 }
+
+// ---------------------------------------------------------------------------
+// Word format, 64-way, full waves: FOUR rounds as one hand-scheduled instruction sequence
+// (rans_word_sse41.h:123-141 / :151-227 for 64 lanes; the D step and the renormalisation are
+// the ones of dec_step / renorm_word_full).  Per round 9 VALU + 2 LDS + 6 SALU:
+//   v_and, v_lshlrev            slot = x & 4095 -> LDS byte address of the slot record
+//   ds_read_b64                 {freq | sym << 24, bias}
+//   v_lshrrev, v_mad_u32_u24    x = freq * (x >> 12) + bias
+//   v_perm                      the symbol joins the three others of this lane (rounds 1..3)
+//   v_cmpx .. v_perm            renormalisation, see renorm_word_full
+// The transposition and the store of the PREVIOUS group's symbols (two DPP + v_perm pairs and a
+// buffer_store_dword) sit in round 0, where the wave would otherwise wait for the slot record, and where
+// the wait states a DPP operand needs after a VALU write (2) are filled by instructions that have to be
+// issued anyway.  pa: in = the previous group's four symbols of this lane, out = this group's.
+// Temporaries are fixed registers (v56..v63) because the halves of a 64-bit asm operand cannot be named.
+// ---------------------------------------------------------------------------
+#define RANS_WORD_RENORM                                   \
+    "v_cmpx_gt_u32_e32 vcc, %[lim], %[x]\n\t"              \
+    "s_bcnt1_i32_b64 %[cnt], vcc\n\t"                      \
+    "s_nop 0\n\t"                                          \
+    "v_mbcnt_lo_u32_b32 v56, vcc_lo, 0\n\t"                \
+    "v_mbcnt_hi_u32_b32 v56, vcc_hi, v56\n\t"              \
+    "v_lshl_add_u32 v56, v56, 1, %[cur]\n\t"               \
+    "ds_read_u16 v57, v56\n\t"                             \
+    "s_lshl1_add_u32 %[cur], %[cnt], %[cur]\n\t"           \
+    "s_waitcnt lgkmcnt(0)\n\t"                             \
+    "v_perm_b32 %[x], %[x], v57, %[selm]\n\t"              \
+    "s_mov_b64 exec, -1\n\t"
+#define RANS_WORD_LOOKUP(E)                                \
+    "v_and_b32_e32 v56, %[m12], %[x]\n\t"                  \
+    "v_lshlrev_b32_e32 v56, 3, v56\n\t"                    \
+    "ds_read_b64 " E ", v56\n\t"                           \
+    "v_lshrrev_b32_e32 v57, 12, %[x]\n\t"
+
+template <bool kStorePrev>
+__device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uint32_t &cur, uint32_t m12,
+                                                  uint32_t k65536, uint32_t sel1, uint32_t sel2, uint32_t selA,
+                                                  uint32_t selB, uint32_t selC, u32x4 orsrc, uint32_t out_lane_off,
+                                                  uint32_t osoff_prev)
+{
+    uint32_t cnt;
+    if constexpr (kStorePrev) {
+        asm volatile(
+            // ---- round 0 (+ the previous group's transposition and store)
+            RANS_WORD_LOOKUP("v[58:59]")
+            "v_mov_b32_dpp v62, %[pa] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_perm_b32 v63, v62, %[pa], %[sel1]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mad_u32_u24 %[x], v58, v57, v59\n\t"
+            "v_mov_b32_dpp v62, v63 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_perm_b32 v62, v62, v63, %[sel2]\n\t"
+            "buffer_store_dword v62, %[ooff], %[orsrc], %[osoff] offen\n\t"
+            RANS_WORD_RENORM
+            // ---- round 1
+            RANS_WORD_LOOKUP("v[60:61]")
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mad_u32_u24 %[x], v60, v57, v61\n\t"
+            "v_perm_b32 %[pa], v60, v58, %[selA]\n\t"
+            RANS_WORD_RENORM
+            // ---- round 2
+            RANS_WORD_LOOKUP("v[58:59]")
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mad_u32_u24 %[x], v58, v57, v59\n\t"
+            "v_perm_b32 %[pa], v58, %[pa], %[selB]\n\t"
+            RANS_WORD_RENORM
+            // ---- round 3
+            RANS_WORD_LOOKUP("v[60:61]")
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mad_u32_u24 %[x], v60, v57, v61\n\t"
+            "v_perm_b32 %[pa], v60, %[pa], %[selC]\n\t"
+            RANS_WORD_RENORM
+            : [x] "+v"(x), [pa] "+v"(pa), [cur] "+s"(cur), [cnt] "=&s"(cnt)
+            : [m12] "v"(m12), [lim] "v"(k65536), [sel1] "v"(sel1), [sel2] "v"(sel2), [selA] "v"(selA), [selB] "v"(selB),
+              [selC] "v"(selC), [selm] "s"(0x05040100u), [orsrc] "s"(orsrc), [ooff] "v"(out_lane_off),
+              [osoff] "s"(osoff_prev)
+            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    } else {
+        asm volatile(
+            RANS_WORD_LOOKUP("v[58:59]")
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mad_u32_u24 %[x], v58, v57, v59\n\t"
+            RANS_WORD_RENORM
+            RANS_WORD_LOOKUP("v[60:61]")
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mad_u32_u24 %[x], v60, v57, v61\n\t"
+            "v_perm_b32 %[pa], v60, v58, %[selA]\n\t"
+            RANS_WORD_RENORM
+            RANS_WORD_LOOKUP("v[58:59]")
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mad_u32_u24 %[x], v58, v57, v59\n\t"
+            "v_perm_b32 %[pa], v58, %[pa], %[selB]\n\t"
+            RANS_WORD_RENORM
+            RANS_WORD_LOOKUP("v[60:61]")
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mad_u32_u24 %[x], v60, v57, v61\n\t"
+            "v_perm_b32 %[pa], v60, %[pa], %[selC]\n\t"
+            RANS_WORD_RENORM
+            : [x] "+v"(x), [pa] "+v"(pa), [cur] "+s"(cur), [cnt] "=&s"(cnt)
+            : [m12] "v"(m12), [lim] "v"(k65536), [selA] "v"(selA), [selB] "v"(selB), [selC] "v"(selC),
+              [selm] "s"(0x05040100u)
+            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    }
+}
+#undef RANS_WORD_RENORM
+#undef RANS_WORD_LOOKUP
 
 // byte `kSymByte` of `raw` goes to byte J of acc, the other bytes of acc stay
 template <int SYMBYTE, int J> __device__ __forceinline__ uint32_t acc_symbol(uint32_t raw, uint32_t acc)
@@ -251,7 +368,10 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     using Tr = FmtTraits<FMT>;
     using state_t = typename Tr::state_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // wave clocks (rans_amd_set_timing(ctx, 2) / RANS_AMD_TRACE): constant 100 MHz clock and shader clock
     const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
+    const unsigned long long c_start = p.trace ? __builtin_readcyclecounter() : 0ull;
+    uint32_t rounds_done = 0;
 
     // ---- stage the tables into LDS (once per block) ----------------------
     const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
@@ -285,7 +405,6 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     static_assert(OUT != OUT_FAST8_LDS || K == 1, "the LDS output tile holds 4 rounds of 64 symbols");
     const uint32_t N = (OUT != OUT_SLOW) ? 64u * K : p.n_ways;
     const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
-    const uint64_t glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
 
     // per-lane constants of the output transpose
     const uint32_t sel1 = (lane & 1u) ? 0x03070105u : 0x06020400u;
@@ -326,7 +445,9 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         uint8_t RANS_GLOBAL *dst = reinterpret_cast<uint8_t RANS_GLOBAL *>(
             reinterpret_cast<uint64_t>(p.out) + first * p.sym_bytes);
 
-        bool ok = ((off & 15u) == 0) && (len >= N * Tr::kStateBytes) && (off + len <= p.container_bytes);
+        // off and len come from the caller's index: compare without forming off + len (which can wrap)
+        bool ok = ((off & 15u) == 0) && (len >= N * Tr::kStateBytes) && (off <= p.container_bytes) &&
+                  (len <= p.container_bytes - off);
         if (!ok) { // wave-uniform
             if (lane == 0)
                 atomicAdd(p.err_count, 1ull);
@@ -350,12 +471,14 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         }
 
         StreamWindow W;
-        // fetch nothing beyond this chunk's own stream (rounded up to the 16-byte granule)
-        const uint64_t climit = (src + len + 15u) & ~uint64_t(15);
-        W.open(ring, src + N * Tr::kStateBytes, climit < glimit ? climit : glimit, lane);
-        uint32_t consumed = N * Tr::kStateBytes;
+        // fetch nothing beyond this chunk's own stream (rounded up to the 16-byte granule) nor beyond the
+        // container's last granule
+        const uint64_t room = ((p.container_bytes + 15u) & ~uint64_t(15)) - off;
+        const uint32_t climit = (len + 15u) & ~15u;
+        W.open(ring, src, N * Tr::kStateBytes, climit < room ? climit : (uint32_t)room, lane);
 
         const uint32_t rounds = uniform(nsym / N);
+        rounds_done += rounds;
         const uint32_t tail = uniform(nsym - rounds * N);
         uint32_t r = 0;
         // sub-steps between two window checkpoints: at most kMaxAdvance bytes are consumed
@@ -382,13 +505,10 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                     for (int k = 0; k < K; ++k) {
                         if ((J * K + k) % kCheckEvery == 0)
                             W.checkpoint(lane);
-                        uint32_t c;
                         if constexpr (FMT == FMT_BYTE || FMT == FMT_ALIAS)
-                            c = renorm_byte_full(x[k], W.cursor_addr(), k2p23, k2p15);
+                            renorm_byte_full(x[k], W.cur, k2p23, k2p15);
                         else
-                            c = dec_renorm<FMT>(W, x[k], true);
-                        W.consume(c);
-                        consumed += c;
+                            W.consume(dec_renorm<FMT>(W, x[k], true));
                     }
                 }
 #pragma unroll
@@ -400,11 +520,46 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                 gdst += 4u * N;
             }
             r = pairs << 1;
+        } else if constexpr (OUT == OUT_FAST8_GROUP) {
+            // ---- groups of 4 full rounds, one hand-scheduled sequence each (decode_group_word); the
+            // transposition and store of a group's symbols ride in the next group's first round
+            static_assert(FMT == FMT_WORD && K == 1, "the hand-scheduled group is the 64-way word decoder");
+            const uint32_t groups = rounds >> 2;
+            if (groups) {
+                const uint64_t dsta = reinterpret_cast<uint64_t>(dst);
+                const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu, nsym, kRsrcFlags};
+                uint32_t selA = 0x03020703u, selB = 0x03070100u, selC = 0x07020100u; // acc_symbol<3, 1..3>
+                uint32_t k65536 = 0x10000u, m12 = 0xfffu;
+                asm volatile("v_mov_b32 %0, %0" : "+v"(selA)); // opaque: live in VGPRs, never rematerialised in the loop
+                asm volatile("v_mov_b32 %0, %0" : "+v"(selB));
+                asm volatile("v_mov_b32 %0, %0" : "+v"(selC));
+                asm volatile("v_mov_b32 %0, %0" : "+v"(k65536));
+                asm volatile("v_mov_b32 %0, %0" : "+v"(m12));
+                uint32_t pa = 0;
+                W.checkpoint(lane);
+                decode_group_word<false>(x[0], pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc,
+                                         out_lane_off, 0u);
+                const uint32_t oend = (groups - 1u) * 256u;
+                uint32_t osoff = 0;
+                for (; osoff != oend; osoff += 256u) {
+                    W.checkpoint(lane);
+                    decode_group_word<true>(x[0], pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc,
+                                            out_lane_off, osoff);
+                }
+                const uint32_t v = quad_transpose(pa, sel1, sel2);
+                *reinterpret_cast<uint32_t RANS_GLOBAL *>(dst + osoff + out_lane_off) = v;
+            }
+            r = groups << 2;
         } else
         if constexpr (OUT != OUT_SLOW) {
             // ---- groups of 4 full rounds, symbols transposed in registers ----
             const uint32_t groups = rounds >> 2;
             uint8_t RANS_GLOBAL *gdst = dst;
+            // symbol stores go through a descriptor of the chunk's output with the running offset in an SGPR
+            // (soffset): no 64-bit VALU pointer arithmetic in the loop
+            const rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>(reinterpret_cast<uint64_t>(dst)), 0, nsym, kRsrcFlags);
+            uint32_t osoff = 0;
             const uint32_t k65536 = 0x10000u + (lane >> 6); // VGPRs holding the renorm limits (lane < 64)
             const uint32_t k2p23 = (1u << 23) + (lane >> 6), k2p15 = (1u << 15) + (lane >> 6);
             for (uint32_t g = 0; g < groups; ++g) {
@@ -422,15 +577,12 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
         if ((J * K + k) % kCheckEvery == 0)                                        \
             W.checkpoint(lane);                                                    \
-        uint32_t c;                                                                \
         if constexpr (FMT == FMT_WORD && (OUT == OUT_FAST8 || OUT == OUT_FAST8_LDS || OUT == OUT_FAST8_BYTE)) \
-            c = 2u * renorm_word_full(x[k], W.cursor_addr(), k65536);              \
+            renorm_word_full(x[k], W.cur, k65536);                                 \
         else if constexpr ((FMT == FMT_BYTE || FMT == FMT_ALIAS) && (OUT == OUT_FAST8 || OUT == OUT_FAST8_BYTE)) \
-            c = renorm_byte_full(x[k], W.cursor_addr(), k2p23, k2p15);             \
+            renorm_byte_full(x[k], W.cur, k2p23, k2p15);                           \
         else                                                                       \
-            c = dec_renorm<FMT>(W, x[k], true);                                    \
-        W.consume(c);                                                              \
-        consumed += c;                                                             \
+            W.consume(dec_renorm<FMT>(W, x[k], true));                             \
     }
                 RANS_ROUND(0)
                 RANS_ROUND(1)
@@ -445,10 +597,11 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const uint32_t v = quad_transpose(acc[k], sel1, sel2);
-                        *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + (out_lane_off + k * 64u)) = v;
+                        __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, out_lane_off + k * 64u, osoff, 0);
                     }
                 }
                 gdst += 4u * N;
+                osoff += 4u * N;
             }
             r = groups << 2;
         }
@@ -476,9 +629,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
             for (int k = 0; k < K; ++k) {
                 const uint32_t idx = k * 64u + lane;
                 W.checkpoint(lane);
-                const uint32_t c = dec_renorm<FMT>(W, x[k], idx < cnt);
-                W.consume(c);
-                consumed += c;
+                W.consume(dec_renorm<FMT>(W, x[k], idx < cnt));
             }
         }
 
@@ -487,15 +638,17 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 #pragma unroll
         for (int k = 0; k < K; ++k)
             good = good && (x[k] == Tr::kL);
-        const bool all_good = __builtin_amdgcn_ballot_w64(!good) == 0 && consumed == len;
+        const bool all_good = __builtin_amdgcn_ballot_w64(!good) == 0 && W.position() == len;
         if (!all_good && lane == 0)
             atomicAdd(p.err_count, 1ull);
     }
-    if (p.trace && lane == 0) { // debug timeline: when did this wave start and stop, on which XCD
-        unsigned long long *t = p.trace + 3ull * ((uint64_t)blockIdx.x * waves_per_block + wave);
+    if (p.trace && lane == 0) { // per wave: start / end on the 100 MHz clock, XCD, shader cycles spent, rounds decoded
+        unsigned long long *t = p.trace + (uint64_t)kTraceWords * ((uint64_t)blockIdx.x * waves_per_block + wave);
         t[0] = t_start;
         t[1] = wall_clock64();
         t[2] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11));
+        t[3] = __builtin_readcyclecounter() - c_start;
+        t[4] = rounds_done;
     }
 }
 
@@ -552,6 +705,11 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
         case 256: return launch_decode_t<FMT_WORD, 4, OUT_FAST8_NOASM>(p, num_cus, s, name);
         default: break;
         }
+    }
+    if constexpr (FMT == FMT_WORD) {
+        static const bool no_group = getenv("RANS_AMD_NO_GROUP") != nullptr; // A/B: the per-round asm of round 1
+        if (fast && p.n_ways == 64 && !no_group)
+            return launch_decode_t<FMT_WORD, 1, OUT_FAST8_GROUP>(p, num_cus, s, name);
     }
     switch (p.n_ways) {
     case 64:

@@ -27,7 +27,10 @@ constexpr int FMT_ALIAS = RANS_AMD_FMT_ALIAS;
 // (ds_write_b8 per round, one ds_read_b32 + global_store_dword per 4 rounds; K == 1 only).
 // OUT_FAST16: u16 symbols, 2 rounds packed per dword and swapped between lane pairs.
 // OUT_FAST8_BYTE: one global_store_byte per lane and round (64 contiguous bytes per wave), no transpose.
-enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST8_NOASM = 2, OUT_FAST8_LDS = 3, OUT_FAST16 = 4, OUT_FAST8_BYTE = 5 };
+// OUT_FAST8_GROUP: word format, 64-way: four rounds + the previous group's transposition and store as ONE
+// hand-scheduled instruction sequence (decode_wave.hip, decode_group_word).
+enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST8_NOASM = 2, OUT_FAST8_LDS = 3, OUT_FAST16 = 4, OUT_FAST8_BYTE = 5,
+               OUT_FAST8_GROUP = 6 };
 constexpr uint32_t kOutTileBytes = 256;
 
 template <int FMT> struct FmtTraits;

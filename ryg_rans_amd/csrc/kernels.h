@@ -19,6 +19,7 @@ constexpr uint32_t kWorkPools = 8;       // chunk hand-out counters per launch (
 constexpr uint32_t kWorkPoolStride = 16; // in uint32: every counter on its own 64-byte line
 constexpr uint32_t kWorkSlots = 64;      // launches that may reuse the counter ring before wrap
 constexpr int kEncBlockThreads = 256;
+constexpr uint32_t kTraceWords = 5;      // per-wave record of DecParams::trace
 
 struct DecParams {
     const uint8_t *container;
@@ -40,7 +41,8 @@ struct DecParams {
     unsigned long long *err_count; // failed chunks (device counter)
     unsigned int *work_counter;    // next chunk to hand out (zero at launch); NULL = static striding
     unsigned int *work_counter_reset; // a counter slot of a LATER launch that this launch zeroes
-    unsigned long long *trace;        // debug (RANS_AMD_TRACE): per wave {start, end, xcc} in 100 MHz ticks
+    unsigned long long *trace;        // wave clocks: per wave kTraceWords words {start, end (100 MHz ticks), xcc,
+                                      // shader cycles, 64-symbol rounds}; NULL = off (wave-per-chunk kernels only)
 };
 
 struct EncParams {

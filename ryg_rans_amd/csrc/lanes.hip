@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
         const uint64_t first = chunk * p.chunk_syms;
         // region base: the line of the batch's first chunk (lane 0 always holds a chunk)
         const uint64_t rb = uniform64(off) & ~uint64_t(kLaneLine - 1);
-        if (valid && ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off + len > p.container_bytes || off < rb ||
+        if (valid && ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
                       off - rb >= (1u << 30))) {
             nbad++;
             valid = false;
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
         const uint32_t len = p.lengths[chunk];
         const uint64_t first = chunk * p.chunk_syms;
         const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
-        if ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off + len > p.container_bytes) {
+        if ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off > p.container_bytes || len > p.container_bytes - off) {
             nbad++;
             continue;
         }

@@ -36,9 +36,22 @@ def ref():
 
 
 @pytest.fixture(scope="session")
-def book1():
+def book1(oracle):
+    """The reference corpus.  Where /root/reference exists it is read from there; elsewhere (the GPU box) it is
+    recovered from tests/golden/book1_word64.bin -- the 64-way word stream the unmodified reference made of it
+     -- by the CPU oracle, and must hash to book1's published sha256."""
+    import hashlib
+    import json
+
     import numpy as np
     path = "/root/reference/book1"
-    if not os.path.exists(path):
-        pytest.skip("reference corpus book1 not present on this box")
-    return np.fromfile(path, dtype=np.uint8)
+    if os.path.exists(path):
+        return np.fromfile(path, dtype=np.uint8)
+    meta = json.load(open(os.path.join(HERE, "golden", "book1_word64.json")))
+    stream = np.fromfile(os.path.join(HERE, "golden", meta["stream"]), dtype=np.uint8)
+    assert hashlib.sha256(stream.tobytes()).hexdigest() == meta["stream_sha256"]
+    om = oracle.model(np.array(meta["freqs"]["12"], dtype=np.uint32), 12)
+    data = oracle.decode(meta["fmt"], om, stream, meta["n"], meta["n_ways"])
+    known = json.load(open(os.path.join(HERE, "golden", "book1_golden.json")))
+    assert hashlib.sha256(data.tobytes()).hexdigest() == known["input_sha256"]
+    return data

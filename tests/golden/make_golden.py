@@ -46,6 +46,35 @@ def main():
                "made_by": "tests/golden/make_golden.py via oracle/_ref (unmodified reference headers)"},
               open(os.path.join(HERE, "ref_streams.json"), "w"))
     print("wrote %d streams, %d bytes" % (len(streams), pos))
+    make_book1(ref)
+
+
+def make_book1(ref):
+    """tests/golden/book1_word64.bin: the reference corpus as the 64-way word-format stream the unmodified
+    reference headers produce for it (435 798 bytes, sha256 84cc03c8...), plus the
+    normalised frequencies at 12 / 14 / 16 bits.  GPU-box tests (no /root/reference there) decode it on the GPU --
+    the result must hash to book1's sha256 -- and re-encode it into every appendix B stream."""
+    import hashlib
+    path = "/root/reference/book1"
+    if not os.path.exists(path):
+        print("book1 not found: fixture left as it is")
+        return
+    data = np.fromfile(path, dtype=np.uint8)
+    known = json.load(open(os.path.join(HERE, "book1_golden.json")))
+    assert hashlib.sha256(data.tobytes()).hexdigest() == known["input_sha256"]
+    freqs = {}
+    for sb in (12, 14, 16):
+        f, _ = ref.build_model(data, 1 << sb)
+        freqs[str(sb)] = [int(v) for v in f]
+    s = ref.encode(FMT_WORD, np.array(freqs["12"], dtype=np.uint32), 12, data, 64)
+    want = [e for e in known["streams"] if e["fmt"] == "word" and e["n_ways"] == 64][0]
+    assert s.size == want["size"] and hashlib.sha256(s.tobytes()).hexdigest() == want["sha256"]
+    s.tofile(os.path.join(HERE, "book1_word64.bin"))
+    json.dump({"stream": "book1_word64.bin", "fmt": FMT_WORD, "scale_bits": 12, "n_ways": 64, "n": int(data.size),
+               "stream_sha256": want["sha256"], "freqs": freqs,
+               "made_by": "tests/golden/make_golden.py via oracle/_ref (unmodified reference headers)"},
+              open(os.path.join(HERE, "book1_word64.json"), "w"))
+    print("wrote book1_word64.bin, %d bytes" % s.size)
 
 
 if __name__ == "__main__":

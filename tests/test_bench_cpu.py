@@ -1,0 +1,70 @@
+"""CPU-side checks of bench.py's helpers and of the committed book1 fixture (no GPU needed)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_bench_generator_equals_oracle(oracle):
+    """bench.gen_zipf (torch tensors, here on the CPU) is the SURVEY 8(d) generator oracle.gen_zipf implements."""
+    import torch
+
+    import bench
+    for K, seed, n in ((256, 1, 200003), (4096, 1, 100000), (256, 9, 999), (4096, 2, 65537)):
+        got = bench.gen_zipf(torch, n, K, 1.0, seed, "cpu").numpy()
+        if got.dtype == np.int16:
+            got = got.view(np.uint16)
+        assert np.array_equal(got, oracle.gen_zipf(n, K=K, s=1.0, seed=seed)), (K, seed)
+
+
+def test_book1_fixture_decodes_to_the_corpus(oracle):
+    """tests/golden/book1_word64.bin (made by the unmodified reference) is book1: the oracle decodes it to the
+    published sha256, with the committed 12-bit frequencies."""
+    meta = json.load(open(os.path.join(HERE, "golden", "book1_word64.json")))
+    known = json.load(open(os.path.join(HERE, "golden", "book1_golden.json")))
+    stream = np.fromfile(os.path.join(HERE, "golden", meta["stream"]), dtype=np.uint8)
+    assert hashlib.sha256(stream.tobytes()).hexdigest() == meta["stream_sha256"]
+    want = [e for e in known["streams"] if e["fmt"] == "word" and e["n_ways"] == 64][0]
+    assert stream.size == want["size"] and meta["stream_sha256"] == want["sha256"]
+    om = oracle.model(np.array(meta["freqs"]["12"], dtype=np.uint32), 12)
+    data = oracle.decode(meta["fmt"], om, stream, meta["n"], meta["n_ways"])
+    assert hashlib.sha256(data.tobytes()).hexdigest() == known["input_sha256"]
+    # and the frequencies are what the oracle's model builder makes of the corpus
+    counts = oracle.count_freqs(data, 256)
+    for sb in (12, 14, 16):
+        f, _ = oracle.normalize(counts, 1 << sb)
+        assert [int(v) for v in f] == meta["freqs"][str(sb)]
+
+
+def test_index_check_rejects_a_wrong_index(oracle):
+    """bench.oracle_check_chunks: the sampled-chunk comparison really compares (a flipped byte or a shifted
+    offset fails it)."""
+    import pytest
+    import torch
+
+    import bench
+    from _oracle import FMT_WORD
+    data = oracle.gen_zipf(50000, K=256, s=1.0, seed=3)
+    f, _ = oracle.normalize(oracle.count_freqs(data, 256), 4096)
+    om = oracle.model(f, 12)
+    cont, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, 64, 4096, align=16)
+    art = {"fmt": FMT_WORD, "sb": 12, "K": 256, "ways": 64, "chunk": 4096, "n": data.size, "freqs": f,
+           "d_syms": torch.from_numpy(data), "cont": torch.from_numpy(cont.copy()),
+           "offs": torch.from_numpy(offs.astype(np.int64)), "lens": torch.from_numpy(lens.astype(np.int32)),
+           "total": int(cont.size)}
+    assert bench.oracle_check_chunks(art, want=8) >= 5
+    bad = dict(art)
+    c = cont.copy()
+    c[int(offs[0]) + 300] ^= 1
+    bad["cont"] = torch.from_numpy(c)
+    with pytest.raises(AssertionError):
+        bench.oracle_check_chunks(bad, want=8)
+    bad = dict(art)
+    o = offs.astype(np.int64).copy()
+    o[3] += 16
+    bad["offs"] = torch.from_numpy(o)
+    with pytest.raises(AssertionError):
+        bench.oracle_check_chunks(bad, want=8)

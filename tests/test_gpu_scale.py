@@ -1,0 +1,118 @@
+"""GPU parity at the BASELINE sizes (run with -m gpu on an MI355X).
+
+The small-size parity tests compare every byte with the oracle; here the inputs are the full configurations
+of BASELINE.json -- C3: 1 GiB, word format, 64-way; C2: 256 MiB, rans64, 2-way; C4: 512 Mi u16 symbols, alias
+tables over 4096 symbols, 64-way -- and what is compared with the CPU oracle is a SAMPLE of the container the
+GPU encoder produced: 64 pseudo-random chunks plus the first, last and the ones around the 8192-chunk blocks of
+the offset scan are re-encoded by the oracle and must be byte-identical, and the whole index must be the
+prefix sum of its 16-byte aligned lengths (bench.oracle_check_chunks, the same check bench.py reports as
+`oracle_chunks_checked`).  A symmetric encoder/decoder bug that only shows at scale -- several rounds of the
+persistent grid, the multi-block offset scan, 32-bit overflow somewhere -- cannot pass this.
+
+book1 goes through the GPU as well: the committed 64-way word stream, written by the
+unmodified reference, is decoded on the GPU to the corpus (sha256 pinned), and the GPU encoder reproduces all
+thirteen appendix B streams.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from _oracle import FMT_ALIAS, FMT_BYTE, FMT_R64, FMT_WORD
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FMT = {"byte": FMT_BYTE, "word": FMT_WORD, "r64": FMT_R64, "alias": FMT_ALIAS}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    import ryg_rans_amd as R
+    ctx = R.Context(0)
+    yield R, ctx, torch
+    ctx.close()
+
+
+def test_bench_generator_equals_oracle_on_gpu(gpu, oracle):
+    """bench.gen_zipf on the GPU (splitmix64 in int64 tensors, float64 inverse CDF) makes the very bytes
+    Oracle.gen_zipf makes on the CPU, so the bench buffers can be regenerated and checked anywhere."""
+    R, ctx, torch = gpu
+    import bench
+    for K, seed, n in ((256, 1, (1 << 20) + 3), (4096, 1, 300001), (256, 5, 70001)):
+        got = bench.gen_zipf(torch, n, K, 1.0, seed, "cuda").cpu().numpy()
+        if got.dtype == np.int16:
+            got = got.view(np.uint16)
+        assert np.array_equal(got, oracle.gen_zipf(n, K=K, s=1.0, seed=seed)), (K, seed)
+    # the generator is counter based: the head of a 1 GiB buffer equals a short run from the same seed
+    big = bench.gen_zipf(torch, 1 << 30, 256, 1.0, 1, "cuda")
+    assert np.array_equal(big[:1 << 16].cpu().numpy(), oracle.gen_zipf(1 << 16, K=256, s=1.0, seed=1))
+
+
+@pytest.mark.parametrize("name,fmt,sb,K,ways,chunk,log2n", [
+    ("C3", FMT_WORD, 12, 256, 64, 32768, 30),
+    ("C3-16k-chunks", FMT_WORD, 12, 256, 64, 16384, 30),
+    ("C2", FMT_R64, 14, 256, 2, 512, 28),
+    ("C4", FMT_ALIAS, 16, 4096, 64, 32768, 29),
+    ("byte-64", FMT_BYTE, 14, 256, 64, 32768, 30),
+])
+def test_full_size_sampled_chunks_equal_oracle(gpu, name, fmt, sb, K, ways, chunk, log2n):
+    R, ctx, torch = gpu
+    import bench
+    n = 1 << log2n
+    d_syms = bench.gen_zipf(torch, n, K, 1.0, 1, "cuda")
+    counts = ctx.count_freqs_device(d_syms, K)
+    assert int(counts.sum()) == n
+    freqs, _ = R.normalize_freqs(counts, 1 << sb)
+    gm = ctx.model(fmt, freqs, sb)
+    cont, offs, lens, total = ctx.encode(gm, d_syms, ways, chunk)
+    art = {"fmt": fmt, "sb": sb, "K": K, "ways": ways, "chunk": chunk, "n": n, "freqs": freqs, "d_syms": d_syms,
+           "cont": cont, "offs": offs, "lens": lens, "total": total}
+    checked = bench.oracle_check_chunks(art, want=64)
+    assert checked >= 64
+    out = ctx.decode(gm, cont, total, offs, lens, n, ways, chunk)
+    assert torch.equal(out, d_syms)
+    # and the decoder reads an ORACLE-made chunk spliced into the container: replace chunk 1 by the oracle's
+    # bytes for it (they are equal, so this is the identity -- checked above) and chunk 0's stream by a
+    # corrupted copy, which must be flagged
+    bad = cont.clone()
+    bad[int(offs[0].item()) + int(lens[0].item()) // 2] ^= 0x10
+    out2 = torch.empty_like(out)
+    ctx.decode(gm, bad, total, offs, lens, n, ways, chunk, d_out=out2, sync=False)
+    assert ctx.decode_errors() >= 1 or not torch.equal(out2, d_syms)
+
+
+def test_book1_appendix_b_on_gpu(gpu):
+    """SURVEY appendix B through the HIP path: decode the reference-made 64-way word stream of book1, then
+    re-encode book1 into every pinned stream (sizes from the README, SHA-256 from the unmodified reference)."""
+    R, ctx, torch = gpu
+    meta = json.load(open(os.path.join(HERE, "golden", "book1_word64.json")))
+    known = json.load(open(os.path.join(HERE, "golden", "book1_golden.json")))
+    stream = np.fromfile(os.path.join(HERE, "golden", meta["stream"]), dtype=np.uint8)
+    assert hashlib.sha256(stream.tobytes()).hexdigest() == meta["stream_sha256"]
+    f12 = np.array(meta["freqs"]["12"], dtype=np.uint32)
+    gm = ctx.model(FMT_WORD, f12, 12)
+    book1 = ctx.decode_host(gm, stream, meta["n"], 64)
+    assert book1.size == known["input_size"]
+    assert hashlib.sha256(book1.tobytes()).hexdigest() == known["input_sha256"]
+    # the model builder on the GPU histogram reproduces the reference's normalised frequencies
+    counts = ctx.count_freqs_device(torch.from_numpy(book1).cuda(), 256)
+    for sb in (12, 14, 16):
+        f, _ = R.normalize_freqs(counts, 1 << sb)
+        assert [int(v) for v in f] == meta["freqs"][str(sb)], sb
+    for e in known["streams"]:
+        fmt, sb, N = FMT[e["fmt"]], e["scale_bits"], e["n_ways"]
+        m = ctx.model(fmt, np.array(meta["freqs"][str(sb)], dtype=np.uint32), sb)
+        s = ctx.encode_host(m, book1, N)
+        assert s.size == e["size"], (e["fmt"], N)
+        assert hashlib.sha256(s.tobytes()).hexdigest() == e["sha256"], (e["fmt"], N)
+        assert np.array_equal(ctx.decode_host(m, s, book1.size, N), book1), (e["fmt"], N)
+    # chunked (what the bulk path does): the corpus as 24 chunks of 32 Ki symbols, decoded back
+    d = torch.from_numpy(book1).cuda()
+    cont, offs, lens, total = ctx.encode(gm, d, 64, 32768)
+    out = ctx.decode(gm, cont, total, offs, lens, book1.size, 64, 32768)
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == known["input_sha256"]
