@@ -360,6 +360,12 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
 
+    # first wave start .. last wave end of each timed launch (recorded by the kernel itself, always on)
+    try:
+        spans = ctx.launch_spans(min(args.steps, 32))
+    except Exception:  # noqa: BLE001  (an older library build in an A/B run)
+        spans = []
+
     # ---- verification (after the timed region) -------------------------------------
     bad = ctx.decode_errors()
     exact = bool(torch.equal(out, d_syms))
@@ -409,6 +415,11 @@ def main():
                 "kernel": ctx.last_decode_kernel(), "kernel_ms_avg": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": n + total,
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
+                # what a launch spends inside its wavefronts (first wave start .. last wave end, mean over the timed
+                # launches of rank 0); the rest of kernel_ms_avg is dispatch, the hand-over between back-to-back
+                # kernels and the write-back at the kernel's end
+                "wave_span_ms_avg": round(sum(v for v in spans if v > 0) / max(1, sum(1 for v in spans if v > 0)), 4)
+                if spans else None,
             },
         }
         # per-wave clocks, measured by the kernel in one extra (untimed, instrumented) launch

@@ -272,6 +272,12 @@ typedef struct rans_amd_wave_clocks {
 /* shader_cycles / rounds = clocks one wave spends per round of 64 symbols (waiting included); divide by the
  * waves resident per SIMD (8) for the issue cycles a SIMD spends per round. */
 int rans_amd_last_wave_clocks(rans_amd_ctx *ctx, rans_amd_wave_clocks *out);
+/* Always on, no cost worth naming: every decode launch records when its first wavefront started and its last
+ * one ended (constant 100 MHz clock).  span_ms[0..count) receives those spans for the last `count` (<= 32)
+ * decode launches of this context, oldest first (-1 where there was none); synchronises `stream`.  The
+ * difference to the HIP-event time of a launch is what the launch spends outside its wavefronts: dispatch,
+ * the wait for the previous kernel of the stream, the cache write-back at its end. */
+int rans_amd_launch_spans(rans_amd_ctx *ctx, uint32_t count, double *span_ms, void *stream);
 int rans_amd_last_kernel_ms(rans_amd_ctx *ctx, float *decode_ms, float *encode_ms);
 /* Name of the dominant device kernel the last decode used (for profile matching). */
 const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx);

@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "rans_amd_encode", "rans_amd_decode", "rans_amd_decode_errors",
     "rans_amd_encode_host", "rans_amd_decode_host",
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_wave_clocks",
+    "rans_amd_launch_spans",
     "rans_amd_offsets_from_lengths", "rans_amd_container_bytes", "rans_amd_container_pack",
     "rans_amd_container_parse", "rans_amd_encode_workspace_bytes", "rans_amd_build_model_o0",
 ]
@@ -108,6 +109,7 @@ def _load():
         "rans_amd_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "rans_amd_last_decode_kernel": (C.c_char_p, [vp]),
         "rans_amd_last_wave_clocks": (i32, [vp, C.POINTER(WaveClocks)]),
+        "rans_amd_launch_spans": (i32, [vp, u32, C.POINTER(C.c_double), vp]),
         "rans_amd_encode_workspace_bytes": (u64, [i32, u64, u32, u32]),
         "rans_amd_build_model_o0": (i32, [vp, i32, vp, u64, i32, u32, u32, u32p, C.POINTER(vp), vp]),
         "rans_amd_offsets_from_lengths": (i32, [u32p, u64, u64p]),
@@ -205,6 +207,12 @@ class Context:
     def set_timing(self, on=True):
         """True/1: HIP events around every launch; 2: per-wave clocks as well (slower, synchronising)."""
         _check(_lib.rans_amd_set_timing(self._h, int(on)), "set_timing")
+
+    def launch_spans(self, count):
+        """First-wave-start to last-wave-end (ms) of the last `count` decode launches, oldest first."""
+        out = (C.c_double * count)()
+        _check(_lib.rans_amd_launch_spans(self._h, count, out, _torch_stream()), "launch_spans")
+        return [float(v) for v in out]
 
     def last_wave_clocks(self):
         """Per-wave clocks of the last decode launched under set_timing(2), as a dict."""

@@ -203,7 +203,7 @@ int rans_amd_ctx_create(int device, rans_amd_ctx **out_ctx)
         return fail(RANS_AMD_E_NOMEM, "ctx");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const size_t words_bytes = 256 + (size_t)kWorkSlots * kWorkPools * kWorkPoolStride * 4;
+    const size_t words_bytes = 256 + (size_t)kWorkSlots * kWorkSlotWords * 4;
     e = hipMalloc(reinterpret_cast<void **>(&ctx->d_words), words_bytes);
     if (e == hipSuccess)
         e = hipMemset(ctx->d_words, 0, words_bytes);
@@ -609,11 +609,16 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         // needed and up to 32 decode launches of one context may be in flight at once.
         dp.work_counter = nullptr;
         dp.work_counter_reset = nullptr;
+        dp.span = nullptr;
+        dp.span_reset = nullptr;
         if (!static_sched && nchunks < 0xffffffffull) {
             unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);
-            const uint32_t per_slot = kWorkPools * kWorkPoolStride;
+            const uint32_t per_slot = kWorkSlotWords;
             dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * per_slot;
             dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * per_slot;
+            // the slot's last line: first wave start / last wave end of the launch (rans_amd_launch_spans)
+            dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
+            dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
         }
         // wave clocks (rans_amd_set_timing(ctx, 2)) and the debug timeline (RANS_AMD_TRACE=<file>): per-wave
         // start/end ticks, XCD, shader cycles and rounds, read back after a sync
@@ -822,6 +827,29 @@ int rans_amd_last_kernel_ms(rans_amd_ctx *ctx, float *decode_ms, float *encode_m
 }
 
 const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+int rans_amd_launch_spans(rans_amd_ctx *ctx, uint32_t count, double *span_ms, void *stream)
+{
+    if (!ctx || !span_ms || count == 0 || count > kWorkSlots / 2)
+        return fail(RANS_AMD_E_ARG, "launch_spans: 1 <= count <= 32 launches");
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<uint32_t> host((size_t)kWorkSlots * kWorkSlotWords);
+    HIP_TRY(hipMemcpyAsync(host.data(), ctx->d_words + 256, host.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < count; ++i) {
+        span_ms[i] = -1.0;
+        if (ctx->launch_seq < count - i)
+            continue; // fewer launches than asked for
+        const uint32_t seq = ctx->launch_seq - (count - i); // oldest first
+        unsigned long long rec[2];
+        memcpy(rec, &host[(size_t)(seq % kWorkSlots) * kWorkSlotWords + kWorkPools * kWorkPoolStride], sizeof(rec));
+        if (rec[1])
+            span_ms[i] = (double)(rec[1] - ~rec[0]) * 1e-5; // 100 MHz ticks
+    }
+    return RANS_AMD_OK;
+}
 
 int rans_amd_last_wave_clocks(rans_amd_ctx *ctx, rans_amd_wave_clocks *out)
 {

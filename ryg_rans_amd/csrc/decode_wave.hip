@@ -71,7 +71,7 @@ struct StreamWindow {
     uint32_t ring_addr; // the same as a raw LDS byte address
     uint32_t cur, mark;
     uint32_t lapped;    // stream bytes that lie before ring offset 0 of the current lap
-    uint32_t gnext;     // byte offset (within the chunk) of the next 1 KiB block to fetch
+    uint32_t gnext;     // byte offset (within the descriptor, i.e. from the first stream block) of the next fetch
     rsrc_t rsrc;
     u32x4 pre;          // prefetched block (16 B per lane)
 
@@ -89,20 +89,45 @@ struct StreamWindow {
         if (at == 0 && lane < kRingMirror / 16u)
             *reinterpret_cast<u32x4 *>(ring + kRingBytes + lane * 16u) = v;
     }
-    // chunk_base: 16-byte aligned global address of the chunk; first: offset of the first renormalisation
-    // unit in it (behind the initial states); fetchable: 16-byte aligned number of bytes that may be read
+    // The descriptor of a chunk's stream starts at the 16-byte granule of its first renormalisation unit (behind
+    // the initial states): block k of the stream is at buffer offset 1024 k, so the blocks of the opening are
+    // reached with immediate offsets from one per-lane VGPR.
+    // chunk_base: 16-byte aligned global address of the chunk; first: offset of the first unit in it;
+    // fetchable: 16-byte aligned number of bytes of the chunk that may be read.
+    static __device__ __forceinline__ rsrc_t stream_rsrc(uint64_t chunk_base, uint32_t first, uint32_t fetchable)
+    {
+        const uint32_t skip = first & ~15u;
+        // fetchable >= skip: callers have checked len >= the initial states.  (Plain subtraction on purpose: a
+        // saturating one is matched to v_sub_u32 ... clamp, the descriptor lands in VGPRs and every fetch
+        // becomes a waterfall loop.)
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(chunk_base + skip), 0, fetchable - skip,
+                                                 kRsrcFlags);
+    }
     __device__ __forceinline__ void open(uint8_t *lds, uint64_t chunk_base, uint32_t first, uint32_t fetchable,
                                          uint32_t lane)
     {
+        const rsrc_t r = stream_rsrc(chunk_base, first, fetchable);
+        u32x4 b0, b1;
+        prefetch(r, lane, b0, b1);
+        install(lds, r, first, lane, b0, b1);
+    }
+    // open() in two halves, so that a chunk's first two blocks can be requested while the previous chunk is
+    // still being decoded: prefetch() only issues loads, install() takes over the ring and requests block 2.
+    static __device__ __forceinline__ void prefetch(rsrc_t r, uint32_t lane, u32x4 &b0, u32x4 &b1)
+    {
+        b0 = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16u, 0, kAuxNt);
+        b1 = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16u + kRingBlock, 0, kAuxNt);
+    }
+    __device__ __forceinline__ void install(uint8_t *lds, rsrc_t r, uint32_t first, uint32_t lane, const u32x4 &b0,
+                                            const u32x4 &b1)
+    {
         ring = lds;
         ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(chunk_base), 0, fetchable, kRsrcFlags);
-        gnext = first & ~15u;
-        lapped = gnext;
+        rsrc = r;
+        lapped = first & ~15u;
+        gnext = 2u * kRingBlock;
         cur = ring_addr + (first & 15u);
         mark = ring_addr + kRingBlock;
-        u32x4 b0 = fetch(lane);
-        u32x4 b1 = fetch(lane);
         pre = fetch(lane);
         put(lane, 0, b0);
         put(lane, kRingBlock, b1);
@@ -254,7 +279,7 @@ __device__ __forceinline__ void renorm_byte_full(uint32_t &x, uint32_t &cur, uin
 // buffer_store_dword) sit in round 0, where the wave would otherwise wait for the slot record, and where
 // the wait states a DPP operand needs after a VALU write (2) are filled by instructions that have to be
 // issued anyway.  pa: in = the previous group's four symbols of this lane, out = this group's.
-// Temporaries are fixed registers (v56..v63) because the halves of a 64-bit asm operand cannot be named.
+// Temporaries are fixed registers (v56..v61) because the halves of a 64-bit asm operand cannot be named.
 // ---------------------------------------------------------------------------
 #define RANS_WORD_RENORM                                   \
     "v_cmpx_gt_u32_e32 vcc, %[lim], %[x]\n\t"              \
@@ -285,13 +310,13 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
         asm volatile(
             // ---- round 0 (+ the previous group's transposition and store)
             RANS_WORD_LOOKUP("v[58:59]")
-            "v_mov_b32_dpp v62, %[pa] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_perm_b32 v63, v62, %[pa], %[sel1]\n\t"
+            "v_mov_b32_dpp v60, %[pa] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_perm_b32 v61, v60, %[pa], %[sel1]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "v_mad_u32_u24 %[x], v58, v57, v59\n\t"
-            "v_mov_b32_dpp v62, v63 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_perm_b32 v62, v62, v63, %[sel2]\n\t"
-            "buffer_store_dword v62, %[ooff], %[orsrc], %[osoff] offen\n\t"
+            "v_mov_b32_dpp v60, v61 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_perm_b32 v60, v60, v61, %[sel2]\n\t"
+            "buffer_store_dword v60, %[ooff], %[orsrc], %[osoff] offen\n\t"
             RANS_WORD_RENORM
             // ---- round 1
             RANS_WORD_LOOKUP("v[60:61]")
@@ -315,7 +340,11 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
             : [m12] "v"(m12), [lim] "v"(k65536), [sel1] "v"(sel1), [sel2] "v"(sel2), [selA] "v"(selA), [selB] "v"(selB),
               [selC] "v"(selC), [selm] "s"(0x05040100u), [orsrc] "s"(orsrc), [ooff] "v"(out_lane_off),
               [osoff] "s"(osoff_prev)
-            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61");
+        // (The store is deliberately inside the sequence, in round 0.  The compiler does not see it, so the
+        // s_waitcnt vmcnt(0) it puts in front of a window refill -- which happens after round 3 -- also waits
+        // for this store; by then it is ~1000 cycles old and done.  A store the compiler knows about makes it
+        // wait with vmcnt(1) at the top of EVERY group, i.e. for the window prefetch right after each refill.)
     } else {
         asm volatile(
             RANS_WORD_LOOKUP("v[58:59]")
@@ -340,7 +369,7 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
             : [x] "+v"(x), [pa] "+v"(pa), [cur] "+s"(cur), [cnt] "=&s"(cnt)
             : [m12] "v"(m12), [lim] "v"(k65536), [selA] "v"(selA), [selB] "v"(selB), [selC] "v"(selC),
               [selm] "s"(0x05040100u)
-            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61");
     }
 }
 #undef RANS_WORD_RENORM
@@ -369,7 +398,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     using state_t = typename Tr::state_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // wave clocks (rans_amd_set_timing(ctx, 2) / RANS_AMD_TRACE): constant 100 MHz clock and shader clock
-    const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
+    const unsigned long long t_start = (p.trace || p.span) ? wall_clock64() : 0ull;
     const unsigned long long c_start = p.trace ? __builtin_readcyclecounter() : 0ull;
     uint32_t rounds_done = 0;
 
@@ -413,6 +442,8 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 
     if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
         p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u;
+    if (p.span_reset && blockIdx.x == 0 && threadIdx.x < 2)
+        p.span_reset[threadIdx.x] = 0ull;
     // Chunks are handed out dynamically.  The SIMD arbitrates VALU issue by wave age, so the
     // waves of the older of a CU's two workgroups run ~20 % faster than the younger ones
     // (measured: 314 vs 372 us for the same work); with a static split the kernel lasts as long
@@ -527,7 +558,8 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
             const uint32_t groups = rounds >> 2;
             if (groups) {
                 const uint64_t dsta = reinterpret_cast<uint64_t>(dst);
-                const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu, nsym, kRsrcFlags};
+                const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu, uniform(nsym),
+                                     kRsrcFlags};
                 uint32_t selA = 0x03020703u, selB = 0x03070100u, selC = 0x07020100u; // acc_symbol<3, 1..3>
                 uint32_t k65536 = 0x10000u, m12 = 0xfffu;
                 asm volatile("v_mov_b32 %0, %0" : "+v"(selA)); // opaque: live in VGPRs, never rematerialised in the loop
@@ -642,6 +674,10 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         if (!all_good && lane == 0)
             atomicAdd(p.err_count, 1ull);
     }
+    if (p.span && lane == 0) { // first wave start .. last wave end of this launch (rans_amd_launch_spans)
+        atomicMax(p.span, ~t_start);
+        atomicMax(p.span + 1, wall_clock64());
+    }
     if (p.trace && lane == 0) { // per wave: start / end on the 100 MHz clock, XCD, shader cycles spent, rounds decoded
         unsigned long long *t = p.trace + (uint64_t)kTraceWords * ((uint64_t)blockIdx.x * waves_per_block + wave);
         t[0] = t_start;
@@ -650,6 +686,253 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         t[3] = __builtin_readcyclecounter() - c_start;
         t[4] = rounds_done;
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_decode_word64 -- the headline configuration on its own: word format, 64-way, u8 symbols, 4-byte aligned
+// output (main_simd.cpp:313-332 for 64 lanes).  Same decoding as k_decode<FMT_WORD, 1, OUT_FAST8_GROUP>,
+// plus the hand-over between chunks taken off the critical path: a wave that stops to claim a chunk, read
+// its index entry, then its initial states and first stream blocks sits through three dependent memory
+// round trips (~3 us, and every SIMD has 8 waves doing that once per chunk).  Here the three steps of the
+// NEXT chunk are issued while the last rounds of the current one are decoded:
+//     kClaimAhead  groups before the end   atomic on the chunk counter                          (claim)
+//     kDataAhead                           offsets[next], lengths[next] through the scalar cache,
+//                                          then initial states and stream blocks 0 and 1         (data, 9 VGPRs)
+// so the switch itself is two LDS block writes.  Claims are made late on purpose: a claimed chunk is work
+// committed to this wave, and the slow (young) waves of a SIMD should not sit on chunks at the end.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kClaimAhead = 10, kDataAhead = 5; // in groups of 4 rounds
+
+// buffer descriptor of one 64-way word chunk's stream (StreamWindow::stream_rsrc): what may be fetched is the
+// chunk's length rounded up to the 16-byte granule, clipped to the container's last granule
+__device__ __forceinline__ rsrc_t chunk_rsrc(uint64_t cbase, uint64_t cbytes16, uint64_t off, uint32_t len)
+{
+    // off and len are wave-uniform (scalar loads); saying so here keeps the descriptor in SGPRs whatever the
+    // compiler concluded about the loop-carried copies (a descriptor in VGPRs turns every fetch into a waterfall loop)
+    off = uniform64(off);
+    len = uniform(len);
+    const uint64_t room = cbytes16 - off;
+    const uint32_t climit = (len + 15u) & ~15u;
+    return StreamWindow::stream_rsrc(cbase + off, 64u * 4u, climit < room ? climit : (uint32_t)room);
+}
+
+__global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const DecParams p)
+{
+    using Tr = FmtTraits<FMT_WORD>;
+    constexpr uint32_t N = 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const unsigned long long t_start = (p.trace || p.span) ? wall_clock64() : 0ull;
+    const unsigned long long c_start = p.trace ? __builtin_readcyclecounter() : 0ull;
+    uint32_t rounds_done = 0;
+
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    DecTables<FMT_WORD> T;
+    T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+    if (!lds_starts_at_zero(smem)) {
+        if (threadIdx.x == 0)
+            atomicAdd(p.err_count, 1ull << 32);
+        return;
+    }
+    uint8_t *ring = smem + t0_bytes + wave * kRingStride;
+    const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
+    const uint64_t cbytes16 = (p.container_bytes + 15u) & ~uint64_t(15);
+
+    const uint32_t sel1 = (lane & 1u) ? 0x03070105u : 0x06020400u;
+    const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
+    const uint32_t out_lane_off = (lane & 3u) * N + (lane & ~3u);
+    uint32_t selA = 0x03020703u, selB = 0x03070100u, selC = 0x07020100u; // acc_symbol<3, 1..3>
+    uint32_t k65536 = 0x10000u, m12 = 0xfffu;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(selA)); // opaque: live in VGPRs, never rematerialised in the loop
+    asm volatile("v_mov_b32 %0, %0" : "+v"(selB));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(selC));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(k65536));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(m12));
+
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u;
+    if (p.span_reset && blockIdx.x == 0 && threadIdx.x < 2)
+        p.span_reset[threadIdx.x] = 0ull;
+
+    // ---- chunk hand-out (see k_decode): one counter per XCD, or static striding without counters
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    uint64_t static_next = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint32_t npools = gridDim.x < kWorkPools ? gridDim.x : kWorkPools;
+    const uint32_t pool = blockIdx.x % npools;
+    uint32_t claimed_v = 0; // lane 0: what the atomic returned
+
+    // ---- the three steps of taking a chunk; state of the chunk being taken: n_* ----------------------
+    uint64_t n_idx = 0;               // chunk index
+    uint64_t n_off = 0;               // its index entry: scalar loads, i.e. SGPRs from the start
+    uint32_t n_len = 0;
+    uint32_t n_x = 0;                 // initial state of this lane (RansDecInit order: lane l's state is the l-th)
+    u32x4 n_b0 = {0u, 0u, 0u, 0u}, n_b1 = n_b0; // stream blocks 0 and 1
+    bool n_any = false, n_ok = false; // a chunk was claimed / its index entry passed validation and data is on its way
+
+#define RANS_STEP_CLAIM()                                                                   \
+    do {                                                                                    \
+        if (p.work_counter && lane == 0)                                                    \
+            claimed_v = atomicAdd(p.work_counter + pool * kWorkPoolStride, 1u);             \
+    } while (0)
+    // The index entry comes through the scalar cache (s_load_dwordx2 / s_load_dword + wait, ~0.2 us on an L2
+    // hit, once per chunk): it lands in SGPRs, no VGPR is tied up.  off and len come from the caller: compare
+    // without forming off + len (which can wrap); fetch nothing beyond the chunk's own stream (16-byte granule)
+    // nor beyond the container's last granule.
+#define RANS_STEP_DATA()                                                                    \
+    do {                                                                                    \
+        if (p.work_counter) {                                                               \
+            n_idx = (uint64_t)uniform(claimed_v) * npools + pool;                           \
+        } else {                                                                            \
+            n_idx = uniform64(static_next);                                                 \
+            static_next += total_waves;                                                     \
+        }                                                                                   \
+        n_any = n_idx < p.nchunks;                                                          \
+        n_ok = false;                                                                       \
+        if (n_any) {                                                                        \
+            asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" \
+                         : "=&s"(n_off), "=&s"(n_len)                                       \
+                         : "s"(uniform64(reinterpret_cast<uint64_t>(p.offsets + n_idx))),   \
+                           "s"(uniform64(reinterpret_cast<uint64_t>(p.lengths + n_idx)))    \
+                         : "memory");                                                       \
+            n_off = uniform64(n_off); /* (asm results count as divergent: say what they are) */ \
+            n_len = uniform(n_len);                                                         \
+            n_ok = ((n_off & 15u) == 0) && (n_len >= N * Tr::kStateBytes) && (n_off <= p.container_bytes) && \
+                   (n_len <= p.container_bytes - n_off);                                    \
+            if (n_ok) {                                                                     \
+                n_x = *(reinterpret_cast<const uint32_t RANS_GLOBAL *>(cbase + n_off) + lane); \
+                StreamWindow::prefetch(chunk_rsrc(cbase, cbytes16, n_off, n_len), lane, n_b0, n_b1); \
+            } else if (lane == 0) {                                                         \
+                atomicAdd(p.err_count, 1ull);                                               \
+            }                                                                               \
+        }                                                                                   \
+    } while (0)
+
+    // the first chunk: all three in a row (and again after a chunk whose index entry was rejected)
+    for (;;) {
+        RANS_STEP_CLAIM();
+        RANS_STEP_DATA();
+        if (n_ok || !n_any)
+            break;
+    }
+    while (n_ok) {
+        // ---- the chunk that was being taken becomes the current one ----
+        // (everything about the chunk is wave-uniform by construction; saying so keeps it, and the descriptors
+        // built from it, in SGPRs whatever the compiler concluded about the loop-carried n_* copies)
+        const uint64_t c_idx = uniform64(n_idx);
+        const uint32_t c_len = uniform(n_len);
+        StreamWindow W;
+        W.install(ring, chunk_rsrc(cbase, cbytes16, n_off, n_len), N * Tr::kStateBytes, lane, n_b0, n_b1);
+        uint32_t x = n_x;
+        const uint64_t first_sym = c_idx * p.chunk_syms;
+        const uint32_t nsym = uniform((uint32_t)((p.n - first_sym) < p.chunk_syms ? (p.n - first_sym) : p.chunk_syms));
+        uint8_t RANS_GLOBAL *dst = reinterpret_cast<uint8_t RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + first_sym);
+        const uint32_t rounds = uniform(nsym / N);
+        const uint32_t tail = uniform(nsym - rounds * N);
+        const uint32_t groups = rounds >> 2;
+        rounds_done += rounds;
+        n_any = false;
+        n_ok = false;
+        uint32_t stage = 0; // steps of the next chunk already issued
+
+        if (groups) {
+            const uint64_t dsta = reinterpret_cast<uint64_t>(dst);
+            const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu, uniform(nsym),
+                                 kRsrcFlags};
+            uint32_t pa = 0;
+            W.checkpoint(lane);
+            decode_group_word<false>(x, pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc, out_lane_off, 0u);
+            // groups 1 .. groups-1 store their predecessor's symbols; osoff = 256 * (group - 1).  One scalar
+            // compare per group watches for the point where the next step of the hand-over is due.
+            const uint32_t oend = (groups - 1u) * 256u;
+            uint32_t trigger = groups > kClaimAhead ? (groups - kClaimAhead) * 256u : 0u;
+            for (uint32_t osoff = 0; osoff != oend; osoff += 256u) {
+                if (osoff == trigger) {
+                    if (stage == 0) {
+                        RANS_STEP_CLAIM();
+                        trigger += (kClaimAhead - kDataAhead) * 256u;
+                    } else {
+                        RANS_STEP_DATA();
+                        trigger = ~0u;
+                    }
+                    ++stage;
+                }
+                W.checkpoint(lane);
+                decode_group_word<true>(x, pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc, out_lane_off, osoff);
+            }
+            const uint32_t v = quad_transpose(pa, sel1, sel2);
+            *reinterpret_cast<uint32_t RANS_GLOBAL *>(dst + oend + out_lane_off) = v;
+        }
+        // short chunks: whatever step of the hand-over has not been issued yet
+        if (stage < 1)
+            RANS_STEP_CLAIM();
+        if (stage < 2)
+            RANS_STEP_DATA();
+
+        // ---- remaining full rounds and the partial tail round: element stores
+        for (uint32_t r = groups << 2; r <= rounds; ++r) {
+            const uint32_t cnt = (r < rounds) ? N : tail;
+            if (cnt == 0)
+                break;
+            if (lane < cnt) {
+                const uint32_t sy = dec_step<FMT_WORD>(T, x);
+                dst[(uint64_t)r * N + lane] = (uint8_t)(sy >> 24);
+            }
+            W.checkpoint(lane);
+            W.consume(dec_renorm<FMT_WORD>(W, x, lane < cnt));
+        }
+
+        // ---- integrity: every state back at L, cursor exactly at the end ----
+        const bool all_good = __builtin_amdgcn_ballot_w64(x != Tr::kL) == 0 && W.position() == c_len;
+        if (!all_good && lane == 0)
+            atomicAdd(p.err_count, 1ull);
+
+        // the next chunk's index entry was rejected (already counted): look further, one step after the other
+        while (n_any && !n_ok) {
+            RANS_STEP_CLAIM();
+            RANS_STEP_DATA();
+        }
+    }
+#undef RANS_STEP_CLAIM
+#undef RANS_STEP_DATA
+    if (p.span && lane == 0) {
+        atomicMax(p.span, ~t_start);
+        atomicMax(p.span + 1, wall_clock64());
+    }
+    if (p.trace && lane == 0) {
+        unsigned long long *t = p.trace + (uint64_t)kTraceWords * ((uint64_t)blockIdx.x * waves_per_block + wave);
+        t[0] = t_start;
+        t[1] = wall_clock64();
+        t[2] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11));
+        t[3] = __builtin_readcyclecounter() - c_start;
+        t[4] = rounds_done;
+    }
+}
+
+hipError_t launch_decode_word64(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
+{
+    const uint32_t t0 = (p.table0_bytes + 15u) & ~15u;
+    const uint32_t waves = kDecBlockThreads / 64;
+    const size_t lds = (size_t)t0 + (size_t)waves * kRingStride;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_decode_word64), 160 * 1024, lds_ok); e != hipSuccess)
+        return e;
+    const uint64_t want = (p.nchunks + waves - 1) / waves;
+    const uint64_t cap = (uint64_t)num_cus * 2u;
+    const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    if (name)
+        *name = "k_decode_word64";
+    RANS_LAUNCH(k_decode_word64, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
+    return hipGetLastError();
 }
 
 template <int FMT, int K, int OUT>
@@ -708,6 +991,9 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
     }
     if constexpr (FMT == FMT_WORD) {
         static const bool no_group = getenv("RANS_AMD_NO_GROUP") != nullptr; // A/B: the per-round asm of round 1
+        static const bool no_pipe = getenv("RANS_AMD_NO_PIPE") != nullptr;   // A/B: groups, but serial chunk hand-over
+        if (fast && p.n_ways == 64 && !no_group && !no_pipe)
+            return launch_decode_word64(p, num_cus, s, name);
         if (fast && p.n_ways == 64 && !no_group)
             return launch_decode_t<FMT_WORD, 1, OUT_FAST8_GROUP>(p, num_cus, s, name);
     }

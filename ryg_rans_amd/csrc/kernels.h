@@ -18,6 +18,8 @@ constexpr int kDecBlockThreads = 1024; // 16 waves share one table image
 constexpr uint32_t kWorkPools = 8;       // chunk hand-out counters per launch (one per XCD)
 constexpr uint32_t kWorkPoolStride = 16; // in uint32: every counter on its own 64-byte line
 constexpr uint32_t kWorkSlots = 64;      // launches that may reuse the counter ring before wrap
+// one ring slot = kWorkPools counters (a 64-byte line each) + one line for the launch's wave span record
+constexpr uint32_t kWorkSlotWords = (kWorkPools + 1) * kWorkPoolStride;
 constexpr int kEncBlockThreads = 256;
 constexpr uint32_t kTraceWords = 5;      // per-wave record of DecParams::trace
 
@@ -41,6 +43,8 @@ struct DecParams {
     unsigned long long *err_count; // failed chunks (device counter)
     unsigned int *work_counter;    // next chunk to hand out (zero at launch); NULL = static striding
     unsigned int *work_counter_reset; // a counter slot of a LATER launch that this launch zeroes
+    unsigned long long *span;         // this launch's {max of ~(wave start), max of wave end} in 100 MHz ticks, or NULL
+    unsigned long long *span_reset;   // the span record of a LATER launch that this launch zeroes
     unsigned long long *trace;        // wave clocks: per wave kTraceWords words {start, end (100 MHz ticks), xcc,
                                       // shader cycles, 64-symbol rounds}; NULL = off (wave-per-chunk kernels only)
 };

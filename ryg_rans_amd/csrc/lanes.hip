@@ -183,6 +183,8 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
 
     if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
         p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
+    if (p.span_reset && blockIdx.x == 0 && threadIdx.x < 2)
+        p.span_reset[threadIdx.x] = 0ull;
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x >> 6);
     const uint32_t waves_per_block = blockDim.x >> 6;
@@ -380,6 +382,8 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
 
     if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
         p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u; // keep the wave kernels' counter ring consistent
+    if (p.span_reset && blockIdx.x == 0 && threadIdx.x < 2)
+        p.span_reset[threadIdx.x] = 0ull;
     const uint8_t RANS_GLOBAL *cbase = (const uint8_t RANS_GLOBAL *)p.container;
     const uint64_t glimit = (reinterpret_cast<uint64_t>(p.container) + p.container_bytes + 15u) & ~uint64_t(15);
     const bool wide_out = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 15u) == 0;

@@ -109,7 +109,8 @@ def test_book1_appendix_b_on_gpu(gpu):
         m = ctx.model(fmt, np.array(meta["freqs"][str(sb)], dtype=np.uint32), sb)
         s = ctx.encode_host(m, book1, N)
         assert s.size == e["size"], (e["fmt"], N)
-        assert hashlib.sha256(s.tobytes()).hexdigest() == e["sha256"], (e["fmt"], N)
+        if e["sha256"]:  # (entries without a hash carry the size only)
+            assert hashlib.sha256(s.tobytes()).hexdigest() == e["sha256"], (e["fmt"], N)
         assert np.array_equal(ctx.decode_host(m, s, book1.size, N), book1), (e["fmt"], N)
     # chunked (what the bulk path does): the corpus as 24 chunks of 32 Ki symbols, decoded back
     d = torch.from_numpy(book1).cuda()
