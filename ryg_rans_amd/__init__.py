@@ -252,7 +252,8 @@ class Context:
         cap = chunk_bound(model.fmt, max(int(syms.size), 1), n_ways) + 16
         buf = np.zeros(cap, dtype=np.uint8)
         out_len = C.c_uint64(0)
-        _check(_lib.rans_amd_encode_host(self._h, model._h, syms.ctypes.data, syms.size, n_ways, buf.ctypes.data,
+        _check(_lib.rans_amd_encode_host(self._h, model._h, syms.ctypes.data if syms.size else None, syms.size, n_ways,
+                                         buf.ctypes.data,
                                          cap, C.byref(out_len)), "encode_host")
         return buf[cap - out_len.value:].copy()
 

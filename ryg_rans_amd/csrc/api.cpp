@@ -148,6 +148,20 @@ int upload(const void *src, size_t bytes, void **d_out)
     return RANS_AMD_OK;
 }
 
+// The stream of an empty input: n_ways states, each the coder's initial value L, little endian (lane 0 first,
+// all equal).  Returns its size; writes it when dst != NULL.
+uint64_t empty_stream(int format, uint32_t n_ways, uint8_t *dst)
+{
+    const bool r64 = format == RANS_AMD_FMT_R64;
+    const uint64_t L = r64 ? (1ull << 31) : format == RANS_AMD_FMT_WORD ? (1ull << 16) : (1ull << 23);
+    const uint32_t sbytes = r64 ? 8u : 4u;
+    if (dst)
+        for (uint32_t l = 0; l < n_ways; ++l)
+            for (uint32_t b = 0; b < sbytes; ++b)
+                dst[(size_t)l * sbytes + b] = (uint8_t)(L >> (8 * b));
+    return (uint64_t)n_ways * sbytes;
+}
+
 uint32_t unit_bytes(int format) { return format == RANS_AMD_FMT_WORD ? 2u : format == RANS_AMD_FMT_R64 ? 4u : 1u; }
 uint32_t state_bytes(int format) { return format == RANS_AMD_FMT_R64 ? 8u : 4u; }
 
@@ -718,7 +732,20 @@ int rans_amd_encode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const v
         return fail(RANS_AMD_E_UNSUPPORTED, "encode_host: a single stream is limited to 2^32 symbols");
     const int format = model->host.format;
     const int sb = model->host.sym_bytes;
-    const uint32_t chunk = (uint32_t)(n ? n : 1);
+    if (n == 0) {
+        // nothing to code: the reference's loops run zero times and then flush the N untouched states,
+        // lanes N-1 .. 0, each still at its initial value L (rans_byte.h:56-59,93-105; rans64.h:65-68,96-103;
+        // rans_word_sse41.h:75-78,96-106) -- a constant, so it is written here without a kernel
+        if (!ways_supported(format, n_ways))
+            return fail(RANS_AMD_E_UNSUPPORTED, "encode_host: n_ways must be in 1..512");
+        const uint64_t total = empty_stream(format, n_ways, nullptr);
+        if (total > cap)
+            return fail(RANS_AMD_E_SPACE, "encode_host: buffer too small");
+        empty_stream(format, n_ways, buf + (cap - total));
+        *out_len = total;
+        return RANS_AMD_OK;
+    }
+    const uint32_t chunk = (uint32_t)n;
     const uint64_t bound = rans_amd_chunk_bound(format, chunk, n_ways);
     DeviceGuard guard(ctx->device);
     uint8_t *d_in = nullptr, *d_out = nullptr;
@@ -735,10 +762,6 @@ int rans_amd_encode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const v
         rc = hip_fail(e, "encode_host: device staging");
     if (rc == RANS_AMD_OK)
         rc = rans_amd_encode(ctx, model, d_in, n, n_ways, chunk, d_out, bound, d_off, d_len, &total, nullptr);
-    if (rc == RANS_AMD_OK && n == 0) {
-        // no chunk was produced: an empty input is still a valid stream of N flushed states
-        rc = fail(RANS_AMD_E_ARG, "encode_host: n == 0");
-    }
     if (rc == RANS_AMD_OK) {
         if (total > cap)
             rc = fail(RANS_AMD_E_SPACE, "encode_host: buffer too small");
@@ -760,8 +783,17 @@ int rans_amd_decode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const u
 {
     if (!ctx || !model || !stream_bytes || (n && !out))
         return fail(RANS_AMD_E_ARG, "decode_host: NULL argument");
-    if (n == 0 || n > 0xffffffffull - 64 || len > 0xffffffffull)
-        return fail(RANS_AMD_E_UNSUPPORTED, "decode_host: 1 <= n < 2^32 and len < 2^32 required");
+    if (n > 0xffffffffull - 64 || len > 0xffffffffull)
+        return fail(RANS_AMD_E_UNSUPPORTED, "decode_host: n < 2^32 and len < 2^32 required");
+    if (n == 0) { // the stream of an empty input: exactly the N initial states (see encode_host)
+        if (!ways_supported(model->host.format, n_ways))
+            return fail(RANS_AMD_E_UNSUPPORTED, "decode_host: n_ways must be in 1..512");
+        uint8_t want[512 * 8];
+        const uint64_t total = empty_stream(model->host.format, n_ways, want);
+        if (len != total || memcmp(want, stream_bytes, (size_t)total) != 0)
+            return fail(RANS_AMD_E_CORRUPT, "decode_host: n == 0 but the stream is not N untouched states");
+        return RANS_AMD_OK;
+    }
     const int sb = model->host.sym_bytes;
     DeviceGuard guard(ctx->device);
     uint8_t *d_in = nullptr, *d_out = nullptr;

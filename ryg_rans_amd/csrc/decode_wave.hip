@@ -279,7 +279,9 @@ __device__ __forceinline__ void renorm_byte_full(uint32_t &x, uint32_t &cur, uin
 // buffer_store_dword) sit in round 0, where the wave would otherwise wait for the slot record, and where
 // the wait states a DPP operand needs after a VALU write (2) are filled by instructions that have to be
 // issued anyway.  pa: in = the previous group's four symbols of this lane, out = this group's.
-// Temporaries are fixed registers (v56..v61) because the halves of a 64-bit asm operand cannot be named.
+// Temporaries are fixed registers (v56..v62) because the halves of a 64-bit asm operand cannot be named; the
+// store's data register (v62) is written nowhere else, so that nothing has to wait for the store to have read it
+// (with the data in v60, round 1's ds_read_b64 v[60:61] stalled every group: +15 % kernel time).
 // ---------------------------------------------------------------------------
 #define RANS_WORD_RENORM                                   \
     "v_cmpx_gt_u32_e32 vcc, %[lim], %[x]\n\t"              \
@@ -315,8 +317,8 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
             "s_waitcnt lgkmcnt(0)\n\t"
             "v_mad_u32_u24 %[x], v58, v57, v59\n\t"
             "v_mov_b32_dpp v60, v61 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_perm_b32 v60, v60, v61, %[sel2]\n\t"
-            "buffer_store_dword v60, %[ooff], %[orsrc], %[osoff] offen\n\t"
+            "v_perm_b32 v62, v60, v61, %[sel2]\n\t"
+            "buffer_store_dword v62, %[ooff], %[orsrc], %[osoff] offen\n\t"
             RANS_WORD_RENORM
             // ---- round 1
             RANS_WORD_LOOKUP("v[60:61]")
@@ -340,7 +342,7 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
             : [m12] "v"(m12), [lim] "v"(k65536), [sel1] "v"(sel1), [sel2] "v"(sel2), [selA] "v"(selA), [selB] "v"(selB),
               [selC] "v"(selC), [selm] "s"(0x05040100u), [orsrc] "s"(orsrc), [ooff] "v"(out_lane_off),
               [osoff] "s"(osoff_prev)
-            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61");
+            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
         // (The store is deliberately inside the sequence, in round 0.  The compiler does not see it, so the
         // s_waitcnt vmcnt(0) it puts in front of a window refill -- which happens after round 3 -- also waits
         // for this store; by then it is ~1000 cycles old and done.  A store the compiler knows about makes it
@@ -369,11 +371,33 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
             : [x] "+v"(x), [pa] "+v"(pa), [cur] "+s"(cur), [cnt] "=&s"(cnt)
             : [m12] "v"(m12), [lim] "v"(k65536), [selA] "v"(selA), [selB] "v"(selB), [selC] "v"(selC),
               [selm] "s"(0x05040100u)
-            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61");
+            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
     }
 }
 #undef RANS_WORD_RENORM
 #undef RANS_WORD_LOOKUP
+
+// First wave start .. last wave end of a launch (rans_amd_launch_spans): the block's waves leave their end
+// times in LDS (the tables there are dead by now), one thread folds them into the launch's record with two
+// atomics.  One pair per BLOCK: 8192 waves hammering two words cost ~80 us per launch (an L2 atomic unit
+// retires ~90 same-address atomics per microsecond).
+__device__ __forceinline__ void record_span(const DecParams &p, unsigned long long t_start, uint8_t *smem)
+{
+    if (!p.span)
+        return;
+    unsigned long long *ends = reinterpret_cast<unsigned long long *>(smem);
+    __syncthreads(); // every wave of the block is done with the tables
+    if ((threadIdx.x & 63u) == 0)
+        ends[threadIdx.x >> 6] = wall_clock64();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long last = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w)
+            last = ends[w] > last ? ends[w] : last;
+        atomicMax(p.span, ~t_start);
+        atomicMax(p.span + 1, last);
+    }
+}
 
 // byte `kSymByte` of `raw` goes to byte J of acc, the other bytes of acc stay
 template <int SYMBYTE, int J> __device__ __forceinline__ uint32_t acc_symbol(uint32_t raw, uint32_t acc)
@@ -674,10 +698,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         if (!all_good && lane == 0)
             atomicAdd(p.err_count, 1ull);
     }
-    if (p.span && lane == 0) { // first wave start .. last wave end of this launch (rans_amd_launch_spans)
-        atomicMax(p.span, ~t_start);
-        atomicMax(p.span + 1, wall_clock64());
-    }
+    record_span(p, t_start, smem);
     if (p.trace && lane == 0) { // per wave: start / end on the 100 MHz clock, XCD, shader cycles spent, rounds decoded
         unsigned long long *t = p.trace + (uint64_t)kTraceWords * ((uint64_t)blockIdx.x * waves_per_block + wave);
         t[0] = t_start;
@@ -904,10 +925,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
     }
 #undef RANS_STEP_CLAIM
 #undef RANS_STEP_DATA
-    if (p.span && lane == 0) {
-        atomicMax(p.span, ~t_start);
-        atomicMax(p.span + 1, wall_clock64());
-    }
+    record_span(p, t_start, smem);
     if (p.trace && lane == 0) {
         unsigned long long *t = p.trace + (uint64_t)kTraceWords * ((uint64_t)blockIdx.x * waves_per_block + wave);
         t[0] = t_start;

@@ -155,7 +155,13 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
     cum.assign(ns + 1, 0);
     uint64_t run = 0;
     for (uint32_t s = 0; s < ns; ++s) {
-        if (freqs[s] >= M) // one-symbol model, or garbage
+        if (freqs[s] > M) // garbage
+            return RANS_AMD_E_MODEL;
+        // A one-symbol model (freq == M) is inside the working range of the byte, alias and rans64 coders
+        // (rans_byte.h:176-178, rans64.h:169-171: x_max = 2^31 resp. 2^63 is never reached, C and D are the
+        // identity, the stream is the N flushed states).  In the word format the 32-bit renormalisation
+        // threshold wraps to 0 for freq == 4096 (rans_word_sse41.h:85): rejected.
+        if (freqs[s] == M && fmt == RANS_AMD_FMT_WORD)
             return RANS_AMD_E_MODEL;
         run += freqs[s];
         if (run > M)

@@ -108,8 +108,8 @@ def test_tiny_and_ragged_sizes(gpu, oracle, n):
     R, ctx, torch = gpu
     data = oracle.gen_zipf(5000, K=256, s=1.0, seed=3)[:n]
     for fmt, sb in FORMATS:
-        if len(np.unique(data)) < 2:
-            continue  # one-symbol model is rejected (freq == M)
+        if len(np.unique(data)) < 2 and fmt == FMT_WORD:
+            continue  # a one-symbol model is rejected by the word format only (freq == M wraps its threshold)
         om, gm = _models(R, ctx, oracle, fmt, sb, data)
         for n_ways in (64, 256, 3):
             want = oracle.encode(fmt, om, data, n_ways)
@@ -444,3 +444,79 @@ def test_model_may_outlive_its_context(gpu, oracle):
     cont, offs, lens, total = ctx.encode(gm, torch.from_numpy(data).cuda(), 64, 4096)
     out = ctx.decode(gm, cont, total, offs, lens, data.size, 64, 4096)
     assert np.array_equal(out.cpu().numpy(), data)
+
+
+def _ref_or_none():
+    from _oracle import Ref
+    return Ref() if Ref.available() else None
+
+
+def test_empty_input_is_n_flushed_states(gpu, oracle):
+    """n == 0: the reference's loops run zero times and flush N untouched states (rans_byte.h:93-105 etc.);
+    the host entry points produce and accept exactly that stream."""
+    R, ctx, torch = gpu
+    ref = _ref_or_none()
+    data = oracle.gen_zipf(1000, K=256, s=1.0, seed=1)
+    empty = np.zeros(0, np.uint8)
+    for fmt, sb in FORMATS:
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        for n_ways in (1, 2, 64, 100, 512):
+            want = oracle.encode(fmt, om, empty, n_ways)
+            if ref is not None and n_ways <= 64:
+                assert np.array_equal(ref.encode(fmt, om.freqs, sb, empty, n_ways), want)
+            got = ctx.encode_host(gm, empty, n_ways)
+            assert np.array_equal(got, want), (fmt, n_ways)
+            assert ctx.decode_host(gm, want, 0, n_ways).size == 0
+            bad = want.copy()
+            bad[-1] ^= 1
+            out, rc = ctx.decode_host(gm, bad, 0, n_ways, check=False)
+            assert rc == R.E_CORRUPT
+    # the bulk entry points: zero chunks, zero bytes
+    gm = ctx.model(FMT_WORD, oracle.normalize(oracle.count_freqs(data, 256), 4096)[0], 12)
+    cont, offs, lens, total = ctx.encode(gm, torch.zeros(0, dtype=torch.uint8, device="cuda"), 64, 4096)
+    assert total == 0
+
+
+def test_single_symbol_models(gpu, oracle):
+    """freq == M (a constant input, which the reference's mains compress): inside the working range of the byte,
+    alias and rans64 coders (rans_byte.h:176-178, rans64.h:169-171) -- the state never moves, the stream is the
+    flushed states -- and bit-exact here; the word format's threshold wraps: E_MODEL."""
+    R, ctx, torch = gpu
+    ref = _ref_or_none()
+    n = 70001
+    for fmt, sb, nsyms, sym in ((FMT_BYTE, 14, 256, 65), (FMT_BYTE, 8, 256, 0), (FMT_BYTE, 16, 256, 255),
+                                (FMT_R64, 14, 256, 7), (FMT_R64, 16, 256, 200), (FMT_ALIAS, 16, 256, 3),
+                                (FMT_ALIAS, 12, 4096, 4095)):
+        f = np.zeros(nsyms, np.uint32)
+        f[sym] = 1 << sb
+        data = np.full(n, sym, np.uint8 if nsyms <= 256 else np.uint16)
+        om = oracle.model(f, sb, with_alias=(fmt == FMT_ALIAS))
+        gm = ctx.model(fmt, f, sb)
+        for n_ways in (1, 2, 64, 100, 256):
+            want = oracle.encode(fmt, om, data, n_ways)
+            if ref is not None and n_ways <= 2 and nsyms == 256:
+                assert np.array_equal(ref.encode(fmt, f, sb, data, n_ways), want)
+            assert np.array_equal(ctx.encode_host(gm, data, n_ways), want), (fmt, sb, n_ways)
+            assert np.array_equal(ctx.decode_host(gm, want, n, n_ways), data), (fmt, sb, n_ways)
+        # chunked, and a stray other symbol is still E_MODEL
+        d = torch.from_numpy(data.view(np.int16) if data.dtype == np.uint16 else data).cuda()
+        for n_ways, chunk in ((64, 4096), (2, 512)):
+            want, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+            cont, d_offs, d_lens, total = ctx.encode(gm, d, n_ways, chunk)
+            assert total == want.size and np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens)
+            got = cont[:total].cpu().numpy()
+            for c in (0, len(lens) // 2, len(lens) - 1):
+                o, ln = int(offs[c]), int(lens[c])
+                assert np.array_equal(got[o:o + ln], want[o:o + ln]), (fmt, sb, n_ways, c)
+            out = ctx.decode(gm, cont, total, d_offs, d_lens, n, n_ways, chunk)
+            assert torch.equal(out, d)
+        bad = data.copy()
+        bad[1234] = (sym + 1) % nsyms
+        with pytest.raises(R.RansAmdError) as e:
+            ctx.encode_host(gm, bad, 64)
+        assert e.value.status == R.E_MODEL
+    f = np.zeros(256, np.uint32)
+    f[9] = 4096
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.model(FMT_WORD, f, 12)
+    assert e.value.status == R.E_MODEL
