@@ -83,6 +83,7 @@ struct rans_amd_ctx {
     DeviceBuffer lengths;   // encode lengths when the caller passes none
     DeviceBuffer hist;
     DeviceBuffer layout_sums; // per-block totals of the offset scan (many-chunk containers)
+    DeviceBuffer wave_scratch; // one 64-byte line per resident decoder wave (DecParams::wave_scratch)
     DeviceBuffer trace;       // per-wave clock records (rans_amd_set_timing(ctx, 2) / RANS_AMD_TRACE)
     rans_amd_wave_clocks wave_clocks = {0, 0, 0, 0.0, 0.0};
     bool wave_clocks_on = false;
@@ -241,6 +242,7 @@ int rans_amd_ctx_destroy(rans_amd_ctx *ctx)
     ctx->hist.release();
     ctx->layout_sums.release();
     ctx->trace.release();
+    ctx->wave_scratch.release();
     if (ctx->d_words)
         (void)hipFree(ctx->d_words);
     for (int i = 0; i < 4; ++i)
@@ -353,6 +355,13 @@ int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_fr
         break;
     }
     case RANS_AMD_FMT_ALIAS:
+        // the device packs a half bucket's frequency into 16 bits: 65536 (one symbol owning the whole 16-bit
+        // range) does not fit; such a model exists as a host-only model, or at scale_bits <= 15
+        for (uint32_t f : h.slot_freqs)
+            if (f > 0xffffu)
+                rc = fail(RANS_AMD_E_UNSUPPORTED, "model_create: alias model with a 65536-wide symbol (use scale_bits <= 15)");
+        if (rc)
+            break;
         m->table0_bytes = (uint32_t)(h.alias_halves.size() * sizeof(AliasHalf));
         rc = upload(h.alias_halves.data(), m->table0_bytes, &m->d_table0);
         if (rc == RANS_AMD_OK) {
@@ -625,14 +634,25 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         dp.work_counter_reset = nullptr;
         dp.span = nullptr;
         dp.span_reset = nullptr;
+        {   // (small, allocated once, kept: not part of what rans_amd_ctx_trim drops)
+            int wrc = ctx->wave_scratch.reserve((size_t)ctx->num_cus * 2u * (kDecBlockThreads / 64) * 64u);
+            if (wrc)
+                return wrc;
+            dp.wave_scratch = static_cast<uint8_t *>(ctx->wave_scratch.ptr);
+        }
+        static const char *debug_env = getenv("RANS_AMD_DEBUG"); // measurement knobs, see kernels.h
+        dp.debug = debug_env ? (uint32_t)strtoul(debug_env, nullptr, 0) : 0u;
         if (!static_sched && nchunks < 0xffffffffull) {
             unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);
             const uint32_t per_slot = kWorkSlotWords;
             dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * per_slot;
             dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * per_slot;
             // the slot's last line: first wave start / last wave end of the launch (rans_amd_launch_spans)
-            dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
-            dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
+            static const bool no_span = getenv("RANS_AMD_NO_SPAN") != nullptr; // A/B: cost of the span record
+            if (!no_span) {
+                dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
+                dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
+            }
         }
         // wave clocks (rans_amd_set_timing(ctx, 2)) and the debug timeline (RANS_AMD_TRACE=<file>): per-wave
         // start/end ticks, XCD, shader cycles and rounds, read back after a sync

@@ -62,7 +62,10 @@ namespace {
 constexpr uint32_t kMaxAdvance = 512;
 static_assert(kRingMirror >= kMaxAdvance + 256, "mirror must cover one checkpoint interval plus one sub-step");
 constexpr uint32_t kRsrcFlags = 0x00020000u; // raw buffer, 32-bit data format (gfx9 family)
-constexpr int kAuxNt = 2;                    // non-temporal: every stream byte is read exactly once
+#ifndef RANS_LOAD_AUX
+#define RANS_LOAD_AUX 2
+#endif
+constexpr int kAuxNt = RANS_LOAD_AUX;        // 2 = non-temporal: every stream byte is read exactly once
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
@@ -132,7 +135,15 @@ struct StreamWindow {
         put(lane, 0, b0);
         put(lane, kRingBlock, b1);
     }
-    __device__ __forceinline__ void checkpoint(uint32_t lane)
+    // kMarker (the hand-scheduled decoders, whose symbol stores sit inside asm statements the compiler cannot see):
+    // the compiler would wait for the prefetched block with s_waitcnt vmcnt(0) -- it knows of no younger VMEM
+    // operation -- and so for every symbol store in flight as well, the newest one included; under a saturated
+    // memory system that is a stall per refill.  A 4-byte marker store the compiler DOES see, issued right behind
+    // each prefetch, makes it count vmcnt(1): the prefetch and everything older must have landed, the newest
+    // operation (in reality: the newest symbol store) may still be on its way.  Only lane 0's marker is in range
+    // of its descriptor (4 records): the hardware drops the other 63, no branch.
+    rsrc_t marker_rsrc;
+    template <bool kMarker = false> __device__ __forceinline__ void checkpoint(uint32_t lane)
     {
         if (cur >= mark) { // wave-uniform: a scalar compare + branch
             if (mark == ring_addr + kRingBlock) {
@@ -145,6 +156,8 @@ struct StreamWindow {
                 mark = ring_addr + kRingBlock;
             }
             pre = fetch(lane);
+            if constexpr (kMarker)
+                __builtin_amdgcn_raw_buffer_store_b32(gnext, marker_rsrc, lane * 4u, 0, 0);
         }
     }
     // ring offset of the read cursor (no wrap between checkpoints)
@@ -301,6 +314,31 @@ __device__ __forceinline__ void renorm_byte_full(uint32_t &x, uint32_t &cur, uin
     "ds_read_b64 " E ", v56\n\t"                           \
     "v_lshrrev_b32_e32 v57, 12, %[x]\n\t"
 
+// Code placement (experiment knob, see DESIGN): RANS_GROUP_ALIGN = log2 of the alignment of the sequence's
+// first instruction (padding is s_nop, executed once per group), RANS_GROUP_PAD = extra 4-byte s_nops after it.
+#ifndef RANS_GROUP_ALIGN
+#define RANS_GROUP_ALIGN 0
+#endif
+#ifndef RANS_GROUP_PAD
+#define RANS_GROUP_PAD 0
+#endif
+#define RANS_STR2(x) #x
+#define RANS_STR(x) RANS_STR2(x)
+#if RANS_GROUP_PAD == 1
+#define RANS_GROUP_HEAD ".p2align " RANS_STR(RANS_GROUP_ALIGN) "\n\ts_nop 0\n\t"
+#else
+#define RANS_GROUP_HEAD ".p2align " RANS_STR(RANS_GROUP_ALIGN) "\n\t"
+#endif
+
+// Cache policy of the symbol stores: non-temporal, system scope -- decoded symbols are written once and not
+// read back by this kernel, so they should stream through instead of sitting dirty in L2 / Infinity Cache until the
+// next launch has to push them out.  Measured on the headline workload (1 GiB, sustained launches): plain stores
+// 0.438 ms, nt 0.412, sc1 0.422, nt sc1 0.409 (the policy of the stream LOADS makes no difference).
+#ifndef RANS_STORE_MODS
+#define RANS_STORE_MODS " nt sc1"
+#endif
+constexpr int kAuxStore = 2 | 16; // the same for stores issued through builtins: nt | sc1
+
 template <bool kStorePrev>
 __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uint32_t &cur, uint32_t m12,
                                                   uint32_t k65536, uint32_t sel1, uint32_t sel2, uint32_t selA,
@@ -310,15 +348,26 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
     uint32_t cnt;
     if constexpr (kStorePrev) {
         asm volatile(
+            RANS_GROUP_HEAD
             // ---- round 0 (+ the previous group's transposition and store)
             RANS_WORD_LOOKUP("v[58:59]")
+#ifdef RANS_OLD_TEMPS
+            "v_mov_b32_dpp v62, %[pa] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_perm_b32 v63, v62, %[pa], %[sel1]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mad_u32_u24 %[x], v58, v57, v59\n\t"
+            "v_mov_b32_dpp v62, v63 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_perm_b32 v62, v62, v63, %[sel2]\n\t"
+            "buffer_store_dword v62, %[ooff], %[orsrc], %[osoff] offen\n\t"
+#else
             "v_mov_b32_dpp v60, %[pa] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
             "v_perm_b32 v61, v60, %[pa], %[sel1]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "v_mad_u32_u24 %[x], v58, v57, v59\n\t"
             "v_mov_b32_dpp v60, v61 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
             "v_perm_b32 v62, v60, v61, %[sel2]\n\t"
-            "buffer_store_dword v62, %[ooff], %[orsrc], %[osoff] offen\n\t"
+            "buffer_store_dword v62, %[ooff], %[orsrc], %[osoff] offen" RANS_STORE_MODS "\n\t"
+#endif
             RANS_WORD_RENORM
             // ---- round 1
             RANS_WORD_LOOKUP("v[60:61]")
@@ -342,7 +391,11 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
             : [m12] "v"(m12), [lim] "v"(k65536), [sel1] "v"(sel1), [sel2] "v"(sel2), [selA] "v"(selA), [selB] "v"(selB),
               [selC] "v"(selC), [selm] "s"(0x05040100u), [orsrc] "s"(orsrc), [ooff] "v"(out_lane_off),
               [osoff] "s"(osoff_prev)
-            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
+            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62"
+#ifdef RANS_OLD_TEMPS
+              , "v63"
+#endif
+            );
         // (The store is deliberately inside the sequence, in round 0.  The compiler does not see it, so the
         // s_waitcnt vmcnt(0) it puts in front of a window refill -- which happens after round 3 -- also waits
         // for this store; by then it is ~1000 cycles old and done.  A store the compiler knows about makes it
@@ -371,11 +424,23 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
             : [x] "+v"(x), [pa] "+v"(pa), [cur] "+s"(cur), [cnt] "=&s"(cnt)
             : [m12] "v"(m12), [lim] "v"(k65536), [selA] "v"(selA), [selB] "v"(selB), [selC] "v"(selC),
               [selm] "s"(0x05040100u)
-            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
+            : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62"
+#ifdef RANS_OLD_TEMPS
+              , "v63"
+#endif
+            );
     }
 }
 #undef RANS_WORD_RENORM
 #undef RANS_WORD_LOOKUP
+
+// Descriptor of this wave's marker word (StreamWindow::checkpoint<true>): 4 records, i.e. lane 0 only.
+__device__ __forceinline__ rsrc_t marker_rsrc(const DecParams &p, uint32_t wave_in_grid)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(uniform64(reinterpret_cast<uint64_t>(p.wave_scratch) + (uint64_t)uniform(wave_in_grid) * 64u)),
+        0, p.wave_scratch ? 4u : 0u, kRsrcFlags);
+}
 
 // First wave start .. last wave end of a launch (rans_amd_launch_spans): the block's waves leave their end
 // times in LDS (the tables there are dead by now), one thread folds them into the launch's record with two
@@ -582,8 +647,8 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
             const uint32_t groups = rounds >> 2;
             if (groups) {
                 const uint64_t dsta = reinterpret_cast<uint64_t>(dst);
-                const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu, uniform(nsym),
-                                     kRsrcFlags};
+                const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu,
+                                     (p.debug & 1u) ? 0u : uniform(nsym), kRsrcFlags};
                 uint32_t selA = 0x03020703u, selB = 0x03070100u, selC = 0x07020100u; // acc_symbol<3, 1..3>
                 uint32_t k65536 = 0x10000u, m12 = 0xfffu;
                 asm volatile("v_mov_b32 %0, %0" : "+v"(selA)); // opaque: live in VGPRs, never rematerialised in the loop
@@ -592,13 +657,14 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                 asm volatile("v_mov_b32 %0, %0" : "+v"(k65536));
                 asm volatile("v_mov_b32 %0, %0" : "+v"(m12));
                 uint32_t pa = 0;
-                W.checkpoint(lane);
+                W.marker_rsrc = marker_rsrc(p, blockIdx.x * waves_per_block + wave);
+                W.template checkpoint<true>(lane);
                 decode_group_word<false>(x[0], pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc,
                                          out_lane_off, 0u);
                 const uint32_t oend = (groups - 1u) * 256u;
                 uint32_t osoff = 0;
                 for (; osoff != oend; osoff += 256u) {
-                    W.checkpoint(lane);
+                    W.template checkpoint<true>(lane);
                     decode_group_word<true>(x[0], pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc,
                                             out_lane_off, osoff);
                 }
@@ -653,7 +719,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const uint32_t v = quad_transpose(acc[k], sel1, sel2);
-                        __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, out_lane_off + k * 64u, osoff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, out_lane_off + k * 64u, osoff, kAuxStore);
                     }
                 }
                 gdst += 4u * N;
@@ -698,7 +764,6 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         if (!all_good && lane == 0)
             atomicAdd(p.err_count, 1ull);
     }
-    record_span(p, t_start, smem);
     if (p.trace && lane == 0) { // per wave: start / end on the 100 MHz clock, XCD, shader cycles spent, rounds decoded
         unsigned long long *t = p.trace + (uint64_t)kTraceWords * ((uint64_t)blockIdx.x * waves_per_block + wave);
         t[0] = t_start;
@@ -707,6 +772,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         t[3] = __builtin_readcyclecounter() - c_start;
         t[4] = rounds_done;
     }
+    record_span(p, t_start, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -867,10 +933,11 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
 
         if (groups) {
             const uint64_t dsta = reinterpret_cast<uint64_t>(dst);
-            const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu, uniform(nsym),
-                                 kRsrcFlags};
+            const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu,
+                                 (p.debug & 1u) ? 0u : uniform(nsym), kRsrcFlags};
             uint32_t pa = 0;
-            W.checkpoint(lane);
+            W.marker_rsrc = marker_rsrc(p, blockIdx.x * waves_per_block + wave);
+            W.template checkpoint<true>(lane);
             decode_group_word<false>(x, pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc, out_lane_off, 0u);
             // groups 1 .. groups-1 store their predecessor's symbols; osoff = 256 * (group - 1).  One scalar
             // compare per group watches for the point where the next step of the hand-over is due.
@@ -887,7 +954,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
                     }
                     ++stage;
                 }
-                W.checkpoint(lane);
+                W.template checkpoint<true>(lane);
                 decode_group_word<true>(x, pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc, out_lane_off, osoff);
             }
             const uint32_t v = quad_transpose(pa, sel1, sel2);
@@ -925,7 +992,6 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
     }
 #undef RANS_STEP_CLAIM
 #undef RANS_STEP_DATA
-    record_span(p, t_start, smem);
     if (p.trace && lane == 0) {
         unsigned long long *t = p.trace + (uint64_t)kTraceWords * ((uint64_t)blockIdx.x * waves_per_block + wave);
         t[0] = t_start;
@@ -934,6 +1000,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
         t[3] = __builtin_readcyclecounter() - c_start;
         t[4] = rounds_done;
     }
+    record_span(p, t_start, smem);
 }
 
 hipError_t launch_decode_word64(const DecParams &p, int num_cus, hipStream_t stream, const char **name)

@@ -43,6 +43,9 @@ struct DecParams {
     unsigned long long *err_count; // failed chunks (device counter)
     unsigned int *work_counter;    // next chunk to hand out (zero at launch); NULL = static striding
     unsigned int *work_counter_reset; // a counter slot of a LATER launch that this launch zeroes
+    uint8_t *wave_scratch;            // one 64-byte line per resident wave (marker stores of the window refills), or NULL
+    uint32_t debug;                   // measurement knobs (RANS_AMD_DEBUG): bit 0 = drop the symbol stores of the
+                                      // 64-way word decoders (their descriptor gets zero records)
     unsigned long long *span;         // this launch's {max of ~(wave start), max of wave end} in 100 MHz ticks, or NULL
     unsigned long long *span_reset;   // the span record of a LATER launch that this launch zeroes
     unsigned long long *trace;        // wave clocks: per wave kTraceWords words {start, end (100 MHz ticks), xcc,

@@ -108,8 +108,8 @@ def test_tiny_and_ragged_sizes(gpu, oracle, n):
     R, ctx, torch = gpu
     data = oracle.gen_zipf(5000, K=256, s=1.0, seed=3)[:n]
     for fmt, sb in FORMATS:
-        if len(np.unique(data)) < 2 and fmt == FMT_WORD:
-            continue  # a one-symbol model is rejected by the word format only (freq == M wraps its threshold)
+        if len(np.unique(data)) < 2 and (fmt == FMT_WORD or (fmt == FMT_ALIAS and sb == 16)):
+            continue  # one-symbol models: the word format rejects them, the device alias tables stop at scale_bits 15
         om, gm = _models(R, ctx, oracle, fmt, sb, data)
         for n_ways in (64, 256, 3):
             want = oracle.encode(fmt, om, data, n_ways)
@@ -485,7 +485,7 @@ def test_single_symbol_models(gpu, oracle):
     ref = _ref_or_none()
     n = 70001
     for fmt, sb, nsyms, sym in ((FMT_BYTE, 14, 256, 65), (FMT_BYTE, 8, 256, 0), (FMT_BYTE, 16, 256, 255),
-                                (FMT_R64, 14, 256, 7), (FMT_R64, 16, 256, 200), (FMT_ALIAS, 16, 256, 3),
+                                (FMT_R64, 14, 256, 7), (FMT_R64, 16, 256, 200), (FMT_ALIAS, 15, 256, 3),
                                 (FMT_ALIAS, 12, 4096, 4095)):
         f = np.zeros(nsyms, np.uint32)
         f[sym] = 1 << sb
@@ -520,3 +520,9 @@ def test_single_symbol_models(gpu, oracle):
     with pytest.raises(R.RansAmdError) as e:
         ctx.model(FMT_WORD, f, 12)
     assert e.value.status == R.E_MODEL
+    # the device's alias records hold a half bucket's frequency in 16 bits: a 65536-wide symbol is a host-only model
+    f[9] = 65536
+    R.Model(None, FMT_ALIAS, f, 16)
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.model(FMT_ALIAS, f, 16)
+    assert e.value.status == R.E_UNSUPPORTED
