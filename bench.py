@@ -55,9 +55,11 @@ def parse_args():
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
                     help="setup: run the decoder this long before the warm-up steps (clocks settle); 0 = off")
     ap.add_argument("--dump-launch-ms", action="store_true", help="add the per-launch HIP-event times to the JSON line")
-    ap.add_argument("--debug-same-chunk", action="store_true",
-                    help="measurement aid: every index entry points at chunk 0 (stream reads come from cache); the "
-                         "round trip check is skipped and the line says so")
+    ap.add_argument("--debug-out-offset", type=int, default=0, help="measurement aid: shift the output buffer (bytes, multiple of 16)")
+    ap.add_argument("--debug-cont-offset", type=int, default=0, help="measurement aid: shift the container (bytes, multiple of 16)")
+    ap.add_argument("--debug-same-chunk", type=int, default=0, metavar="K",
+                    help="measurement aid: index entry c points at chunk c mod K (stream reads come from cache); the "
+                         "round trip check is skipped")
     ap.add_argument("--config-steps", type=int, default=20, help="back-to-back launches per `configs` entry")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device", type=int, default=None,
@@ -339,11 +341,16 @@ def main():
     freqs, _ = R.normalize_freqs(counts, 1 << sb)
     model = ctx.model(fmt, freqs, sb)
     cont, offs, lens, total = ctx.encode(model, d_syms, args.ways, args.chunk)
-    out = torch.empty(n, dtype=torch.uint8, device=device)
+    out = torch.empty(n + args.debug_out_offset, dtype=torch.uint8, device=device)[args.debug_out_offset:]
+    if args.debug_cont_offset:
+        moved = torch.empty(cont.numel() + args.debug_cont_offset, dtype=torch.uint8, device=device)[args.debug_cont_offset:]
+        moved[:total] = cont[:total]
+        cont = moved
     if args.debug_same_chunk:
-        offs = torch.zeros_like(offs)
-        offs[-1] = total
-        lens = torch.full_like(lens, int(lens[0].item()))
+        k = args.debug_same_chunk
+        idx = torch.arange(lens.numel(), device=device) % k
+        offs = torch.cat([offs[:-1][idx], offs[-1:]])
+        lens = lens[idx].contiguous()
     torch.cuda.synchronize()
 
     def step():

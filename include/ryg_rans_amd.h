@@ -135,10 +135,14 @@ int rans_amd_normalize_freqs(uint32_t *freqs, uint32_t *cum_freqs, uint32_t nsym
  * frequencies (sum == 1<<scale_bits) and upload them.
  *   BYTE : cum2sym[M] + RansDecSymbol/RansEncSymbol per symbol   (scale_bits <= 16)
  *   WORD : RansWordTables slots                                  (scale_bits == 12, nsyms <= 256)
- *   R64  : cum2sym[M] + Rans64Dec/EncSymbol                      (scale_bits <= 16 on the GPU path)
+ *   R64  : cum2sym[M] + Rans64Dec/EncSymbol                      (scale_bits 7..16: table decoder; 1..6 and
+ *          17..31: no 2^scale_bits table, the kernels search the cumulative frequencies -- same stream, slower)
  *   ALIAS: divider/slot_adjust/slot_freqs/sym_id (+alias_remap)  (nsyms a power of two dividing M)
- * A model in which one symbol owns the whole range (freq == M) is rejected with
- * RANS_AMD_E_MODEL (outside the reference's working range).
+ * A model in which one symbol owns the whole range (freq == M) is accepted by the byte, alias and rans64
+ * coders as the reference accepts it (rans_byte.h:176-178, rans64.h:169-171: the state never moves, the
+ * stream is the flushed initial states); the word format rejects it with RANS_AMD_E_MODEL (its 32-bit
+ * renormalisation threshold wraps to 0), and an alias model holding a 65536-wide symbol
+ * (scale_bits 16) exists as a host-only model only (RANS_AMD_E_UNSUPPORTED with a context).
  * ctx may be NULL: the model is then host-only (its tables can be exported with
  * rans_amd_model_table, encode/decode reject it with RANS_AMD_E_ARG). */
 int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_freqs, uint32_t nsyms,

@@ -339,6 +339,19 @@ int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_fr
         break;
     case RANS_AMD_FMT_BYTE:
     case RANS_AMD_FMT_R64: {
+        if (h.r64_search) { // table0 = padded cum[], table1 = {freq, start} per symbol
+            if (h.sym_bytes != 1) {
+                rc = fail(RANS_AMD_E_UNSUPPORTED, "rans64 decoders support alphabets up to 256 symbols");
+                break;
+            }
+            m->table0_bytes = (uint32_t)(h.cum_padded.size() * 4);
+            rc = upload(h.cum_padded.data(), m->table0_bytes, &m->d_table0);
+            if (rc == RANS_AMD_OK) {
+                m->table1_bytes = (uint32_t)(h.sym_recs.size() * sizeof(SymRec));
+                rc = upload(h.sym_recs.data(), m->table1_bytes, &m->d_table1);
+            }
+            break;
+        }
         if (h.sym_bytes != 1) { // u16 cum2sym does not fit beside the stream windows; use FMT_ALIAS
             rc = fail(RANS_AMD_E_UNSUPPORTED, "cum2sym decoders support alphabets up to 256 symbols");
             break;
@@ -538,7 +551,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         ep.scale_bits = model->host.scale_bits;
         ep.sym_bytes = (uint32_t)model->host.sym_bytes;
         ep.flags = ctx->d_enc_flags();
-        HIP_TRY(launch_encode(format, ep, ctx->num_cus, s));
+        HIP_TRY(launch_encode(model->host.r64_search ? kKernelFormatR64Search : format, ep, ctx->num_cus, s));
     }
     LayoutParams lp;
     lp.lengths = d_lengths;
@@ -622,6 +635,11 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         dp.table1_bytes = model->table1_bytes;
         dp.scale_bits = model->host.scale_bits;
         dp.log2nsyms = model->host.log2nsyms;
+        if (model->host.r64_search) { // log2 of the padded cum table
+            dp.log2nsyms = 0;
+            while ((1u << dp.log2nsyms) < model->host.cum_padded.size())
+                dp.log2nsyms++;
+        }
         dp.sym_bytes = (uint32_t)model->host.sym_bytes;
         dp.err_count = ctx->d_err();
         // dynamic chunk hand-out: a 4-byte counter zeroed in stream order ahead of the kernel
@@ -669,7 +687,8 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         }
         if (ctx->timing)
             HIP_TRY(hipEventRecord(ctx->ev[0], s));
-        HIP_TRY(launch_decode(format, dp, ctx->num_cus, s, &ctx->last_kernel));
+        HIP_TRY(launch_decode(model->host.r64_search ? kKernelFormatR64Search : format, dp, ctx->num_cus, s,
+                              &ctx->last_kernel));
         // the launch that uses slot i zeroes slot i + 32: move on only once it really is in the stream,
         // or a later launch would start from a counter nobody reset
         if (dp.work_counter)

@@ -143,6 +143,7 @@ struct StreamWindow {
     // operation (in reality: the newest symbol store) may still be on its way.  Only lane 0's marker is in range
     // of its descriptor (4 records): the hardware drops the other 63, no branch.
     rsrc_t marker_rsrc;
+    u32x4 rsrc4; // the stream descriptor once more, as the four words an asm operand can take (RANS_TOUCH_AHEAD)
     template <bool kMarker = false> __device__ __forceinline__ void checkpoint(uint32_t lane)
     {
         if (cur >= mark) { // wave-uniform: a scalar compare + branch
@@ -156,8 +157,16 @@ struct StreamWindow {
                 mark = ring_addr + kRingBlock;
             }
             pre = fetch(lane);
-            if constexpr (kMarker)
+            if constexpr (kMarker) {
+#ifdef RANS_TOUCH_AHEAD // (experiment) pull the block AFTER the one just requested into L2: one dword per 16 bytes,
+                        // into a register nobody reads; invisible to the compiler, never waited for on its own
+                asm volatile("buffer_load_dword v63, %0, %1, 0 offen" ::"v"(gnext + lane * 16u), "s"(rsrc4) : "v63", "memory");
+#endif
                 __builtin_amdgcn_raw_buffer_store_b32(gnext, marker_rsrc, lane * 4u, 0, 0);
+#ifdef RANS_TWO_MARKERS // (experiment: vmcnt(2), i.e. the two newest operations may stay in flight)
+                __builtin_amdgcn_raw_buffer_store_b32(gnext, marker_rsrc, lane * 4u, 0, 0);
+#endif
+            }
         }
     }
     // ring offset of the read cursor (no wrap between checkpoints)
@@ -184,7 +193,7 @@ __device__ __forceinline__ uint32_t dec_renorm(const StreamWindow &W, typename F
         const uint32_t w = *reinterpret_cast<const uint16_t *>(W.ring + at);
         x = need ? ((x << 16) | w) : x;
         return 2u * (uint32_t)__builtin_popcountll(m);
-    } else if constexpr (FMT == FMT_R64) {
+    } else if constexpr (kIsR64<FMT>) {
         // rans64.h:305-316
         const bool need = active && x < (1ull << 31);
         const uint64_t m = __builtin_amdgcn_ballot_w64(need);
@@ -581,7 +590,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
             const uint32_t idx = k * 64u + lane;
             x[k] = Tr::kL;
             if (idx < N) {
-                if constexpr (FMT == FMT_R64) {
+                if constexpr (kIsR64<FMT>) {
                     const u32x2 v = *(reinterpret_cast<const u32x2 RANS_GLOBAL *>(src) + idx);
                     x[k] = (uint64_t)v.x | ((uint64_t)v.y << 32);
                 } else {
@@ -602,7 +611,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         const uint32_t tail = uniform(nsym - rounds * N);
         uint32_t r = 0;
         // sub-steps between two window checkpoints: at most kMaxAdvance bytes are consumed
-        constexpr int kCheckEvery = (FMT == FMT_R64) ? 2 : 4;
+        constexpr int kCheckEvery = kIsR64<FMT> ? 2 : 4;
 
         if constexpr (OUT == OUT_FAST16) {
             // ---- pairs of full rounds, u16 symbols: lane 2i ends up with round r's symbols of
@@ -635,7 +644,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                 for (int k = 0; k < K; ++k) {
                     const uint32_t o = quad_perm<1, 0, 3, 2>(acc[k]);
                     const uint32_t v = __builtin_amdgcn_perm(o, acc[k], sel16);
-                    *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + (lane_off16 + k * 128u)) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + (lane_off16 + k * 128u)));
                 }
                 gdst += 4u * N;
             }
@@ -669,7 +678,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                                             out_lane_off, osoff);
                 }
                 const uint32_t v = quad_transpose(pa, sel1, sel2);
-                *reinterpret_cast<uint32_t RANS_GLOBAL *>(dst + osoff + out_lane_off) = v;
+                __builtin_nontemporal_store(v, reinterpret_cast<uint32_t RANS_GLOBAL *>(dst + osoff + out_lane_off));
             }
             r = groups << 2;
         } else
@@ -714,7 +723,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                 if constexpr (OUT == OUT_FAST8_LDS) {
                     // LDS ops of one wave execute in order: the read sees the four writes
                     const uint32_t v = reinterpret_cast<const uint32_t *>(tile)[lane];
-                    *reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + lane * 4u) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + lane * 4u));
                 } else if constexpr (OUT != OUT_FAST8_BYTE) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
@@ -788,7 +797,11 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 // so the switch itself is two LDS block writes.  Claims are made late on purpose: a claimed chunk is work
 // committed to this wave, and the slow (young) waves of a SIMD should not sit on chunks at the end.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kClaimAhead = 10, kDataAhead = 5; // in groups of 4 rounds
+#ifndef RANS_CLAIM_AHEAD
+#define RANS_CLAIM_AHEAD 10
+#define RANS_DATA_AHEAD 5
+#endif
+constexpr uint32_t kClaimAhead = RANS_CLAIM_AHEAD, kDataAhead = RANS_DATA_AHEAD; // in groups of 4 rounds
 
 // buffer descriptor of one 64-way word chunk's stream (StreamWindow::stream_rsrc): what may be fetched is the
 // chunk's length rounded up to the 16-byte granule, clipped to the container's last granule
@@ -919,6 +932,15 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
         const uint32_t c_len = uniform(n_len);
         StreamWindow W;
         W.install(ring, chunk_rsrc(cbase, cbytes16, n_off, n_len), N * Tr::kStateBytes, lane, n_b0, n_b1);
+#ifdef RANS_TOUCH_AHEAD
+        {
+            const uint64_t sa = cbase + uniform64(n_off) + N * Tr::kStateBytes;
+            const uint64_t room = cbytes16 - uniform64(n_off);
+            const uint32_t climit = (uniform(n_len) + 15u) & ~15u;
+            W.rsrc4 = u32x4{uniform((uint32_t)sa), uniform((uint32_t)(sa >> 32)) & 0xffffu,
+                            (climit < room ? climit : (uint32_t)room) - N * Tr::kStateBytes, kRsrcFlags};
+        }
+#endif
         uint32_t x = n_x;
         const uint64_t first_sym = c_idx * p.chunk_syms;
         const uint32_t nsym = uniform((uint32_t)((p.n - first_sym) < p.chunk_syms ? (p.n - first_sym) : p.chunk_syms));
@@ -958,7 +980,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
                 decode_group_word<true>(x, pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc, out_lane_off, osoff);
             }
             const uint32_t v = quad_transpose(pa, sel1, sel2);
-            *reinterpret_cast<uint32_t RANS_GLOBAL *>(dst + oend + out_lane_off) = v;
+            __builtin_nontemporal_store(v, reinterpret_cast<uint32_t RANS_GLOBAL *>(dst + oend + out_lane_off));
         }
         // short chunks: whatever step of the hand-over has not been issued yet
         if (stage < 1)
@@ -1038,7 +1060,7 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
     if (name)
         *name = FMT == FMT_WORD ? "k_decode<word>" : FMT == FMT_BYTE ? "k_decode<byte>"
-                : FMT == FMT_R64 ? "k_decode<r64>" : "k_decode<alias>";
+                : FMT == FMT_R64 ? "k_decode<r64>" : FMT == FMT_R64S ? "k_decode<r64 search>" : "k_decode<alias>";
     RANS_LAUNCH(kern, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
     return hipGetLastError();
 }
@@ -1118,6 +1140,16 @@ hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipSt
     case FMT_WORD: return launch_decode_f<FMT_WORD>(p, num_cus, stream, name);
     case FMT_BYTE: return launch_decode_f<FMT_BYTE>(p, num_cus, stream, name);
     case FMT_R64: return launch_decode_f<FMT_R64>(p, num_cus, stream, name);
+    case FMT_R64S: // the search decoder exists in its general form only (any N, element stores)
+        if (p.n_ways >= 1 && p.n_ways <= 64)
+            return launch_decode_t<FMT_R64S, 1, OUT_SLOW>(p, num_cus, stream, name);
+        if (p.n_ways <= 128)
+            return launch_decode_t<FMT_R64S, 2, OUT_SLOW>(p, num_cus, stream, name);
+        if (p.n_ways <= 256)
+            return launch_decode_t<FMT_R64S, 4, OUT_SLOW>(p, num_cus, stream, name);
+        if (p.n_ways <= 512)
+            return launch_decode_t<FMT_R64S, 8, OUT_SLOW>(p, num_cus, stream, name);
+        return hipErrorInvalidValue;
     case FMT_ALIAS: return launch_decode_f<FMT_ALIAS>(p, num_cus, stream, name);
     default: return hipErrorInvalidValue;
     }

@@ -20,6 +20,13 @@ constexpr int FMT_BYTE = RANS_AMD_FMT_BYTE;
 constexpr int FMT_WORD = RANS_AMD_FMT_WORD;
 constexpr int FMT_R64 = RANS_AMD_FMT_R64;
 constexpr int FMT_ALIAS = RANS_AMD_FMT_ALIAS;
+// Internal kernel format: rans64 (RANS_AMD_FMT_R64 to the caller) for the scale_bits the cum2sym decoder
+// cannot take -- 17..31, where a 2^scale_bits lookup table fits no LDS, and 1..6, where its 24-bit partial
+// products do not hold.  The symbol comes from a binary search over the cumulative frequencies
+// (nsyms + 1 words in LDS), the state updates use full 64 x 32 multiplies.  Same stream, any
+// scale_bits rans64.h accepts (rans64.h:169: <= 31); several times slower than the table decoder.
+constexpr int FMT_R64S = 4;
+template <int FMT> constexpr bool kIsR64 = (FMT == FMT_R64 || FMT == FMT_R64S);
 
 // OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
 // symbols transposed in registers.  OUT_FAST8_NOASM: same with the compiler-scheduled renorm
@@ -58,6 +65,7 @@ template <> struct FmtTraits<FMT_R64> {
     static constexpr uint64_t kL = 1ull << 31; // rans64.h:59
     static constexpr int kSymByte = 0;
 };
+template <> struct FmtTraits<FMT_R64S> : FmtTraits<FMT_R64> {};
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -125,7 +133,7 @@ template <int FMT> struct DecTables {
         t1 = table1;
         scale_bits = sb;
         mask = (1u << sb) - 1u;
-        bucket_shift = sb - log2nsyms;
+        bucket_shift = FMT == FMT_R64S ? log2nsyms /* log2 of the padded cum table */ : sb - log2nsyms;
         mask12v = 0xfffu;
         maskv = mask;
         sbv = sb;
@@ -167,6 +175,21 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         const uint64_t xs = x >> T.scale_bits;
         const uint32_t bias = cf - r.y;
         x = (uint64_t)r.x * (uint32_t)xs + bias + ((uint64_t)__umul24(r.x, (uint32_t)(xs >> 32)) << 32);
+        return s;
+    } else if constexpr (FMT == FMT_R64S) {
+        // rans64.h:118-121 (get) with the cum2sym lookup replaced by a search: t0 = cum[] padded with ~0 to a
+        // power of two (2^bucket_shift entries, cum[0] = 0); the symbol is the LAST index whose cumulative
+        // frequency is <= cf (symbols of frequency 0 share their successor's value and are never hit).
+        // rans64.h:126-142 (advance): freq < 2^31 and x >> scale_bits < 2^(63 - scale_bits): the product is
+        // below 2^63, computed in full.
+        const uint32_t cf = (uint32_t)x & T.mask;
+        uint32_t s = 0;
+        for (uint32_t half = 1u << (T.bucket_shift - 1u); half; half >>= 1) {
+            const uint32_t c = reinterpret_cast<const uint32_t *>(T.t0)[s + half];
+            s += (c <= cf) ? half : 0u;
+        }
+        const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s]; // {freq, start}
+        x = (uint64_t)r.x * (x >> T.scale_bits) + (cf - r.y);
         return s;
     } else {
         // main_alias.cpp:252-267; the subtraction wraps in 32 bits on purpose
@@ -241,6 +264,19 @@ __device__ __forceinline__ uint32_t enc_update_byte(uint32_t y, const uint4 &rec
 // with bias = start (freq >= 2) or start + M - 1 (freq == 1): no remainder, no correction step, no
 // selects.  rec = {freq | rshift << 24, bias, rcp lo, rcp hi} (model.cpp).  q < 2^49 and
 // M - freq < 2^16: the high word of q needs only a 24-bit multiply.
+// The same for any scale_bits up to 31 (FMT_R64S): rec = {freq, bias, rcp lo, rcp hi}; the shift is
+// ceil(log2 freq) - 1 as in rans64.h:207-240, recomputed from freq (there is no room for it in the record), and
+// q * (M - freq) is a full 64 x 32 multiply (M - freq reaches 2^31, q 2^62 / freq).
+__device__ __forceinline__ uint64_t enc_update_r64s(uint64_t y, const uint4 &rec, uint32_t scale_bits)
+{
+    const uint64_t rcp = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
+    const uint32_t freq = rec.x;
+    const uint32_t rshift = freq >= 2u ? 31u - (uint32_t)__builtin_clz(freq - 1u) : 0u; // ceil(log2 freq) - 1
+    const uint64_t q = __umul64hi(y, rcp) >> rshift;
+    const uint32_t cmpl = (uint32_t)((1ull << scale_bits) - freq);
+    return y + rec.y + q * cmpl;
+}
+
 __device__ __forceinline__ uint64_t enc_update_r64(uint64_t y, const uint4 &rec, uint32_t scale_bits)
 {
     const uint64_t rcp = (uint64_t)rec.z | ((uint64_t)rec.w << 32);

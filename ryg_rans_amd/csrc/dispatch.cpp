@@ -5,7 +5,7 @@ namespace rans_amd {
 
 bool ways_supported(int format, uint32_t n_ways)
 {
-    if (format < 0 || format > 3)
+    if (format < 0 || format > 3) // (the public formats; the internal search variant is rans64 to the caller)
         return false;
     return n_ways >= 1 && n_ways <= 512;
 }
@@ -14,14 +14,14 @@ bool ways_supported(int format, uint32_t n_ways)
 // one chunk per wave
 hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name)
 {
-    if (lanes_applicable(p.nchunks, p.n_ways))
+    if (format != kKernelFormatR64Search && lanes_applicable(p.nchunks, p.n_ways))
         return launch_decode_lanes(format, p, num_cus, stream, kernel_name);
     return launch_decode_wave(format, p, num_cus, stream, kernel_name);
 }
 
 hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream)
 {
-    if (lanes_applicable(p.nchunks, p.n_ways))
+    if (format != kKernelFormatR64Search && lanes_applicable(p.nchunks, p.n_ways))
         return launch_encode_lanes(format, p, num_cus, stream);
     return launch_encode_wave(format, p, num_cus, stream);
 }

@@ -34,6 +34,8 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
     const bool in_alphabet = PADDED || sym < T.nsyms;
     const uint4 rec = T.recs[PADDED ? sym : (in_alphabet ? sym : 0u)];
     const uint32_t freq = (FMT == FMT_R64 || FMT == FMT_BYTE) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
+    (void)start;
+    (void)rcp;
     if (active && (!in_alphabet || freq == 0)) {
         bad = true;
         active = false;
@@ -50,7 +52,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         uint32_t y = emit ? (x >> 16) : x;
         const uint32_t xn = enc_update_word(y, rec);
         x = active ? xn : x;
-    } else if constexpr (FMT == FMT_R64) {
+    } else if constexpr (kIsR64<FMT>) {
         // rans64.h:77-93
         const uint64_t x_max = ((uint64_t)freq) << (63u - T.scale_bits); // ((L >> sb) << 32) * freq
         const bool emit = active && x >= x_max;
@@ -60,7 +62,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         if (emit)
             *reinterpret_cast<uint32_t RANS_GLOBAL *>(slot + wp + 4u * rank_below(m)) = (uint32_t)x;
         uint64_t y = emit ? (x >> 32) : x;
-        const uint64_t xn = enc_update_r64(y, rec, T.scale_bits);
+        const uint64_t xn = FMT == FMT_R64S ? enc_update_r64s(y, rec, T.scale_bits) : enc_update_r64(y, rec, T.scale_bits);
         x = active ? xn : x;
     } else {
         // rans_byte.h:62-74 (renorm: 0, 1 or 2 bytes for scale_bits <= 16), :83-90 (put),
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
             const uint32_t idx = k * 64u + lane;
             if (idx < N) {
                 uint8_t RANS_GLOBAL *at = slot + wp + idx * Tr::kStateBytes;
-                if constexpr (FMT == FMT_R64) {
+                if constexpr (kIsR64<FMT>) {
                     reinterpret_cast<uint32_t RANS_GLOBAL *>(at)[0] = (uint32_t)x[k];
                     reinterpret_cast<uint32_t RANS_GLOBAL *>(at)[1] = (uint32_t)(x[k] >> 32);
                 } else if constexpr (FMT == FMT_WORD) {
@@ -358,6 +360,7 @@ hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipSt
     case FMT_WORD: return launch_encode_f<FMT_WORD>(p, num_cus, stream);
     case FMT_BYTE: return launch_encode_f<FMT_BYTE>(p, num_cus, stream);
     case FMT_R64: return launch_encode_f<FMT_R64>(p, num_cus, stream);
+    case FMT_R64S: return launch_encode_f<FMT_R64S>(p, num_cus, stream);
     case FMT_ALIAS: return launch_encode_f<FMT_ALIAS>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }

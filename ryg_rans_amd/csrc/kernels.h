@@ -21,6 +21,10 @@ constexpr uint32_t kWorkSlots = 64;      // launches that may reuse the counter 
 // one ring slot = kWorkPools counters (a 64-byte line each) + one line for the launch's wave span record
 constexpr uint32_t kWorkSlotWords = (kWorkPools + 1) * kWorkPoolStride;
 constexpr int kEncBlockThreads = 256;
+// Kernel-side format number of rans64 with a binary search over the cumulative frequencies instead of the cum2sym
+// table (scale_bits 1..6 and 17..31; device_common.hpp FMT_R64S).  launch_decode / launch_encode take it in place
+// of RANS_AMD_FMT_R64; DecParams::table0 is then the cum table padded with ~0 to 2^log2nsyms words.
+constexpr int kKernelFormatR64Search = 4;
 constexpr uint32_t kTraceWords = 5;      // per-wave record of DecParams::trace
 
 struct DecParams {

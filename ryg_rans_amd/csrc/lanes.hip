@@ -303,10 +303,17 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
                 if (left) {
                     q3 = decode16();
                     u32x4 RANS_GLOBAL *o = reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i0);
+#ifdef RANS_LANES_NT_OUT // (experiment: the lane's 64-byte line as four non-temporal 16-byte stores)
+                    __builtin_nontemporal_store(q0, o + 0);
+                    __builtin_nontemporal_store(q1, o + 1);
+                    __builtin_nontemporal_store(q2, o + 2);
+                    __builtin_nontemporal_store(q3, o + 3);
+#else
                     o[0] = q0;
                     o[1] = q1;
                     o[2] = q2;
                     o[3] = q3;
+#endif
                 }
                 continue;
             }
@@ -319,7 +326,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
                 const uint32_t cnt = nsym - j0 < 16u ? nsym - j0 : 16u;
                 if (cnt == 16u && wide_out) {
                     const u32x4 q = decode16();
-                    *reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + j0) = q;
+                    __builtin_nontemporal_store(q, reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + j0)); // written once, never read back
                 } else {
                     for (uint32_t i = 0; i < cnt; i += NW) {
                         const uint32_t c = cnt - i < (uint32_t)NW ? cnt - i : (uint32_t)NW;
@@ -437,7 +444,7 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
                     for (int l = 0; l < NW; ++l)
                         lane_renorm<FMT>(x[l], W, true);
                 }
-                *reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i) = pack;
+                __builtin_nontemporal_store(pack, reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i));
                 i += 16;
             }
         }

@@ -138,13 +138,14 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
     case RANS_AMD_FMT_R64:
         if (sb == 0 || sb > 31) // rans64.h:169
             return RANS_AMD_E_UNSUPPORTED;
-        if (sb > 16) // cum2sym would not fit LDS; the GPU path stops at 16 bits
-            return RANS_AMD_E_UNSUPPORTED;
         break;
     default:
         return RANS_AMD_E_ARG;
     }
     format = fmt;
+    // rans64 outside 7..16 bits: no cum2sym table (2^scale_bits entries fit no LDS beyond 16 bits, and below 7
+    // the table decoder's 24-bit partial products do not hold): the kernels search the cumulative frequencies
+    r64_search = fmt == RANS_AMD_FMT_R64 && (sb > 16 || sb < 7);
     nsyms = ns;
     log2nsyms = ceil_log2(ns);
     scale_bits = sb;
@@ -171,10 +172,23 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
     if (run != M)
         return RANS_AMD_E_MODEL;
 
-    // main.cpp:143-148
-    cum2sym.assign(M, 0);
-    for (uint32_t s = 0; s < ns; ++s)
-        std::fill(cum2sym.begin() + cum[s], cum2sym.begin() + cum[s + 1], (uint16_t)s);
+    // main.cpp:143-148 (not for the wide rans64 models: up to 2^31 entries nobody reads)
+    cum2sym.clear();
+    if (sb <= 16) {
+        cum2sym.assign(M, 0);
+        for (uint32_t s = 0; s < ns; ++s)
+            std::fill(cum2sym.begin() + cum[s], cum2sym.begin() + cum[s + 1], (uint16_t)s);
+    }
+    cum_padded.clear();
+    if (r64_search) {
+        // cum[0..ns] followed by ~0 up to a power of two: "last index with cum <= cf" by halving steps
+        uint32_t p2 = 2;
+        while (p2 < ns + 1)
+            p2 <<= 1;
+        cum_padded.assign(p2, 0xffffffffu);
+        std::copy(cum.begin(), cum.end(), cum_padded.begin());
+        // entries ns+1.. stay ~0; cum[ns] = M is > every cf as well, so symbol ns is never chosen
+    }
 
     // per-symbol records
     sym_recs.resize(ns);
@@ -197,7 +211,8 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
                 rshift = sh - 1;
                 bias = cum[s];
             }
-            enc_recs[s] = EncRec{f | (rshift << 24), bias, (uint32_t)rcp64, (uint32_t)(rcp64 >> 32)};
+            // (search variant: freq needs all 32 bits, the kernel recomputes rshift from it)
+            enc_recs[s] = EncRec{r64_search ? f : (f | (rshift << 24)), bias, (uint32_t)rcp64, (uint32_t)(rcp64 >> 32)};
             continue;
         }
         if (fmt == RANS_AMD_FMT_BYTE) {
@@ -365,6 +380,8 @@ int HostModel::export_table(int which, std::vector<uint8_t> &out) const
         append_bytes(out, cum.data(), cum.size());
         return RANS_AMD_OK;
     case RANS_AMD_TAB_CUM2SYM:
+        if (cum2sym.empty())
+            return RANS_AMD_E_ARG; // wide rans64 model: there is no such table
         if (sym_bytes == 1) {
             out.resize(M);
             for (uint32_t i = 0; i < M; ++i)

@@ -102,7 +102,9 @@ struct HostModel {
 
     std::vector<uint32_t> freqs;    // [nsyms]
     std::vector<uint32_t> cum;      // [nsyms+1]
-    std::vector<uint16_t> cum2sym;  // [M] (exported as u8 when nsyms <= 256)
+    std::vector<uint16_t> cum2sym;  // [M] (exported as u8 when nsyms <= 256); empty for scale_bits > 16
+    bool r64_search = false;        // rans64 with scale_bits 1..6 or 17..31: symbol by search, see build()
+    std::vector<uint32_t> cum_padded; // r64_search: cum[] padded with ~0 to a power of two
 
     // alias (main_alias.cpp:56-63)
     std::vector<uint32_t> divider, slot_adjust, slot_freqs, sym_id, alias_remap;

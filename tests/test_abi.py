@@ -193,6 +193,18 @@ def test_model_rejections():
     assert e.value.status == R.E_UNSUPPORTED
     with pytest.raises(R.RansAmdError):
         R.Model(None, FMT_BYTE, f, 17)  # rans_byte.h:176
+    # rans64 takes scale_bits up to 31 (rans64.h:169); beyond 16 there is no cum2sym table to export
+    g = np.zeros(256, np.uint32)
+    g[1], g[2] = (1 << 31) - 5, 5
+    wide = R.Model(None, FMT_R64, g, 31)
+    assert wide.table(R.TAB_CUM_FREQS, np.uint32)[-1] == 1 << 31
+    enc = wide.table(R.TAB_ENC_SYMBOLS)
+    assert enc.size == 256 * 24
+    with pytest.raises(R.RansAmdError):
+        wide.table(R.TAB_CUM2SYM)
+    with pytest.raises(R.RansAmdError) as e:
+        R.Model(None, FMT_R64, g, 32)
+    assert e.value.status == R.E_UNSUPPORTED
 
 
 def test_build_model_o0_host_only(oracle):
