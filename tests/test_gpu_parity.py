@@ -537,7 +537,7 @@ def test_rans64_any_scale_bits(gpu, oracle):
     n = 50001
     cases = [(8, 3), (16, 5), (64, 6), (256, 17), (256, 20), (256, 24), (200, 19)]
     for nsyms, sb in cases:
-        data = (oracle.gen_zipf(n, K=256, s=1.0, seed=sb) % nsyms).astype(np.uint8)
+        data = (oracle.gen_zipf(n, K=256, s=1.0, seed=sb).astype(np.int32) % nsyms).astype(np.uint8)
         f, _ = oracle.normalize(oracle.count_freqs(data, nsyms), 1 << sb)
         om = oracle.model(f, sb)
         gm = ctx.model(FMT_R64, f, sb)
