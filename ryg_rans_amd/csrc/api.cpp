@@ -108,6 +108,7 @@ struct rans_amd_model {
     void *d_enc = nullptr;
     void *d_word_enc = nullptr;
     void *d_remap = nullptr;
+    void *d_alias_recs8 = nullptr, *d_alias_remap16 = nullptr; // alias encoder's LDS tables, when they fit
     uint32_t table0_bytes = 0, table1_bytes = 0;
 };
 
@@ -383,6 +384,11 @@ int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_fr
         }
         if (rc == RANS_AMD_OK)
             rc = upload(h.alias_remap.data(), h.alias_remap.size() * 4, &m->d_remap);
+        if (rc == RANS_AMD_OK && !h.alias_remap16.empty()) {
+            rc = upload(h.alias_recs8.data(), h.alias_recs8.size() * 8, &m->d_alias_recs8);
+            if (rc == RANS_AMD_OK)
+                rc = upload(h.alias_remap16.data(), h.alias_remap16.size() * 2, &m->d_alias_remap16);
+        }
         break;
     default:
         rc = RANS_AMD_E_ARG;
@@ -411,7 +417,7 @@ int rans_amd_model_destroy(rans_amd_model *m)
         return RANS_AMD_OK;
     if (m->device >= 0) { // not m->ctx->device: a model may outlive its context
         DeviceGuard guard(m->device);
-        for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_word_enc, m->d_remap})
+        for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_word_enc, m->d_remap, m->d_alias_recs8, m->d_alias_remap16})
             if (p)
                 (void)hipFree(p);
     }
@@ -547,11 +553,18 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         ep.enc_recs = model->d_enc;
         ep.word_enc_recs = model->d_word_enc;
         ep.alias_remap = static_cast<const uint32_t *>(model->d_remap);
+        ep.alias_recs8 = model->d_alias_recs8;
+        ep.alias_remap16 = static_cast<const uint16_t *>(model->d_alias_remap16);
+        // RANS_AMD_ALIAS_L2=1: A/B knob, the general alias encoder (alias_remap gathered from L2)
+        static const bool alias_l2 = getenv("RANS_AMD_ALIAS_L2") != nullptr;
+        const int enc_format = model->host.r64_search ? kKernelFormatR64Search
+                               : (format == RANS_AMD_FMT_ALIAS && model->d_alias_remap16 && !alias_l2) ? kKernelFormatAliasLds
+                                                                                                      : format;
         ep.nsyms = model->host.nsyms;
         ep.scale_bits = model->host.scale_bits;
         ep.sym_bytes = (uint32_t)model->host.sym_bytes;
         ep.flags = ctx->d_enc_flags();
-        HIP_TRY(launch_encode(model->host.r64_search ? kKernelFormatR64Search : format, ep, ctx->num_cus, s));
+        HIP_TRY(launch_encode(enc_format, ep, ctx->num_cus, s));
     }
     LayoutParams lp;
     lp.lengths = d_lengths;

@@ -27,6 +27,12 @@ constexpr int FMT_ALIAS = RANS_AMD_FMT_ALIAS;
 // scale_bits rans64.h accepts (rans64.h:169: <= 31); several times slower than the table decoder.
 constexpr int FMT_R64S = 4;
 template <int FMT> constexpr bool kIsR64 = (FMT == FMT_R64 || FMT == FMT_R64S);
+// Internal kernel format of the ENCODER: alias coding (RANS_AMD_FMT_ALIAS to the caller) with the slot
+// permutation alias_remap (main_alias.cpp:63,225-228) held in LDS as u16 next to 8-byte symbol records, for the
+// models where both fit (2 M + 8 nsyms <= 160 KiB: every model up to 4096 symbols at 16 bits).  The general
+// alias encoder gathers alias_remap from L2: 64 random dwords per sub-step drag 64 cache lines through the L1.
+constexpr int FMT_ALIAS_LDS = 5;
+template <int FMT> constexpr bool kIsAlias = (FMT == FMT_ALIAS || FMT == FMT_ALIAS_LDS);
 
 // OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
 // symbols transposed in registers.  OUT_FAST8_NOASM: same with the compiler-scheduled renorm
@@ -66,6 +72,7 @@ template <> struct FmtTraits<FMT_R64> {
     static constexpr int kSymByte = 0;
 };
 template <> struct FmtTraits<FMT_R64S> : FmtTraits<FMT_R64> {};
+template <> struct FmtTraits<FMT_ALIAS_LDS> : FmtTraits<FMT_ALIAS> {};
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 

@@ -1,6 +1,8 @@
 // dispatch.cpp -- chooses the kernel family for a (format, n_ways, chunk count) request.
 #include "launchers.hpp"
 
+#include "../../include/ryg_rans_amd.h"
+
 namespace rans_amd {
 
 bool ways_supported(int format, uint32_t n_ways)
@@ -21,8 +23,9 @@ hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_
 
 hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream)
 {
-    if (format != kKernelFormatR64Search && lanes_applicable(p.nchunks, p.n_ways))
-        return launch_encode_lanes(format, p, num_cus, stream);
+    // (the lane encoders know the public formats: a narrow alias interleave gathers alias_remap from L2)
+    if (lanes_applicable(p.nchunks, p.n_ways) && format != kKernelFormatR64Search)
+        return launch_encode_lanes(format == kKernelFormatAliasLds ? (int)RANS_AMD_FMT_ALIAS : format, p, num_cus, stream);
     return launch_encode_wave(format, p, num_cus, stream);
 }
 

@@ -16,8 +16,9 @@ namespace {
 // ===========================================================================
 
 template <int FMT> struct EncTables {
-    const uint4 *recs; // LDS: EncRec {freq, start, rcp, remap}
+    const uint4 *recs; // LDS: EncRec {freq, start, rcp, remap}  (FMT_ALIAS_LDS: uint2 {freq | start << 16, rcp})
     const uint32_t *alias_remap; // global
+    const uint16_t *remap16;     // LDS (FMT_ALIAS_LDS)
     uint32_t scale_bits;
     uint32_t nsyms;
 };
@@ -32,7 +33,13 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
                                             bool &bad)
 {
     const bool in_alphabet = PADDED || sym < T.nsyms;
-    const uint4 rec = T.recs[PADDED ? sym : (in_alphabet ? sym : 0u)];
+    uint4 rec;
+    if constexpr (FMT == FMT_ALIAS_LDS) { // 8-byte records: {freq | start << 16, rcp}
+        const uint2 r8 = reinterpret_cast<const uint2 *>(T.recs)[PADDED ? sym : (in_alphabet ? sym : 0u)];
+        rec = uint4{r8.x & 0xffffu, r8.x >> 16, r8.y, 0u};
+    } else {
+        rec = T.recs[PADDED ? sym : (in_alphabet ? sym : 0u)];
+    }
     const uint32_t freq = (FMT == FMT_R64 || FMT == FMT_BYTE) ? (rec.x & 0xffffffu) : rec.x, start = rec.y, rcp = rec.z;
     (void)start;
     (void)rcp;
@@ -91,6 +98,12 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
             uint32_t q, rem;
             divmod_rcp(y, freq, rcp, q, rem);
             xn = (q << T.scale_bits) + (active ? T.alias_remap[rem + start] : 0u);
+        } else if constexpr (FMT == FMT_ALIAS_LDS) {
+            // main_alias.cpp:249 with alias_remap in LDS (u16: slots are < M <= 2^16); the index of an inactive
+            // or invalid lane is garbage, hence the mask -- its result is discarded below
+            uint32_t q, rem;
+            divmod_rcp(y, freq, rcp, q, rem);
+            xn = (q << T.scale_bits) + T.remap16[(rem + start) & ((1u << T.scale_bits) - 1u)];
         } else {
             xn = enc_update_byte(y, rec, T.scale_bits);
         }
@@ -140,8 +153,10 @@ __device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x3 &rec, uin
                  : "vcc", "scc", "memory");
 }
 
+constexpr int kEncAliasLdsThreads = 1024; // FMT_ALIAS_LDS: 16 waves share the (up to 160 KiB) tables of a CU
+
 template <int FMT, int K>
-__global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
+__global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : kEncBlockThreads) k_encode(const EncParams p)
 {
     using Tr = FmtTraits<FMT>;
     using state_t = typename Tr::state_t;
@@ -156,13 +171,24 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x)
             l[i] = g[i];
     }
-    {
+    const uint32_t nrecs = p.nsyms < 256u ? 256u : p.nsyms; // byte alphabets: 256 entries, freq 0 behind nsyms
+    if constexpr (FMT == FMT_ALIAS_LDS) {
+        // 8-byte records (the host pads them to nrecs entries), then alias_remap as u16[M]; both in 16-byte pieces
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.alias_recs8);
+        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < nrecs / 2u; i += blockDim.x)
+            l[i] = g[i];
+        const uint4 *gr = reinterpret_cast<const uint4 *>(p.alias_remap16);
+        uint4 *lr = reinterpret_cast<uint4 *>(smem + (size_t)nrecs * 8u);
+        for (uint32_t i = threadIdx.x; i < (2u << p.scale_bits) / 16u; i += blockDim.x)
+            lr[i] = gr[i];
+    } else {
         const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
         uint4 *l = reinterpret_cast<uint4 *>(smem + kWordRecBytes);
         for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
             l[i] = g[i];
-        for (uint32_t i = p.nsyms + threadIdx.x; i < 256u; i += blockDim.x) // byte alphabets: 256 entries,
-            l[i] = uint4{0u, 0u, 0u, 0u};                                    // freq 0 behind nsyms
+        for (uint32_t i = p.nsyms + threadIdx.x; i < 256u; i += blockDim.x)
+            l[i] = uint4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
 
@@ -174,6 +200,7 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
     EncTables<FMT> T;
     T.recs = reinterpret_cast<const uint4 *>(smem + kWordRecBytes);
     T.alias_remap = p.alias_remap;
+    T.remap16 = reinterpret_cast<const uint16_t *>(smem + (size_t)nrecs * 8u);
     T.scale_bits = p.scale_bits;
     T.nsyms = p.nsyms;
 
@@ -208,7 +235,13 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
                              ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 3u) == 0;
         // (the word path addresses its record table by raw LDS address: dynamic LDS must start at 0)
         const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem == 0u;
-        const uint32_t fast_rounds = (fast_in && (FMT != FMT_WORD || lds_at_zero)) ? (rounds & ~15u) : 0u;
+        // The same for u16 symbols (alias coding over more than 256 symbols): two rounds per dword, lane pairs
+        // swap halves (the mirror image of the decoder's OUT_FAST16 stores).
+        // (K <= 2: sixteen rounds in flight twice over are 32 K registers)
+        const bool fast_in16 = kIsAlias<FMT> && K <= 2 && p.sym_bytes == 2 && N == 64u * K &&
+                               ((reinterpret_cast<uintptr_t>(p.syms) | (p.chunk_syms * 2u)) & 3u) == 0;
+        const uint32_t fast_rounds =
+            ((fast_in && (FMT != FMT_WORD || lds_at_zero)) || fast_in16) ? (rounds & ~15u) : 0u;
 
         // rounds from last to first; round `rounds` is the partial one
         for (uint32_t rr = rounds + 1; rr-- > fast_rounds;) {
@@ -233,7 +266,45 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
         }
 
         uint32_t worst = 0; // word fast path: max of cmpl_sh, > 0x0fffffff iff a symbol has no record
-        if (fast_rounds) {
+        if (fast_rounds && fast_in16) {
+            if constexpr (kIsAlias<FMT> && K <= 2) {
+                // lane l of a pair loads the dword {row 2j + (l & 1), columns l & ~1 and (l & ~1) + 1}
+                const uint32_t sel16 = (lane & 1u) ? 0x03020706u : 0x05040100u;
+                const uint32_t in_off16 = ((lane & 1u) * N + (lane & ~1u)) * 2u;
+                uint32_t cur[8][K], nxt[8][K];
+                auto load_super16 = [&](uint32_t (&dstq)[8][K], uint32_t sg) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+                            dstq[j][k] = *reinterpret_cast<const uint32_t RANS_GLOBAL *>(
+                                src + (uint64_t)(sg * 16u + j * 2u) * N * 2u + in_off16 + k * 128u);
+                };
+                uint32_t sg = fast_rounds >> 4;
+                load_super16(cur, sg - 1);
+                while (sg-- > 0) {
+                    if (sg > 0)
+                        load_super16(nxt, sg - 1);
+#pragma unroll
+                    for (int j = 7; j >= 0; --j) {
+                        uint32_t t[K]; // this lane's symbol of row 2j (low half) and of row 2j + 1 (high half)
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+                            t[k] = __builtin_amdgcn_perm(quad_perm<1, 0, 3, 2>(cur[j][k]), cur[j][k], sel16);
+#pragma unroll
+                        for (int h = 1; h >= 0; --h)
+#pragma unroll
+                            for (int k = K - 1; k >= 0; --k)
+                                enc_substep<FMT>(T, x[k], (t[k] >> (16 * h)) & 0xffffu, true, slot, wp, bad);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+                            cur[j][k] = nxt[j][k];
+                }
+            }
+        } else if (fast_rounds) {
             uint32_t rec_mask = 0xff0u;
             asm volatile("" : "+v"(rec_mask)); // keep the mask in a VGPR (a literal operand costs a slower VALU form)
             uint32_t cur[4][K], nxt[4][K];
@@ -322,18 +393,27 @@ __global__ void __launch_bounds__(kEncBlockThreads) k_encode(const EncParams p)
 
 template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num_cus, hipStream_t stream)
 {
-    const uint32_t waves = kEncBlockThreads / 64;
-    const size_t lds = (size_t)(p.nsyms < 256 ? 256 : p.nsyms) * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
-    if (lds > 128 * 1024 || (FMT == FMT_WORD && !p.word_enc_recs))
+    const uint32_t threads = FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : kEncBlockThreads;
+    const uint32_t waves = threads / 64;
+    const size_t nrecs = p.nsyms < 256 ? 256 : p.nsyms;
+    const size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
+                                            : nrecs * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
+    const size_t lds_cap = FMT == FMT_ALIAS_LDS ? 160 * 1024 : 128 * 1024;
+    if (lds > lds_cap || (FMT == FMT_WORD && !p.word_enc_recs) ||
+        (FMT == FMT_ALIAS_LDS && (!p.alias_recs8 || !p.alias_remap16)))
         return hipErrorInvalidValue;
     auto kern = k_encode<FMT, K>;
     static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 128 * 1024, lds_ok); e != hipSuccess)
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), (int)lds_cap, lds_ok); e != hipSuccess)
         return e;
     uint64_t want = (p.nchunks + waves - 1) / waves;
-    uint64_t cap = (uint64_t)num_cus * 8;
+    // blocks per CU: what the LDS allows, within the 32 resident waves of a CU
+    uint64_t per_cu = lds ? (160 * 1024) / lds : 8;
+    per_cu = per_cu < 1 ? 1 : per_cu;
+    per_cu = per_cu * waves > 32 ? 32 / waves : per_cu;
+    uint64_t cap = (uint64_t)num_cus * (FMT == FMT_ALIAS_LDS ? per_cu : 8);
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
-    RANS_LAUNCH(kern, dim3(grid), dim3(kEncBlockThreads), lds, stream, p);
+    RANS_LAUNCH(kern, dim3(grid), dim3(threads), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -361,6 +441,7 @@ hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipSt
     case FMT_BYTE: return launch_encode_f<FMT_BYTE>(p, num_cus, stream);
     case FMT_R64: return launch_encode_f<FMT_R64>(p, num_cus, stream);
     case FMT_R64S: return launch_encode_f<FMT_R64S>(p, num_cus, stream);
+    case FMT_ALIAS_LDS: return launch_encode_f<FMT_ALIAS_LDS>(p, num_cus, stream);
     case FMT_ALIAS: return launch_encode_f<FMT_ALIAS>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }

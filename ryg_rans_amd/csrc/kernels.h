@@ -25,6 +25,9 @@ constexpr int kEncBlockThreads = 256;
 // table (scale_bits 1..6 and 17..31; device_common.hpp FMT_R64S).  launch_decode / launch_encode take it in place
 // of RANS_AMD_FMT_R64; DecParams::table0 is then the cum table padded with ~0 to 2^log2nsyms words.
 constexpr int kKernelFormatR64Search = 4;
+// Kernel-side format number of the alias ENCODER with alias_remap in LDS (device_common.hpp FMT_ALIAS_LDS);
+// EncParams::alias_recs8 / alias_remap16 are then set.
+constexpr int kKernelFormatAliasLds = 5;
 constexpr uint32_t kTraceWords = 5;      // per-wave record of DecParams::trace
 
 struct DecParams {
@@ -68,6 +71,8 @@ struct EncParams {
     const void *enc_recs; // EncRec[nsyms]
     const void *word_enc_recs; // WordEncRec[256] (FMT_WORD only, else NULL)
     const uint32_t *alias_remap;
+    const void *alias_recs8;        // FMT_ALIAS_LDS: {freq | start << 16, floor(2^32 / freq)} per symbol (>= 256 entries)
+    const uint16_t *alias_remap16;  // FMT_ALIAS_LDS: alias_remap as u16[1 << scale_bits]
     uint32_t nsyms;
     uint32_t scale_bits;
     uint32_t sym_bytes;

@@ -364,6 +364,25 @@ int HostModel::build_alias()
     alias_halves.resize(2 * (size_t)ns);
     for (size_t h = 0; h < alias_halves.size(); ++h)
         alias_halves[h] = AliasHalf{slot_freqs[h] | (sym_id[h] << 16), slot_adjust[h]};
+    // the encoder's LDS tables (kernels.h kKernelFormatAliasLds), where they fit and every frequency and start
+    // fits 16 bits (a 65536-wide symbol does not: that model is host-only anyway)
+    alias_recs8.clear();
+    alias_remap16.clear();
+    const size_t nrecs = ns < 256 ? 256 : ns;
+    bool narrow = true;
+    for (uint32_t s = 0; s < ns; ++s)
+        narrow = narrow && freqs[s] <= 0xffffu && cum[s] <= 0xffffu;
+    if (narrow && nrecs * 8 + ((size_t)2 << scale_bits) <= 160 * 1024) {
+        alias_recs8.assign(nrecs, 0);
+        for (uint32_t s = 0; s < ns; ++s) {
+            const uint32_t f = freqs[s];
+            const uint32_t rcp = f <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / f);
+            alias_recs8[s] = (uint64_t)(f | (cum[s] << 16)) | ((uint64_t)rcp << 32);
+        }
+        alias_remap16.resize(alias_remap.size());
+        for (size_t i = 0; i < alias_remap.size(); ++i)
+            alias_remap16[i] = (uint16_t)alias_remap[i];
+    }
     return RANS_AMD_OK;
 }
 

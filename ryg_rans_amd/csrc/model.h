@@ -115,6 +115,10 @@ struct HostModel {
     std::vector<AliasHalf> alias_halves; // [2*nsyms]        FMT_ALIAS
     std::vector<EncRec> enc_recs;       // [nsyms]          all formats
     std::vector<WordEncRec> word_enc_recs; // [256]         FMT_WORD
+    // FMT_ALIAS, when 2 M + 8 max(nsyms, 256) bytes fit in LDS: the encoder's tables in their LDS form --
+    // {freq | start << 16, floor(2^32 / freq)} per symbol (zero records up to 256) and alias_remap as u16
+    std::vector<uint64_t> alias_recs8;
+    std::vector<uint16_t> alias_remap16;
 
     // Returns a rans_amd_status.
     int build(int format, const uint32_t *norm_freqs, uint32_t nsyms, uint32_t scale_bits);
