@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) k_compact(const CompactParams p)
             case 2: r = funnel16<2>(a, b, bsh); break;
             default: r = funnel16<3>(a, b, bsh); break;
             }
-            dst[i] = r;
+            dst[i] = r; // (a non-temporal store here measured 5 % slower on the 1 GiB word encode)
         }
     }
 }
