@@ -29,7 +29,7 @@ def short_name(name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -58,7 +58,7 @@ def main():
             lines.append("| %s | %s | %.1f | %.1f | %.1f | %s |" % (short, r["Calls"], float(r["AverageNs"]) / 1e3,
                                                                   float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
                                                                   r["Percentage"]))
-            if "k_decode" in name:
+            if "k_decode_word64" in name:  # the headline kernel
                 out["decode_kernel_avg_us_rocprof"] = float(r["AverageNs"]) / 1e3
         lines.append("")
 
@@ -82,7 +82,7 @@ def main():
             wr = v.get("WRITE_SIZE", 0) * 1024
             lines.append("| %s | %.0f | %.4g | %.0f | %.4g | %.4g |" % (k, v.get("FETCH_SIZE", 0), rd,
                                                                       v.get("WRITE_SIZE", 0), wr, rd + wr))
-            if "k_decode" in k:
+            if "k_decode_word64" in k:
                 out["hbm_bytes_per_launch"] = rd + wr
                 out["hbm_read_bytes"] = rd
                 out["hbm_write_bytes"] = wr
@@ -96,6 +96,14 @@ def main():
     if os.path.exists(sq):
         lines += ["## SQ counters, decode kernel (avg per launch)", "", "```"] + open(sq).read().splitlines() + ["```", ""]
 
+    # which kernel sources the measurement belongs to: bench.py quotes it as roofline.traffic only on a match
+    sys.path.insert(0, ROOT)
+    try:
+        import bench
+        out["kernel_source_tag"] = bench.kernel_source_tag()
+    except Exception as e:  # noqa: BLE001
+        out["kernel_source_tag"] = None
+        print("kernel_source_tag unavailable: %r" % (e,))
     json.dump(out, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
     open(os.path.join(dst, tag + "_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
