@@ -558,6 +558,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         // RANS_AMD_ALIAS_L2=1: A/B knob, the general alias encoder (alias_remap gathered from L2)
         static const bool alias_l2 = getenv("RANS_AMD_ALIAS_L2") != nullptr;
         const int enc_format = model->host.r64_search ? kKernelFormatR64Search
+                               : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
                                : (format == RANS_AMD_FMT_ALIAS && model->d_alias_remap16 && !alias_l2) ? kKernelFormatAliasLds
                                                                                                       : format;
         ep.nsyms = model->host.nsyms;
@@ -700,8 +701,10 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         }
         if (ctx->timing)
             HIP_TRY(hipEventRecord(ctx->ev[0], s));
-        HIP_TRY(launch_decode(model->host.r64_search ? kKernelFormatR64Search : format, dp, ctx->num_cus, s,
-                              &ctx->last_kernel));
+        const int dec_format = model->host.r64_search ? kKernelFormatR64Search
+                               : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
+                                                                                           : format;
+        HIP_TRY(launch_decode(dec_format, dp, ctx->num_cus, s, &ctx->last_kernel));
         // the launch that uses slot i zeroes slot i + 32: move on only once it really is in the stream,
         // or a later launch would start from a counter nobody reset
         if (dp.work_counter)

@@ -185,7 +185,7 @@ template <int FMT>
 __device__ __forceinline__ uint32_t dec_renorm(const StreamWindow &W, typename FmtTraits<FMT>::state_t &x,
                                                bool active)
 {
-    if constexpr (FMT == FMT_WORD) {
+    if constexpr (kIsWord<FMT>) {
         // rans_word_sse41.h:134-141 / :182-227
         const bool need = active && x < (1u << 16);
         const uint64_t m = __builtin_amdgcn_ballot_w64(need);
@@ -621,6 +621,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
             const uint32_t sel16 = (lane & 1u) ? 0x03020706u : 0x05040100u;
             const uint32_t lane_off16 = ((lane & 1u) * N + (lane & ~1u)) * 2u;
             const uint32_t k2p23 = (1u << 23) + (lane >> 6), k2p15 = (1u << 15) + (lane >> 6);
+            const uint32_t k65536w = 0x10000u + (lane >> 6);
             for (uint32_t g = 0; g < pairs; ++g) {
                 uint32_t acc[K];
 #pragma unroll
@@ -636,6 +637,8 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                             W.checkpoint(lane);
                         if constexpr (FMT == FMT_BYTE || FMT == FMT_ALIAS)
                             renorm_byte_full(x[k], W.cur, k2p23, k2p15);
+                        else if constexpr (FMT == FMT_WORD16)
+                            renorm_word_full(x[k], W.cur, k65536w);
                         else
                             W.consume(dec_renorm<FMT>(W, x[k], true));
                     }
@@ -1060,7 +1063,8 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
     if (name)
         *name = FMT == FMT_WORD ? "k_decode<word>" : FMT == FMT_BYTE ? "k_decode<byte>"
-                : FMT == FMT_R64 ? "k_decode<r64>" : FMT == FMT_R64S ? "k_decode<r64 search>" : "k_decode<alias>";
+                : FMT == FMT_R64 ? "k_decode<r64>" : FMT == FMT_R64S ? "k_decode<r64 search>"
+                : FMT == FMT_WORD16 ? "k_decode<word, u16 symbols>" : "k_decode<alias>";
     RANS_LAUNCH(kern, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
     return hipGetLastError();
 }
@@ -1140,6 +1144,22 @@ hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipSt
     case FMT_WORD: return launch_decode_f<FMT_WORD>(p, num_cus, stream, name);
     case FMT_BYTE: return launch_decode_f<FMT_BYTE>(p, num_cus, stream, name);
     case FMT_R64: return launch_decode_f<FMT_R64>(p, num_cus, stream, name);
+    case FMT_WORD16: { // u16 symbols: paired-round stores for full waves, element stores otherwise
+        const bool aligned = ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)p.chunk_syms * 2u) & 3u) == 0;
+        if (aligned && p.n_ways == 64)
+            return launch_decode_t<FMT_WORD16, 1, OUT_FAST16>(p, num_cus, stream, name);
+        if (aligned && p.n_ways == 128)
+            return launch_decode_t<FMT_WORD16, 2, OUT_FAST16>(p, num_cus, stream, name);
+        if (p.n_ways >= 1 && p.n_ways <= 64)
+            return launch_decode_t<FMT_WORD16, 1, OUT_SLOW>(p, num_cus, stream, name);
+        if (p.n_ways <= 128)
+            return launch_decode_t<FMT_WORD16, 2, OUT_SLOW>(p, num_cus, stream, name);
+        if (p.n_ways <= 256)
+            return launch_decode_t<FMT_WORD16, 4, OUT_SLOW>(p, num_cus, stream, name);
+        if (p.n_ways <= 512)
+            return launch_decode_t<FMT_WORD16, 8, OUT_SLOW>(p, num_cus, stream, name);
+        return hipErrorInvalidValue;
+    }
     case FMT_R64S: // the search decoder exists in its general form only (any N, element stores)
         if (p.n_ways >= 1 && p.n_ways <= 64)
             return launch_decode_t<FMT_R64S, 1, OUT_SLOW>(p, num_cus, stream, name);

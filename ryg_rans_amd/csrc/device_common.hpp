@@ -33,6 +33,11 @@ template <int FMT> constexpr bool kIsR64 = (FMT == FMT_R64 || FMT == FMT_R64S);
 // alias encoder gathers alias_remap from L2: 64 random dwords per sub-step drag 64 cache lines through the L1.
 constexpr int FMT_ALIAS_LDS = 5;
 template <int FMT> constexpr bool kIsAlias = (FMT == FMT_ALIAS || FMT == FMT_ALIAS_LDS);
+// Internal kernel format of the DECODER: the word format (RANS_AMD_FMT_WORD to the caller) over an alphabet of more
+// than 256 symbols -- SURVEY 8(f)4's "16-bit-symbol word format"; rans_word_sse41.h:41 fixes 256, the stream
+// format itself does not care.  Slot record {freq, bias | sym << 16}: one more v_and than the byte-symbol record.
+constexpr int FMT_WORD16 = 6;
+template <int FMT> constexpr bool kIsWord = (FMT == FMT_WORD || FMT == FMT_WORD16);
 
 // OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
 // symbols transposed in registers.  OUT_FAST8_NOASM: same with the compiler-scheduled renorm
@@ -73,6 +78,9 @@ template <> struct FmtTraits<FMT_R64> {
 };
 template <> struct FmtTraits<FMT_R64S> : FmtTraits<FMT_R64> {};
 template <> struct FmtTraits<FMT_ALIAS_LDS> : FmtTraits<FMT_ALIAS> {};
+template <> struct FmtTraits<FMT_WORD16> : FmtTraits<FMT_WORD> {
+    static constexpr int kSymByte = 0; // dec_step returns the symbol itself
+};
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -162,6 +170,11 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[x & T.mask12v];
         x = (e.x & 0xffffffu) * (x >> 12) + e.y;
         return e.x;
+    } else if constexpr (FMT == FMT_WORD16) {
+        // the same with a 16-bit symbol in the record's second word: {freq, bias | sym << 16}
+        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[x & T.mask12v];
+        x = (e.x & 0xffffffu) * (x >> 12) + (e.y & 0xffffu);
+        return e.y >> 16;
     } else if constexpr (FMT == FMT_BYTE) {
         // rans_byte.h:125-128 (get), :291-298 (step)
         const uint32_t cf = x & T.maskv;

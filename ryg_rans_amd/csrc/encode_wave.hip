@@ -166,10 +166,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
     // the per-symbol EncRec table of the general path behind them
     constexpr uint32_t kWordRecBytes = FMT == FMT_WORD ? 256u * (uint32_t)sizeof(WordEncRec) : 0u;
     if constexpr (FMT == FMT_WORD) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(p.word_enc_recs);
-        uint4 *l = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x)
-            l[i] = g[i];
+        if (p.word_enc_recs) { // (absent for alphabets beyond 256 symbols: they never take the full-wave path)
+            const uint4 *g = reinterpret_cast<const uint4 *>(p.word_enc_recs);
+            uint4 *l = reinterpret_cast<uint4 *>(smem);
+            for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x)
+                l[i] = g[i];
+        }
     }
     const uint32_t nrecs = p.nsyms < 256u ? 256u : p.nsyms; // byte alphabets: 256 entries, freq 0 behind nsyms
     if constexpr (FMT == FMT_ALIAS_LDS) {
@@ -238,7 +240,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
         // The same for u16 symbols (alias coding over more than 256 symbols): two rounds per dword, lane pairs
         // swap halves (the mirror image of the decoder's OUT_FAST16 stores).
         // (K <= 2: sixteen rounds in flight twice over are 32 K registers)
-        const bool fast_in16 = kIsAlias<FMT> && K <= 2 && p.sym_bytes == 2 && N == 64u * K &&
+        const bool fast_in16 = (kIsAlias<FMT> || FMT == FMT_WORD) && K <= 2 && p.sym_bytes == 2 && N == 64u * K &&
                                ((reinterpret_cast<uintptr_t>(p.syms) | (p.chunk_syms * 2u)) & 3u) == 0;
         const uint32_t fast_rounds =
             ((fast_in && (FMT != FMT_WORD || lds_at_zero)) || fast_in16) ? (rounds & ~15u) : 0u;
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
 
         uint32_t worst = 0; // word fast path: max of cmpl_sh, > 0x0fffffff iff a symbol has no record
         if (fast_rounds && fast_in16) {
-            if constexpr (kIsAlias<FMT> && K <= 2) {
+            if constexpr ((kIsAlias<FMT> || FMT == FMT_WORD) && K <= 2) {
                 // lane l of a pair loads the dword {row 2j + (l & 1), columns l & ~1 and (l & ~1) + 1}
                 const uint32_t sel16 = (lane & 1u) ? 0x03020706u : 0x05040100u;
                 const uint32_t in_off16 = ((lane & 1u) * N + (lane & ~1u)) * 2u;
@@ -399,7 +401,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     const size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
                                             : nrecs * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
     const size_t lds_cap = FMT == FMT_ALIAS_LDS ? 160 * 1024 : 128 * 1024;
-    if (lds > lds_cap || (FMT == FMT_WORD && !p.word_enc_recs) ||
+    if (lds > lds_cap || (FMT == FMT_WORD && !p.word_enc_recs && p.sym_bytes == 1) ||
         (FMT == FMT_ALIAS_LDS && (!p.alias_recs8 || !p.alias_remap16)))
         return hipErrorInvalidValue;
     auto kern = k_encode<FMT, K>;

@@ -28,6 +28,9 @@ constexpr int kKernelFormatR64Search = 4;
 // Kernel-side format number of the alias ENCODER with alias_remap in LDS (device_common.hpp FMT_ALIAS_LDS);
 // EncParams::alias_recs8 / alias_remap16 are then set.
 constexpr int kKernelFormatAliasLds = 5;
+// Kernel-side format number of the word-format DECODER over more than 256 symbols (device_common.hpp FMT_WORD16):
+// DecParams::table0 holds {freq, bias | sym << 16} per slot, symbols are u16.
+constexpr int kKernelFormatWord16 = 6;
 constexpr uint32_t kTraceWords = 5;      // per-wave record of DecParams::trace
 
 struct DecParams {

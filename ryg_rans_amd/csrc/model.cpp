@@ -132,7 +132,9 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
             return RANS_AMD_E_UNSUPPORTED;
         break;
     case RANS_AMD_FMT_WORD:
-        if (sb != 12 || ns > 256) // rans_word_sse41.h:37,41
+        // rans_word_sse41.h:37 fixes 12 bits; :41 fixes 256 symbols -- the stream format does not depend on the
+        // alphabet, so up to 4096 symbols (one slot each at least) are taken, with u16 symbols beyond 256
+        if (sb != 12 || ns > 4096)
             return RANS_AMD_E_UNSUPPORTED;
         break;
     case RANS_AMD_FMT_R64:
@@ -250,10 +252,14 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
         word_slots.resize(M);
         for (uint32_t slot = 0; slot < M; ++slot) {
             uint32_t s = cum2sym[slot];
-            word_slots[slot] = WordSlot{freqs[s] | (s << 24), slot - cum[s]};
+            // byte symbols: {freq | sym << 24, bias}; u16 symbols: {freq, bias | sym << 16}
+            word_slots[slot] = ns <= 256 ? WordSlot{freqs[s] | (s << 24), slot - cum[s]}
+                                         : WordSlot{freqs[s], (slot - cum[s]) | (s << 16)};
         }
-        word_enc_recs.assign(256, WordEncRec{0u, 0xffffffffu, 0u, 0u});
-        for (uint32_t s = 0; s < ns; ++s) {
+        word_enc_recs.clear(); // (the full-wave encoder path and its 256 records are for byte symbols)
+        if (ns <= 256)
+            word_enc_recs.assign(256, WordEncRec{0u, 0xffffffffu, 0u, 0u});
+        for (uint32_t s = 0; s < ns && ns <= 256; ++s) {
             const uint32_t f = freqs[s];
             if (f == 0)
                 continue;

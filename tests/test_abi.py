@@ -188,6 +188,7 @@ def test_model_rejections():
         R.Model(None, FMT_WORD, f, 12)  # sum != M
     f[4] = 1
     R.Model(None, FMT_WORD, f, 12)
+    assert R.Model(None, FMT_WORD, np.full(1024, 4, np.uint32), 12).sym_bytes == 2  # beyond 256 symbols: u16
     with pytest.raises(R.RansAmdError) as e:
         R.Model(None, FMT_WORD, f, 13)  # word format is 12-bit only (rans_word_sse41.h:37)
     assert e.value.status == R.E_UNSUPPORTED

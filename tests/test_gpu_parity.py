@@ -573,3 +573,37 @@ def test_rans64_any_scale_bits(gpu, oracle):
     bad[len(bad) // 2] ^= 0x20
     out, rc = ctx.decode_host(gm, bad, data.size, 64, check=False)
     assert rc == R.E_CORRUPT or not np.array_equal(out, data)
+
+
+def test_word_format_with_u16_symbols(gpu, oracle):
+    """the word format over alphabets beyond 256 symbols (rans_word_sse41.h:41 fixes 256; the stream
+    format -- 16-bit renormalisation, 12-bit probabilities -- does not depend on it).  Symbols are u16, the slot
+    record carries a 16-bit symbol; streams equal the oracle's, whose arithmetic is the pinned word coder's."""
+    R, ctx, torch = gpu
+    for nsyms, seed in ((1024, 1), (4096, 2), (300, 3)):
+        n = 300001
+        data = (oracle.gen_zipf(n, K=4096, s=1.0, seed=seed).astype(np.uint32) % nsyms).astype(np.uint16)
+        f, _ = oracle.normalize(oracle.count_freqs(data, nsyms), 4096)
+        om = oracle.model(f, 12)
+        gm = ctx.model(FMT_WORD, f, 12)
+        assert gm.sym_bytes == 2
+        for n_ways in (64, 1, 2, 100, 128):
+            want = oracle.encode(FMT_WORD, om, data[:60001], n_ways)
+            assert np.array_equal(ctx.encode_host(gm, data[:60001], n_ways), want), (nsyms, n_ways, "encode")
+            assert np.array_equal(ctx.decode_host(gm, want, 60001, n_ways), data[:60001]), (nsyms, n_ways, "decode")
+        d = torch.from_numpy(data.view(np.int16)).cuda()
+        for n_ways, chunk in ((64, 8192), (128, 16384), (2, 512), (64, 5000)):
+            want, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, n_ways, chunk, align=16)
+            cont, d_offs, d_lens, total = ctx.encode(gm, d, n_ways, chunk)
+            assert total == want.size and np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens), (nsyms, n_ways)
+            got = cont[:total].cpu().numpy()
+            for c in (0, 1, len(lens) // 2, len(lens) - 1):
+                o, ln = int(offs[c]), int(lens[c])
+                assert np.array_equal(got[o:o + ln], want[o:o + ln]), (nsyms, n_ways, c)
+            d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
+            out = ctx.decode(gm, d_cont, want.size, torch.from_numpy(offs.astype(np.int64)).cuda(),
+                             torch.from_numpy(lens.astype(np.int32)).cuda(), n, n_ways, chunk)
+            assert np.array_equal(out.cpu().numpy().view(np.uint16), data), (nsyms, n_ways)
+    # more symbols than slots cannot be a model
+    with pytest.raises(R.RansAmdError):
+        ctx.model(FMT_WORD, np.ones(8192, np.uint32), 12)
