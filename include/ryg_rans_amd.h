@@ -209,6 +209,26 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
  * by asynchronous rans_amd_decode calls on this context. */
 int rans_amd_decode_errors(rans_amd_ctx *ctx, uint64_t *h_bad_chunks, void *stream);
 
+/* ---- per-chunk adaptive models ------------------------------------------------
+ *
+ * The reference builds ONE order-0 model per input (main.cpp:139-162: count_freqs, normalize_freqs,
+ * RansEncSymbolInit / RansDecSymbolInit, cum2sym).  Here every CHUNK is such an input: its own histogram, its own
+ * normalised frequencies (exactly normalize_freqs of that chunk), its own tables -- built by the wavefront that
+ * codes the chunk, in its LDS, from the chunk's 256 frequencies.  Byte format (rans_byte.h), 256 symbols,
+ * scale_bits 8..12; n_ways 1..512.  Chunk c's stream is the reference-format stream of a model built for chunk c
+ * alone; the container layout and index are those of rans_amd_encode.  d_chunk_freqs (device, u16[256] per chunk,
+ * rans_amd_chunk_freqs_bytes) travels with the container: rans_amd_encode_adaptive fills it, rans_amd_decode_adaptive
+ * reads it (a chunk whose frequencies do not sum to 1 << scale_bits is counted as corrupt, never decoded). */
+uint64_t rans_amd_chunk_freqs_bytes(uint64_t n, uint32_t chunk_syms);
+/* Histograms on the GPU, normalize_freqs on the host (synchronises `stream`), encode + layout + compaction on the GPU. */
+int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
+                             uint32_t scale_bits, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
+                             uint32_t *d_lengths, uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream);
+int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_t container_bytes,
+                             const uint64_t *d_offsets, const uint32_t *d_lengths, const uint16_t *d_chunk_freqs,
+                             uint64_t n, uint32_t n_ways, uint32_t chunk_syms, uint32_t scale_bits, void *d_out,
+                             uint64_t *h_bad_chunks, void *stream);
+
 /* ---- host-buffer convenience: one raw reference-format stream -------------- */
 
 /* Exactly the reference encoder loops: the stream is written BACKWARDS and ends

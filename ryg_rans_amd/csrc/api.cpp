@@ -541,7 +541,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     if (ctx->timing)
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
     if (nchunks) {
-        EncParams ep;
+        EncParams ep{};
         ep.syms = static_cast<const uint8_t *>(d_syms);
         ep.n = n;
         ep.nchunks = nchunks;
@@ -633,7 +633,7 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     if (nchunks) {
-        DecParams dp;
+        DecParams dp{};
         dp.container = static_cast<const uint8_t *>(d_container);
         dp.container_bytes = container_bytes;
         dp.offsets = d_offsets;
@@ -774,6 +774,184 @@ int rans_amd_decode_errors(rans_amd_ctx *ctx, uint64_t *h_bad_chunks, void *stre
     HIP_TRY(hipStreamSynchronize(s));
     *h_bad_chunks = bad;
     return bad ? fail(RANS_AMD_E_CORRUPT, "decode: at least one chunk failed its integrity check") : RANS_AMD_OK;
+}
+
+
+/* ---- per-chunk adaptive models ------------------------------ */
+
+uint64_t rans_amd_chunk_freqs_bytes(uint64_t n, uint32_t chunk_syms)
+{
+    return rans_amd_num_chunks(n, chunk_syms) * 256u * sizeof(uint16_t);
+}
+
+int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
+                             uint32_t scale_bits, void *d_out, uint64_t out_cap, uint64_t *d_offsets, uint32_t *d_lengths,
+                             uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream)
+{
+    if (!ctx || !d_out || !d_offsets || !d_lengths || !d_chunk_freqs || (n && !d_syms) || chunk_syms == 0)
+        return fail(RANS_AMD_E_ARG, "encode_adaptive: NULL argument or chunk_syms == 0");
+    if (scale_bits < 8 || scale_bits > 12)
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive: scale_bits must be 8..12 (a chunk's tables live in one wave's LDS)");
+    if (!ways_supported(RANS_AMD_FMT_BYTE, n_ways))
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive: n_ways must be in 1..512");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0)
+        return fail(RANS_AMD_E_ARG, "encode_adaptive: d_out must be 16-byte aligned");
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t slot = encode_slot_bytes(RANS_AMD_FMT_BYTE, n, n_ways, chunk_syms);
+    if (slot > 0xfffffff0ull)
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive: chunk_syms too large");
+    int rc = ctx->scratch.reserve((size_t)(nchunks * slot + 64));
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
+    if (nchunks) {
+        // 1. count_freqs per chunk on the GPU (main.cpp:59-66, one wave per chunk)
+        rc = ctx->hist.reserve((size_t)nchunks * 256u * 4u);
+        if (rc)
+            return rc;
+        uint32_t *d_counts = static_cast<uint32_t *>(ctx->hist.ptr);
+        HIP_TRY(launch_histogram_chunks(d_syms, n, chunk_syms, nchunks, d_counts, ctx->num_cus, s));
+        std::vector<uint32_t> counts((size_t)nchunks * 256u);
+        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // 2. normalize_freqs per chunk on the host, exactly the reference's (main.cpp:75-129); u16 each
+        std::vector<uint16_t> freqs16(counts.size());
+        uint32_t cum[257];
+        for (uint64_t c = 0; c < nchunks; ++c) {
+            uint32_t *f = &counts[(size_t)c * 256u];
+            rc = normalize_freqs(f, cum, 256, 1u << scale_bits);
+            if (rc)
+                return fail(rc, "encode_adaptive: normalize_freqs failed for a chunk");
+            for (int i = 0; i < 256; ++i)
+                freqs16[(size_t)c * 256u + i] = (uint16_t)f[i]; // <= 4096
+        }
+        HIP_TRY(hipMemcpyAsync(d_chunk_freqs, freqs16.data(), freqs16.size() * 2, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s)); // (freqs16 is about to go out of scope)
+        // 3. encode: every wave builds the records of the chunk it codes
+        if (ctx->timing)
+            HIP_TRY(hipEventRecord(ctx->ev[2], s));
+        EncParams ep{};
+        ep.syms = static_cast<const uint8_t *>(d_syms);
+        ep.n = n;
+        ep.nchunks = nchunks;
+        ep.chunk_syms = chunk_syms;
+        ep.n_ways = n_ways;
+        ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr);
+        ep.slot_bytes = slot;
+        ep.lengths = d_lengths;
+        ep.nsyms = 256;
+        ep.scale_bits = scale_bits;
+        ep.sym_bytes = 1;
+        ep.flags = ctx->d_enc_flags();
+        ep.chunk_freqs = d_chunk_freqs;
+        HIP_TRY(launch_encode(kKernelFormatByteAdaptive, ep, ctx->num_cus, s));
+    }
+    LayoutParams lp;
+    lp.lengths = d_lengths;
+    lp.offsets = d_offsets;
+    lp.nchunks = nchunks;
+    lp.out_cap = out_cap;
+    lp.flags = ctx->d_enc_flags();
+    lp.block_sums = nullptr;
+    if (layout_blocks(nchunks) > 1) {
+        rc = ctx->layout_sums.reserve((size_t)layout_blocks(nchunks) * 8);
+        if (rc)
+            return rc;
+        lp.block_sums = static_cast<uint64_t *>(ctx->layout_sums.ptr);
+    }
+    HIP_TRY(launch_layout(lp, s));
+    if (nchunks) {
+        CompactParams cp;
+        cp.scratch = static_cast<const uint8_t *>(ctx->scratch.ptr);
+        cp.slot_bytes = slot;
+        cp.lengths = d_lengths;
+        cp.offsets = d_offsets;
+        cp.out = static_cast<uint8_t *>(d_out);
+        cp.nchunks = nchunks;
+        cp.flags = ctx->d_enc_flags();
+        HIP_TRY(launch_compact(cp, ctx->num_cus, s));
+    }
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev[3], s));
+        ctx->enc_timed = true;
+    }
+    if (h_total_bytes) {
+        uint32_t flags = 0;
+        uint64_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&flags, ctx->d_enc_flags(), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&total, d_offsets + nchunks, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *h_total_bytes = total;
+        if (flags & 1u)
+            return fail(RANS_AMD_E_MODEL, "encode_adaptive: a symbol without a slot was met (internal error)");
+        if (flags & 2u)
+            return fail(RANS_AMD_E_SPACE, "encode_adaptive: container does not fit out_cap");
+    }
+    return RANS_AMD_OK;
+}
+
+int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_t container_bytes, const uint64_t *d_offsets,
+                             const uint32_t *d_lengths, const uint16_t *d_chunk_freqs, uint64_t n, uint32_t n_ways,
+                             uint32_t chunk_syms, uint32_t scale_bits, void *d_out, uint64_t *h_bad_chunks, void *stream)
+{
+    if (!ctx || (n && (!d_container || !d_offsets || !d_lengths || !d_chunk_freqs || !d_out)) || chunk_syms == 0)
+        return fail(RANS_AMD_E_ARG, "decode_adaptive: NULL argument or chunk_syms == 0");
+    if (scale_bits < 8 || scale_bits > 12)
+        return fail(RANS_AMD_E_UNSUPPORTED, "decode_adaptive: scale_bits must be 8..12");
+    if (!ways_supported(RANS_AMD_FMT_BYTE, n_ways))
+        return fail(RANS_AMD_E_UNSUPPORTED, "decode_adaptive: n_ways must be in 1..512");
+    if ((reinterpret_cast<uintptr_t>(d_container) & 15u) != 0)
+        return fail(RANS_AMD_E_ARG, "decode_adaptive: d_container must be 16-byte aligned");
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (nchunks) {
+        DecParams dp{};
+        dp.container = static_cast<const uint8_t *>(d_container);
+        dp.container_bytes = container_bytes;
+        dp.offsets = d_offsets;
+        dp.lengths = d_lengths;
+        dp.out = static_cast<uint8_t *>(d_out);
+        dp.n = n;
+        dp.nchunks = nchunks;
+        dp.chunk_syms = chunk_syms;
+        dp.n_ways = n_ways;
+        dp.scale_bits = scale_bits;
+        dp.log2nsyms = 8;
+        dp.sym_bytes = 1;
+        dp.err_count = ctx->d_err();
+        dp.chunk_freqs = d_chunk_freqs;
+        if (nchunks < 0xffffffffull) {
+            unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);
+            dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * kWorkSlotWords;
+            dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * kWorkSlotWords;
+            dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
+            dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
+        }
+        if (ctx->timing)
+            HIP_TRY(hipEventRecord(ctx->ev[0], s));
+        HIP_TRY(launch_decode(kKernelFormatByteAdaptive, dp, ctx->num_cus, s, &ctx->last_kernel));
+        if (dp.work_counter)
+            ctx->launch_seq++;
+        if (ctx->timing) {
+            HIP_TRY(hipEventRecord(ctx->ev[1], s));
+            ctx->dec_timed = true;
+        }
+    }
+    if (h_bad_chunks) {
+        unsigned long long bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, ctx->d_err(), 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemsetAsync(ctx->d_err(), 0, 8, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *h_bad_chunks = bad;
+        if (bad)
+            return fail(RANS_AMD_E_CORRUPT, "decode_adaptive: at least one chunk failed its integrity check");
+    }
+    return RANS_AMD_OK;
 }
 
 /* ---- host-buffer wrappers: one raw reference-format stream ----------------- */

@@ -322,6 +322,55 @@ hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t strea
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// count_freqs (main.cpp:59-66) per CHUNK: one wave per chunk of u8 symbols, 256 counters in the wave's LDS,
+// written out as u32[256] per chunk (the model of every chunk is built from these).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_histogram_chunks(const uint8_t *syms, uint64_t n, uint32_t chunk_syms,
+                                                          uint64_t nchunks, uint32_t *counts)
+{
+    __shared__ uint32_t hist[4][256];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    uint32_t *h = hist[wave];
+    const uint64_t total_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t c = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < nchunks; c += total_waves) {
+        const uint64_t first = c * chunk_syms;
+        const uint32_t nsym = (uint32_t)((n - first) < chunk_syms ? (n - first) : chunk_syms);
+        const uint8_t *src = syms + first;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            h[lane + 64 * i] = 0u;
+        const bool aligned = (reinterpret_cast<uintptr_t>(src) & 3u) == 0;
+        const uint32_t body = aligned ? (nsym & ~3u) : 0u;
+        for (uint32_t i = lane * 4u; i < body; i += 256u) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(src + i);
+            atomicAdd(&h[v & 0xffu], 1u);
+            atomicAdd(&h[(v >> 8) & 0xffu], 1u);
+            atomicAdd(&h[(v >> 16) & 0xffu], 1u);
+            atomicAdd(&h[v >> 24], 1u);
+        }
+        for (uint32_t i = body + lane; i < nsym; i += 64u)
+            atomicAdd(&h[src[i]], 1u);
+        // (LDS operations of one wave execute in order: the reads below see every lane's increments)
+        uint32_t *out = counts + c * 256u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            out[lane + 64 * i] = h[lane + 64 * i];
+    }
+}
+
+hipError_t launch_histogram_chunks(const void *syms, uint64_t n, uint32_t chunk_syms, uint64_t nchunks, uint32_t *d_counts,
+                                   int num_cus, hipStream_t stream)
+{
+    const uint64_t want = (nchunks + 3) / 4;
+    const uint64_t cap = (uint64_t)num_cus * 8;
+    const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    RANS_LAUNCH(k_histogram_chunks, dim3(grid), dim3(256), 0, stream, static_cast<const uint8_t *>(syms), n, chunk_syms, nchunks,
+                d_counts);
+    return hipGetLastError();
+}
+
 hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
                             uint32_t *d_flags, int num_cus, hipStream_t stream)
 {

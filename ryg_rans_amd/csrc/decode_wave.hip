@@ -501,9 +501,10 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     uint32_t rounds_done = 0;
 
     // ---- stage the tables into LDS (once per block) ----------------------
-    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
-    const uint32_t t1_bytes = (p.table1_bytes + 15u) & ~15u;
-    {
+    // (per-chunk models: no shared tables -- "table 0" is the waves' own regions, filled per chunk below)
+    const uint32_t t0_bytes = FMT == FMT_BYTEA ? (blockDim.x >> 6) * kAdaptDecWaveLds : (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1_bytes = FMT == FMT_BYTEA ? 0u : (p.table1_bytes + 15u) & ~15u;
+    if constexpr (FMT != FMT_BYTEA) {
         const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
         uint4 *l0 = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
@@ -520,7 +521,11 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     const uint32_t waves_per_block = blockDim.x >> 6;
 
     DecTables<FMT> T;
-    T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+    if constexpr (FMT == FMT_BYTEA) // cum2sym[M] then {freq, start}[256] of the chunk in hand, this wave's own
+        T.init(smem + wave * kAdaptDecWaveLds, smem + wave * kAdaptDecWaveLds + (1u << kAdaptMaxScaleBits), p.scale_bits,
+               p.log2nsyms);
+    else
+        T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
     if (!lds_starts_at_zero(smem)) { // cannot happen without static LDS; never decode on a wrong assumption
         if (threadIdx.x == 0)
             atomicAdd(p.err_count, 1ull << 32);
@@ -583,6 +588,15 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
             continue;
         }
 
+        if constexpr (FMT == FMT_BYTEA) { // this chunk's model -> this wave's tables (main.cpp:139-162 per chunk)
+            if (!adapt_build_dec(p.chunk_freqs + chunk * 256u, p.scale_bits, lane, const_cast<uint8_t *>(T.t0),
+                                 reinterpret_cast<uint2 *>(const_cast<uint8_t *>(T.t1)))) {
+                if (lane == 0)
+                    atomicAdd(p.err_count, 1ull);
+                continue;
+            }
+        }
+
         // ---- initial states: lane 0's first (RansDecInit order, main.cpp:261-262)
         state_t x[K];
 #pragma unroll
@@ -635,7 +649,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                     for (int k = 0; k < K; ++k) {
                         if ((J * K + k) % kCheckEvery == 0)
                             W.checkpoint(lane);
-                        if constexpr (FMT == FMT_BYTE || FMT == FMT_ALIAS)
+                        if constexpr (kIsByteStream<FMT>)
                             renorm_byte_full(x[k], W.cur, k2p23, k2p15);
                         else if constexpr (FMT == FMT_WORD16)
                             renorm_word_full(x[k], W.cur, k65536w);
@@ -713,7 +727,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
             W.checkpoint(lane);                                                    \
         if constexpr (FMT == FMT_WORD && (OUT == OUT_FAST8 || OUT == OUT_FAST8_LDS || OUT == OUT_FAST8_BYTE)) \
             renorm_word_full(x[k], W.cur, k65536);                                 \
-        else if constexpr ((FMT == FMT_BYTE || FMT == FMT_ALIAS) && (OUT == OUT_FAST8 || OUT == OUT_FAST8_BYTE)) \
+        else if constexpr (kIsByteStream<FMT> && (OUT == OUT_FAST8 || OUT == OUT_FAST8_BYTE)) \
             renorm_byte_full(x[k], W.cur, k2p23, k2p15);                           \
         else                                                                       \
             W.consume(dec_renorm<FMT>(W, x[k], true));                             \
@@ -1048,8 +1062,11 @@ hipError_t launch_decode_word64(const DecParams &p, int num_cus, hipStream_t str
 template <int FMT, int K, int OUT>
 hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
-    const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
     const uint32_t waves = kDecBlockThreads / 64;
+    const uint32_t t0 = FMT == FMT_BYTEA ? waves * kAdaptDecWaveLds : (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1 = FMT == FMT_BYTEA ? 0u : (p.table1_bytes + 15u) & ~15u;
+    if (FMT == FMT_BYTEA && (!p.chunk_freqs || p.scale_bits > kAdaptMaxScaleBits || p.scale_bits < 8))
+        return hipErrorInvalidValue;
     const size_t lds = (size_t)t0 + t1 + (size_t)waves * kRingStride + (OUT == OUT_FAST8_LDS ? waves * kOutTileBytes : 0);
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
@@ -1064,7 +1081,8 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     if (name)
         *name = FMT == FMT_WORD ? "k_decode<word>" : FMT == FMT_BYTE ? "k_decode<byte>"
                 : FMT == FMT_R64 ? "k_decode<r64>" : FMT == FMT_R64S ? "k_decode<r64 search>"
-                : FMT == FMT_WORD16 ? "k_decode<word, u16 symbols>" : "k_decode<alias>";
+                : FMT == FMT_WORD16 ? "k_decode<word, u16 symbols>"
+                : FMT == FMT_BYTEA ? "k_decode<byte, per-chunk models>" : "k_decode<alias>";
     RANS_LAUNCH(kern, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
     return hipGetLastError();
 }
@@ -1144,6 +1162,7 @@ hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipSt
     case FMT_WORD: return launch_decode_f<FMT_WORD>(p, num_cus, stream, name);
     case FMT_BYTE: return launch_decode_f<FMT_BYTE>(p, num_cus, stream, name);
     case FMT_R64: return launch_decode_f<FMT_R64>(p, num_cus, stream, name);
+    case FMT_BYTEA: return launch_decode_f<FMT_BYTEA>(p, num_cus, stream, name);
     case FMT_WORD16: { // u16 symbols: paired-round stores for full waves, element stores otherwise
         const bool aligned = ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)p.chunk_syms * 2u) & 3u) == 0;
         if (aligned && p.n_ways == 64)

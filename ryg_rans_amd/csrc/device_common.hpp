@@ -37,6 +37,11 @@ template <int FMT> constexpr bool kIsAlias = (FMT == FMT_ALIAS || FMT == FMT_ALI
 // than 256 symbols -- SURVEY 8(f)4's "16-bit-symbol word format"; rans_word_sse41.h:41 fixes 256, the stream
 // format itself does not care.  Slot record {freq, bias | sym << 16}: one more v_and than the byte-symbol record.
 constexpr int FMT_WORD16 = 6;
+// Internal kernel format of the DECODER: byte format with one model PER CHUNK: every wave builds
+// cum2sym + symbol records of its chunk in its own LDS region from the chunk's 256 normalised frequencies
+// (scale_bits <= 12: 4 KiB + 2 KiB per wave), so the tables are addressed through per-wave pointers.
+constexpr int FMT_BYTEA = 7;
+template <int FMT> constexpr bool kIsByteStream = (FMT == FMT_BYTE || FMT == FMT_ALIAS || FMT == FMT_ALIAS_LDS || FMT == FMT_BYTEA);
 template <int FMT> constexpr bool kIsWord = (FMT == FMT_WORD || FMT == FMT_WORD16);
 
 // OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
@@ -78,6 +83,7 @@ template <> struct FmtTraits<FMT_R64> {
 };
 template <> struct FmtTraits<FMT_R64S> : FmtTraits<FMT_R64> {};
 template <> struct FmtTraits<FMT_ALIAS_LDS> : FmtTraits<FMT_ALIAS> {};
+template <> struct FmtTraits<FMT_BYTEA> : FmtTraits<FMT_BYTE> {};
 template <> struct FmtTraits<FMT_WORD16> : FmtTraits<FMT_WORD> {
     static constexpr int kSymByte = 0; // dec_step returns the symbol itself
 };
@@ -183,6 +189,13 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         // freq <= 2^16 and x >> scale_bits < 2^23 (scale_bits >= 8): 24-bit multiply is exact
         x = (r.x & 0xffffffu) * ((x >> T.sbv) & 0xffffffu) + cf - r.y;
         return s;
+    } else if constexpr (FMT == FMT_BYTEA) {
+        // the same through the wave's own table pointers (per-chunk models)
+        const uint32_t cf = x & T.maskv;
+        const uint32_t s = T.t0[cf];
+        const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s];
+        x = (r.x & 0xffffffu) * ((x >> T.sbv) & 0xffffffu) + cf - r.y;
+        return s;
     } else if constexpr (FMT == FMT_R64) {
         // rans64.h:118-121 (get), :286-292 (step)
         const uint32_t cf = (uint32_t)x & T.maskv;
@@ -223,6 +236,95 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[half]; // {freq | sym << 16, adjust}
         x = (e.x & 0xffffu) * ((x >> T.sbv) & 0xffffffu) + xm - e.y;
         return e.x >> 16;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Per-chunk models (the reference builds one model per input, main.cpp:139-162): a wave turns the
+// 256 normalised frequencies of ITS chunk (u16 each, sum = 1 << scale_bits, scale_bits 8..12) into the tables
+// of the byte coder, in its own LDS region.  Lane l owns symbols 4l .. 4l+3.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kAdaptMaxScaleBits = 12;
+constexpr uint32_t kAdaptDecWaveLds = (1u << kAdaptMaxScaleBits) + 256u * 8u; // cum2sym + {freq, start} records
+constexpr uint32_t kAdaptEncWaveLds = 256u * 16u;                             // EncRec per symbol
+
+// frequencies and exclusive cumulative frequencies of this lane's four symbols
+__device__ __forceinline__ void adapt_load_cum(const uint16_t *chunk_freqs, uint32_t lane, uint32_t (&f)[4], uint32_t (&c)[4])
+{
+    const u32x2 v = *reinterpret_cast<const u32x2 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(chunk_freqs) + 8u * lane);
+    f[0] = v.x & 0xffffu;
+    f[1] = v.x >> 16;
+    f[2] = v.y & 0xffffu;
+    f[3] = v.y >> 16;
+    const uint32_t own = f[0] + f[1] + f[2] + f[3];
+    uint32_t incl = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+        incl += lane >= (uint32_t)d ? t : 0u;
+    }
+    c[0] = incl - own;
+    c[1] = c[0] + f[0];
+    c[2] = c[1] + f[1];
+    c[3] = c[2] + f[2];
+}
+
+// decoder tables (main.cpp:143-148 cum2sym, :159-162 RansDecSymbolInit): recs[s] = {freq, start}, cum2sym[M]
+// Returns false (wave-uniform) when the frequencies do not sum to 1 << scale_bits: they come from the caller's
+// container, and a table built from them must not be walked (the fill below relies on the sum).
+__device__ __forceinline__ bool adapt_build_dec(const uint16_t *chunk_freqs, uint32_t scale_bits, uint32_t lane,
+                                                uint8_t *cum2sym, uint2 *recs)
+{
+    uint32_t f[4], c[4];
+    adapt_load_cum(chunk_freqs, lane, f, c);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(c[3] + f[3]), 63);
+    if (total != (1u << scale_bits))
+        return false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        recs[4u * lane + i] = uint2{f[i], c[i]};
+    // (LDS operations of one wave execute in order: the reads below see every lane's records)
+    const uint32_t per = (1u << scale_bits) >> 6; // positions per lane: 4 .. 64
+    uint32_t pos = lane * per;
+    uint32_t s = 0; // the last symbol whose start is <= pos; symbols of frequency 0 are stepped over below
+#pragma unroll
+    for (uint32_t half = 128; half; half >>= 1)
+        s += recs[s + half].y <= pos ? half : 0u;
+    uint32_t end = recs[s].y + recs[s].x;
+    for (uint32_t i = 0; i < per; i += 4) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            while (pos >= end && s < 255u) { // next symbol with a slot at pos (pos < M = the last symbol's end)
+                ++s;
+                end = recs[s].y + recs[s].x;
+            }
+            w |= s << (8 * b);
+            ++pos;
+        }
+        *reinterpret_cast<uint32_t *>(cum2sym + pos - 4u) = w;
+    }
+    return true;
+}
+
+// encoder records (RansEncSymbolInit, rans_byte.h:174-243), in the layout enc_update_byte reads:
+// {freq | rshift << 24, bias, rcp, 0}; zero records for symbols the chunk does not hold
+__device__ __forceinline__ void adapt_build_enc(const uint16_t *chunk_freqs, uint32_t scale_bits, uint32_t lane, uint4 *recs)
+{
+    uint32_t f[4], c[4];
+    adapt_load_cum(chunk_freqs, lane, f, c);
+    const uint32_t M = 1u << scale_bits;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint4 r = {0u, 0u, 0u, 0u};
+        if (f[i] == 1u) {
+            r = uint4{1u, c[i] + M - 1u, 0xffffffffu, 0u};
+        } else if (f[i] >= 2u) {
+            const uint32_t sh = 32u - (uint32_t)__builtin_clz(f[i] - 1u); // ceil(log2 freq)
+            const uint32_t rcp = (uint32_t)(((1ull << (sh + 31u)) + f[i] - 1u) / f[i]);
+            r = uint4{f[i] | ((sh - 1u) << 24), c[i], rcp, 0u};
+        }
+        recs[4u * lane + i] = r;
     }
 }
 

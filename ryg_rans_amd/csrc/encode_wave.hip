@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
         uint4 *lr = reinterpret_cast<uint4 *>(smem + (size_t)nrecs * 8u);
         for (uint32_t i = threadIdx.x; i < (2u << p.scale_bits) / 16u; i += blockDim.x)
             lr[i] = gr[i];
-    } else {
+    } else if (!(FMT == FMT_BYTE && p.chunk_freqs)) { // (per-chunk models: every wave builds its own records below)
         const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
         uint4 *l = reinterpret_cast<uint4 *>(smem + kWordRecBytes);
         for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
@@ -201,6 +201,9 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
 
     EncTables<FMT> T;
     T.recs = reinterpret_cast<const uint4 *>(smem + kWordRecBytes);
+    const bool adaptive = FMT == FMT_BYTE && p.chunk_freqs; // one model per chunk
+    if (adaptive)
+        T.recs = reinterpret_cast<const uint4 *>(smem + wave * kAdaptEncWaveLds);
     T.alias_remap = p.alias_remap;
     T.remap16 = reinterpret_cast<const uint16_t *>(smem + (size_t)nrecs * 8u);
     T.scale_bits = p.scale_bits;
@@ -221,6 +224,9 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
         const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + first * p.sym_bytes;
         uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + chunk * p.slot_bytes;
         uint32_t wp = (uint32_t)p.slot_bytes;
+
+        if (adaptive) // this chunk's model -> this wave's records (RansEncSymbolInit per chunk, main.cpp:159-162)
+            adapt_build_enc(p.chunk_freqs + chunk * 256u, p.scale_bits, lane, const_cast<uint4 *>(T.recs));
 
         state_t x[K];
 #pragma unroll
@@ -399,6 +405,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     const uint32_t waves = threads / 64;
     const size_t nrecs = p.nsyms < 256 ? 256 : p.nsyms;
     const size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
+                       : (FMT == FMT_BYTE && p.chunk_freqs) ? (size_t)waves * kAdaptEncWaveLds
                                             : nrecs * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
     const size_t lds_cap = FMT == FMT_ALIAS_LDS ? 160 * 1024 : 128 * 1024;
     if (lds > lds_cap || (FMT == FMT_WORD && !p.word_enc_recs && p.sym_bytes == 1) ||

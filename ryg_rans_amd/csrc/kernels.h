@@ -31,6 +31,9 @@ constexpr int kKernelFormatAliasLds = 5;
 // Kernel-side format number of the word-format DECODER over more than 256 symbols (device_common.hpp FMT_WORD16):
 // DecParams::table0 holds {freq, bias | sym << 16} per slot, symbols are u16.
 constexpr int kKernelFormatWord16 = 6;
+// Kernel-side format number of the byte-format DECODER with one model per chunk (device_common.hpp FMT_BYTEA):
+// DecParams::chunk_freqs holds u16[256] per chunk; no table0/table1.
+constexpr int kKernelFormatByteAdaptive = 7;
 constexpr uint32_t kTraceWords = 5;      // per-wave record of DecParams::trace
 
 struct DecParams {
@@ -53,6 +56,7 @@ struct DecParams {
     unsigned long long *err_count; // failed chunks (device counter)
     unsigned int *work_counter;    // next chunk to hand out (zero at launch); NULL = static striding
     unsigned int *work_counter_reset; // a counter slot of a LATER launch that this launch zeroes
+    const uint16_t *chunk_freqs;      // FMT_BYTEA: normalised frequencies, u16[256] per chunk (else NULL)
     uint8_t *wave_scratch;            // one 64-byte line per resident wave (marker stores of the window refills), or NULL
     uint32_t debug;                   // measurement knobs (RANS_AMD_DEBUG): bit 0 = drop the symbol stores of the
                                       // 64-way word decoders (their descriptor gets zero records)
@@ -74,6 +78,8 @@ struct EncParams {
     const void *enc_recs; // EncRec[nsyms]
     const void *word_enc_recs; // WordEncRec[256] (FMT_WORD only, else NULL)
     const uint32_t *alias_remap;
+    const uint16_t *chunk_freqs;    // byte format with one model per chunk: u16[256] per chunk (else NULL); the waves
+                                    // build their chunk's records in LDS themselves
     const void *alias_recs8;        // FMT_ALIAS_LDS: {freq | start << 16, floor(2^32 / freq)} per symbol (>= 256 entries)
     const uint16_t *alias_remap16;  // FMT_ALIAS_LDS: alias_remap as u16[1 << scale_bits]
     uint32_t nsyms;
@@ -110,6 +116,9 @@ hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t strea
 hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
                             uint32_t *d_flags, int num_cus, hipStream_t stream);
 
+// per-chunk histograms of u8 symbols: d_counts[nchunks][256]
+hipError_t launch_histogram_chunks(const void *syms, uint64_t n, uint32_t chunk_syms, uint64_t nchunks, uint32_t *d_counts,
+                                   int num_cus, hipStream_t stream);
 // (format, n_ways) combinations with a kernel.
 bool ways_supported(int format, uint32_t n_ways);
 

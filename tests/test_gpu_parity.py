@@ -607,3 +607,60 @@ def test_word_format_with_u16_symbols(gpu, oracle):
     # more symbols than slots cannot be a model
     with pytest.raises(R.RansAmdError):
         ctx.model(FMT_WORD, np.ones(8192, np.uint32), 12)
+
+
+def test_per_chunk_adaptive_models(gpu, oracle):
+    """one order-0 model per chunk, built as the reference builds its one model per input
+    (main.cpp:139-162) -- GPU histogram per chunk, normalize_freqs on the host, tables by the coding wavefront.
+    Every chunk's frequencies must be the oracle's normalize(count_freqs(chunk)), every chunk's stream the oracle's
+    stream for a model of that chunk alone; the input changes statistics from chunk to chunk on purpose."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(31)
+    chunk = 8192
+    parts = []
+    for c in range(37):  # every chunk its own distribution: skewed, two symbols, uniform, constant, text-like
+        kind = c % 5
+        if kind == 0:
+            parts.append(np.minimum(rng.geometric(0.02 + 0.01 * c, chunk) - 1, 255))
+        elif kind == 1:
+            parts.append(rng.integers(0, 2, chunk) * (c + 3))
+        elif kind == 2:
+            parts.append(rng.integers(0, 256, chunk))
+        elif kind == 3:
+            parts.append(np.full(chunk, c))
+        else:
+            parts.append((oracle.gen_zipf(chunk, K=256, s=1.0, seed=c).astype(np.int64) + 7 * c) % 256)
+    data = np.concatenate(parts).astype(np.uint8)[:37 * chunk - 1234]  # ragged last chunk
+    n = data.size
+    d = torch.from_numpy(data).cuda()
+    for sb in (12, 10, 8):
+        for n_ways in (64, 2, 128, 100):
+            cont, offs, lens, freqs, total = ctx.encode_adaptive(d, n_ways, chunk, sb)
+            h_freqs = freqs.cpu().numpy().view(np.uint16).reshape(-1, 256)
+            h_offs = offs.cpu().numpy().astype(np.uint64)
+            h_lens = lens.cpu().numpy().astype(np.uint32)
+            got = cont[:total].cpu().numpy()
+            nchunks = (n + chunk - 1) // chunk
+            pos = 0
+            for c in range(nchunks):
+                part = data[c * chunk:(c + 1) * chunk]
+                f, _ = oracle.normalize(oracle.count_freqs(part, 256), 1 << sb)
+                assert np.array_equal(h_freqs[c].astype(np.uint32), f), (sb, n_ways, c, "model")
+                want = oracle.encode(FMT_BYTE, oracle.model(f, sb), part, n_ways)
+                assert int(h_offs[c]) == pos and int(h_lens[c]) == want.size, (sb, n_ways, c, "index")
+                assert np.array_equal(got[pos:pos + want.size], want), (sb, n_ways, c, "stream")
+                pos += (want.size + 15) & ~15
+            out = ctx.decode_adaptive(cont, total, offs, lens, freqs, n, n_ways, chunk, sb)
+            assert np.array_equal(out.cpu().numpy(), data), (sb, n_ways, "decode")
+    # adaptive beats one global model on this input, and a damaged frequency row is flagged, not decoded
+    cont, offs, lens, freqs, total = ctx.encode_adaptive(d, 64, chunk, 12)
+    gm = ctx.model_for(FMT_BYTE, data, 256, 12)
+    _, _, _, total_global = ctx.encode(gm, d, 64, chunk)
+    assert total + freqs.numel() * 2 < total_global
+    bad = freqs.clone()
+    bad[5 * 256 + 3] += 1
+    out = ctx.decode_adaptive(cont, total, offs, lens, bad, n, 64, chunk, 12, sync=False)
+    assert ctx.decode_errors() >= 1
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.encode_adaptive(d, 64, chunk, 14)
+    assert e.value.status == R.E_UNSUPPORTED
