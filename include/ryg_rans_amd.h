@@ -277,6 +277,16 @@ int rans_amd_container_pack(const rans_amd_container_info *info, const uint32_t 
 int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container_info *info,
                              const uint32_t **freqs, const uint32_t **lengths, const void **payload);
 
+/* Version 2 of the same wrapper, for rans_amd_encode_adaptive containers: the single frequency table is replaced by
+ * u16 chunk_freqs[n_chunks][256] (info->format == RANS_AMD_FMT_BYTE, nsyms 256, sym_bytes 1, scale_bits 8..12):
+ *   [ 80-byte header (version 2) | u16 chunk_freqs[n_chunks][256] | u32 lengths[n_chunks] | pad to 16 | payload ] */
+uint64_t rans_amd_container_bytes_adaptive(const rans_amd_container_info *info);
+int rans_amd_container_pack_adaptive(const rans_amd_container_info *info, const uint16_t *chunk_freqs,
+                                     const uint32_t *lengths, const void *payload, void *dst, uint64_t cap,
+                                     uint64_t *out_bytes);
+int rans_amd_container_parse_adaptive(const void *src, uint64_t bytes, rans_amd_container_info *info,
+                                      const uint16_t **chunk_freqs, const uint32_t **lengths, const void **payload);
+
 /* ---- measurement helpers ---------------------------------------------------- */
 
 /* Duration in milliseconds of the most recent decode / encode kernel group that

@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_wave_clocks",
     "rans_amd_launch_spans",
     "rans_amd_chunk_freqs_bytes", "rans_amd_encode_adaptive", "rans_amd_decode_adaptive",
+    "rans_amd_container_bytes_adaptive", "rans_amd_container_pack_adaptive", "rans_amd_container_parse_adaptive",
     "rans_amd_offsets_from_lengths", "rans_amd_container_bytes", "rans_amd_container_pack",
     "rans_amd_container_parse", "rans_amd_encode_workspace_bytes", "rans_amd_build_model_o0",
 ]
@@ -121,6 +122,10 @@ def _load():
         "rans_amd_container_pack": (i32, [C.POINTER(ContainerInfo), u32p, u32p, vp, vp, u64, u64p]),
         "rans_amd_container_parse": (i32, [vp, u64, C.POINTER(ContainerInfo), C.POINTER(u32p), C.POINTER(u32p),
                                          C.POINTER(vp)]),
+        "rans_amd_container_bytes_adaptive": (u64, [C.POINTER(ContainerInfo)]),
+        "rans_amd_container_pack_adaptive": (i32, [C.POINTER(ContainerInfo), vp, u32p, vp, vp, u64, u64p]),
+        "rans_amd_container_parse_adaptive": (i32, [vp, u64, C.POINTER(ContainerInfo), C.POINTER(vp), C.POINTER(u32p),
+                                                  C.POINTER(vp)]),
     }
     for name, (res, args) in sig.items():
         if not hasattr(lib, name) and os.environ.get("RANS_AMD_LIB"):
@@ -418,6 +423,43 @@ def parse_container(blob):
     l_off = f_off + 4 * info.nsyms
     p_off = pp.value - base
     freqs = blob[f_off:f_off + 4 * info.nsyms].view(np.uint32)
+    lengths = blob[l_off:l_off + 4 * info.n_chunks].view(np.uint32)
+    payload = blob[p_off:p_off + info.payload_bytes]
+    return info, freqs, lengths, payload
+
+
+def pack_container_adaptive(scale_bits, n_symbols, n_ways, chunk_syms, chunk_freqs, lengths, payload):
+    """Version-2 container (one model per chunk): chunk_freqs is u16[n_chunks * 256]."""
+    cf = np.ascontiguousarray(chunk_freqs, dtype=np.uint16)
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    info = ContainerInfo(FMT_BYTE, scale_bits, 256, n_ways, chunk_syms, 1, n_symbols, num_chunks(n_symbols, chunk_syms),
+                         payload.size)
+    if lengths.size != info.n_chunks or cf.size != info.n_chunks * 256:
+        raise RansAmdError(E_ARG, "container_pack_adaptive", "lengths / chunk_freqs do not match the number of chunks")
+    total = int(_lib.rans_amd_container_bytes_adaptive(C.byref(info)))
+    if total == 0:
+        raise RansAmdError(E_ARG, "container_bytes_adaptive", "inconsistent container description")
+    out = np.zeros(total, dtype=np.uint8)
+    wrote = C.c_uint64(0)
+    _check(_lib.rans_amd_container_pack_adaptive(C.byref(info), cf.ctypes.data, lengths.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                 payload.ctypes.data, out.ctypes.data, out.size, C.byref(wrote)),
+           "container_pack_adaptive")
+    return out[:wrote.value]
+
+
+def parse_container_adaptive(blob):
+    """-> (ContainerInfo, chunk_freqs u16[n_chunks, 256], lengths, payload) as numpy views into `blob`."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    info = ContainerInfo()
+    pf, pl, pp = C.c_void_p(), C.POINTER(C.c_uint32)(), C.c_void_p()
+    _check(_lib.rans_amd_container_parse_adaptive(blob.ctypes.data, blob.size, C.byref(info), C.byref(pf), C.byref(pl),
+                                                  C.byref(pp)), "container_parse_adaptive")
+    base = blob.ctypes.data
+    f_off = pf.value - base
+    l_off = f_off + 512 * info.n_chunks
+    p_off = pp.value - base
+    freqs = blob[f_off:f_off + 512 * info.n_chunks].view(np.uint16).reshape(-1, 256)
     lengths = blob[l_off:l_off + 4 * info.n_chunks].view(np.uint32)
     payload = blob[p_off:p_off + info.payload_bytes]
     return info, freqs, lengths, payload

@@ -188,4 +188,130 @@ int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container
     return RANS_AMD_OK;
 }
 
+
+/* ---- version 2: one model per chunk (rans_amd_encode_adaptive) ------------------------------
+ *   [ 80-byte header (version 2, reserved = 1) | u16 chunk_freqs[n_chunks][256] | u32 lengths[n_chunks] | pad to 16 | payload ]
+ * info->format is RANS_AMD_FMT_BYTE, nsyms 256, sym_bytes 1; the checksum covers header, frequencies and lengths. */
+static uint64_t meta_bytes_v2(const rans_amd_container_info *i)
+{
+    return align16(kHeaderBytes + 512ull * i->n_chunks + 4ull * i->n_chunks);
+}
+
+static bool info_sane_v2(const rans_amd_container_info *i)
+{
+    return info_sane(i) && i->format == RANS_AMD_FMT_BYTE && i->nsyms == 256 && i->sym_bytes == 1 && i->scale_bits >= 8 &&
+           i->scale_bits <= 12;
+}
+
+uint64_t rans_amd_container_bytes_adaptive(const rans_amd_container_info *info)
+{
+    if (!info_sane_v2(info))
+        return 0;
+    return meta_bytes_v2(info) + info->payload_bytes;
+}
+
+int rans_amd_container_pack_adaptive(const rans_amd_container_info *info, const uint16_t *chunk_freqs,
+                                     const uint32_t *lengths, const void *payload, void *dst, uint64_t cap,
+                                     uint64_t *out_bytes)
+{
+    if (!info_sane_v2(info) || !dst || (info->n_chunks && (!chunk_freqs || !lengths || !payload)))
+        return RANS_AMD_E_ARG;
+    uint64_t at = 0;
+    for (uint64_t c = 0; c < info->n_chunks; ++c)
+        at = (c + 1 == info->n_chunks) ? at + lengths[c] : at + align16(lengths[c]);
+    if (at != info->payload_bytes)
+        return RANS_AMD_E_ARG;
+    for (uint64_t c = 0; c < info->n_chunks; ++c) { // every chunk's model must be a model
+        uint32_t sum = 0;
+        for (int s = 0; s < 256; ++s)
+            sum += chunk_freqs[c * 256 + s];
+        if (sum != (1u << info->scale_bits))
+            return RANS_AMD_E_MODEL;
+    }
+    const uint64_t meta = meta_bytes_v2(info), total = meta + info->payload_bytes;
+    if (cap < total)
+        return RANS_AMD_E_SPACE;
+    uint8_t *out = static_cast<uint8_t *>(dst);
+    memset(out, 0, (size_t)meta);
+    Header h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, kMagic, 8);
+    h.version = 2;
+    h.reserved = 1; // model mode: per-chunk u16 frequencies
+    h.format = info->format;
+    h.scale_bits = info->scale_bits;
+    h.nsyms = info->nsyms;
+    h.n_ways = info->n_ways;
+    h.chunk_syms = info->chunk_syms;
+    h.sym_bytes = info->sym_bytes;
+    h.n_symbols = info->n_symbols;
+    h.n_chunks = info->n_chunks;
+    h.payload_bytes = info->payload_bytes;
+    uint64_t ck = fnv1a(0xcbf29ce484222325ull, &h, sizeof(h));
+    ck = fnv1a(ck, chunk_freqs, 512ull * info->n_chunks);
+    ck = fnv1a(ck, lengths, 4ull * info->n_chunks);
+    h.checksum = ck;
+    memcpy(out, &h, sizeof(h));
+    if (info->n_chunks) {
+        memcpy(out + kHeaderBytes, chunk_freqs, 512ull * info->n_chunks);
+        memcpy(out + kHeaderBytes + 512ull * info->n_chunks, lengths, 4ull * info->n_chunks);
+    }
+    if (info->payload_bytes)
+        memcpy(out + meta, payload, (size_t)info->payload_bytes);
+    if (out_bytes)
+        *out_bytes = total;
+    return RANS_AMD_OK;
+}
+
+int rans_amd_container_parse_adaptive(const void *src, uint64_t bytes, rans_amd_container_info *info,
+                                      const uint16_t **chunk_freqs, const uint32_t **lengths, const void **payload)
+{
+    if (!src || !info)
+        return RANS_AMD_E_ARG;
+    if (bytes < kHeaderBytes)
+        return RANS_AMD_E_CORRUPT;
+    Header h;
+    memcpy(&h, src, sizeof(h));
+    if (memcmp(h.magic, kMagic, 8) != 0 || h.version != 2 || h.reserved != 1)
+        return RANS_AMD_E_CORRUPT;
+    rans_amd_container_info i;
+    i.format = h.format;
+    i.scale_bits = h.scale_bits;
+    i.nsyms = h.nsyms;
+    i.n_ways = h.n_ways;
+    i.chunk_syms = h.chunk_syms;
+    i.sym_bytes = h.sym_bytes;
+    i.n_symbols = h.n_symbols;
+    i.n_chunks = h.n_chunks;
+    i.payload_bytes = h.payload_bytes;
+    if (!info_sane_v2(&i))
+        return RANS_AMD_E_CORRUPT;
+    const uint64_t meta = meta_bytes_v2(&i);
+    if (meta > bytes || i.payload_bytes > bytes - meta)
+        return RANS_AMD_E_CORRUPT;
+    const uint8_t *p = static_cast<const uint8_t *>(src);
+    const uint16_t *f = reinterpret_cast<const uint16_t *>(p + kHeaderBytes);
+    const uint32_t *l = reinterpret_cast<const uint32_t *>(p + kHeaderBytes + 512ull * i.n_chunks);
+    const uint64_t stored = h.checksum;
+    h.checksum = 0;
+    uint64_t ck = fnv1a(0xcbf29ce484222325ull, &h, sizeof(h));
+    ck = fnv1a(ck, f, 512ull * i.n_chunks);
+    ck = fnv1a(ck, l, 4ull * i.n_chunks);
+    if (ck != stored)
+        return RANS_AMD_E_CORRUPT;
+    uint64_t at = 0;
+    for (uint64_t c = 0; c < i.n_chunks; ++c)
+        at = (c + 1 == i.n_chunks) ? at + l[c] : at + align16(l[c]);
+    if (at != i.payload_bytes)
+        return RANS_AMD_E_CORRUPT;
+    *info = i;
+    if (chunk_freqs)
+        *chunk_freqs = f;
+    if (lengths)
+        *lengths = l;
+    if (payload)
+        *payload = p + meta;
+    return RANS_AMD_OK;
+}
+
 } // extern "C"

@@ -85,3 +85,102 @@ def test_gpu_encode_file_decode(tmp_path, oracle):
     om = oracle.model(f2, 12)
     assert np.array_equal(oracle.decode_chunked(FMT_WORD, om, p2, R.offsets_from_lengths(l2), l2, data.size, 64, 32768),
                           data)
+
+
+def _oracle_adaptive(oracle, data, sb, n_ways, chunk):
+    """Per-chunk models on the CPU: each chunk counted, normalised and encoded with ITS OWN table (byte format)."""
+    rows, parts, lens = [], [], []
+    for lo in range(0, data.size, chunk):
+        piece = data[lo:lo + chunk]
+        f, _ = oracle.normalize(oracle.count_freqs(piece, 256), 1 << sb)
+        rows.append(f.astype(np.uint16))
+        stream = oracle.encode(FMT_BYTE, oracle.model(f, sb), piece, n_ways)
+        lens.append(stream.size)
+        pad = (-stream.size) % 16 if lo + chunk < data.size else 0
+        parts.append(np.concatenate([stream, np.zeros(pad, np.uint8)]))
+    payload = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    return np.stack(rows) if rows else np.zeros((0, 256), np.uint16), np.array(lens, np.uint32), payload
+
+
+def test_adaptive_container_roundtrip(oracle):
+    rng = np.random.default_rng(3)
+    # two regimes so the per-chunk models differ
+    data = np.concatenate([oracle.gen_zipf(9000, K=64, s=1.2, seed=1), rng.integers(100, 256, 7001).astype(np.uint8)])
+    rows, lens, payload = _oracle_adaptive(oracle, data, 12, 32, 4096)
+    blob = R.pack_container_adaptive(12, data.size, 32, 4096, rows, lens, payload)
+    info, f2, l2, p2 = R.parse_container_adaptive(blob)
+    assert (info.format, info.scale_bits, info.nsyms, info.n_ways, info.chunk_syms, info.sym_bytes) == \
+        (FMT_BYTE, 12, 256, 32, 4096, 1)
+    assert info.n_symbols == data.size and info.n_chunks == 4
+    assert np.array_equal(f2, rows) and np.array_equal(l2, lens) and np.array_equal(p2, payload)
+    assert not np.array_equal(f2[0], f2[3])
+    # each chunk decodes with its own stored row
+    offs = R.offsets_from_lengths(l2)
+    for c in range(info.n_chunks):
+        n_c = min(4096, data.size - c * 4096)
+        got = oracle.decode(FMT_BYTE, oracle.model(f2[c].astype(np.uint32), 12), p2[offs[c]:offs[c] + l2[c]], n_c, 32)
+        assert np.array_equal(got, data[c * 4096:c * 4096 + n_c])
+    # the two container versions do not parse as each other
+    with pytest.raises(R.RansAmdError) as e:
+        R.parse_container(blob)
+    assert e.value.status == R.E_CORRUPT
+    f, _ = oracle.normalize(oracle.count_freqs(data, 256), 4096)
+    v1 = R.pack_container(FMT_BYTE, f, 12, data.size, 32, 4096, lens, payload)
+    with pytest.raises(R.RansAmdError):
+        R.parse_container_adaptive(v1)
+
+
+def test_adaptive_container_rejects_damage(oracle):
+    data = oracle.gen_zipf(10000, K=256, s=1.0, seed=2)
+    rows, lens, payload = _oracle_adaptive(oracle, data, 11, 64, 4096)
+    blob = R.pack_container_adaptive(11, data.size, 64, 4096, rows, lens, payload)
+    for pos in (3, 8, 16, 80 + 5, 80 + 512 * 3 + 1):  # magic, version, format, a frequency, a length
+        bad = blob.copy()
+        bad[pos] ^= 0x21
+        with pytest.raises(R.RansAmdError) as e:
+            R.parse_container_adaptive(bad)
+        assert e.value.status == R.E_CORRUPT, pos
+    with pytest.raises(R.RansAmdError):
+        R.parse_container_adaptive(blob[:-3])
+    worse = rows.copy(); worse[1, 0] += 1
+    with pytest.raises(R.RansAmdError) as e:
+        R.pack_container_adaptive(11, data.size, 64, 4096, worse, lens, payload)   # a row that is not a model
+    assert e.value.status == R.E_MODEL
+    with pytest.raises(R.RansAmdError):
+        R.pack_container_adaptive(14, data.size, 64, 4096, rows, lens, payload)    # u16 rows stop at 12 bits here
+    blob0 = R.pack_container_adaptive(12, 0, 64, 4096, np.zeros((0, 256), np.uint16), np.zeros(0, np.uint32),
+                                      np.zeros(0, np.uint8))
+    info, f0, l0, p0 = R.parse_container_adaptive(blob0)
+    assert info.n_chunks == 0 and f0.shape == (0, 256) and p0.size == 0
+
+
+@pytest.mark.gpu
+def test_gpu_adaptive_file_roundtrip(tmp_path, oracle):
+    """encode_adaptive on the GPU -> version-2 file -> a fresh reader decodes on the GPU, and the oracle decodes
+    sampled chunks of the file with the stored rows (reference byte-format streams inside)."""
+    import torch
+    ctx = R.Context(0)
+    rng = np.random.default_rng(11)
+    data = np.concatenate([oracle.gen_zipf(1 << 19, K=256, s=1.0, seed=8),
+                           rng.integers(0, 40, (1 << 19) + 12345).astype(np.uint8)])
+    d = torch.from_numpy(data).cuda()
+    cont, offs, lens, freqs, total = ctx.encode_adaptive(d, 64, 32768, 12)
+    nch = R.num_chunks(data.size, 32768)
+    blob = R.pack_container_adaptive(12, data.size, 64, 32768, freqs.cpu().numpy().view(np.uint16)[:nch * 256],
+                                     lens.cpu().numpy().astype(np.uint32)[:nch], cont[:total].cpu().numpy())
+    path = tmp_path / "mixed.rans2"
+    blob.tofile(path)
+
+    info, f2, l2, p2 = R.parse_container_adaptive(np.fromfile(path, dtype=np.uint8))
+    o2 = R.offsets_from_lengths(l2)
+    d_cont = torch.from_numpy(np.concatenate([p2, np.zeros(64, np.uint8)])).cuda()
+    d_offs = torch.from_numpy(o2.astype(np.int64)).cuda()
+    d_lens = torch.from_numpy(l2.astype(np.int32)).cuda()
+    d_f = torch.from_numpy(np.ascontiguousarray(f2).view(np.int16).reshape(-1)).cuda()
+    out = ctx.decode_adaptive(d_cont, info.payload_bytes, d_offs, d_lens, d_f, info.n_symbols, info.n_ways,
+                              info.chunk_syms, info.scale_bits)
+    assert np.array_equal(out.cpu().numpy(), data)
+    for c in (0, nch // 2, nch - 1):
+        n_c = min(32768, data.size - c * 32768)
+        got = oracle.decode(FMT_BYTE, oracle.model(f2[c].astype(np.uint32), 12), p2[o2[c]:o2[c] + l2[c]], n_c, 64)
+        assert np.array_equal(got, data[c * 32768:c * 32768 + n_c]), c
