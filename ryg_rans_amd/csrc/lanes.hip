@@ -7,6 +7,8 @@ namespace rans_amd {
 
 namespace {
 
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
 // ===========================================================================
 // Lane-per-stream kernels for narrow interleaves (N = 1, 2, 4, 8; BASELINE config 2 is
 // the reference's 2-way rans64 loop, main64.cpp:224-287).  An N-way stream with N << 64
@@ -248,7 +250,9 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
             for (int j = 0; j < 4; ++j) {
                 r[j] = req[16 * j + grp]; // LDS ops of one wave execute in order: sees the writes above
                 v[j] = u32x4{0u, 0u, 0u, 0u};
-                const uint64_t a = cbase + rb + (r[j] & ~(kLaneLine - 1u)) + part * 16u;
+                uint64_t a = cbase + rb + (r[j] & ~(kLaneLine - 1u)) + part * 16u;
+                if (p.debug & 2u) // measurement only: every refill hits the same (cached) line
+                    a = cbase + part * 16u;
                 if ((r[j] & 1u) && a < glimit)
                     v[j] = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(a));
             }
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
                 refill();
                 if (left) {
                     q3 = decode16();
-                    u32x4 RANS_GLOBAL *o = reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + i0);
+                    u32x4 RANS_GLOBAL *o = reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + ((p.debug & 4u) ? (i0 & 64u) : i0));
 #ifdef RANS_LANES_NT_OUT // (experiment: the lane's 64-byte line as four non-temporal 16-byte stores)
                     __builtin_nontemporal_store(q0, o + 0);
                     __builtin_nontemporal_store(q1, o + 1);
@@ -358,6 +362,367 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
     if (nbad)
         atomicAdd(p.err_count, (unsigned long long)nbad);
 }
+
+// ---------------------------------------------------------------------------
+// k_decode_lanes_r64x2: the reference's 2-way rans64 loop (main64.cpp:261-282), one chunk per lane, third
+// generation.  What bounds the staged kernel above (rocprofv3 counters, profiles/r02_lanes_counters.md): neither the
+// VALU (30 % busy) nor the LDS pipe (42 %) but the vector-memory ADDRESS path -- TA busy 86 % of the kernel: every
+// lane's 16-byte store is its own request (64 per instruction, 16.8 M write requests for 256 MiB), and so is every
+// 16-byte piece a lane fetches for itself.  And, per wave, four DEPENDENT LDS round trips per pair of symbols.  Here
+//  * global accesses are made by QUADS of lanes: the four lanes of a quad fetch the four 16-byte pieces of ONE
+//    chunk's 64-byte line (instruction t serves the quad's lane t: address and exec mask by DPP broadcast) and write
+//    them straight into that lane's ring row; the 64 symbols a lane has decoded are transposed inside the quad (4 x 4
+//    pieces, v_cndmask_b32_dpp) so that store instruction t writes chunk (quad, t)'s whole line: 64-byte requests;
+//  * the next 8 stream bytes of a lane sit in two registers (the "window"); a renormalisation takes the first
+//    dword under an exec mask (v_cmpx), and only the lanes that consumed something re-read their window
+//    (ds_read2_b32, exec-masked) while the NEXT pair's table lookups are in flight: two LDS round trips per pair;
+//  * a line is requested as soon as the ring has room for it (<= 64 B staged ahead), ONE GROUP (16 symbols) before
+//    it is written to the ring: the pieces stay in registers over the group.  A valid stream consumes <= 40 B per
+//    group (5 renormalisations per state: 8 x 16 bits out, 32 bits in each) and the window reads 8 B ahead, so
+//    >= 48 B ahead at a group boundary is the invariant; a lane below that (streams of 2^-16 symbols) is served
+//    synchronously on a side path;
+//  * the whole trip loop is ONE asm statement: states, window, parked pieces, packed symbols and temporaries in
+//    fixed registers (64-bit operands need their halves named; nothing in flight crosses a statement the compiler
+//    schedules).  The 64 symbols of a trip are stored at the start of the next trip, after its first vmcnt wait, so
+//    that the stores have a whole group to complete.
+// Requirements (launcher): scale_bits 7..16 (cum2sym), u8 symbols, chunk_syms % 64 == 0, 64-byte aligned output,
+// every chunk full (a ragged last chunk goes through the staged kernel in a second launch).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kR64RingStride = 2 * kLaneLine + 8; // 128-byte ring + mirror of its first dword (+ 4 pad)
+constexpr uint32_t kR64WaveLds = 64 * kR64RingStride;
+
+// Registers of the trip loop: v[8:23] packed symbols of the trip (set g = group g = piece g of the lane's line),
+// v[24:39] parked pieces (set t = fetch instruction t), v[40:41] state 0, v[42:43] state 1, v[44:45] window,
+// v46..v62 temporaries, v[64:67] ring addresses of the parked pieces; s[36:39] renormalisation masks,
+// s[40:47] lanes with a parked piece per fetch instruction, s50 "not the first trip".
+//
+// One pair of symbols, first half: slots, cum2sym, records (rans64.h:286-292 for both states)
+#define R64_LOOKUP                                                                                                      \
+    "v_and_b32 v46, %[maskv], v40\n\t"                                                                                  \
+    "v_and_b32 v47, %[maskv], v42\n\t"                                                                                  \
+    "ds_read_u8 v48, v46\n\t"                                                                                           \
+    "ds_read_u8 v49, v47\n\t"                                                                                           \
+    "v_lshrrev_b64 v[50:51], %[sbv], v[40:41]\n\t"                                                                      \
+    "v_lshrrev_b64 v[52:53], %[sbv], v[42:43]\n\t"                                                                      \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                          \
+    "v_lshl_add_u32 v62, v48, 3, %[t1v]\n\t"                                                                            \
+    "ds_read_b64 v[54:55], v62\n\t"                                                                                     \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                          \
+    "v_lshl_add_u32 v62, v49, 3, %[t1v]\n\t"                                                                            \
+    "ds_read_b64 v[56:57], v62\n\t"
+// second half: x = freq * (x >> scale_bits) + slot - start, renormalisation (rans64.h:305-316: x < 2^31 -> x = x << 32
+// | next dword) from the window under an exec mask, window re-read by the lanes that took from it
+#define R64_UPDATE                                                                                                      \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                          \
+    "v_sub_u32 v58, v46, v55\n\t"                                                                                       \
+    "v_mul_u32_u24 v59, v54, v51\n\t"           /* freq * (q >> 32): freq <= 2^16, q >> 32 < 2^24 */                    \
+    "v_mad_u64_u32 v[40:41], vcc, v50, v54, v[58:59]\n\t"                                                               \
+    "v_cmpx_gt_u64 s[36:37], %[kL], v[40:41]\n\t"                                                                       \
+    "v_mov_b32 v41, v40\n\t"                                                                                            \
+    "v_mov_b32 v40, v44\n\t"                                                                                            \
+    "v_mov_b32 v44, v45\n\t"                                                                                            \
+    "v_add_u32 %[cur], 4, %[cur]\n\t"                                                                                   \
+    "s_mov_b64 exec, -1\n\t"                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                          \
+    "v_sub_u32 v60, v47, v57\n\t"                                                                                       \
+    "v_mul_u32_u24 v61, v56, v53\n\t"                                                                                   \
+    "v_mad_u64_u32 v[42:43], vcc, v52, v56, v[60:61]\n\t"                                                               \
+    "v_cmpx_gt_u64 s[38:39], %[kL], v[42:43]\n\t"                                                                       \
+    "v_mov_b32 v43, v42\n\t"                                                                                            \
+    "v_mov_b32 v42, v44\n\t"                                                                                            \
+    "v_add_u32 %[cur], 4, %[cur]\n\t"                                                                                   \
+    "s_or_b64 exec, s[36:37], s[38:39]\n\t"                                                                             \
+    "v_and_b32 v62, 0x7f, %[cur]\n\t"                                                                                   \
+    "v_add_u32 v62, %[row], v62\n\t"                                                                                    \
+    "ds_read2_b32 v[44:45], v62 offset1:1\n\t"                                                                          \
+    "s_mov_b64 exec, -1\n\t"
+// four symbols into one dword of the trip's output
+#define R64_QUAD(PK)                                                                                                    \
+    R64_LOOKUP "v_lshl_or_b32 " PK ", v49, 8, v48\n\t" R64_UPDATE                                                       \
+    R64_LOOKUP "v_lshl_or_b32 " PK ", v48, 16, " PK "\n\tv_lshl_or_b32 " PK ", v49, 24, " PK "\n\t" R64_UPDATE
+#define R64_GROUP(P0, P1, P2, P3) R64_QUAD(P0) R64_QUAD(P1) R64_QUAD(P2) R64_QUAD(P3)
+// parked pieces -> ring.  Lane 4k+m holds piece m of the line of lane 4k+t (fetch instruction t): it goes to that
+// lane's row, rq0 + 136 t + slot (rq0 = own row - 136 m + 16 m); piece 0 of slot 0 also refreshes the mirror dword.
+#define R64_COMMIT                                                                                                      \
+    "s_waitcnt vmcnt(0)\n\t" \
+    "s_mov_b64 exec, s[40:41]\n\t" \
+    "ds_write2_b64 v64, v[24:25], v[26:27] offset0:0 offset1:1\n\t" \
+    "s_and_b64 exec, exec, %[m0]\n\t" \
+    "v_cmpx_eq_u32 vcc, %[rq0], v64\n\t" \
+    "ds_write_b32 %[rq0], v24 offset:128\n\t" \
+    "s_mov_b64 exec, s[42:43]\n\t" \
+    "ds_write2_b64 v65, v[28:29], v[30:31] offset0:17 offset1:18\n\t" \
+    "s_and_b64 exec, exec, %[m0]\n\t" \
+    "v_cmpx_eq_u32 vcc, %[rq0], v65\n\t" \
+    "ds_write_b32 %[rq0], v28 offset:264\n\t" \
+    "s_mov_b64 exec, s[44:45]\n\t" \
+    "ds_write2_b64 v66, v[32:33], v[34:35] offset0:34 offset1:35\n\t" \
+    "s_and_b64 exec, exec, %[m0]\n\t" \
+    "v_cmpx_eq_u32 vcc, %[rq0], v66\n\t" \
+    "ds_write_b32 %[rq0], v32 offset:400\n\t" \
+    "s_mov_b64 exec, s[46:47]\n\t" \
+    "ds_write2_b64 v67, v[36:37], v[38:39] offset0:51 offset1:52\n\t" \
+    "s_and_b64 exec, exec, %[m0]\n\t" \
+    "v_cmpx_eq_u32 vcc, %[rq0], v67\n\t" \
+    "ds_write_b32 %[rq0], v36 offset:536\n\t" \
+    "s_mov_b64 exec, -1\n\t"
+// bytes staged ahead in v46 -> lanes with room for their next line (<= 64 ahead) ask for it: ld advances, the quad
+// fetches (a = ld of the quad's lane t + 16 m by DPP; the sign bit marks "nothing asked")
+#define R64_FETCH                                                                                                       \
+    "v_bfrev_b32 v63, 1\n\t" \
+    "v_cmp_ge_i32 vcc, 64, v46\n\t" \
+    "v_cndmask_b32 v47, v63, %[ld], vcc\n\t" \
+    "s_mov_b64 exec, vcc\n\t" \
+    "v_add_u32 %[ld], 64, %[ld]\n\t" \
+    "s_mov_b64 exec, -1\n\t" \
+    "s_nop 4\n\t" \
+    "v_add_u32_dpp v64, v47, %[l16] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_u32_dpp v65, v47, %[l16] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_u32_dpp v66, v47, %[l16] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_u32_dpp v67, v47, %[l16] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmpx_le_i32 s[40:41], 0, v64\n\t" \
+    "buffer_load_dwordx4 v[24:27], v64, %[rsrc], 0 offen nt\n\t" \
+    "v_and_b32 v64, 64, v64\n\t" \
+    "v_add_u32 v64, %[rq0], v64\n\t" \
+    "s_mov_b64 exec, -1\n\t" \
+    "v_cmpx_le_i32 s[42:43], 0, v65\n\t" \
+    "buffer_load_dwordx4 v[28:31], v65, %[rsrc], 0 offen nt\n\t" \
+    "v_and_b32 v65, 64, v65\n\t" \
+    "v_add_u32 v65, %[rq0], v65\n\t" \
+    "s_mov_b64 exec, -1\n\t" \
+    "v_cmpx_le_i32 s[44:45], 0, v66\n\t" \
+    "buffer_load_dwordx4 v[32:35], v66, %[rsrc], 0 offen nt\n\t" \
+    "v_and_b32 v66, 64, v66\n\t" \
+    "v_add_u32 v66, %[rq0], v66\n\t" \
+    "s_mov_b64 exec, -1\n\t" \
+    "v_cmpx_le_i32 s[46:47], 0, v67\n\t" \
+    "buffer_load_dwordx4 v[36:39], v67, %[rsrc], 0 offen nt\n\t" \
+    "v_and_b32 v67, 64, v67\n\t" \
+    "v_add_u32 v67, %[rq0], v67\n\t" \
+    "s_mov_b64 exec, -1\n\t" \
+    "s_nop 4\n\t"
+// 4 x 4 transpose of 16-byte pieces inside every quad: lane 4k+m, set t  <->  lane 4k+t, set m
+#define R64_TRANSPOSE                                                                                                   \
+    "v_mov_b32 v46, v8\n\t" \
+    "v_mov_b32 v47, v9\n\t" \
+    "v_mov_b32 v48, v10\n\t" \
+    "v_mov_b32 v49, v11\n\t" \
+    "v_mov_b32 v50, v16\n\t" \
+    "v_mov_b32 v51, v17\n\t" \
+    "v_mov_b32 v52, v18\n\t" \
+    "v_mov_b32 v53, v19\n\t" \
+    "s_mov_b32 vcc_lo, 0x55555555\n\t" \
+    "s_mov_b32 vcc_hi, 0x55555555\n\t" \
+    "s_nop 1\n\t" \
+    "v_cndmask_b32_dpp v8, v12, v8, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v9, v13, v9, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v10, v14, v10, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v11, v15, v11, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v16, v20, v16, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v17, v21, v17, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v18, v22, v18, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v19, v23, v19, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "s_mov_b32 vcc_lo, 0xaaaaaaaa\n\t" \
+    "s_mov_b32 vcc_hi, 0xaaaaaaaa\n\t" \
+    "s_nop 1\n\t" \
+    "v_cndmask_b32_dpp v12, v46, v12, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v13, v47, v13, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v14, v48, v14, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v15, v49, v15, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v20, v50, v20, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v21, v51, v21, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v22, v52, v22, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v23, v53, v23, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mov_b32 v46, v8\n\t" \
+    "v_mov_b32 v47, v9\n\t" \
+    "v_mov_b32 v48, v10\n\t" \
+    "v_mov_b32 v49, v11\n\t" \
+    "v_mov_b32 v50, v12\n\t" \
+    "v_mov_b32 v51, v13\n\t" \
+    "v_mov_b32 v52, v14\n\t" \
+    "v_mov_b32 v53, v15\n\t" \
+    "s_mov_b32 vcc_lo, 0x33333333\n\t" \
+    "s_mov_b32 vcc_hi, 0x33333333\n\t" \
+    "s_nop 1\n\t" \
+    "v_cndmask_b32_dpp v8, v16, v8, vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v9, v17, v9, vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v10, v18, v10, vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v11, v19, v11, vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v12, v20, v12, vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v13, v21, v13, vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v14, v22, v14, vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v15, v23, v15, vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "s_mov_b32 vcc_lo, 0xcccccccc\n\t" \
+    "s_mov_b32 vcc_hi, 0xcccccccc\n\t" \
+    "s_nop 1\n\t" \
+    "v_cndmask_b32_dpp v16, v46, v16, vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v17, v47, v17, vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v18, v48, v18, vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v19, v49, v19, vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v20, v50, v20, vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v21, v51, v21, vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v22, v52, v22, vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cndmask_b32_dpp v23, v53, v23, vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t"
+// store instruction t: the line of chunk (quad, t), 16 bytes per lane of the quad
+#define R64_STORES                                                                                                      \
+    "s_mov_b64 exec, %[vq0]\n\t" \
+    "global_store_dwordx4 %[at0], v[8:11], off\n\t" \
+    "s_mov_b64 exec, %[vq1]\n\t" \
+    "global_store_dwordx4 %[at1], v[12:15], off\n\t" \
+    "s_mov_b64 exec, %[vq2]\n\t" \
+    "global_store_dwordx4 %[at2], v[16:19], off\n\t" \
+    "s_mov_b64 exec, %[vq3]\n\t" \
+    "global_store_dwordx4 %[at3], v[20:23], off\n\t" \
+    "s_mov_b64 exec, -1\n\t" \
+    "v_lshl_add_u64 %[at0], %[at0], 0, 64\n\t" \
+    "v_lshl_add_u64 %[at1], %[at1], 0, 64\n\t" \
+    "v_lshl_add_u64 %[at2], %[at2], 0, 64\n\t" \
+    "v_lshl_add_u64 %[at3], %[at3], 0, 64\n\t"
+#define R64_CLOBBERS                                                                                                    \
+    "vcc", "scc", "memory", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21",   \
+        "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", \
+        "v39", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", \
+        "v62", "v63", "v64", "v65", "v66", "v67", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", \
+        "s47", "s50"
+
+__global__ void __launch_bounds__(1024) k_decode_lanes_r64x2(const DecParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1_bytes = (p.table1_bytes + 15u) & ~15u;
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+        const uint4 *g1 = reinterpret_cast<const uint4 *>(p.table1);
+        uint4 *l1 = reinterpret_cast<uint4 *>(smem + t0_bytes);
+        for (uint32_t i = threadIdx.x; i < t1_bytes / 16u; i += blockDim.x)
+            l1[i] = g1[i];
+    }
+    __syncthreads();
+    if (!lds_starts_at_zero(smem)) { // the asm addresses LDS by raw offsets
+        if (threadIdx.x == 0)
+            atomicAdd(p.err_count, 1ull << 32);
+        return;
+    }
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u;
+    if (p.span_reset && blockIdx.x == 0 && threadIdx.x < 2)
+        p.span_reset[threadIdx.x] = 0ull;
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t row = t0_bytes + t1_bytes + wave * kR64WaveLds + lane * kR64RingStride; // LDS byte offset
+    const uint32_t m = lane & 3u;
+    const uint32_t rq0 = row - m * kR64RingStride + m * 16u; // piece m in the row of the quad's lane 0
+    const uint32_t l16 = m * 16u;
+    const uint8_t *rowp = smem + row;
+    uint32_t maskv = (1u << p.scale_bits) - 1u, sbv = p.scale_bits, t1v = t0_bytes;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(maskv)); // VGPR copies: a VALU op with an SGPR operand issues slower
+    asm volatile("v_mov_b32 %0, %0" : "+v"(sbv));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(t1v));
+    const uint64_t kL = 1ull << 31;
+    const uint64_t m0 = 0x1111111111111111ull; // lane 0 of every quad
+
+    const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
+    const uint64_t cbytes16 = (p.container_bytes + 15u) & ~uint64_t(15);
+    uint32_t nbad = 0;
+    const uint64_t nbatches = (p.nchunks + 63u) / 64u;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += total_waves) {
+        const uint64_t batch = uniform64(batch_v);
+        const uint64_t chunk = batch * 64u + lane;
+        bool valid = chunk < p.nchunks;
+        const uint64_t off = valid ? p.offsets[chunk] : 0;
+        const uint32_t len = valid ? p.lengths[chunk] : 0;
+        const uint64_t rb = uniform64(off) & ~uint64_t(kLaneLine - 1); // lane 0 always holds a chunk
+        if (valid && ((off & 15u) != 0 || len < 16u || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
+                      off - rb >= (1u << 30))) {
+            nbad++;
+            valid = false;
+        }
+        // the batch's window onto the container: offsets from rb, reads past the last 16-byte granule return 0
+        const uint64_t span = cbytes16 - (rb < cbytes16 ? rb : cbytes16);
+        const uint32_t nrec = uniform((uint32_t)(span < 0x7ffffff0ull ? span : 0x7ffffff0ull));
+        const uint64_t wbase = uniform64(cbase + rb);
+        const u32x4 rsrc4 = {uniform((uint32_t)wbase), uniform((uint32_t)(wbase >> 32)) & 0xffffu, nrec, 0x00020000u};
+        // store addresses: instruction t writes the line of the quad's lane t, this lane its piece m
+        const uint64_t dst = reinterpret_cast<uint64_t>(p.out) + chunk * p.chunk_syms;
+        uint64_t at[4], vq[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int src = (int)((lane & ~3u) + t);
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)dst, src), hi = (uint32_t)__shfl((int)(uint32_t)(dst >> 32), src);
+            at[t] = (((uint64_t)hi << 32) | lo) + l16;
+            vq[t] = __builtin_amdgcn_ballot_w64(__shfl((int)valid, src) != 0);
+        }
+
+        uint32_t cur = valid ? (uint32_t)(off - rb) : 0u; // position in the batch's window (ring index = cur & 127)
+        const uint32_t cur0 = cur;
+        uint32_t ld = valid ? (cur & ~(kLaneLine - 1u)) : 0x40000000u; // next line not yet requested (never, without a chunk)
+        // opening: the first two lines (the states are the first 16 bytes of the stream, rans64.h:251-262)
+        asm volatile("v_sub_u32 v46, %[ld], %[cur]\n\t" R64_FETCH R64_COMMIT "v_sub_u32 v46, %[ld], %[cur]\n\t" R64_FETCH R64_COMMIT
+                     "s_waitcnt lgkmcnt(0)"
+                     : [ld] "+v"(ld)
+                     : [cur] "v"(cur), [l16] "v"(l16), [rq0] "v"(rq0), [m0] "s"(m0), [rsrc] "s"(rsrc4)
+                     : R64_CLOBBERS);
+        uint64_t xA, xB, win;
+        {
+            const u32x2 a = *reinterpret_cast<const u32x2 *>(rowp + (cur & 127u));
+            const u32x2 b = *reinterpret_cast<const u32x2 *>(rowp + ((cur + 8u) & 127u));
+            xA = (uint64_t)a.x | ((uint64_t)a.y << 32);
+            xB = (uint64_t)b.x | ((uint64_t)b.y << 32);
+            cur += 16u;
+            const uint32_t w0 = *reinterpret_cast<const uint32_t *>(rowp + (cur & 127u));
+            const uint32_t w1 = *reinterpret_cast<const uint32_t *>(rowp + ((cur + 4u) & 127u));
+            win = (uint64_t)w0 | ((uint64_t)w1 << 32);
+        }
+        uint32_t trips = uniform(p.chunk_syms >> 6);
+        asm volatile("s_mov_b64 s[40:41], 0\n\t"
+                     "s_mov_b64 s[42:43], 0\n\t"
+                     "s_mov_b64 s[44:45], 0\n\t"
+                     "s_mov_b64 s[46:47], 0\n\t"
+                     "s_mov_b32 s50, 0\n\t"
+                     ".Lr64trip_%=:\n\t"
+                     R64_COMMIT
+                     "s_cmp_eq_u32 s50, 0\n\t"
+                     "s_cbranch_scc1 .Lr64first_%=\n\t"
+                     R64_TRANSPOSE R64_STORES
+                     ".Lr64first_%=:\n\t"
+#define R64_BOUNDARY(N)                                                                                                 \
+    "v_sub_u32 v46, %[ld], %[cur]\n\t"                                                                                  \
+    "v_cmp_gt_i32 vcc, 48, v46\n\t"                                                                                     \
+    "s_cbranch_vccz .Lr64ok" N "_%=\n\t"                                                                                \
+    /* side path (some lane is about to starve): everybody with room asks now, and we wait */                          \
+    R64_FETCH R64_COMMIT                                                             \
+    "v_sub_u32 v46, %[ld], %[cur]\n\t"                                                                                  \
+    ".Lr64ok" N "_%=:\n\t" R64_FETCH
+                     R64_BOUNDARY("0") R64_GROUP("v8", "v9", "v10", "v11")
+                     R64_COMMIT R64_BOUNDARY("1") R64_GROUP("v12", "v13", "v14", "v15")
+                     R64_COMMIT R64_BOUNDARY("2") R64_GROUP("v16", "v17", "v18", "v19")
+                     R64_COMMIT R64_BOUNDARY("3") R64_GROUP("v20", "v21", "v22", "v23")
+                     "s_mov_b32 s50, 1\n\t"
+                     "s_sub_u32 %[trips], %[trips], 1\n\t"
+                     "s_cmp_lg_u32 %[trips], 0\n\t"
+                     "s_cbranch_scc1 .Lr64trip_%=\n\t"
+                     R64_TRANSPOSE R64_STORES
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+{v[40:41]}"(xA), "+{v[42:43]}"(xB), "+{v[44:45]}"(win), [cur] "+v"(cur), [ld] "+v"(ld), [at0] "+v"(at[0]),
+                       [at1] "+v"(at[1]), [at2] "+v"(at[2]), [at3] "+v"(at[3]), [trips] "+s"(trips)
+                     : [maskv] "v"(maskv), [sbv] "v"(sbv), [t1v] "v"(t1v), [row] "v"(row), [l16] "v"(l16), [rq0] "v"(rq0),
+                       [kL] "s"(kL), [m0] "s"(m0), [vq0] "s"(vq[0]), [vq1] "s"(vq[1]), [vq2] "s"(vq[2]), [vq3] "s"(vq[3]),
+                       [rsrc] "s"(rsrc4)
+                     : R64_CLOBBERS);
+        // RansDec end state: both states back at L, every byte of the chunk consumed (main64.cpp has no check; ours)
+        if (valid && (xA != kL || xB != kL || cur - cur0 != len))
+            nbad++;
+    }
+    if (nbad)
+        atomicAdd(p.err_count, (unsigned long long)nbad);
+}
+#undef R64_BOUNDARY
 
 template <int FMT, int NW>
 __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
@@ -863,6 +1228,53 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
             const uint64_t rounds = (per_cu + sw - 1) / sw;
             const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
             sw = (uint32_t)(even ? even : 1);
+        }
+    }
+    if constexpr (FMT == FMT_R64 && NW == 2) {
+        // third generation for the reference's own 2-way rans64 layout (config 2): full 64-symbol trips only; a ragged
+        // last chunk is decoded by the staged kernel in a second launch
+        static const bool off = getenv("RANS_AMD_NO_R64X2") != nullptr;
+        const bool aligned = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 63u) == 0 &&
+                             (reinterpret_cast<uintptr_t>(p.container) & 15u) == 0;
+        if (!off && force == 0 && staged && aligned && p.nchunks >= 64 && !p.trace) {
+            const uint64_t full = p.n / p.chunk_syms; // chunks with chunk_syms symbols
+            uint32_t sw3 = (uint32_t)((160 * 1024 - table_lds) / kR64WaveLds);
+            sw3 = sw3 > 16 ? 16 : sw3;
+            const uint64_t batches = (full + 63) / 64;
+            const uint64_t per_cu = (batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
+            const uint64_t rounds = (per_cu + sw3 - 1) / sw3;
+            const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
+            sw3 = (uint32_t)(even ? even : 1);
+            static std::atomic<uint64_t> lds_ok3{0};
+            if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_decode_lanes_r64x2), 160 * 1024, lds_ok3);
+                e != hipSuccess)
+                return e;
+            DecParams q = p;
+            q.nchunks = full;
+            q.n = full * p.chunk_syms;
+            const uint64_t want_blocks = (batches + sw3 - 1) / sw3;
+            const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
+            if (name)
+                *name = "k_decode_lanes_r64x2";
+            RANS_LAUNCH(k_decode_lanes_r64x2, dim3(grid), dim3(64 * sw3), table_lds + (size_t)sw3 * kR64WaveLds, stream, q);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess)
+                return e;
+            if (full == p.nchunks)
+                return hipSuccess;
+            DecParams r = p; // the ragged last chunk
+            r.offsets = p.offsets + full;
+            r.lengths = p.lengths + full;
+            r.out = static_cast<uint8_t *>(p.out) + full * p.chunk_syms;
+            r.n = p.n - full * p.chunk_syms;
+            r.nchunks = 1;
+            r.work_counter_reset = nullptr;
+            r.span_reset = nullptr;
+            auto tail = k_decode_lanes_staged<FMT, NW>;
+            static std::atomic<uint64_t> lds_ok4{0};
+            if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(tail), 160 * 1024, lds_ok4); e != hipSuccess)
+                return e;
+            RANS_LAUNCH(tail, dim3(1), dim3(64), table_lds + kLaneWaveLds, stream, r);
+            return hipGetLastError();
         }
     }
     const size_t lds = staged ? table_lds + (size_t)sw * kLaneWaveLds : table_lds;

@@ -664,3 +664,64 @@ def test_per_chunk_adaptive_models(gpu, oracle):
     with pytest.raises(R.RansAmdError) as e:
         ctx.encode_adaptive(d, 64, chunk, 14)
     assert e.value.status == R.E_UNSUPPORTED
+
+
+def test_rans64_two_way_lane_kernel(gpu, oracle):
+    """BASELINE config 2's layout (the reference's 2-way rans64 loop, main64.cpp:228-282) through the dedicated
+    lane-per-chunk decoder k_decode_lanes_r64x2: every scale_bits with a cum2sym table, chunk sizes of one and many
+    64-symbol trips, a ragged last chunk (second launch), few and many batches, alphabets that make a stream consume
+    the most bytes per symbol a valid stream can (symbols of probability 2^-scale_bits), the ORACLE's container
+    and the GPU's own; then damaged containers: flagged, never a crash."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(5)
+    zipf = oracle.gen_zipf(600000 + 333, K=256, s=1.0, seed=23)
+    flat = rng.integers(0, 256, 300000).astype(np.uint8)
+    cases = [(zipf, 14, 512), (zipf, 14, 64), (zipf, 12, 1024), (zipf, 16, 4096), (zipf, 8, 128), (zipf[:64 * 64], 14, 64),
+             (zipf[:70 * 512 + 5], 11, 512), (flat, 14, 512), (flat, 16, 192)]
+    for data, sb, chunk in cases:
+        om, gm = _models(R, ctx, oracle, FMT_R64, sb, data)
+        want, offs, lens = oracle.encode_chunked(FMT_R64, om, data, 2, chunk, align=16)
+        d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
+        d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+        d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+        out = ctx.decode(gm, d_cont, want.size, d_offs, d_lens, data.size, 2, chunk)
+        assert ctx.last_decode_kernel() == "k_decode_lanes_r64x2", ctx.last_decode_kernel()
+        assert np.array_equal(out.cpu().numpy(), data), (sb, chunk, data.size)
+        d_syms = torch.from_numpy(data).cuda()
+        cont, o2, l2, total = ctx.encode(gm, d_syms, 2, chunk)
+        got = cont[:total].cpu().numpy()
+        assert total == want.size and np.array_equal(l2.cpu().numpy().astype(np.uint32), lens), (sb, chunk)
+        for c in range(len(lens)):  # (the padding between chunks is not defined)
+            o, ln = int(offs[c]), int(lens[c])
+            assert np.array_equal(got[o:o + ln], want[o:o + ln]), (sb, chunk, c)
+        out = ctx.decode(gm, cont, total, o2, l2, data.size, 2, chunk)
+        assert np.array_equal(out.cpu().numpy(), data), (sb, chunk, "own container")
+    # rare symbols only: 16 bits leave the state per symbol, the most a valid rans64 stream can consume
+    sb = 16
+    f = np.ones(256, np.uint32)
+    f[0] = (1 << sb) - 255
+    rare = rng.integers(1, 256, 64 * 1024).astype(np.uint8)
+    om, gm = oracle.model(f, sb), ctx.model(FMT_R64, f, sb)
+    want, offs, lens = oracle.encode_chunked(FMT_R64, om, rare, 2, 256, align=16)
+    assert want.size > 2 * rare.size - 4096  # ~2 bytes per symbol
+    out = ctx.decode(gm, torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda(), want.size,
+                     torch.from_numpy(offs.astype(np.int64)).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda(),
+                     rare.size, 2, 256)
+    assert ctx.last_decode_kernel() == "k_decode_lanes_r64x2"
+    assert np.array_equal(out.cpu().numpy(), rare)
+    # damage: flipped stream bytes, a length that lies, an offset off its 16-byte grid
+    data, sb, chunk = zipf[:128 * 512], 14, 512
+    om, gm = _models(R, ctx, oracle, FMT_R64, sb, data)
+    want, offs, lens = oracle.encode_chunked(FMT_R64, om, data, 2, chunk, align=16)
+    for kind in range(3):
+        bad, o, l = want.copy(), offs.astype(np.int64).copy(), lens.astype(np.int32).copy()
+        if kind == 0:
+            for pos in rng.integers(0, want.size, 20):
+                bad[pos] ^= 0x40
+        elif kind == 1:
+            l[7] += 4
+        else:
+            o[9] += 4
+        ctx.decode(gm, torch.from_numpy(np.concatenate([bad, np.zeros(64, np.uint8)])).cuda(), want.size,
+                   torch.from_numpy(o).cuda(), torch.from_numpy(l).cuda(), data.size, 2, chunk, sync=False)
+        assert ctx.decode_errors() >= 1, kind
