@@ -155,6 +155,39 @@ template <int FMT> struct LaneRing {
     }
 };
 
+// 4 x 4 transpose of 16-byte pieces inside every quad of lanes: lane 4k+m, piece t  <->  lane 4k+t, piece m.  A
+// lane that stores its own 64-byte line issues four 16-byte requests, and 64 lanes 64 of them per instruction -- the
+// vector-memory address path (TA) was 86 % busy in these kernels (profiles/r02_lanes_counters.md); after the
+// transpose store instruction t writes the whole line of the quad's lane t: one 64-byte request per quad.
+template <int CTRL> __device__ __forceinline__ uint32_t quad_perm(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ void quad_transpose(u32x4 &q0, u32x4 &q1, u32x4 &q2, u32x4 &q3, uint32_t lane)
+{
+    const bool b0 = (lane & 1u) != 0, b1 = (lane & 2u) != 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { // lane bit 0 <-> piece bit 0
+        const uint32_t a = q0[d], b = q1[d], c = q2[d], e = q3[d];
+        const uint32_t fa = quad_perm<0xA0>(b), fb = quad_perm<0xF5>(a); // [0,0,2,2]: from lane - 1, [1,1,3,3]: from lane + 1
+        const uint32_t fc = quad_perm<0xA0>(e), fe = quad_perm<0xF5>(c);
+        q0[d] = b0 ? fa : a;
+        q1[d] = b0 ? b : fb;
+        q2[d] = b0 ? fc : c;
+        q3[d] = b0 ? e : fe;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { // lane bit 1 <-> piece bit 1
+        const uint32_t a = q0[d], b = q1[d], c = q2[d], e = q3[d];
+        const uint32_t fa = quad_perm<0x44>(c), fc = quad_perm<0xEE>(a); // [0,1,0,1]: from lane - 2, [2,3,2,3]: from lane + 2
+        const uint32_t fb = quad_perm<0x44>(e), fe = quad_perm<0xEE>(b);
+        q0[d] = b1 ? fa : a;
+        q2[d] = b1 ? c : fc;
+        q1[d] = b1 ? fb : b;
+        q3[d] = b1 ? e : fe;
+    }
+}
+
 template <int FMT, int NW>
 __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
 {
@@ -285,6 +318,17 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
             return u32x4{pk[0], pk[1], pk[2], pk[3]};
         };
 
+        // store addresses of the transposed output: instruction t writes the line of the quad's lane t
+        uint64_t at[4];
+        bool vq[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int src = (int)((lane & ~3u) + t);
+            const uint64_t d64 = reinterpret_cast<uint64_t>(dst);
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)d64, src), hi = (uint32_t)__shfl((int)(uint32_t)(d64 >> 32), src);
+            at[t] = (((uint64_t)hi << 32) | lo) + (lane & 3u) * 16u;
+            vq[t] = __shfl((int)valid, src) != 0;
+        }
         refill(); // two lines ahead to start with
         // 64 symbols per trip: four groups of 16 (a refill before each), then the lane writes its 64
         // bytes with four back-to-back 16-byte stores.  One 16-byte store per group left every line
@@ -304,21 +348,19 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
                 if (left)
                     q2 = decode16();
                 refill();
-                if (left) {
+                if (left)
                     q3 = decode16();
-                    u32x4 RANS_GLOBAL *o = reinterpret_cast<u32x4 RANS_GLOBAL *>(dst + ((p.debug & 4u) ? (i0 & 64u) : i0));
-#ifdef RANS_LANES_NT_OUT // (experiment: the lane's 64-byte line as four non-temporal 16-byte stores)
-                    __builtin_nontemporal_store(q0, o + 0);
-                    __builtin_nontemporal_store(q1, o + 1);
-                    __builtin_nontemporal_store(q2, o + 2);
-                    __builtin_nontemporal_store(q3, o + 3);
-#else
-                    o[0] = q0;
-                    o[1] = q1;
-                    o[2] = q2;
-                    o[3] = q3;
-#endif
-                }
+                // (every valid lane has its 64 symbols here; lanes without a chunk carry zeros)
+                quad_transpose(q0, q1, q2, q3, lane);
+                const uint32_t o = (p.debug & 4u) ? (i0 & 64u) : i0;
+                if (vq[0])
+                    *reinterpret_cast<u32x4 RANS_GLOBAL *>(at[0] + o) = q0;
+                if (vq[1])
+                    *reinterpret_cast<u32x4 RANS_GLOBAL *>(at[1] + o) = q1;
+                if (vq[2])
+                    *reinterpret_cast<u32x4 RANS_GLOBAL *>(at[2] + o) = q2;
+                if (vq[3])
+                    *reinterpret_cast<u32x4 RANS_GLOBAL *>(at[3] + o) = q3;
                 continue;
             }
             // ragged end of a chunk, unaligned or 16-bit output: 16 symbols at a time
