@@ -155,6 +155,22 @@ template <int FMT> struct LaneRing {
     }
 };
 
+// Smallest stream offset among the lanes that hold a chunk (wave-uniform): the base of the wave's 32-bit window
+// onto the container.  Offsets need not ascend with the chunk index -- any layout whose 64 chunks of a batch lie
+// within 1 GiB of each other decodes; a chunk further away is counted as bad.
+__device__ __forceinline__ uint64_t wave_min_offset(uint64_t off, bool valid)
+{
+    uint32_t lo = valid ? (uint32_t)off : 0xffffffffu, hi = valid ? (uint32_t)(off >> 32) : 0xffffffffu;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t olo = (uint32_t)__shfl_xor((int)lo, d), ohi = (uint32_t)__shfl_xor((int)hi, d);
+        const bool less = ohi < hi || (ohi == hi && olo < lo);
+        lo = less ? olo : lo;
+        hi = less ? ohi : hi;
+    }
+    return uniform64(((uint64_t)hi << 32) | lo);
+}
+
 // 4 x 4 transpose of 16-byte pieces inside every quad of lanes: lane 4k+m, piece t  <->  lane 4k+t, piece m.  A
 // lane that stores its own 64-byte line issues four 16-byte requests, and 64 lanes 64 of them per instruction -- the
 // vector-memory address path (TA) was 86 % busy in these kernels (profiles/r02_lanes_counters.md); after the
@@ -241,7 +257,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
         const uint32_t len = valid ? p.lengths[chunk] : 0;
         const uint64_t first = chunk * p.chunk_syms;
         // region base: the line of the batch's first chunk (lane 0 always holds a chunk)
-        const uint64_t rb = uniform64(off) & ~uint64_t(kLaneLine - 1);
+        const uint64_t rb = wave_min_offset(off, valid) & ~uint64_t(kLaneLine - 1);
         if (valid && ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
                       off - rb >= (1u << 30))) {
             nbad++;
@@ -446,16 +462,15 @@ constexpr uint32_t kR64WaveLds = 64 * kR64RingStride;
     "ds_read_u8 v49, v47\n\t"                                                                                           \
     "v_lshrrev_b64 v[50:51], %[sbv], v[40:41]\n\t"                                                                      \
     "v_lshrrev_b64 v[52:53], %[sbv], v[42:43]\n\t"                                                                      \
-    "s_waitcnt lgkmcnt(1)\n\t"                                                                                          \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                          \
     "v_lshl_add_u32 v62, v48, 3, %[t1v]\n\t"                                                                            \
+    "v_lshl_add_u32 v63, v49, 3, %[t1v]\n\t"                                                                            \
     "ds_read_b64 v[54:55], v62\n\t"                                                                                     \
-    "s_waitcnt lgkmcnt(1)\n\t"                                                                                          \
-    "v_lshl_add_u32 v62, v49, 3, %[t1v]\n\t"                                                                            \
-    "ds_read_b64 v[56:57], v62\n\t"
+    "ds_read_b64 v[56:57], v63\n\t"
 // second half: x = freq * (x >> scale_bits) + slot - start, renormalisation (rans64.h:305-316: x < 2^31 -> x = x << 32
 // | next dword) from the window under an exec mask, window re-read by the lanes that took from it
 #define R64_UPDATE                                                                                                      \
-    "s_waitcnt lgkmcnt(1)\n\t"                                                                                          \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                          \
     "v_sub_u32 v58, v46, v55\n\t"                                                                                       \
     "v_mul_u32_u24 v59, v54, v51\n\t"           /* freq * (q >> 32): freq <= 2^16, q >> 32 < 2^24 */                    \
     "v_mad_u64_u32 v[40:41], vcc, v50, v54, v[58:59]\n\t"                                                               \
@@ -465,7 +480,6 @@ constexpr uint32_t kR64WaveLds = 64 * kR64RingStride;
     "v_mov_b32 v44, v45\n\t"                                                                                            \
     "v_add_u32 %[cur], 4, %[cur]\n\t"                                                                                   \
     "s_mov_b64 exec, -1\n\t"                                                                                            \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                          \
     "v_sub_u32 v60, v47, v57\n\t"                                                                                       \
     "v_mul_u32_u24 v61, v56, v53\n\t"                                                                                   \
     "v_mad_u64_u32 v[42:43], vcc, v52, v56, v[60:61]\n\t"                                                               \
@@ -679,7 +693,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_r64x2(const DecParams p)
         bool valid = chunk < p.nchunks;
         const uint64_t off = valid ? p.offsets[chunk] : 0;
         const uint32_t len = valid ? p.lengths[chunk] : 0;
-        const uint64_t rb = uniform64(off) & ~uint64_t(kLaneLine - 1); // lane 0 always holds a chunk
+        const uint64_t rb = wave_min_offset(off, valid) & ~uint64_t(kLaneLine - 1);
         if (valid && ((off & 15u) != 0 || len < 16u || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
                       off - rb >= (1u << 30))) {
             nbad++;

@@ -696,6 +696,21 @@ def test_rans64_two_way_lane_kernel(gpu, oracle):
             assert np.array_equal(got[o:o + ln], want[o:o + ln]), (sb, chunk, c)
         out = ctx.decode(gm, cont, total, o2, l2, data.size, 2, chunk)
         assert np.array_equal(out.cpu().numpy(), data), (sb, chunk, "own container")
+    # offsets need not ascend: the same chunks laid out back to front (and the general staged kernel on the word format)
+    for fmt, sb in ((FMT_R64, 14), (FMT_WORD, 12)):
+        data, chunk = zipf[:200 * 512], 512
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        want, offs, lens = oracle.encode_chunked(fmt, om, data, 2, chunk, align=16)
+        rev = np.zeros(want.size + 64, np.uint8)
+        roffs = np.zeros_like(offs)
+        pos = 0
+        for c in range(len(lens) - 1, -1, -1):
+            roffs[c] = pos
+            rev[pos:pos + lens[c]] = want[int(offs[c]):int(offs[c]) + int(lens[c])]
+            pos += (int(lens[c]) + 15) & ~15
+        out = ctx.decode(gm, torch.from_numpy(rev).cuda(), pos, torch.from_numpy(roffs.astype(np.int64)).cuda(),
+                         torch.from_numpy(lens.astype(np.int32)).cuda(), data.size, 2, chunk)
+        assert np.array_equal(out.cpu().numpy(), data), (fmt, "reversed layout")
     # rare symbols only: 16 bits leave the state per symbol, the most a valid rans64 stream can consume
     sb = 16
     f = np.ones(256, np.uint32)
