@@ -121,6 +121,9 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 //   x / freq    round-up reciprocal (model.h, WordEncRec): one v_mul_hi_u32 and four cheap ops,
 //               exact, so no compare/select; x' = x + bias + q * cmpl in one v_mad_u32_u24 + add
 // 15 VALU, no v_cndmask, no branch.  `wp` is the byte offset of the lowest word written so far.
+#ifndef RANS_ENC_STORE // (experiment knob: -DRANS_ENC_STORE='""' drops the stream stores of the word encoder)
+#define RANS_ENC_STORE "global_store_short %[t], %[x], %[base]\n\t"
+#endif
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x3 &rec, uint32_t &wp,
                                               const uint8_t RANS_GLOBAL *slot, uint32_t &worst)
@@ -136,7 +139,7 @@ __device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x3 &rec, uin
                  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
                  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
                  "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
-                 "global_store_short %[t], %[x], %[base]\n\t"
+                 RANS_ENC_STORE
                  "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
                  "s_mov_b64 exec, -1\n\t"
                  "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
