@@ -257,6 +257,7 @@ __device__ __forceinline__ void renorm_word_full(uint32_t &x, uint32_t &cur, uin
 __device__ __forceinline__ void renorm_byte_full(uint32_t &x, uint32_t &cur, uint32_t k2p23, uint32_t k2p15)
 {
     uint32_t t, b0, b1, c1, c2;
+#ifdef RANS_BYTE_RENORM_R1 // round 1's sequence (11 SALU): kept for A/B runs
     uint64_t m1;
     asm volatile("v_cmp_gt_u32_e32 vcc, %[l23], %[x]\n\t"
                  "s_nop 1\n\t"
@@ -286,6 +287,34 @@ __device__ __forceinline__ void renorm_byte_full(uint32_t &x, uint32_t &cur, uin
                    [m1] "=&s"(m1), [cur] "+s"(cur)
                  : [l23] "v"(k2p23), [l15] "v"(k2p15)
                  : "vcc", "scc", "memory");
+#else
+    // s[52:53] = lanes that take at least one byte, vcc = lanes that take two (a subset).  Lane i's bytes are
+    // consecutive (rans_byte.h:307-318 reads them in one loop), at cur + (bytes taken by the lanes below it); both
+    // bytes are read under the first mask (the second read of a one-byte lane is dropped by the exec mask of its
+    // v_lshl_or), which saves two exec switches: 7 SALU instead of 11 per renormalisation.
+    asm volatile("v_cmp_gt_u32_e64 s[52:53], %[l23], %[x]\n\t"
+                 "v_cmp_gt_u32_e32 vcc, %[l15], %[x]\n\t"
+                 "s_bcnt1_i32_b64 %[c1], s[52:53]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], s52, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], s53, %[t]\n\t"
+                 "s_bcnt1_i32_b64 %[c2], vcc\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, %[t]\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "v_add_u32_e32 %[t], %[cur], %[t]\n\t"
+                 "s_add_i32 %[cur], %[cur], %[c1]\n\t"
+                 "s_mov_b64 exec, s[52:53]\n\t"
+                 "ds_read_u8 %[b0], %[t]\n\t"
+                 "ds_read_u8 %[b1], %[t] offset:1\n\t"
+                 "s_add_i32 %[cur], %[cur], %[c2]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_lshl_or_b32 %[x], %[x], 8, %[b0]\n\t"
+                 "s_mov_b64 exec, vcc\n\t"
+                 "v_lshl_or_b32 %[x], %[x], 8, %[b1]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [x] "+v"(x), [t] "=&v"(t), [b0] "=&v"(b0), [b1] "=&v"(b1), [c1] "=&s"(c1), [c2] "=&s"(c2), [cur] "+s"(cur)
+                 : [l23] "v"(k2p23), [l15] "v"(k2p15)
+                 : "vcc", "scc", "memory", "s52", "s53");
+#endif
 }
 
 // ---------------------------------------------------------------------------
