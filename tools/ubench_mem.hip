@@ -79,6 +79,28 @@ __global__ void __launch_bounds__(1024) k_decoder_shape(const uint32_t *src, uin
         sink[0] = acc;
 }
 
+// one tile per block, no loop (the shape of an elementwise library kernel): block b writes bytes [b, b + 1) * TILE
+template <int W, int U, int NT> // W dwords per lane per store, U stores per lane, NT = non-temporal
+__global__ void __launch_bounds__(256) k_write_tile(uint32_t *dst, uint32_t val)
+{
+    uint32_t *d = dst + (uint64_t)blockIdx.x * (256u * W * U) + threadIdx.x * W;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if constexpr (W == 4) {
+            const u32x4 v = {val, val, val, val};
+            if constexpr (NT)
+                __builtin_nontemporal_store(v, (u32x4 GLOBAL *)(uintptr_t)(d + u * 256 * W));
+            else
+                *(u32x4 GLOBAL *)(uintptr_t)(d + u * 256 * W) = v;
+        } else {
+            if constexpr (NT)
+                __builtin_nontemporal_store(val, (uint32_t GLOBAL *)(uintptr_t)(d + u * 256 * W));
+            else
+                *(uint32_t GLOBAL *)(uintptr_t)(d + u * 256 * W) = val;
+        }
+    }
+}
+
 template <typename F> static float time_ms(F launch)
 {
     hipEvent_t e0, e1;
@@ -131,6 +153,21 @@ int main()
     }
     RUN("write   4 B/lane plain", 2, 0, 1, cus * 16);
     RUN("write   4 B/lane nt", 2, 1, 1, cus * 16);
+#define RUNT(LABEL, W, U, NT)                                                                                         \
+    {                                                                                                                \
+        const uint32_t blocks = (uint32_t)(ndw / (256u * W * U));                                                     \
+        const float ms = time_ms([&] { hipLaunchKernelGGL((k_write_tile<W, U, NT>), dim3(blocks), dim3(256), 0, 0, dst, 7u); }); \
+        printf("%-44s blocks %7u  %.4f ms  %.0f GB/s\n", LABEL, blocks, ms, bytes / 1e9 / (ms * 1e-3));               \
+        fflush(stdout);                                                                                              \
+    }
+    RUNT("write tile 16 B/lane x1 plain", 4, 1, 0);
+    RUNT("write tile 16 B/lane x4 plain", 4, 4, 0);
+    RUNT("write tile 16 B/lane x4 nt", 4, 4, 1);
+    RUNT("write tile 16 B/lane x16 plain", 4, 16, 0);
+    RUNT("write tile  4 B/lane x4 plain", 1, 4, 0);
+    RUNT("write tile  4 B/lane x16 plain", 1, 16, 0);
+    RUNT("write tile  4 B/lane x16 nt", 1, 16, 1);
+    RUNT("write tile  4 B/lane x64 plain", 1, 64, 0);
     {
         const uint32_t nchunks = 32768;
         const float ms1 = time_ms([&] { hipLaunchKernelGGL((k_decoder_shape<1>), dim3(cus * 2), dim3(1024), 0, 0, src, dst, nchunks, sink); });
