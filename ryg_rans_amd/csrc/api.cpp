@@ -83,6 +83,7 @@ struct rans_amd_ctx {
     DeviceBuffer lengths;   // encode lengths when the caller passes none
     DeviceBuffer hist;
     DeviceBuffer layout_sums; // per-block totals of the offset scan (many-chunk containers)
+    DeviceBuffer enc_status;  // fused encoder: look-back word per chunk + the claim counters (EncParams::status)
     DeviceBuffer wave_scratch; // one 64-byte line per resident decoder wave (DecParams::wave_scratch)
     DeviceBuffer trace;       // per-wave clock records (rans_amd_set_timing(ctx, 2) / RANS_AMD_TRACE)
     rans_amd_wave_clocks wave_clocks = {0, 0, 0, 0.0, 0.0};
@@ -242,6 +243,7 @@ int rans_amd_ctx_destroy(rans_amd_ctx *ctx)
     ctx->lengths.release();
     ctx->hist.release();
     ctx->layout_sums.release();
+    ctx->enc_status.release();
     ctx->trace.release();
     ctx->wave_scratch.release();
     if (ctx->d_words)
@@ -263,6 +265,7 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx)
     ctx->lengths.release();
     ctx->hist.release();
     ctx->layout_sums.release();
+    ctx->enc_status.release();
     ctx->trace.release();
     return RANS_AMD_OK;
 }
@@ -538,6 +541,26 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
 
+    // Wave-per-chunk encoders place and copy their chunks themselves (EncParams::status, encode_wave.hip): no
+    // k_layout / k_compact.  The lane-per-chunk encoders (N = 1, 2, 4, 8 with many chunks) keep the three-kernel path.
+    // RANS_AMD_ENCODE_UNFUSED=1: A/B knob.
+    static const bool unfused_env = getenv("RANS_AMD_ENCODE_UNFUSED") != nullptr;
+    // RANS_AMD_ALIAS_L2=1: A/B knob, the general alias encoder (alias_remap gathered from L2)
+    static const bool alias_l2 = getenv("RANS_AMD_ALIAS_L2") != nullptr;
+    const int enc_format = model->host.r64_search ? kKernelFormatR64Search
+                           : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
+                           : (format == RANS_AMD_FMT_ALIAS && model->d_alias_remap16 && !alias_l2) ? kKernelFormatAliasLds
+                                                                                                  : format;
+    const bool fused = nchunks > 0 && nchunks < (1ull << 31) && !unfused_env && !encode_uses_lanes(enc_format, nchunks, n_ways) &&
+                       encode_fused_fits(enc_format, model->host.nsyms, model->host.scale_bits);
+    if (fused) {
+        const size_t status_bytes = (size_t)(nchunks + 8u * kWorkPools) * 8;
+        rc = ctx->enc_status.reserve(status_bytes);
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemsetAsync(ctx->enc_status.ptr, 0, status_bytes, s));
+    }
+
     if (ctx->timing)
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
     if (nchunks) {
@@ -555,42 +578,44 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         ep.alias_remap = static_cast<const uint32_t *>(model->d_remap);
         ep.alias_recs8 = model->d_alias_recs8;
         ep.alias_remap16 = static_cast<const uint16_t *>(model->d_alias_remap16);
-        // RANS_AMD_ALIAS_L2=1: A/B knob, the general alias encoder (alias_remap gathered from L2)
-        static const bool alias_l2 = getenv("RANS_AMD_ALIAS_L2") != nullptr;
-        const int enc_format = model->host.r64_search ? kKernelFormatR64Search
-                               : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
-                               : (format == RANS_AMD_FMT_ALIAS && model->d_alias_remap16 && !alias_l2) ? kKernelFormatAliasLds
-                                                                                                      : format;
         ep.nsyms = model->host.nsyms;
         ep.scale_bits = model->host.scale_bits;
         ep.sym_bytes = (uint32_t)model->host.sym_bytes;
         ep.flags = ctx->d_enc_flags();
+        if (fused) {
+            ep.status = static_cast<unsigned long long *>(ctx->enc_status.ptr);
+            ep.offsets = d_offsets;
+            ep.out = static_cast<uint8_t *>(d_out);
+            ep.out_cap = out_cap;
+        }
         HIP_TRY(launch_encode(enc_format, ep, ctx->num_cus, s));
     }
-    LayoutParams lp;
-    lp.lengths = d_lengths;
-    lp.offsets = d_offsets;
-    lp.nchunks = nchunks;
-    lp.out_cap = out_cap;
-    lp.flags = ctx->d_enc_flags();
-    lp.block_sums = nullptr;
-    if (layout_blocks(nchunks) > 1) {
-        int rc = ctx->layout_sums.reserve((size_t)layout_blocks(nchunks) * 8);
-        if (rc)
-            return rc;
-        lp.block_sums = static_cast<uint64_t *>(ctx->layout_sums.ptr);
-    }
-    HIP_TRY(launch_layout(lp, s));
-    if (nchunks) {
-        CompactParams cp;
-        cp.scratch = static_cast<const uint8_t *>(ctx->scratch.ptr);
-        cp.slot_bytes = slot;
-        cp.lengths = d_lengths;
-        cp.offsets = d_offsets;
-        cp.out = static_cast<uint8_t *>(d_out);
-        cp.nchunks = nchunks;
-        cp.flags = ctx->d_enc_flags();
-        HIP_TRY(launch_compact(cp, ctx->num_cus, s));
+    if (!fused) {
+        LayoutParams lp;
+        lp.lengths = d_lengths;
+        lp.offsets = d_offsets;
+        lp.nchunks = nchunks;
+        lp.out_cap = out_cap;
+        lp.flags = ctx->d_enc_flags();
+        lp.block_sums = nullptr;
+        if (layout_blocks(nchunks) > 1) {
+            int rc = ctx->layout_sums.reserve((size_t)layout_blocks(nchunks) * 8);
+            if (rc)
+                return rc;
+            lp.block_sums = static_cast<uint64_t *>(ctx->layout_sums.ptr);
+        }
+        HIP_TRY(launch_layout(lp, s));
+        if (nchunks) {
+            CompactParams cp;
+            cp.scratch = static_cast<const uint8_t *>(ctx->scratch.ptr);
+            cp.slot_bytes = slot;
+            cp.lengths = d_lengths;
+            cp.offsets = d_offsets;
+            cp.out = static_cast<uint8_t *>(d_out);
+            cp.nchunks = nchunks;
+            cp.flags = ctx->d_enc_flags();
+            HIP_TRY(launch_compact(cp, ctx->num_cus, s));
+        }
     }
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev[3], s));

@@ -22,6 +22,23 @@ hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_
     return launch_decode_wave(format, p, num_cus, stream, kernel_name);
 }
 
+// fused placement needs a mailbox behind the tables in LDS: the alias tables of a 16-bit model over 4096 symbols
+// fill the CU's 160 KiB to the last byte (config 4 keeps the three-kernel path)
+bool encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits)
+{
+    if (format != kKernelFormatAliasLds)
+        return true;
+    const size_t nrecs = nsyms < 256 ? 256 : nsyms;
+    return nrecs * 8 + ((size_t)2 << scale_bits) + 16 + kEncMailboxBytes <= 160 * 1024;
+}
+
+// true when launch_encode hands this shape to the lane-per-chunk encoders (no fused placement there)
+bool encode_uses_lanes(int format, uint64_t nchunks, uint32_t n_ways)
+{
+    return format != kKernelFormatByteAdaptive && lanes_applicable(nchunks, n_ways) && format != kKernelFormatR64Search &&
+           format != kKernelFormatWord16;
+}
+
 hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream)
 {
     // (the lane encoders know the public formats: a narrow alias interleave gathers alias_remap from L2)

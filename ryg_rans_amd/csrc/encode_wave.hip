@@ -158,8 +158,118 @@ __device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x3 &rec, uin
 
 constexpr int kEncAliasLdsThreads = 1024; // FMT_ALIAS_LDS: 16 waves share the (up to 160 KiB) tables of a CU
 
-template <int FMT, int K>
-__global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : kEncBlockThreads) k_encode(const EncParams p)
+// ---------------------------------------------------------------------------
+// Fused placement (EncParams::status).  The container's layout is the oracle's: chunk c starts at the sum of the
+// 16-byte aligned lengths of the chunks before it.  A chunk's length is known when its last symbol is coded; the
+// three-kernel path therefore codes into per-chunk scratch slots, scans the lengths (k_layout) and copies everything
+// once more (k_compact: 0.33 ms per GiB on top of 0.66 ms of coding).  Here the copy runs INSIDE the coding kernel,
+// beside the arithmetic: the last wave(s) of every block are copiers.
+//   encoder wave, chunk done:  stores complete (s_waitcnt), status[c] = AGGREGATE | align16(len), {c, len} into the
+//                              block's mailbox (LDS);
+//   copier wave:               takes {c, len} from the mailbox; looks back over status[c-1], status[c-2], ... 64 at a
+//                              time until a published inclusive PREFIX is met (chunk 0's virtual predecessor is one),
+//                              waiting for predecessors that are still being coded; publishes status[c] = PREFIX |
+//                              (base + align16(len)), writes offsets[c]; copies the stream from the scratch slot to
+//                              out + base, 8 KiB per trip (eight 16-byte loads per lane in flight, source unaligned).
+// Why copiers of the SAME block: the L2 caches of different XCDs are not coherent for ordinary stores -- a reader on
+// another XCD would need the encoder's stream stores written through (measured: +0.33 ms on the word encoder) -- but
+// a block lives on one CU, so its copier reads what its encoders wrote through the same L2.  The status words are
+// the only data that cross XCDs: agent-scope atomics.
+// Forward progress: chunks are claimed in ascending order per pool (blockIdx % kWorkPools) by running waves only, an
+// encoder waits for nothing but a free mailbox entry of its own block, and a copier only for chunks smaller than its
+// own -- every chain of waits ends at the smallest unfinished chunk, whose encoder is running.
+// ---------------------------------------------------------------------------
+constexpr unsigned long long kStAggregate = 1ull << 62, kStPrefix = 2ull << 62, kStValue = (1ull << 62) - 1;
+
+struct EncMailbox {
+    uint32_t tail;     // entries handed out to encoders
+    uint32_t claim;    // entries handed out to copiers
+    uint32_t finished; // encoder waves that have left their loop
+    uint32_t pad;
+    uint2 entries[64]; // {chunk + 1, stream bytes}; x == 0: empty
+};
+static_assert(sizeof(EncMailbox) == kEncMailboxBytes, "mailbox layout");
+
+__device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t chunk, uint32_t len)
+{
+    const uint32_t i = atomicAdd(&mb->tail, 1u) & 63u;
+    volatile uint2 *e = &mb->entries[i];
+    while (e->x != 0u) // (64 entries for at most 15 encoders: the copier would have to be 4 chunks per encoder behind)
+        __builtin_amdgcn_s_sleep(4);
+    *reinterpret_cast<volatile unsigned long long *>(e) = (unsigned long long)(chunk + 1u) | ((unsigned long long)len << 32);
+}
+
+__device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chunk, uint64_t sa, uint32_t len, uint32_t lane)
+{
+    const unsigned long long alen = (len + 15u) & ~15u;
+    unsigned long long base = 0;
+    for (uint64_t j = chunk;;) { // status[j-1], status[j-2], ... are still to be added
+        unsigned long long st = kStPrefix; // virtual predecessor of chunk 0: an inclusive prefix of 0
+        if (lane < j)
+            st = __hip_atomic_load(p.status + (j - 1 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t ready = __builtin_amdgcn_ballot_w64((st >> 62) != 0);
+        const uint64_t pref = __builtin_amdgcn_ballot_w64((st >> 62) == 2);
+        const uint32_t first_pref = pref ? (uint32_t)__builtin_ctzll(pref) : 64u;
+        const uint64_t need = first_pref >= 63u ? ~0ull : ((2ull << first_pref) - 1ull); // lanes 0 .. first_pref
+        if ((ready & need) != need) { // a predecessor in that range has not finished its chunk yet
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        unsigned long long v = lane <= first_pref ? (st & kStValue) : 0ull;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
+            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
+            v += (unsigned long long)lo | ((unsigned long long)hi << 32);
+        }
+        base += uniform64(v);
+        if (first_pref < 64u)
+            break;
+        j -= 64;
+    }
+    if (lane == 0) {
+        __hip_atomic_store(p.status + chunk, kStPrefix | (base + alen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.offsets[chunk] = base;
+        if (chunk + 1 == p.nchunks)
+            p.offsets[p.nchunks] = base + len;
+    }
+    if (base + len > p.out_cap) { // wave-uniform
+        if (lane == 0)
+            atomicOr(p.flags, 2u);
+        return;
+    }
+    u32x4 RANS_GLOBAL *dst = reinterpret_cast<u32x4 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + base);
+    const uint32_t n16 = (len + 15u) >> 4; // (the last piece may read up to 15 bytes of the next slot: scratch is padded)
+#ifndef RANS_COPY_DEPTH
+#define RANS_COPY_DEPTH 8
+#endif
+    for (uint32_t i0 = lane; i0 < n16; i0 += 64u * RANS_COPY_DEPTH) { // (nt: the slot is read once, the container written once)
+        u32x4 v[RANS_COPY_DEPTH];
+#pragma unroll
+        for (int j = 0; j < RANS_COPY_DEPTH; ++j)
+            if (i0 + 64u * j < n16) {
+#ifndef RANS_COPY_PLAIN_LOAD
+                v[j] = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(sa + 16ull * (i0 + 64u * j)));
+#else
+                v[j] = *reinterpret_cast<gvec_cptr>(sa + 16ull * (i0 + 64u * j)); // unaligned 16-byte load
+#endif
+            }
+#pragma unroll
+        for (int j = 0; j < RANS_COPY_DEPTH; ++j)
+            if (i0 + 64u * j < n16) {
+#ifndef RANS_COPY_PLAIN_STORE
+                __builtin_nontemporal_store(v[j], dst + i0 + 64u * j);
+#else
+                dst[i0 + 64u * j] = v[j];
+#endif
+            }
+    }
+}
+
+template <int FMT, int K, bool FUSED>
+__global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (FUSED ? kEncFusedThreads : kEncBlockThreads),
+                                  (FUSED && FMT != FMT_ALIAS_LDS) ? 8 : 1) // fused: 4 blocks of 8 waves per CU, 64 VGPRs
+    k_encode(const EncParams p)
 {
     using Tr = FmtTraits<FMT>;
     using state_t = typename Tr::state_t;
@@ -195,12 +305,56 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
         for (uint32_t i = p.nsyms + threadIdx.x; i < 256u; i += blockDim.x)
             l[i] = uint4{0u, 0u, 0u, 0u};
     }
+    EncMailbox *mb = reinterpret_cast<EncMailbox *>(smem + p.mailbox_off);
+    if constexpr (FUSED) {
+        if (threadIdx.x < kEncMailboxBytes / 4u)
+            reinterpret_cast<uint32_t *>(mb)[threadIdx.x] = 0u;
+    }
     __syncthreads();
 
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x >> 6);
-    const uint32_t waves_per_block = blockDim.x >> 6;
+    // fused: the last wave of a block (the last two of a 16-wave block) copies, the others encode
+    const uint32_t copiers = FUSED ? ((blockDim.x >> 6) >= 16u ? kEncFusedCopiers16 : 1u) : 0u;
+    const uint32_t waves_per_block = (blockDim.x >> 6) - copiers;
     const uint32_t N = p.n_ways; // <= 64 * K; lanes idx >= N idle
+
+    if constexpr (FUSED) {
+        if (wave >= waves_per_block) { // ---- copier wave
+            for (;;) {
+                uint32_t h = 0;
+                if (lane == 0)
+                    h = atomicAdd(&mb->claim, 1u);
+                h = uniform(h);
+                volatile uint2 *e = &mb->entries[h & 63u];
+                uint32_t ex = 0, ey = 0;
+                bool stop = false;
+                for (;;) {
+                    const unsigned long long ev = *reinterpret_cast<volatile unsigned long long *>(e);
+                    ex = uniform((uint32_t)ev);
+                    ey = uniform((uint32_t)(ev >> 32));
+                    if (ex != 0u)
+                        break;
+                    // nothing there: done when every encoder has left and fewer than h + 1 entries were ever pushed
+                    const uint32_t fin = uniform(*reinterpret_cast<volatile uint32_t *>(&mb->finished));
+                    const uint32_t tail = uniform(*reinterpret_cast<volatile uint32_t *>(&mb->tail));
+                    if (fin == waves_per_block && (int32_t)(tail - h) <= 0) {
+                        stop = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (stop)
+                    break;
+                if (lane == 0)
+                    *reinterpret_cast<volatile unsigned long long *>(e) = 0ull;
+                const uint64_t chunk = ex - 1u;
+                const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1u) * p.slot_bytes - ey;
+                place_and_copy(p, chunk, sa, ey, lane);
+            }
+            return;
+        }
+    }
 
     EncTables<FMT> T;
     T.recs = reinterpret_cast<const uint4 *>(smem + kWordRecBytes);
@@ -219,8 +373,19 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
     const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
     const uint32_t in_lane_off = (lane & 3u) * N + (lane & ~3u);
 
-    for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave; chunk_v < p.nchunks;
-         chunk_v += total_waves) {
+    for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave;; chunk_v += total_waves) {
+        if constexpr (FUSED) {
+            // ascending claims, one counter per pool of blocks (a 64-byte line each, behind the status words; pool q
+            // hands out the chunks c with c % npools == q): a single counter retires ~90 claims per microsecond
+            const uint32_t npools = gridDim.x < kWorkPools ? gridDim.x : kWorkPools;
+            const uint32_t pool = blockIdx.x % npools;
+            uint32_t got = 0;
+            if (lane == 0)
+                got = atomicAdd(reinterpret_cast<unsigned int *>(p.status + p.nchunks + 8u * pool), 1u);
+            chunk_v = (uint64_t)uniform(got) * npools + pool;
+        }
+        if (chunk_v >= p.nchunks)
+            break;
         const uint64_t chunk = uniform64(chunk_v);
         const uint64_t first = chunk * p.chunk_syms;
         const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
@@ -395,8 +560,21 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
                 }
             }
         }
+        const uint32_t len = (uint32_t)p.slot_bytes - wp;
         if (lane == 0)
-            p.lengths[chunk] = (uint32_t)p.slot_bytes - wp;
+            p.lengths[chunk] = len;
+        if constexpr (FUSED) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // every lane's stream stores have reached L2
+            if (lane == 0) {
+                __hip_atomic_store(p.status + chunk, kStAggregate | (unsigned long long)((len + 15u) & ~15u), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                mailbox_push(mb, (uint32_t)chunk, len);
+            }
+        }
+    }
+    if constexpr (FUSED) {
+        if (lane == 0)
+            atomicAdd(&mb->finished, 1u);
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
         atomicOr(p.flags, 1u);
@@ -404,28 +582,44 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : k
 
 template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num_cus, hipStream_t stream)
 {
-    const uint32_t threads = FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : kEncBlockThreads;
+    const bool fused = p.status != nullptr;
+    const uint32_t threads = FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (fused ? kEncFusedThreads : kEncBlockThreads);
     const uint32_t waves = threads / 64;
+    const uint32_t enc_waves = fused ? waves - (waves >= 16 ? kEncFusedCopiers16 : 1) : waves;
     const size_t nrecs = p.nsyms < 256 ? 256 : p.nsyms;
-    const size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
-                       : (FMT == FMT_BYTE && p.chunk_freqs) ? (size_t)waves * kAdaptEncWaveLds
-                                            : nrecs * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
+    size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
+                 : (FMT == FMT_BYTE && p.chunk_freqs) ? (size_t)waves * kAdaptEncWaveLds
+                                                      : nrecs * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
+    EncParams q = p;
+    if (fused) {
+        lds = (lds + 15) & ~(size_t)15;
+        q.mailbox_off = (uint32_t)lds;
+        lds += kEncMailboxBytes;
+    }
     const size_t lds_cap = FMT == FMT_ALIAS_LDS ? 160 * 1024 : 128 * 1024;
     if (lds > lds_cap || (FMT == FMT_WORD && !p.word_enc_recs && p.sym_bytes == 1) ||
         (FMT == FMT_ALIAS_LDS && (!p.alias_recs8 || !p.alias_remap16)))
         return hipErrorInvalidValue;
-    auto kern = k_encode<FMT, K>;
-    static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), (int)lds_cap, lds_ok); e != hipSuccess)
-        return e;
-    uint64_t want = (p.nchunks + waves - 1) / waves;
+    uint64_t want = (p.nchunks + enc_waves - 1) / enc_waves;
     // blocks per CU: what the LDS allows, within the 32 resident waves of a CU
     uint64_t per_cu = lds ? (160 * 1024) / lds : 8;
     per_cu = per_cu < 1 ? 1 : per_cu;
     per_cu = per_cu * waves > 32 ? 32 / waves : per_cu;
-    uint64_t cap = (uint64_t)num_cus * (FMT == FMT_ALIAS_LDS ? per_cu : 8);
+    uint64_t cap = (uint64_t)num_cus * (FMT == FMT_ALIAS_LDS || fused ? per_cu : 8);
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
-    RANS_LAUNCH(kern, dim3(grid), dim3(threads), lds, stream, p);
+    if (fused) {
+        auto kern = k_encode<FMT, K, true>;
+        static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
+        if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), (int)lds_cap, lds_ok); e != hipSuccess)
+            return e;
+        RANS_LAUNCH(kern, dim3(grid), dim3(threads), lds, stream, q);
+        return hipGetLastError();
+    }
+    auto kern = k_encode<FMT, K, false>;
+    static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), (int)lds_cap, lds_ok); e != hipSuccess)
+        return e;
+    RANS_LAUNCH(kern, dim3(grid), dim3(threads), lds, stream, q);
     return hipGetLastError();
 }
 

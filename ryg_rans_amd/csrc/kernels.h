@@ -85,8 +85,27 @@ struct EncParams {
     uint32_t nsyms;
     uint32_t scale_bits;
     uint32_t sym_bytes;
-    uint32_t *flags;      // bit0: symbol with freq 0 / outside alphabet met
+    uint32_t *flags;      // bit0: symbol with freq 0 / outside alphabet met; fused: bit1 = container does not fit out_cap
+    // Fused placement (wave-per-chunk encoders, k_encode<.., FUSED = true>): every block carries copier waves that
+    // move the finished streams of ITS encoder waves from their scratch slots to their final place, found by a
+    // decoupled look-back over status[] -- offsets[], lengths[] and the container come out of this one kernel, no
+    // k_layout / k_compact.  status: one word per chunk (zero at launch), then kWorkPools claim counters on a 64-byte
+    // line each.
+    unsigned long long *status; // or NULL: the three-kernel path
+    uint64_t *offsets;          // fused: out, [nchunks + 1]
+    uint8_t *out;               // fused: the container
+    uint64_t out_cap;
+    uint32_t mailbox_off;       // fused: LDS byte offset of the block's mailbox (set by the launcher)
 };
+#ifndef RANS_FUSED_THREADS
+#define RANS_FUSED_THREADS 512
+#endif
+#ifndef RANS_FUSED_COPIERS16
+#define RANS_FUSED_COPIERS16 2
+#endif
+constexpr uint32_t kEncFusedThreads = RANS_FUSED_THREADS; // 7 encoder waves + 1 copier wave; 4 blocks per CU
+constexpr uint32_t kEncFusedCopiers16 = RANS_FUSED_COPIERS16; // copier waves of a 16-wave block
+constexpr uint32_t kEncMailboxBytes = 16 + 64 * 8;
 
 struct LayoutParams {
     const uint32_t *lengths;
@@ -110,6 +129,8 @@ struct CompactParams {
 // All launchers return hipSuccess or the launch error; they never synchronise.
 hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name);
 hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream);
+bool encode_uses_lanes(int format, uint64_t nchunks, uint32_t n_ways);
+bool encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits);
 hipError_t launch_layout(const LayoutParams &p, hipStream_t stream);
 uint32_t layout_blocks(uint64_t nchunks); // blocks (and block_sums entries) launch_layout uses
 hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t stream);
