@@ -315,6 +315,9 @@ int rans_amd_launch_spans(rans_amd_ctx *ctx, uint32_t count, double *span_ms, vo
 int rans_amd_last_kernel_ms(rans_amd_ctx *ctx, float *decode_ms, float *encode_ms);
 /* Name of the dominant device kernel the last decode used (for profile matching). */
 const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx);
+/* Name of the coding kernel the last encode used; *fused_placement (may be NULL) = 1 when that kernel also placed the
+ * chunks in the container itself, 0 when the offset scan and the compaction ran as kernels of their own behind it. */
+const char *rans_amd_last_encode_kernel(rans_amd_ctx *ctx, int *fused_placement);
 
 #ifdef __cplusplus
 }

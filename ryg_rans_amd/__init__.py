@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "rans_amd_num_chunks", "rans_amd_chunk_bound", "rans_amd_encode_bound", "rans_amd_ways_supported",
     "rans_amd_encode", "rans_amd_decode", "rans_amd_decode_errors",
     "rans_amd_encode_host", "rans_amd_decode_host",
-    "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_wave_clocks",
+    "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_encode_kernel", "rans_amd_last_wave_clocks",
     "rans_amd_launch_spans",
     "rans_amd_chunk_freqs_bytes", "rans_amd_encode_adaptive", "rans_amd_decode_adaptive",
     "rans_amd_container_bytes_adaptive", "rans_amd_container_pack_adaptive", "rans_amd_container_parse_adaptive",
@@ -110,6 +110,7 @@ def _load():
         "rans_amd_set_timing": (i32, [vp, i32]),
         "rans_amd_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "rans_amd_last_decode_kernel": (C.c_char_p, [vp]),
+        "rans_amd_last_encode_kernel": (C.c_char_p, [vp, C.POINTER(C.c_int)]),
         "rans_amd_last_wave_clocks": (i32, [vp, C.POINTER(WaveClocks)]),
         "rans_amd_launch_spans": (i32, [vp, u32, C.POINTER(C.c_double), vp]),
         "rans_amd_chunk_freqs_bytes": (u64, [u64, u32]),
@@ -237,6 +238,12 @@ class Context:
 
     def last_decode_kernel(self):
         return _lib.rans_amd_last_decode_kernel(self._h).decode()
+
+    def last_encode_kernel(self):
+        """(name of the coding kernel of the last encode, True if it placed the chunks itself)"""
+        fused = C.c_int(0)
+        name = _lib.rans_amd_last_encode_kernel(self._h, C.byref(fused)).decode()
+        return name, bool(fused.value)
 
     # -- model
     def model(self, fmt, norm_freqs, scale_bits):

@@ -93,6 +93,8 @@ struct rans_amd_ctx {
     bool dec_timed = false, enc_timed = false;
     uint32_t launch_seq = 0; // selects one of kWorkSlots chunk counters at d_words + 256
     const char *last_kernel = "";
+    const char *last_enc_kernel = ""; // the coding kernel of the last encode call
+    bool last_enc_fused = false;      // ... and whether it placed its chunks itself (no k_layout / k_compact)
     std::mutex mu;
 
     unsigned long long *d_err() { return reinterpret_cast<unsigned long long *>(d_words); }
@@ -541,8 +543,9 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
 
-    // Wave-per-chunk encoders place and copy their chunks themselves (EncParams::status, encode_wave.hip): no
-    // k_layout / k_compact.  The lane-per-chunk encoders (N = 1, 2, 4, 8 with many chunks) keep the three-kernel path.
+    // The wave-per-chunk encoders place and copy their chunks themselves (EncParams::status; encode_wave.hip
+    // place_and_copy): no k_layout / k_compact.  The lane-per-chunk encoders (N = 1, 2, 4, 8 with many chunks) and the
+    // 160 KiB alias model keep the three-kernel path.
     // RANS_AMD_ENCODE_UNFUSED=1: A/B knob.
     static const bool unfused_env = getenv("RANS_AMD_ENCODE_UNFUSED") != nullptr;
     // RANS_AMD_ALIAS_L2=1: A/B knob, the general alias encoder (alias_remap gathered from L2)
@@ -551,9 +554,25 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
                            : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
                            : (format == RANS_AMD_FMT_ALIAS && model->d_alias_remap16 && !alias_l2) ? kKernelFormatAliasLds
                                                                                                   : format;
-    const bool fused = nchunks > 0 && nchunks < (1ull << 31) && !unfused_env && !encode_uses_lanes(enc_format, nchunks, n_ways) &&
-                       encode_fused_fits(enc_format, model->host.nsyms, model->host.scale_bits);
+    EncParams ep{};
+    ep.syms = static_cast<const uint8_t *>(d_syms);
+    ep.nchunks = nchunks;
+    ep.chunk_syms = chunk_syms;
+    ep.n_ways = n_ways;
+    ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr);
+    ep.slot_bytes = slot;
+    ep.nsyms = model->host.nsyms;
+    ep.sym_bytes = (uint32_t)model->host.sym_bytes;
+    const bool lanes = encode_uses_lanes(enc_format, nchunks, n_ways);
+    // RANS_AMD_LANES_FUSED=1 (read at every call): the lane encoders place their chunks themselves as well -- bit-exact,
+    // tested, and on config 2 no faster than k_layout + k_compact_small behind them (lanes.hip says why), hence opt-in
+    const bool lanes_fused_env = getenv("RANS_AMD_LANES_FUSED") != nullptr;
+    const bool fused = nchunks > 0 && nchunks < (1ull << 31) && !unfused_env &&
+                       (lanes ? lanes_fused_env && encode_lanes_can_fuse(enc_format, ep, ctx->num_cus)
+                              : encode_fused_fits(enc_format, model->host.nsyms, model->host.scale_bits));
     if (fused) {
+        // (wave encoders: a word per chunk; lane encoders: a word per round of a block, at most one per batch of 64
+        //  chunks; then the claim counters)
         const size_t status_bytes = (size_t)(nchunks + 8u * kWorkPools) * 8;
         rc = ctx->enc_status.reserve(status_bytes);
         if (rc)
@@ -564,7 +583,6 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     if (ctx->timing)
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
     if (nchunks) {
-        EncParams ep{};
         ep.syms = static_cast<const uint8_t *>(d_syms);
         ep.n = n;
         ep.nchunks = nchunks;
@@ -582,13 +600,18 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         ep.scale_bits = model->host.scale_bits;
         ep.sym_bytes = (uint32_t)model->host.sym_bytes;
         ep.flags = ctx->d_enc_flags();
+        {
+            static const char *dbg = getenv("RANS_AMD_ENC_DEBUG");
+            ep.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
+        }
         if (fused) {
             ep.status = static_cast<unsigned long long *>(ctx->enc_status.ptr);
             ep.offsets = d_offsets;
             ep.out = static_cast<uint8_t *>(d_out);
             ep.out_cap = out_cap;
         }
-        HIP_TRY(launch_encode(enc_format, ep, ctx->num_cus, s));
+        HIP_TRY(launch_encode(enc_format, ep, ctx->num_cus, s, &ctx->last_enc_kernel));
+        ctx->last_enc_fused = fused;
     }
     if (!fused) {
         LayoutParams lp;
@@ -633,6 +656,13 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
             return fail(RANS_AMD_E_MODEL, "encode: input holds a symbol with frequency 0");
         if (flags & 2u)
             return fail(RANS_AMD_E_SPACE, "encode: container does not fit out_cap");
+        if (flags & 4u) // (a kernel that addresses its LDS tables by raw offsets found them elsewhere: never code on that)
+            return fail(RANS_AMD_E_HIP, "encode: internal error (dynamic LDS does not start at offset 0)");
+        if (flags & ~7u) { // a wait of the fused placement gave up (device_common.hpp kSpinLimit): the container is not valid
+            char msg[160];
+            snprintf(msg, sizeof msg, "encode: internal error (placement protocol timed out, flags 0x%x)", flags);
+            return fail(RANS_AMD_E_HIP, msg);
+        }
     }
     return RANS_AMD_OK;
 }
@@ -872,7 +902,8 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         ep.sym_bytes = 1;
         ep.flags = ctx->d_enc_flags();
         ep.chunk_freqs = d_chunk_freqs;
-        HIP_TRY(launch_encode(kKernelFormatByteAdaptive, ep, ctx->num_cus, s));
+        HIP_TRY(launch_encode(kKernelFormatByteAdaptive, ep, ctx->num_cus, s, &ctx->last_enc_kernel));
+        ctx->last_enc_fused = false;
     }
     LayoutParams lp;
     lp.lengths = d_lengths;
@@ -1117,6 +1148,13 @@ int rans_amd_last_kernel_ms(rans_amd_ctx *ctx, float *decode_ms, float *encode_m
 }
 
 const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+const char *rans_amd_last_encode_kernel(rans_amd_ctx *ctx, int *fused_placement)
+{
+    if (fused_placement)
+        *fused_placement = ctx && ctx->last_enc_fused ? 1 : 0;
+    return ctx ? ctx->last_enc_kernel : "";
+}
 
 int rans_amd_launch_spans(rans_amd_ctx *ctx, uint32_t count, double *span_ms, void *stream)
 {

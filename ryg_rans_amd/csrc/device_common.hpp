@@ -101,6 +101,11 @@ __device__ __forceinline__ uint32_t rank_below(uint64_t m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// Status words of the encoders' decoupled look-back (EncParams::status): top two bits = state, the rest a byte count.
+// AGGREGATE: the unit (a chunk of the wave encoders, a 64-chunk batch of the lane encoders) is coded and this is its
+// own aligned size; PREFIX: this is the inclusive sum up to and including the unit, i.e. where the next one starts.
+constexpr unsigned long long kStAggregate = 1ull << 62, kStPrefix = 2ull << 62, kStValue = (1ull << 62) - 1;
+
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 {
@@ -405,6 +410,68 @@ __device__ __forceinline__ uint64_t enc_update_r64(uint64_t y, const uint4 &rec,
     const uint64_t q = __umul64hi(y, rcp) >> (rec.x >> 24);
     const uint32_t cmpl = (1u << scale_bits) - (rec.x & 0xffffffu);
     return y + rec.y + (uint64_t)(uint32_t)q * cmpl + ((uint64_t)__umul24((uint32_t)(q >> 32), cmpl) << 32);
+}
+
+// Mailbox between the coding waves of a block and its copier wave(s) (fused placement, encode_wave.hip k_encode and
+// lanes.hip): the coder pushes {unit + 1, bytes} when its unit (chunk / batch of 64 chunks) is in the scratch slots,
+// a copier takes the entries in order.  Lives in the block's LDS (EncParams::mailbox_off), zeroed at kernel start.
+struct EncMailbox {
+    uint32_t tail;     // entries handed out to encoders
+    uint32_t claim;    // entries handed out to copiers
+    uint32_t finished; // encoder waves that have left their loop
+    uint32_t pad;
+    uint2 entries[64]; // {unit + 1, stream bytes}; x == 0: empty
+};
+static_assert(sizeof(EncMailbox) == kEncMailboxBytes, "mailbox layout");
+
+// Every wait of the placement protocol gives up after kSpinLimit polls (seconds; waits are microseconds) and sets a
+// bit of EncParams::flags -- 8: mailbox full, 16: (unused), 32: look-back, 64: wait for an own prefix -- which the
+// host turns into an error: a protocol bug must show up as a failed call, not as a hung GPU.
+constexpr uint32_t kSpinLimit = 1u << 21;
+
+__device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t unit, uint32_t len, uint32_t *flags)
+{
+    const uint32_t i = atomicAdd(&mb->tail, 1u) & 63u;
+    volatile uint2 *e = &mb->entries[i];
+    uint32_t spins = 0;
+    while (e->x != 0u) { // (64 entries for at most 15 encoders: the copier would have to be 4 units per encoder behind)
+        if (++spins > kSpinLimit) {
+            atomicOr(flags, 8u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    *reinterpret_cast<volatile unsigned long long *>(e) = (unsigned long long)(unit + 1u) | ((unsigned long long)len << 32);
+}
+
+// Copier side (whole wave): the next entry in order, {ex = unit + 1, ey = bytes}; false when every one of the block's
+// `producers` coding waves has left its loop and nothing is left to take.
+__device__ __forceinline__ bool mailbox_pop(EncMailbox *mb, uint32_t lane, uint32_t producers, uint32_t &ex, uint32_t &ey)
+{
+    uint32_t h = 0;
+    if (lane == 0)
+        h = atomicAdd(&mb->claim, 1u);
+    h = uniform(h);
+    volatile uint2 *e = &mb->entries[h & 63u];
+    for (uint32_t spins = 0;;) {
+        const unsigned long long ev = *reinterpret_cast<volatile unsigned long long *>(e);
+        ex = uniform((uint32_t)ev);
+        ey = uniform((uint32_t)(ev >> 32));
+        if (ex != 0u)
+            break;
+        // nothing there: done when every encoder has left and fewer than h + 1 entries were ever pushed
+        const uint32_t fin = uniform(*reinterpret_cast<volatile uint32_t *>(&mb->finished));
+        const uint32_t tail = uniform(*reinterpret_cast<volatile uint32_t *>(&mb->tail));
+        if (fin == producers && (int32_t)(tail - h) <= 0)
+            return false;
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > 16u * kSpinLimit) // (this wait is as long as a unit takes to code: milliseconds at most)
+            return false;
+    }
+    // (every lane writes the same zero: a trailing `if (lane == 0)` invites the compiler to let the other lanes run ahead
+    //  into code whose readfirstlane / ballot assumes the whole wave -- see lanes.hip, lanes_scan_batch)
+    *reinterpret_cast<volatile unsigned long long *>(e) = 0ull;
+    return true;
 }
 
 } // namespace

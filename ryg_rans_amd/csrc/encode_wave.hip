@@ -179,30 +179,13 @@ constexpr int kEncAliasLdsThreads = 1024; // FMT_ALIAS_LDS: 16 waves share the (
 // encoder waits for nothing but a free mailbox entry of its own block, and a copier only for chunks smaller than its
 // own -- every chain of waits ends at the smallest unfinished chunk, whose encoder is running.
 // ---------------------------------------------------------------------------
-constexpr unsigned long long kStAggregate = 1ull << 62, kStPrefix = 2ull << 62, kStValue = (1ull << 62) - 1;
-
-struct EncMailbox {
-    uint32_t tail;     // entries handed out to encoders
-    uint32_t claim;    // entries handed out to copiers
-    uint32_t finished; // encoder waves that have left their loop
-    uint32_t pad;
-    uint2 entries[64]; // {chunk + 1, stream bytes}; x == 0: empty
-};
-static_assert(sizeof(EncMailbox) == kEncMailboxBytes, "mailbox layout");
-
-__device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t chunk, uint32_t len)
-{
-    const uint32_t i = atomicAdd(&mb->tail, 1u) & 63u;
-    volatile uint2 *e = &mb->entries[i];
-    while (e->x != 0u) // (64 entries for at most 15 encoders: the copier would have to be 4 chunks per encoder behind)
-        __builtin_amdgcn_s_sleep(4);
-    *reinterpret_cast<volatile unsigned long long *>(e) = (unsigned long long)(chunk + 1u) | ((unsigned long long)len << 32);
-}
+// (kStAggregate / kStPrefix / kStValue: device_common.hpp -- the lane encoders place their batches the same way)
 
 __device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chunk, uint64_t sa, uint32_t len, uint32_t lane)
 {
     const unsigned long long alen = (len + 15u) & ~15u;
     unsigned long long base = 0;
+    uint32_t spins = 0;
     for (uint64_t j = chunk;;) { // status[j-1], status[j-2], ... are still to be added
         unsigned long long st = kStPrefix; // virtual predecessor of chunk 0: an inclusive prefix of 0
         if (lane < j)
@@ -212,6 +195,11 @@ __device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chun
         const uint32_t first_pref = pref ? (uint32_t)__builtin_ctzll(pref) : 64u;
         const uint64_t need = first_pref >= 63u ? ~0ull : ((2ull << first_pref) - 1ull); // lanes 0 .. first_pref
         if ((ready & need) != need) { // a predecessor in that range has not finished its chunk yet
+            if (++spins > kSpinLimit) { // (never seen; a protocol error must not hang the GPU)
+                if (lane == 0)
+                    atomicOr(p.flags, 32u);
+                break;
+            }
             __builtin_amdgcn_s_sleep(8);
             continue;
         }
@@ -322,32 +310,9 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
     if constexpr (FUSED) {
         if (wave >= waves_per_block) { // ---- copier wave
             for (;;) {
-                uint32_t h = 0;
-                if (lane == 0)
-                    h = atomicAdd(&mb->claim, 1u);
-                h = uniform(h);
-                volatile uint2 *e = &mb->entries[h & 63u];
                 uint32_t ex = 0, ey = 0;
-                bool stop = false;
-                for (;;) {
-                    const unsigned long long ev = *reinterpret_cast<volatile unsigned long long *>(e);
-                    ex = uniform((uint32_t)ev);
-                    ey = uniform((uint32_t)(ev >> 32));
-                    if (ex != 0u)
-                        break;
-                    // nothing there: done when every encoder has left and fewer than h + 1 entries were ever pushed
-                    const uint32_t fin = uniform(*reinterpret_cast<volatile uint32_t *>(&mb->finished));
-                    const uint32_t tail = uniform(*reinterpret_cast<volatile uint32_t *>(&mb->tail));
-                    if (fin == waves_per_block && (int32_t)(tail - h) <= 0) {
-                        stop = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                if (stop)
+                if (!mailbox_pop(mb, lane, waves_per_block, ex, ey))
                     break;
-                if (lane == 0)
-                    *reinterpret_cast<volatile unsigned long long *>(e) = 0ull;
                 const uint64_t chunk = ex - 1u;
                 const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1u) * p.slot_bytes - ey;
                 place_and_copy(p, chunk, sa, ey, lane);
@@ -568,16 +533,20 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             if (lane == 0) {
                 __hip_atomic_store(p.status + chunk, kStAggregate | (unsigned long long)((len + 15u) & ~15u), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-                mailbox_push(mb, (uint32_t)chunk, len);
+                // (the copier will overwrite that word with the PREFIX: it must not learn of the chunk before the store is done)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a workgroup-scope fence emits no wait for global stores on this target)
+                mailbox_push(mb, (uint32_t)chunk, len, p.flags);
             }
         }
     }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
+        atomicOr(p.flags, 1u);
     if constexpr (FUSED) {
         if (lane == 0)
             atomicAdd(&mb->finished, 1u);
+        // (letting the encoders that have run dry help the copier was tried: 0.867 ms against 0.817 for the 1 GiB word
+        //  encode -- a second copy loop in the kernel costs 13 more spilled SGPRs in the coding loop)
     }
-    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
-        atomicOr(p.flags, 1u);
 }
 
 template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num_cus, hipStream_t stream)
@@ -640,8 +609,15 @@ template <int FMT> hipError_t launch_encode_f(const EncParams &p, int num_cus, h
 
 } // namespace
 
-hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipStream_t stream)
+hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **name)
 {
+    if (name)
+        *name = format == FMT_WORD    ? "k_encode<word>"
+                : format == FMT_BYTE  ? (p.chunk_freqs ? "k_encode<byte, per-chunk models>" : "k_encode<byte>")
+                : format == FMT_R64   ? "k_encode<r64>"
+                : format == FMT_R64S  ? "k_encode<r64 full-width>"
+                : format == FMT_ALIAS_LDS ? "k_encode<alias, LDS remap>"
+                                      : "k_encode<alias>";
     switch (format) {
     case FMT_WORD: return launch_encode_f<FMT_WORD>(p, num_cus, stream);
     case FMT_BYTE: return launch_encode_f<FMT_BYTE>(p, num_cus, stream);

@@ -96,6 +96,15 @@ struct EncParams {
     uint8_t *out;               // fused: the container
     uint64_t out_cap;
     uint32_t mailbox_off;       // fused: LDS byte offset of the block's mailbox (set by the launcher)
+    // Lane-per-chunk encoders (lanes.hip), fused: a launch codes the batches (64 chunks each) [batch_begin, batch_end)
+    // of the nchunks chunks; status holds one word per UNIT -- the C batches the C coding waves of a block take in one
+    // round -- numbered from unit_base, then (from word ceil(nchunks / 64) on) claim counters on a 64-byte line each,
+    // of which this launch uses number claim_slot.  The r64 2-way kernel and the staged kernel that takes the tail
+    // after it share one status array, in stream order.
+    uint64_t batch_begin, batch_end, unit_base; // set by the launcher
+    uint32_t claim_slot;
+    uint32_t debug;             // measurement knobs (RANS_AMD_ENC_DEBUG): bit 0 = the lane encoders' fused placement skips the copy
+                                //   itself, bit 1 = ... does not wait for a batch's place (uses 0); output is wrong by construction
 };
 #ifndef RANS_FUSED_THREADS
 #define RANS_FUSED_THREADS 512
@@ -128,9 +137,10 @@ struct CompactParams {
 
 // All launchers return hipSuccess or the launch error; they never synchronise.
 hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name);
-hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream);
+hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **kernel_names);
 bool encode_uses_lanes(int format, uint64_t nchunks, uint32_t n_ways);
 bool encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits);
+bool encode_lanes_can_fuse(int format, const EncParams &p, int num_cus); // lane-per-chunk encoders: see launchers.hpp
 hipError_t launch_layout(const LayoutParams &p, hipStream_t stream);
 uint32_t layout_blocks(uint64_t nchunks); // blocks (and block_sums entries) launch_layout uses
 hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t stream);

@@ -1023,6 +1023,282 @@ __device__ __forceinline__ void lane_put_staged(typename FmtTraits<FMT>::state_t
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fused placement of the lane encoders (EncParams::status != NULL): no k_layout / k_compact_small afterwards.  The
+// container's layout is the oracle's (chunk c starts at the sum of the 16-byte aligned lengths before it), so the
+// chunks of a batch can be copied to their place once the total of everything before the batch is known.
+//
+// The unit of the scan is a ROUND OF A BLOCK: its C coding waves take C consecutive batches (one claim of the block's
+// scanner wave, the last wave of the block, on a counter behind the status words), code them, and post their totals
+// in LDS; the scanner adds them up, publishes status[unit] = AGGREGATE | total, looks back over the units before it
+// (decoupled look-back, device_common.hpp; kScanWords * 64 units per step) until it meets a PREFIX, publishes its own
+// PREFIX and leaves every coder the place of its batch in LDS.  A coder copies the batch of round r AFTER it has coded
+// round r + 1 -- the scan of round r has had a whole round's time by then, so nobody waits except at the very end, where
+// 256 units (one per CU) finish together and one look-back step resolves them all.
+//
+// What this replaced, all of them measured on config 2 (0.39 ms with the two extra kernels): the coding wave placing
+// its own batch at once (0.54: every wave of the first round finishes at the same moment and the prefix travels 64
+// batches per memory round trip); a copier wave per block that scans and copies batch by batch through a mailbox
+// (0.375-0.52: 6-8 us per batch where the coders deliver one every 8 us); a scanner wave per block working batch by
+// batch while the coders copy (0.40-0.42: with 2816 batches ending together a scanner walks back thousands of status
+// words for each of its 11 batches, one memory round trip per 64 or 256 of them -- as long as coding the round).
+// Units are claimed in ascending order by running blocks and a scanner waits only for smaller units: the smallest
+// unfinished unit always belongs to a running block.  The copy is quad-cooperative like every other access of these
+// kernels: instruction t moves 64 bytes of the chunk of the quad's lane t (16 bytes per lane, source unaligned),
+// kLaneCopyDepth pieces per chunk in flight.
+//
+// A word on control flow: none of the loops below ends in an `if (lane == 0) { ... }`.  With such a tail the compiler
+// let lanes 1..63 run ahead into the next iteration -- whose readfirstlane then read a lane that had not taken part --
+// and parked lane 0's store behind the loop, for ever (found with the watchdogs below: flags 0x40, every status word
+// still AGGREGATE).  Stores that one lane would do are done by all of them with the same value.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kLaneCopiers = 1;   // scanner waves per block (on top of the coding waves the LDS allows, <= 16 in all)
+constexpr int kLaneCopyDepth = 2;
+constexpr int kScanWords = 4;
+
+struct LaneRounds { // the block's control words in LDS (EncParams::mailbox_off), zero at kernel start; index = round & 1
+    uint32_t unit[2];     // unit claimed for the round ...
+    uint32_t unit_seq[2]; // ... valid when this is round + 1
+    uint32_t posted[2];   // coding waves that have posted their total
+    uint32_t base_seq[2]; // bases[] valid when this is round + 1
+    uint32_t totals[2][16];
+    unsigned long long bases[2][16];
+};
+static_assert(sizeof(LaneRounds) <= kEncMailboxBytes, "LaneRounds must fit the LDS reserved for the placement");
+
+struct LaneCoder { // a coding wave's view
+    uint32_t round;      // rounds begun
+    bool have_prev;      // a batch coded and not yet copied
+    uint32_t prev_round; // its round
+    uint64_t prev_batch;
+    uint32_t prev_len;   // this lane's chunk of it
+};
+
+// poll an LDS word until it has the value (whole wave; gives up after kSpinLimit polls and says so in flags)
+__device__ __forceinline__ bool lanes_wait_lds(volatile uint32_t *word, uint32_t value, uint32_t *flags, uint32_t flag_bit, uint32_t lane)
+{
+    for (uint32_t spins = 0;; ++spins) {
+        if (uniform(*word) == value)
+            return true;
+        if (spins > kSpinLimit) {
+            atomicOr(flags, lane == 0 ? flag_bit : 0u);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// coding wave, start of a round: its batch, ~0 - 1 when it has none in this (the last) unit, ~0 when the launch is over
+__device__ __forceinline__ uint64_t lanes_round_begin(const EncParams &p, LaneRounds *ctl, const LaneCoder &cs, uint32_t wave,
+                                                      uint32_t coders, uint32_t lane)
+{
+    const uint32_t r = cs.round;
+    if (!lanes_wait_lds(&ctl->unit_seq[r & 1u], r + 1u, p.flags, 128u, lane))
+        return ~0ull;
+    const uint64_t first = p.batch_begin + (uint64_t)uniform(*(volatile uint32_t *)&ctl->unit[r & 1u]) * coders;
+    if (first >= p.batch_end)
+        return ~0ull;
+    return first + wave < p.batch_end ? first + wave : ~0ull - 1u;
+}
+
+// coding wave: offsets[] of a batch and its copy out of the scratch slots; base = where the batch starts
+__device__ __forceinline__ void lanes_copy_batch(const EncParams &p, uint64_t batch, uint32_t len, unsigned long long base, uint32_t lane)
+{
+    const uint64_t chunk = batch * 64u + lane;
+    const bool valid = chunk < p.nchunks;
+    const uint32_t alen = (len + 15u) & ~15u;
+    uint32_t incl = alen; // inclusive sum over the lanes below
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        incl += lane >= (uint32_t)d ? o : 0u;
+    }
+    const uint64_t off = base + incl - alen;
+    if (valid) {
+        p.offsets[chunk] = off;
+        if (chunk + 1 == p.nchunks)
+            p.offsets[p.nchunks] = off + len;
+    }
+    if (__builtin_amdgcn_ballot_w64(valid && off + len > p.out_cap) != 0) { // (wave-uniform)
+        atomicOr(p.flags, lane == 0 ? 2u : 0u);
+        return;
+    }
+    const uint32_t m = lane & 3u;
+    const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1u) * p.slot_bytes - len; // a stream ends at its slot's end
+    const uint64_t da = reinterpret_cast<uint64_t>(p.out) + off;
+    uint64_t s_t[4], d_t[4];
+    uint32_t n16[4], most = 0; // (the last piece of a chunk may read up to 15 bytes of the next slot: the scratch is padded)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int from = (int)((lane & ~3u) + t);
+        s_t[t] = (uint64_t)(uint32_t)__shfl((int)(uint32_t)sa, from, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(sa >> 32), from, 64) << 32);
+        d_t[t] = (uint64_t)(uint32_t)__shfl((int)(uint32_t)da, from, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(da >> 32), from, 64) << 32);
+        n16[t] = (uint32_t)__shfl((int)(valid ? alen >> 4 : 0u), from, 64);
+        most = n16[t] > most ? n16[t] : most;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)most, d, 64);
+        most = o > most ? o : most;
+    }
+    most = (p.debug & 1u) ? 0u : uniform(most);
+    for (uint32_t i0 = 0; i0 < most; i0 += 4u * kLaneCopyDepth) {
+        u32x4 v[4][kLaneCopyDepth];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < kLaneCopyDepth; ++j) {
+                const uint32_t i = i0 + 4u * j + m;
+                if (i < n16[t])
+                    v[t][j] = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(s_t[t] + 16ull * i));
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < kLaneCopyDepth; ++j) {
+                const uint32_t i = i0 + 4u * j + m;
+                if (i < n16[t])
+                    *reinterpret_cast<u32x4 RANS_GLOBAL *>(d_t[t] + 16ull * i) = v[t][j];
+            }
+    }
+}
+
+// coding wave: the batch of an earlier round goes to its place (its base is in LDS since the scan of that round)
+__device__ __forceinline__ void lanes_copy_prev(const EncParams &p, LaneRounds *ctl, LaneCoder &cs, uint32_t wave, uint32_t lane)
+{
+    if (!cs.have_prev)
+        return;
+    cs.have_prev = false;
+    const uint32_t r = cs.prev_round;
+    if (!(p.debug & 2u) && !lanes_wait_lds(&ctl->base_seq[r & 1u], r + 1u, p.flags, 64u, lane))
+        return;
+    const volatile uint32_t *b = reinterpret_cast<const volatile uint32_t *>(&ctl->bases[r & 1u][wave]);
+    const unsigned long long base = (unsigned long long)uniform(b[0]) | ((unsigned long long)uniform(b[1]) << 32);
+    lanes_copy_batch(p, cs.prev_batch, cs.prev_len, base, lane);
+}
+
+// coding wave, end of a round: post the total (len: this lane's chunk, 0 without one; batch = ~0 - 1: no batch this
+// round), copy the batch of the round before, remember this one
+__device__ __forceinline__ void lanes_round_end(const EncParams &p, LaneRounds *ctl, LaneCoder &cs, uint32_t wave, uint32_t lane,
+                                                uint64_t batch, uint32_t len)
+{
+    const uint32_t r = cs.round;
+    uint32_t sum = (len + 15u) & ~15u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+        sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every flushed line of the batch has left the wave
+    *(volatile uint32_t *)&ctl->totals[r & 1u][wave] = sum; // (every lane, the same value)
+    atomicAdd(&ctl->posted[r & 1u], lane == 0 ? 1u : 0u);
+    lanes_copy_prev(p, ctl, cs, wave, lane);
+    cs.have_prev = batch != ~0ull - 1u;
+    cs.prev_round = r;
+    cs.prev_batch = batch;
+    cs.prev_len = len;
+    cs.round = r + 1u;
+}
+
+// the scanner wave's life
+__device__ __forceinline__ void lanes_scanner(const EncParams &p, LaneRounds *ctl, uint32_t lane, uint32_t coders)
+{
+    const uint64_t nunits = (p.batch_end - p.batch_begin + coders - 1u) / coders;
+    unsigned int *counter = reinterpret_cast<unsigned int *>(p.status + ((p.nchunks + 63u) / 64u) + 8u * p.claim_slot);
+    auto claim = [&]() {
+        uint32_t got = 0;
+        if (lane == 0)
+            got = atomicAdd(counter, 1u);
+        return uniform(got);
+    };
+    const uint32_t slot = lane < 15u ? lane : 15u; // (coders <= 15: slot 15 is nobody's)
+    uint32_t u = claim();
+    *(volatile uint32_t *)&ctl->unit[0] = u;
+    *(volatile uint32_t *)&ctl->unit_seq[0] = 1u;
+    for (uint32_t r = 0; u < nunits; ++r) {
+        const uint32_t un = claim(); // the coders find their next unit as soon as they are through with this one
+        *(volatile uint32_t *)&ctl->unit[(r + 1u) & 1u] = un;
+        *(volatile uint32_t *)&ctl->unit_seq[(r + 1u) & 1u] = r + 2u;
+        if (!lanes_wait_lds(&ctl->posted[r & 1u], coders, p.flags, 16u, lane))
+            return;
+        const uint32_t mine = *(volatile uint32_t *)&ctl->totals[r & 1u][slot];
+        const uint32_t t = lane < coders ? mine : 0u;
+        uint32_t incl = t;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            incl += lane >= (uint32_t)d ? o : 0u;
+        }
+        const unsigned long long total = (uint32_t)__shfl((int)incl, 15, 64);
+        *(volatile uint32_t *)&ctl->posted[r & 1u] = 0u; // (for round r + 2)
+        const uint64_t gu = p.unit_base + u;
+        __hip_atomic_store(p.status + gu, kStAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (every lane)
+        unsigned long long base = 0;
+        uint32_t spins = 0;
+        for (uint64_t j = gu;;) { // status[j-1], status[j-2], ... are still to be added
+            unsigned long long st[kScanWords];
+            uint64_t ready[kScanWords], pref[kScanWords];
+#pragma unroll
+            for (int k = 0; k < kScanWords; ++k) {
+                const uint64_t back = lane + 64u * k; // distance - 1
+                st[k] = kStPrefix; // virtual predecessors of unit 0: an inclusive prefix of 0
+                if (back < j)
+                    st[k] = __hip_atomic_load(p.status + (j - 1 - back), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < kScanWords; ++k) {
+                ready[k] = __builtin_amdgcn_ballot_w64((st[k] >> 62) != 0);
+                pref[k] = __builtin_amdgcn_ballot_w64((st[k] >> 62) == 2);
+            }
+            // the nearest PREFIX: word K, lane `first`; everything nearer must be there (AGGREGATE or PREFIX)
+            int K = kScanWords;
+            uint32_t first = 64u;
+            bool all_ready = true;
+#pragma unroll
+            for (int k = 0; k < kScanWords; ++k) {
+                if (K == kScanWords) {
+                    if (pref[k]) {
+                        K = k;
+                        first = (uint32_t)__builtin_ctzll(pref[k]);
+                        const uint64_t need = first >= 63u ? ~0ull : ((2ull << first) - 1ull); // lanes 0 .. first
+                        all_ready = all_ready && (ready[k] & need) == need;
+                    } else {
+                        all_ready = all_ready && ready[k] == ~0ull;
+                    }
+                }
+            }
+            if (!all_ready) { // a unit in that range is still being coded
+                if (++spins > kSpinLimit) { // (never seen; a protocol error must not hang the GPU)
+                    atomicOr(p.flags, lane == 0 ? 32u : 0u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            unsigned long long v = 0;
+#pragma unroll
+            for (int k = 0; k < kScanWords; ++k)
+                if (k < K || (k == K && lane <= first))
+                    v += st[k] & kStValue;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
+                const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
+                v += (unsigned long long)lo | ((unsigned long long)hi << 32);
+            }
+            base += uniform64(v);
+            if (K < kScanWords)
+                break;
+            j -= 64u * kScanWords;
+        }
+        __hip_atomic_store(p.status + gu, kStPrefix | (base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (every lane)
+        const unsigned long long place = base + incl - t; // of coder `lane`'s batch
+        volatile uint32_t *b = reinterpret_cast<volatile uint32_t *>(&ctl->bases[r & 1u][slot]);
+        b[0] = (uint32_t)place; // (lanes >= 15 all write slot 15)
+        b[1] = (uint32_t)(place >> 32);
+        *(volatile uint32_t *)&ctl->base_seq[r & 1u] = r + 1u;
+        u = un;
+    }
+}
+
 template <int FMT, int NW>
 __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
 {
@@ -1034,12 +1310,21 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
         uint4 *l = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
             l[i] = g[i];
+        if (p.status) // (a block may be as small as one coding wave + the scanner: 128 threads for 132 words)
+            for (uint32_t i = threadIdx.x; i < kEncMailboxBytes / 4u; i += blockDim.x)
+                reinterpret_cast<uint32_t *>(smem + p.mailbox_off)[i] = 0u;
     }
     __syncthreads();
     const uint4 *recs = reinterpret_cast<const uint4 *>(smem);
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x >> 6);
-    const uint32_t waves_per_block = blockDim.x >> 6;
+    const bool fused = p.status != nullptr;
+    const uint32_t waves_per_block = (blockDim.x >> 6) - (fused ? kLaneCopiers : 0u); // coding waves
+    LaneRounds *ctl = reinterpret_cast<LaneRounds *>(smem + p.mailbox_off);
+    if (fused && wave >= waves_per_block) { // ---- copier wave
+        lanes_scanner(p, ctl, lane, waves_per_block);
+        return;
+    }
     uint8_t *rows = smem + p.nsyms * (uint32_t)sizeof(EncRec) + wave * kEncWaveLds;
     uint8_t *rings = rows + 64u * kEncRowStride;
     uint32_t *req = reinterpret_cast<uint32_t *>(rings + 64u * kLaneRingStride);
@@ -1047,9 +1332,18 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
     const uint32_t slot_lines = (uint32_t)(p.slot_bytes / kLaneLine);
 
     bool bad = false;
-    const uint64_t nbatches = (p.nchunks + 63u) / 64u;
+    LaneCoder cs{0, false, 0, 0, 0};
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
-    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += total_waves) {
+    for (uint64_t batch_v = p.batch_begin + (uint64_t)blockIdx.x * waves_per_block + wave;; batch_v += total_waves) {
+        if (fused) { // the block's scanner hands out the rounds
+            batch_v = lanes_round_begin(p, ctl, cs, wave, waves_per_block, lane);
+            if (batch_v == ~0ull - 1u) { // nothing for this wave in the last unit
+                lanes_round_end(p, ctl, cs, wave, lane, batch_v, 0u);
+                continue;
+            }
+        }
+        if (batch_v >= p.batch_end)
+            break;
         const uint64_t chunk0 = uniform64(batch_v) * 64u;
         const uint64_t chunk = chunk0 + lane;
         const bool valid = chunk < p.nchunks;
@@ -1164,9 +1458,267 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
         }
         flush(true);
         flush(true);
+        if (fused)
+            lanes_round_end(p, ctl, cs, wave, lane, chunk0 / 64u, valid ? (uint32_t)p.slot_bytes - O.w : 0u);
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
         atomicOr(p.flags, 1u);
+    if (fused)
+        lanes_copy_prev(p, ctl, cs, wave, lane);
+}
+
+// ---------------------------------------------------------------------------
+// k_encode_lanes_r64x2: the reference's own 2-way rans64 layout (main64.cpp:224-246, config 2) on its own -- the mirror
+// image of k_decode_lanes_r64x2.  The staged kernel above spends 38 VALU instructions per symbol (compiler-scheduled
+// 64-bit arithmetic full of register-pair moves, a branch around every renormalisation, a wait after every record read);
+// here one 16-symbol group is ONE asm statement:
+//  * record {rcp lo, rcp hi, bias | rcp_shift << 26, cmpl} (16 bytes, one ds_read_b128 per symbol; the LDS pipe could
+//    not feed two), the records of the next pair of symbols are read while the current pair is worked on;
+//  * renormalisation test (rans64.h:83: x >= ((L >> scale_bits) << 32) * freq) on the high dword alone: the low dword of
+//    that bound is 0, and x.hi >= (M - cmpl) << k  <=>  x.hi + (cmpl << k) >= 2^31 (k = 31 - scale_bits): one
+//    v_lshl_add + v_cmpx; the lanes that emit run under the exec mask (dword into the ring, x >>= 32 as two moves);
+//  * q = mulhi64(x, rcp) >> rcp_shift (rans64.h:91, exact): v_mul_hi + 3 x v_mad_u64_u32 whose 64-bit addends are
+//    {value, 0} pairs -- a permanently zero register next to the one that takes the value; x += bias + q * cmpl
+//    (rans64.h:92, Rans64EncSymbolInit's identity) as v_lshl_add_u64 + v_mad_u64_u32 + v_mad_u32_u24;
+//    12.5 slow + 10 fast VALU forms per symbol (DESIGN 4.1 "issue cost model");
+//  * output ring per lane: 32 dwords, dword d of lane l at ring + 256 d + 4 l (every ds_write_b32 conflict-free), the ring
+//    8 KiB aligned so that the write position wraps with one v_bfi; a lane's bytes written are never counted per symbol,
+//    the flush derives them from the ring position (at most 64 bytes per group);
+//  * symbols: four 64-byte lines per quad and block (instruction t = the line of the quad's lane t), transposed in
+//    registers, the next block in flight during the current one; flushes by quads as in the staged kernel.
+// Requirements (launcher): rans64 with scale_bits 7..16 and no frequency of 2^16, u8 symbols, chunk_syms % 64 == 0,
+// 16-byte aligned input, full batches of full chunks (the rest goes through the staged kernel in a second launch, which
+// continues the same status array).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kR64EncRing = 8192;   // per coding wave
+constexpr uint32_t kR64EncTable = 8192;  // 256 records of 16 bytes at LDS address 0 (rings behind, 8 KiB aligned)
+
+// state 0 = v[40:41], state 1 = v[42:43]; record sets v[48:51] / v[52:55] (pair in hand) and v[56:59] / v[60:63] (next);
+// temporaries v64..v79 with the permanently zero v65, v69, v77 (the two states are worked on one after the other)
+#define E64_ZERO                                                                                                        \
+    "v_mov_b32 v65, 0\n\tv_mov_b32 v69, 0\n\tv_mov_b32 v77, 0\n\t"
+// address of the record of byte J of symbol dword S: (sym << 4)
+#define E64_ADDR3(D, S) "v_lshrrev_b32 " D ", 20, " S "\n\tv_and_b32 " D ", %[mff0], " D "\n\t"
+#define E64_ADDR2(D, S) "v_lshrrev_b32 " D ", 12, " S "\n\tv_and_b32 " D ", %[mff0], " D "\n\t"
+#define E64_ADDR1(D, S) "v_lshrrev_b32 " D ", 4, " S "\n\tv_and_b32 " D ", %[mff0], " D "\n\t"
+#define E64_ADDR0(D, S) "v_lshlrev_b32 " D ", 4, " S "\n\tv_and_b32 " D ", %[mff0], " D "\n\t"
+// renormalisation of state {XL, XH} with record dword C = cmpl (T: temporary)
+#define E64_FRONT(XL, XH, C, T)                                                                                         \
+    "v_lshl_add_u32 " T ", " C ", %[kv], " XH "\n\t"                                                                    \
+    "v_cmpx_gt_i32 vcc, 0, " T "\n\t"                                                                                   \
+    "v_add_u32 %[wk], %[m256], %[wk]\n\t"                                                                               \
+    "v_bfi_b32 %[wk], %[m1fff], %[wk], %[ring]\n\t"                                                                     \
+    "ds_write_b32 %[wk], " XL "\n\t"                                                                                    \
+    "v_mov_b32 " XL ", " XH "\n\t"                                                                                      \
+    "v_mov_b32 " XH ", 0\n\t"                                                                                           \
+    "s_mov_b64 exec, -1\n\t"
+// x = x + bias + (mulhi64(x, rcp) >> rcp_shift) * cmpl; X = "v[a:b]" of {XL, XH}; record R0..R3; TA / TZ / BP: pairs
+// whose high register is zero (TAL, TZL, BPL their low registers), P1 / P2 / RR pairs with named halves
+#define E64_BACK(X, XL, XH, R0, R1, R2, R3, TA, TAL, P1, P1L, P1H, TZ, TZL, P2, P2H, RR, RRL, RRH, RS, BP, BPL)          \
+    "v_mul_hi_u32 " TAL ", " XL ", " R0 "\n\t"                                                                          \
+    "v_mad_u64_u32 " P1 ", vcc, " XH ", " R0 ", " TA "\n\t"                                                             \
+    "v_lshrrev_b32 " RS ", 26, " R2 "\n\t"                                                                              \
+    "v_and_b32 " BPL ", %[mbias], " R2 "\n\t"                                                                           \
+    "v_mov_b32 " TAL ", " P1L "\n\t"                                                                                    \
+    "v_mad_u64_u32 " P2 ", vcc, " XL ", " R1 ", " TA "\n\t"                                                             \
+    "v_mov_b32 " TZL ", " P1H "\n\t"                                                                                    \
+    "v_mad_u64_u32 " RR ", vcc, " XH ", " R1 ", " TZ "\n\t"                                                             \
+    "v_mov_b32 " TAL ", " P2H "\n\t"                                                                                    \
+    "v_lshl_add_u64 " RR ", " RR ", 0, " TA "\n\t"                                                                      \
+    "v_lshrrev_b64 " RR ", " RS ", " RR "\n\t"                                                                          \
+    "v_lshl_add_u64 " X ", " X ", 0, " BP "\n\t"                                                                        \
+    "v_mad_u64_u32 " X ", vcc, " RRL ", " R3 ", " X "\n\t"                                                              \
+    "v_mad_u32_u24 " XH ", " RRH ", " R3 ", " XH "\n\t"
+#define E64_BACK_A(R0, R1, R2, R3)                                                                                      \
+    E64_BACK("v[40:41]", "v40", "v41", R0, R1, R2, R3, "v[64:65]", "v64", "v[66:67]", "v66", "v67", "v[68:69]", "v68",   \
+             "v[70:71]", "v71", "v[72:73]", "v72", "v73", "v75", "v[76:77]", "v76")
+#define E64_BACK_B(R0, R1, R2, R3)                                                                                      \
+    E64_BACK("v[42:43]", "v42", "v43", R0, R1, R2, R3, "v[64:65]", "v64", "v[66:67]", "v66", "v67", "v[68:69]", "v68",   \
+             "v[70:71]", "v71", "v[72:73]", "v72", "v73", "v75", "v[76:77]", "v76")
+// one pair of symbols (the odd one = state 1 first: it is the later symbol) with its records in set 0 (v48..v55: state 1
+// in v[48:51], state 0 in v[52:55]) or set 1 (v56..v63); PRE = address + read instructions of the NEXT pair, WAIT = lgkmcnt
+#define E64_PAIR0(PRE, WAIT)                                                                                            \
+    PRE "s_waitcnt lgkmcnt(" WAIT ")\n\t"                                                                               \
+    "v_max3_u32 %[worst], %[worst], v51, v55\n\t"                                                                       \
+    E64_FRONT("v42", "v43", "v51", "v74") E64_FRONT("v40", "v41", "v55", "v74")                                         \
+    E64_BACK_B("v48", "v49", "v50", "v51") E64_BACK_A("v52", "v53", "v54", "v55")
+#define E64_PAIR1(PRE, WAIT)                                                                                            \
+    PRE "s_waitcnt lgkmcnt(" WAIT ")\n\t"                                                                               \
+    "v_max3_u32 %[worst], %[worst], v59, v63\n\t"                                                                       \
+    E64_FRONT("v42", "v43", "v59", "v74") E64_FRONT("v40", "v41", "v63", "v74")                                         \
+    E64_BACK_B("v56", "v57", "v58", "v59") E64_BACK_A("v60", "v61", "v62", "v63")
+// reads of a pair into set 0 / set 1: bytes (JB, JA) of symbol dword S
+#define E64_READ0(ADDRB, ADDRA, S)                                                                                      \
+    ADDRB("v78", S) ADDRA("v79", S) "ds_read_b128 v[48:51], v78\n\tds_read_b128 v[52:55], v79\n\t"
+#define E64_READ1(ADDRB, ADDRA, S)                                                                                      \
+    ADDRB("v78", S) ADDRA("v79", S) "ds_read_b128 v[56:59], v78\n\tds_read_b128 v[60:63], v79\n\t"
+#define E64_CLOBBERS                                                                                                    \
+    "vcc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62",  \
+        "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
+
+// 16 symbols (dwords s3 = the last four .. s0 = the first four of the group), last symbol first
+__device__ __forceinline__ void r64x2_encode_group(uint64_t &xA, uint64_t &xB, uint32_t &wk, uint32_t &worst, uint32_t s3,
+                                                   uint32_t s2, uint32_t s1, uint32_t s0, uint32_t mff0, uint32_t m256,
+                                                   uint32_t m1fff, uint32_t ring, uint32_t kv, uint32_t mbias)
+{
+    asm volatile(E64_ZERO
+                 E64_READ0(E64_ADDR3, E64_ADDR2, "%[s3]")
+                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s3]"), "2")
+                 E64_PAIR1(E64_READ0(E64_ADDR3, E64_ADDR2, "%[s2]"), "2")
+                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s2]"), "2")
+                 E64_PAIR1(E64_READ0(E64_ADDR3, E64_ADDR2, "%[s1]"), "2")
+                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s1]"), "2")
+                 E64_PAIR1(E64_READ0(E64_ADDR3, E64_ADDR2, "%[s0]"), "2")
+                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s0]"), "2")
+                 E64_PAIR1("", "0")
+                 : "+{v[40:41]}"(xA), "+{v[42:43]}"(xB), [wk] "+v"(wk), [worst] "+v"(worst)
+                 : [s3] "v"(s3), [s2] "v"(s2), [s1] "v"(s1), [s0] "v"(s0), [mff0] "v"(mff0), [m256] "v"(m256),
+                   [m1fff] "v"(m1fff), [ring] "v"(ring), [kv] "v"(kv), [mbias] "v"(mbias)
+                 : E64_CLOBBERS);
+}
+
+__global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    {   // EncRec {freq | rcp_shift << 24, bias, rcp lo, rcp hi} (model.h) -> {rcp lo, rcp hi, bias | rcp_shift << 26, cmpl};
+        // a symbol without a frequency: cmpl = M (the largest value any record holds: v_max3 finds it), rcp = 0
+        const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
+        uint4 *l = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) {
+            uint4 r = i < p.nsyms ? g[i] : uint4{0u, 0u, 0u, 0u};
+            const uint32_t freq = r.x & 0xffffffu;
+            l[i] = freq ? uint4{r.z, r.w, r.y | ((r.x >> 24) << 26), (1u << p.scale_bits) - freq}
+                        : uint4{0u, 0u, 0u, 1u << p.scale_bits};
+        }
+        if (p.status) // (a block may be as small as one coding wave + the scanner: 128 threads for 132 words)
+            for (uint32_t i = threadIdx.x; i < kEncMailboxBytes / 4u; i += blockDim.x)
+                reinterpret_cast<uint32_t *>(smem + p.mailbox_off)[i] = 0u;
+    }
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const bool fused = p.status != nullptr;
+    const uint32_t waves_per_block = (blockDim.x >> 6) - (fused ? kLaneCopiers : 0u); // coding waves
+    LaneRounds *ctl = reinterpret_cast<LaneRounds *>(smem + p.mailbox_off);
+    if (!lds_starts_at_zero(smem)) { // the asm addresses the record table by raw LDS offsets
+        if (threadIdx.x == 0)
+            atomicOr(p.flags, 4u);
+        return;
+    }
+    if (fused && wave >= waves_per_block) { // ---- copier wave
+        lanes_scanner(p, ctl, lane, waves_per_block);
+        return;
+    }
+    const uint32_t ringbase = kR64EncTable + wave * kR64EncRing; // LDS byte offset, 8 KiB aligned
+    const uint32_t *ringp = reinterpret_cast<const uint32_t *>(smem + ringbase);
+    uint32_t mff0 = 0xff0u, m256 = 0xffffff00u, m1fff = 0x1fffu, ringv = ringbase, kv = 31u - p.scale_bits,
+             mbias = 0x03ffffffu;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(mff0)); // VGPR copies: a VALU op with a literal or an SGPR operand issues slower
+    asm volatile("v_mov_b32 %0, %0" : "+v"(m256));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(m1fff));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(ringv));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(kv));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(mbias));
+    const uint32_t m = lane & 3u, q4 = lane & ~3u;
+    const uint32_t slot_lines = (uint32_t)(p.slot_bytes / kLaneLine);
+    const uint32_t nblocks = p.chunk_syms >> 6;
+    uint32_t worst = 0;
+    LaneCoder cs{0, false, 0, 0, 0};
+
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t batch_v = p.batch_begin + (uint64_t)blockIdx.x * waves_per_block + wave;; batch_v += total_waves) {
+        if (fused) { // the block's scanner hands out the rounds
+            batch_v = lanes_round_begin(p, ctl, cs, wave, waves_per_block, lane);
+            if (batch_v == ~0ull - 1u) { // nothing for this wave in the last unit
+                lanes_round_end(p, ctl, cs, wave, lane, batch_v, 0u);
+                continue;
+            }
+        }
+        if (batch_v >= p.batch_end)
+            break;
+        const uint64_t batch = uniform64(batch_v);
+        const uint64_t chunk0 = batch * 64u;
+        const uint64_t slots0 = reinterpret_cast<uint64_t>(p.scratch) + chunk0 * p.slot_bytes; // wave-uniform
+        // symbol lines: instruction t = the line of the quad's lane t, this lane its piece m
+        const uint64_t src0 = reinterpret_cast<uint64_t>(p.syms) + chunk0 * (uint64_t)p.chunk_syms + 16u * m;
+        auto load_block = [&](u32x4 (&q)[4], uint32_t b) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                q[t] = __builtin_nontemporal_load(
+                    reinterpret_cast<gvec_cptr>(src0 + (uint64_t)(q4 + t) * p.chunk_syms + 64ull * b));
+        };
+
+        uint64_t xA = 1ull << 31, xB = 1ull << 31; // Rans64EncInit
+        uint32_t wk = ringbase + ((((uint32_t)p.slot_bytes & 127u) >> 2) << 8) + lane * 4u; // ring position of slot offset w
+        uint32_t flushed = slot_lines; // lines [flushed, slot_lines) of this lane's slot are in memory
+
+        // bytes of this lane's stream that are in the ring only: below line `flushed`, at most 127
+        auto pending = [&]() { return (((flushed & 1u) << 6) - ((wk >> 6) & 124u)) & 127u; };
+        // the whole wave takes part: lanes say which line they have filled (or, at the end, hold anything of), the quad
+        // writes the line of its lane t with instruction t
+        auto flush = [&](bool need) {
+            const int32_t line = need ? (int32_t)(flushed - 1u) : -1;
+            if (need)
+                flushed -= 1u;
+            if (__builtin_amdgcn_ballot_w64(need) == 0)
+                return;
+            const int32_t lts[4] = {(int32_t)quad_perm<0x00>((uint32_t)line), (int32_t)quad_perm<0x55>((uint32_t)line),
+                                    (int32_t)quad_perm<0xAA>((uint32_t)line), (int32_t)quad_perm<0xFF>((uint32_t)line)};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int32_t lt = lts[t]; // the line asked for by the quad's lane t
+                if (lt >= 0) {
+                    // ring half (lt & 1), dwords 4 m .. 4 m + 3 of lane q4 + t
+                    const uint32_t *at = ringp + ((uint32_t)lt & 1u) * 1024u + m * 256u + q4 + t;
+                    const u32x4 v = {at[0], at[64], at[128], at[192]};
+                    *reinterpret_cast<u32x4 RANS_GLOBAL *>(slots0 + (uint64_t)(q4 + t) * p.slot_bytes + (uint64_t)lt * kLaneLine +
+                                                           16u * m) = v;
+                }
+            }
+        };
+
+        u32x4 cur[4], nxt[4];
+        load_block(cur, nblocks - 1u);
+        quad_transpose(cur[0], cur[1], cur[2], cur[3], lane);
+        for (uint32_t b = nblocks; b-- > 0;) {
+            if (b > 0)
+                load_block(nxt, b - 1u);
+#pragma unroll
+            for (int g = 3; g >= 0; --g) {
+                r64x2_encode_group(xA, xB, wk, worst, cur[g][3], cur[g][2], cur[g][1], cur[g][0], mff0, m256, m1fff, ringv, kv,
+                                   mbias);
+                flush(pending() >= 64u);
+            }
+            if (b > 0) {
+                quad_transpose(nxt[0], nxt[1], nxt[2], nxt[3], lane);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    cur[t] = nxt[t];
+            }
+        }
+        // flush: state 1 first, state 0 ends up first in memory (main64.cpp:244-245; Rans64EncFlush: two dwords, low first)
+        {
+            auto emit = [&](uint32_t v) {
+                wk = ringbase + ((wk - 256u) & 0x1fffu);
+                *reinterpret_cast<uint32_t *>(smem + wk) = v;
+            };
+            emit((uint32_t)(xB >> 32));
+            emit((uint32_t)xB);
+            emit((uint32_t)(xA >> 32));
+            emit((uint32_t)xA);
+        }
+        const uint32_t in_ring = pending(); // <= 63 + 16
+        const uint32_t len = (uint32_t)p.slot_bytes - (flushed * kLaneLine - in_ring);
+        p.lengths[chunk0 + lane] = len;
+        flush(in_ring > 0u); // the line(s) that hold anything; what lies below the stream start in the lowest one is never read
+        flush(in_ring > 64u);
+        if (fused)
+            lanes_round_end(p, ctl, cs, wave, lane, batch, len);
+    }
+    if (__builtin_amdgcn_ballot_w64(worst >= (1u << p.scale_bits)) != 0 && lane == 0)
+        atomicOr(p.flags, 1u);
+    if (fused)
+        lanes_copy_prev(p, ctl, cs, wave, lane);
 }
 
 // Lane-per-stream encoder, second generation: symbols arrive as 16-byte per-lane loads
@@ -1359,26 +1911,82 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
     return hipGetLastError();
 }
 
-template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, int num_cus, hipStream_t stream)
+// The staged lane encoder (coalesced symbol loads, whole-line stream stores, fused placement) takes u8 symbols in
+// 16-byte aligned chunks with slots made of whole lines; RANS_AMD_LANES=regwin keeps the per-lane kernel (A/B runs),
+// =staged forces the staged one whatever the batch count (tests).  Returns the waves per block the LDS allows, 0 = no.
+static uint32_t encode_lanes_staged_waves(const EncParams &p, int num_cus)
 {
     const size_t table_lds = (size_t)p.nsyms * sizeof(EncRec);
-    if (table_lds > 128 * 1024)
-        return hipErrorInvalidValue;
-    // staged kernel (coalesced symbol loads, whole-line stream stores): u8 symbols in 16-byte aligned
-    // chunks, slots made of whole lines; RANS_AMD_LANES=regwin keeps the per-lane kernel (A/B runs), =staged forces
-    // this one whatever the batch count (tests)
     const int force = lanes_force();
-    const bool reg_window = force < 0;
-    uint32_t sw = table_lds + kEncWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - table_lds) / kEncWaveLds) : 0;
-    sw = sw > 16 ? 16 : sw;
-    const bool staged = !reg_window && sw >= 1 && p.sym_bytes == 1 && (p.slot_bytes % kLaneLine) == 0 &&
+    // (room for the mailbox and the copier wave(s) of the fused placement, whether or not this launch uses them)
+    const size_t fixed_lds = table_lds + 16 + kEncMailboxBytes;
+    uint32_t sw = fixed_lds + kEncWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - fixed_lds) / kEncWaveLds) : 0;
+    sw = sw > 16 - kLaneCopiers ? 16 - kLaneCopiers : sw;
+    const bool staged = force >= 0 && sw >= 1 && p.sym_bytes == 1 && (p.slot_bytes % kLaneLine) == 0 &&
                         ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 15u) == 0 &&
                         (reinterpret_cast<uintptr_t>(p.scratch) & 15u) == 0 &&
                         // fewer, longer batches: the per-lane kernel's many small blocks hide latency better
                         (force > 0 || (p.nchunks + 63) / 64 >= (uint64_t)num_cus * 6);
+    return staged ? sw : 0u;
+}
+
+template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p_in, int num_cus, hipStream_t stream, const char **name)
+{
+    EncParams p = p_in;
+    const size_t table_lds = (size_t)p.nsyms * sizeof(EncRec);
+    if (table_lds > 128 * 1024)
+        return hipErrorInvalidValue;
+    uint32_t sw = encode_lanes_staged_waves(p, num_cus);
+    const bool staged = sw >= 1;
+    if (!staged && p.status)
+        return hipErrorInvalidValue; // (api.cpp asks encode_lanes_fused() before it sets up the fused placement)
     if (staged) {
         // same split as the staged decoder: fewest rounds, batches spread evenly over them
-        const uint64_t batches = (p.nchunks + 63) / 64;
+        uint64_t batches = (p.nchunks + 63) / 64;
+        p.batch_begin = 0;
+        p.batch_end = batches;
+        p.claim_slot = 0;
+        p.unit_base = 0;
+        if constexpr (FMT == FMT_R64 && NW == 2) {
+            // the reference's 2-way rans64 layout (config 2) on its own kernel: whole batches of full chunks; what is
+            // left (fewer than 64 chunks, the last one perhaps ragged) goes through the staged kernel below
+            static const bool off = getenv("RANS_AMD_NO_R64X2_ENC") != nullptr;
+            const uint64_t full_batches = (p.n / p.chunk_syms) / 64;
+            if (!off && lanes_force() == 0 && (p.chunk_syms & 63u) == 0 && p.scale_bits >= 7 && p.scale_bits <= 16 &&
+                p.nsyms <= 256 && full_batches >= (uint64_t)num_cus) {
+                uint32_t sw3 = 16 - kLaneCopiers; // 8 KiB of table + 8 KiB of ring per coding wave + the mailbox
+                const uint64_t per_cu = (full_batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
+                const uint64_t rounds = (per_cu + sw3 - 1) / sw3;
+                const uint64_t even = (per_cu + rounds - 1) / rounds;
+                sw3 = (uint32_t)(even ? even : 1);
+                static std::atomic<uint64_t> lds_ok3{0};
+                if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_encode_lanes_r64x2), 160 * 1024, lds_ok3);
+                    e != hipSuccess)
+                    return e;
+                EncParams q = p;
+                q.batch_end = full_batches;
+                size_t lds3 = kR64EncTable + (size_t)sw3 * kR64EncRing;
+                uint32_t waves3 = sw3;
+                if (q.status) {
+                    q.mailbox_off = (uint32_t)lds3;
+                    lds3 += kEncMailboxBytes;
+                    waves3 += kLaneCopiers;
+                }
+                const uint64_t want3 = (full_batches + sw3 - 1) / sw3;
+                const uint32_t grid3 = (uint32_t)(want3 < (uint64_t)num_cus ? want3 : (uint64_t)num_cus);
+                if (name)
+                    *name = "k_encode_lanes_r64x2";
+                RANS_LAUNCH(k_encode_lanes_r64x2, dim3(grid3), dim3(64 * waves3), lds3, stream, q);
+                if (hipError_t e = hipGetLastError(); e != hipSuccess)
+                    return e;
+                if (full_batches == batches)
+                    return hipSuccess;
+                p.batch_begin = full_batches; // the tail: its own claim counter, its units behind the ones of this launch
+                p.claim_slot = 1;
+                p.unit_base = (full_batches + sw3 - 1) / sw3;
+                batches -= full_batches;
+            }
+        }
         const uint64_t per_cu = (batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
         const uint64_t rounds = (per_cu + sw - 1) / sw;
         const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
@@ -1389,7 +1997,17 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, 
             return e;
         const uint64_t want_blocks = (batches + sw - 1) / sw;
         const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
-        RANS_LAUNCH(kern, dim3(grid), dim3(64 * sw), table_lds + (size_t)sw * kEncWaveLds, stream, p);
+        size_t lds = table_lds + (size_t)sw * kEncWaveLds;
+        uint32_t waves = sw;
+        if (p.status) { // fused placement: the block's copier wave(s) and their mailbox
+            lds = (lds + 15) & ~(size_t)15;
+            p.mailbox_off = (uint32_t)lds;
+            lds += kEncMailboxBytes;
+            waves += kLaneCopiers;
+        }
+        if (name && p.batch_begin == 0)
+            *name = "k_encode_lanes_staged";
+        RANS_LAUNCH(kern, dim3(grid), dim3(64 * waves), lds, stream, p);
         return hipGetLastError();
     }
     const size_t lds = table_lds;
@@ -1400,6 +2018,8 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p, 
     const uint64_t want = (p.nchunks + 255) / 256;
     const uint64_t cap = (uint64_t)num_cus * 8;
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    if (name)
+        *name = "k_encode_lanes16";
     RANS_LAUNCH(kern, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
@@ -1415,13 +2035,13 @@ template <int FMT> hipError_t launch_decode_lanes_f(const DecParams &p, int num_
     }
 }
 
-template <int FMT> hipError_t launch_encode_lanes_f(const EncParams &p, int num_cus, hipStream_t s)
+template <int FMT> hipError_t launch_encode_lanes_f(const EncParams &p, int num_cus, hipStream_t s, const char **name)
 {
     switch (p.n_ways) {
-    case 1: return launch_encode_lanes_t<FMT, 1>(p, num_cus, s);
-    case 2: return launch_encode_lanes_t<FMT, 2>(p, num_cus, s);
-    case 4: return launch_encode_lanes_t<FMT, 4>(p, num_cus, s);
-    case 8: return launch_encode_lanes_t<FMT, 8>(p, num_cus, s);
+    case 1: return launch_encode_lanes_t<FMT, 1>(p, num_cus, s, name);
+    case 2: return launch_encode_lanes_t<FMT, 2>(p, num_cus, s, name);
+    case 4: return launch_encode_lanes_t<FMT, 4>(p, num_cus, s, name);
+    case 8: return launch_encode_lanes_t<FMT, 8>(p, num_cus, s, name);
     default: return hipErrorInvalidValue;
     }
 }
@@ -1439,13 +2059,15 @@ hipError_t launch_decode_lanes(int format, const DecParams &p, int num_cus, hipS
     }
 }
 
-hipError_t launch_encode_lanes(int format, const EncParams &p, int num_cus, hipStream_t stream)
+bool encode_lanes_fused(const EncParams &p, int num_cus) { return encode_lanes_staged_waves(p, num_cus) >= 1; }
+
+hipError_t launch_encode_lanes(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **name)
 {
     switch (format) {
-    case FMT_WORD: return launch_encode_lanes_f<FMT_WORD>(p, num_cus, stream);
-    case FMT_BYTE: return launch_encode_lanes_f<FMT_BYTE>(p, num_cus, stream);
-    case FMT_R64: return launch_encode_lanes_f<FMT_R64>(p, num_cus, stream);
-    case FMT_ALIAS: return launch_encode_lanes_f<FMT_ALIAS>(p, num_cus, stream);
+    case FMT_WORD: return launch_encode_lanes_f<FMT_WORD>(p, num_cus, stream, name);
+    case FMT_BYTE: return launch_encode_lanes_f<FMT_BYTE>(p, num_cus, stream, name);
+    case FMT_R64: return launch_encode_lanes_f<FMT_R64>(p, num_cus, stream, name);
+    case FMT_ALIAS: return launch_encode_lanes_f<FMT_ALIAS>(p, num_cus, stream, name);
     default: return hipErrorInvalidValue;
     }
 }

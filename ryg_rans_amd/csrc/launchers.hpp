@@ -35,7 +35,7 @@ inline hipError_t allow_large_lds(const void *kernel, int bytes, std::atomic<uin
 
 // wave-per-chunk kernels (N-way streams with N = 64 K lanes): decode_wave.hip, encode_wave.hip
 hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name);
-hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipStream_t stream);
+hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **name);
 
 // lane-per-stream kernels (N = 1, 2, 4, 8 with at least kLaneKernelMinChunks chunks): lanes.hip
 constexpr uint64_t kLaneKernelMinChunks = 64;
@@ -44,6 +44,9 @@ inline bool lanes_applicable(uint64_t nchunks, uint32_t n_ways)
     return nchunks >= kLaneKernelMinChunks && (n_ways == 1 || n_ways == 2 || n_ways == 4 || n_ways == 8);
 }
 hipError_t launch_decode_lanes(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name);
-hipError_t launch_encode_lanes(int format, const EncParams &p, int num_cus, hipStream_t stream);
+hipError_t launch_encode_lanes(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **name);
+// true when launch_encode_lanes would take the staged kernel for this request -- the one that can place its chunks
+// itself (EncParams::status); everything but status / offsets / out / out_cap must be filled in
+bool encode_lanes_fused(const EncParams &p, int num_cus);
 
 } // namespace rans_amd

@@ -393,13 +393,17 @@ def test_many_chunks_layout(gpu, oracle):
         assert np.array_equal(out.cpu().numpy(), data)
 
 
-@pytest.mark.parametrize("generation", ["staged", "regwin"])
+@pytest.mark.parametrize("generation", ["staged", "regwin", "staged+fused"])
 def test_lane_kernels_both_generations(gpu, oracle, generation, monkeypatch):
     """Narrow interleaves (N = 1, 2, 4, 8): the wave-cooperative staged kernels and the per-lane
     register-window kernels they replaced, pinned through RANS_AMD_LANES, every format, ragged last
     chunk, chunk sizes that are and are not multiples of 16 / 64, against the oracle byte for byte."""
     R, ctx, torch = gpu
-    monkeypatch.setenv("RANS_AMD_LANES", generation)
+    monkeypatch.setenv("RANS_AMD_LANES", generation.split("+")[0])
+    if generation.endswith("+fused"):  # the staged encoders placing their chunks themselves (no k_layout / k_compact_small)
+        monkeypatch.setenv("RANS_AMD_LANES_FUSED", "1")
+    else:
+        monkeypatch.delenv("RANS_AMD_LANES_FUSED", raising=False)
     data = oracle.gen_zipf(200000 + 37, K=256, s=1.0, seed=17)
     d_syms = torch.from_numpy(data).cuda()
     for fmt, sb in FORMATS:
@@ -409,6 +413,9 @@ def test_lane_kernels_both_generations(gpu, oracle, generation, monkeypatch):
             cont, d_offs, d_lens, total = ctx.encode(gm, d_syms, n_ways, chunk)
             assert total == want.size, (fmt, n_ways, chunk)
             assert np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens), (fmt, n_ways, chunk)
+            assert np.array_equal(d_offs.cpu().numpy().astype(np.uint64), offs), (fmt, n_ways, chunk)
+            if generation != "regwin" and chunk % 16 == 0:  # (other chunk sizes: the per-lane kernel, three-kernel path)
+                assert ctx.last_encode_kernel() == ("k_encode_lanes_staged", generation.endswith("+fused"))
             got = cont[:total].cpu().numpy()
             for c in (0, 1, len(lens) // 2, len(lens) - 2, len(lens) - 1):
                 o, ln = int(offs[c]), int(lens[c])
@@ -740,3 +747,66 @@ def test_rans64_two_way_lane_kernel(gpu, oracle):
         ctx.decode(gm, torch.from_numpy(np.concatenate([bad, np.zeros(64, np.uint8)])).cuda(), want.size,
                    torch.from_numpy(o).cuda(), torch.from_numpy(l).cuda(), data.size, 2, chunk, sync=False)
         assert ctx.decode_errors() >= 1, kind
+
+
+@pytest.mark.parametrize("placement", ["kernels", "fused"])
+def test_rans64_two_way_lane_encoder(gpu, oracle, placement, monkeypatch):
+    """BASELINE config 2's encoder: k_encode_lanes_r64x2 (whole batches of 64 full chunks) + the staged kernel for the
+    rest, with k_layout / k_compact_small behind them (the default) and placing their chunks themselves
+    (RANS_AMD_LANES_FUSED: scanner wave per block, decoupled look-back over the blocks' rounds): every chunk, the
+    index and the total against the oracle, for scale_bits at both ends of the cum2sym range, a ragged tail, models
+    with frequency-1 symbols and a single-symbol model; a symbol outside the model is reported."""
+    R, ctx, torch = gpu
+    if placement == "fused":
+        monkeypatch.setenv("RANS_AMD_LANES_FUSED", "1")
+    else:
+        monkeypatch.delenv("RANS_AMD_LANES_FUSED", raising=False)
+    fused = placement == "fused"
+    rng = np.random.default_rng(11)
+    n = 1600 * 64 * 64 + 64 * 33 + 17  # 1600 full batches of 64-symbol chunks, 33 full chunks and a ragged one behind
+    zipf = oracle.gen_zipf(n, K=256, s=1.0, seed=29)
+    narrow = oracle.gen_zipf(n, K=40, s=0.7, seed=31)
+    cases = [(zipf, 14, 64, 256), (narrow, 7, 64, 40), (zipf, 16, 64, 256), (narrow, 12, 64, 40),
+             (oracle.gen_zipf(1700 * 64 * 128 + 5, K=256, s=1.2, seed=37), 15, 128, 256)]
+    for data, sb, chunk, nsyms in cases:
+        om, gm = _models(R, ctx, oracle, FMT_R64, sb, data, nsyms)
+        want, offs, lens = oracle.encode_chunked(FMT_R64, om, data, 2, chunk, align=16)
+        cont, d_offs, d_lens, total = ctx.encode(gm, torch.from_numpy(data).cuda(), 2, chunk)
+        assert ctx.last_encode_kernel() == ("k_encode_lanes_r64x2", fused), ctx.last_encode_kernel()
+        assert total == want.size, (sb, chunk)
+        assert np.array_equal(d_offs.cpu().numpy().astype(np.uint64), offs), (sb, chunk)
+        assert np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens), (sb, chunk)
+        got = cont[:total].cpu().numpy()
+        # every stream byte: compare through a mask of the bytes that belong to chunks (the padding is not defined)
+        mask = np.zeros(want.size + 1, np.int32)
+        np.add.at(mask, offs[:-1].astype(np.int64), 1)
+        np.add.at(mask, offs[:-1].astype(np.int64) + lens.astype(np.int64), -1)
+        inside = np.cumsum(mask[:-1]) > 0
+        assert np.array_equal(got[inside], want[inside]), (sb, chunk)
+        out = ctx.decode(gm, cont, total, d_offs, d_lens, data.size, 2, chunk)
+        assert np.array_equal(out.cpu().numpy(), data), (sb, chunk)
+    # frequency-1 symbols (the reciprocal is 2^64 - 1, rans64.h:173-181) and a model of one symbol (nothing is ever emitted)
+    sb, chunk = 16, 64
+    f = np.ones(256, np.uint32)
+    f[0] = (1 << sb) - 255
+    rare = rng.integers(0, 256, 1600 * 64 * 64).astype(np.uint8)
+    one = np.zeros(256, np.uint32)
+    one[7] = 1 << sb
+    for freqs, data in ((f, rare), (one, np.full(1600 * 64 * 64 + 100, 7, np.uint8))):
+        om, gm = oracle.model(freqs, sb), ctx.model(FMT_R64, freqs, sb)
+        want, offs, lens = oracle.encode_chunked(FMT_R64, om, data, 2, chunk, align=16)
+        cont, d_offs, d_lens, total = ctx.encode(gm, torch.from_numpy(data).cuda(), 2, chunk)
+        assert ctx.last_encode_kernel() == ("k_encode_lanes_r64x2", fused)
+        assert total == want.size and np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens)
+        assert np.array_equal(d_offs.cpu().numpy().astype(np.uint64), offs)
+        got = cont[:total].cpu().numpy()
+        for c in list(range(0, len(lens), 997)) + [len(lens) - 1]:
+            o, ln = int(offs[c]), int(lens[c])
+            assert np.array_equal(got[o:o + ln], want[o:o + ln]), c
+    # a symbol the model has no frequency for
+    om, gm = _models(R, ctx, oracle, FMT_R64, 12, narrow, 40)
+    bad = narrow.copy()
+    bad[123457] = 200
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.encode(gm, torch.from_numpy(bad).cuda(), 2, 64)
+    assert e.value.status == R.E_MODEL
