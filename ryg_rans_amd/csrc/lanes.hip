@@ -1954,7 +1954,8 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p_i
             const uint64_t full_batches = (p.n / p.chunk_syms) / 64;
             if (!off && lanes_force() == 0 && (p.chunk_syms & 63u) == 0 && p.scale_bits >= 7 && p.scale_bits <= 16 &&
                 p.nsyms <= 256 && full_batches >= (uint64_t)num_cus) {
-                uint32_t sw3 = 16 - kLaneCopiers; // 8 KiB of table + 8 KiB of ring per coding wave + the mailbox
+                // 8 KiB of table + 8 KiB of ring per coding wave (+ the scanner wave and its LDS words when it places the chunks)
+                uint32_t sw3 = p.status ? 16 - kLaneCopiers : 16;
                 const uint64_t per_cu = (full_batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
                 const uint64_t rounds = (per_cu + sw3 - 1) / sw3;
                 const uint64_t even = (per_cu + rounds - 1) / rounds;
