@@ -85,6 +85,8 @@ struct rans_amd_ctx {
     DeviceBuffer layout_sums; // per-block totals of the offset scan (many-chunk containers)
     DeviceBuffer enc_status;  // fused encoder: look-back word per chunk + the claim counters (EncParams::status)
     DeviceBuffer wave_scratch; // one 64-byte line per resident decoder wave (DecParams::wave_scratch)
+    DeviceBuffer host_in, host_out, host_idx; // staging of the *_host wrappers, kept between calls (under host_mu)
+    std::mutex host_mu;
     DeviceBuffer trace;       // per-wave clock records (rans_amd_set_timing(ctx, 2) / RANS_AMD_TRACE)
     rans_amd_wave_clocks wave_clocks = {0, 0, 0, 0.0, 0.0};
     bool wave_clocks_on = false;
@@ -246,6 +248,9 @@ int rans_amd_ctx_destroy(rans_amd_ctx *ctx)
     ctx->hist.release();
     ctx->layout_sums.release();
     ctx->enc_status.release();
+    ctx->host_in.release();
+    ctx->host_out.release();
+    ctx->host_idx.release();
     ctx->trace.release();
     ctx->wave_scratch.release();
     if (ctx->d_words)
@@ -268,6 +273,9 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx)
     ctx->hist.release();
     ctx->layout_sums.release();
     ctx->enc_status.release();
+    ctx->host_in.release();
+    ctx->host_out.release();
+    ctx->host_idx.release();
     ctx->trace.release();
     return RANS_AMD_OK;
 }
@@ -1037,15 +1045,19 @@ int rans_amd_encode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const v
     const uint32_t chunk = (uint32_t)n;
     const uint64_t bound = rans_amd_chunk_bound(format, chunk, n_ways);
     DeviceGuard guard(ctx->device);
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    uint64_t *d_off = nullptr;
-    uint32_t *d_len = nullptr;
-    int rc = RANS_AMD_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_in), (size_t)(n * sb + 256));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)bound + 256);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_off), 64);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_len), 64);
-    if (e == hipSuccess && n) e = hipMemcpy(d_in, syms, (size_t)(n * sb), hipMemcpyHostToDevice);
+    // staging buffers live in the context (grown on demand, freed with it): no hipMalloc / hipFree per call
+    std::lock_guard<std::mutex> host_lock(ctx->host_mu);
+    int rc = ctx->host_in.reserve((size_t)(n * sb + 256));
+    if (rc == RANS_AMD_OK)
+        rc = ctx->host_out.reserve((size_t)bound + 256);
+    if (rc == RANS_AMD_OK)
+        rc = ctx->host_idx.reserve(128);
+    if (rc != RANS_AMD_OK)
+        return rc;
+    uint8_t *d_in = static_cast<uint8_t *>(ctx->host_in.ptr), *d_out = static_cast<uint8_t *>(ctx->host_out.ptr);
+    uint64_t *d_off = static_cast<uint64_t *>(ctx->host_idx.ptr);
+    uint32_t *d_len = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->host_idx.ptr) + 64);
+    hipError_t e = hipMemcpy(d_in, syms, (size_t)(n * sb), hipMemcpyHostToDevice);
     uint64_t total = 0;
     if (e != hipSuccess)
         rc = hip_fail(e, "encode_host: device staging");
@@ -1061,9 +1073,6 @@ int rans_amd_encode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const v
             *out_len = total;
         }
     }
-    for (void *p : {(void *)d_in, (void *)d_out, (void *)d_off, (void *)d_len})
-        if (p)
-            (void)hipFree(p);
     return rc;
 }
 
@@ -1085,17 +1094,20 @@ int rans_amd_decode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const u
     }
     const int sb = model->host.sym_bytes;
     DeviceGuard guard(ctx->device);
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    uint64_t *d_off = nullptr;
-    uint32_t *d_len = nullptr;
-    int rc = RANS_AMD_OK;
+    std::lock_guard<std::mutex> host_lock(ctx->host_mu); // (staging buffers of the context, see encode_host)
+    int rc = ctx->host_in.reserve((size_t)len + 256);
+    if (rc == RANS_AMD_OK)
+        rc = ctx->host_out.reserve((size_t)(n * sb + 256));
+    if (rc == RANS_AMD_OK)
+        rc = ctx->host_idx.reserve(128);
+    if (rc != RANS_AMD_OK)
+        return rc;
+    uint8_t *d_in = static_cast<uint8_t *>(ctx->host_in.ptr), *d_out = static_cast<uint8_t *>(ctx->host_out.ptr);
+    uint64_t *d_off = static_cast<uint64_t *>(ctx->host_idx.ptr);
+    uint32_t *d_len = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->host_idx.ptr) + 64);
     const uint64_t offs[2] = {0, len};
     const uint32_t len32 = (uint32_t)len;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_in), (size_t)len + 256);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)(n * sb + 256));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_off), 64);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_len), 64);
-    if (e == hipSuccess) e = hipMemcpy(d_in, stream_bytes, (size_t)len, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(d_in, stream_bytes, (size_t)len, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_off, offs, sizeof(offs), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_len, &len32, 4, hipMemcpyHostToDevice);
     if (e != hipSuccess)
@@ -1108,9 +1120,6 @@ int rans_amd_decode_host(rans_amd_ctx *ctx, const rans_amd_model *model, const u
         if (e != hipSuccess)
             rc = hip_fail(e, "decode_host: copy back");
     }
-    for (void *p : {(void *)d_in, (void *)d_out, (void *)d_off, (void *)d_len})
-        if (p)
-            (void)hipFree(p);
     return rc;
 }
 
