@@ -1918,7 +1918,7 @@ static uint32_t encode_lanes_staged_waves(const EncParams &p, int num_cus)
 {
     const size_t table_lds = (size_t)p.nsyms * sizeof(EncRec);
     const int force = lanes_force();
-    // (room for the mailbox and the copier wave(s) of the fused placement, whether or not this launch uses them)
+    // (room for the scanner wave and the control words of the fused placement, whether or not this launch uses them)
     const size_t fixed_lds = table_lds + 16 + kEncMailboxBytes;
     uint32_t sw = fixed_lds + kEncWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - fixed_lds) / kEncWaveLds) : 0;
     sw = sw > 16 - kLaneCopiers ? 16 - kLaneCopiers : sw;
@@ -2000,7 +2000,7 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p_i
         const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
         size_t lds = table_lds + (size_t)sw * kEncWaveLds;
         uint32_t waves = sw;
-        if (p.status) { // fused placement: the block's copier wave(s) and their mailbox
+        if (p.status) { // fused placement: the block's scanner wave and its control words
             lds = (lds + 15) & ~(size_t)15;
             p.mailbox_off = (uint32_t)lds;
             lds += kEncMailboxBytes;
