@@ -147,21 +147,39 @@ __global__ void __launch_bounds__(256) k_compact(const CompactParams p)
 
 // Small chunks (narrow interleaves: a few hundred bytes each): 16 lanes per chunk, four chunks per
 // wave trip, and the source read with UNALIGNED 16-byte global loads (gfx950 runs global memory in
-// unaligned-access mode; the funnel shift above would need per-lane selects here).
+// unaligned-access mode; the funnel shift above would need per-lane selects here).  A wave takes 64
+// chunks at a time: lane l loads the length and the offset of chunk l once (two coalesced loads per 64
+// chunks -- with every group of 16 lanes fetching its own chunk's pair they were a third of the kernel's
+// vector-memory instructions, and the address path is what bounds it: TA 84 % busy), the groups pick
+// theirs up by ds_bpermute.
 __global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
 {
     if (*p.flags & 2u)
         return;
     const uint32_t lane = lane_id();
-    const uint32_t sub = lane & 15u;
-    const uint64_t groups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
-    for (uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; chunk < p.nchunks; chunk += groups) {
-        const uint32_t len = p.lengths[chunk];
-        const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1) * p.slot_bytes - len;
-        u32x4 RANS_GLOBAL *dst = reinterpret_cast<u32x4 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + p.offsets[chunk]);
-        const uint32_t n16 = (len + 15u) >> 4;
-        for (uint32_t i = sub; i < n16; i += 16u)
-            dst[i] = *reinterpret_cast<gvec_cptr>(sa + 16ull * i);
+    const uint32_t sub = lane & 15u, grp = lane >> 4;
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint64_t c0 = wave * 64u; c0 < p.nchunks; c0 += waves * 64u) {
+        const uint64_t mine = c0 + lane;
+        uint32_t len = 0;
+        uint64_t off = 0;
+        if (mine < p.nchunks) {
+            len = p.lengths[mine];
+            off = p.offsets[mine];
+        }
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int src = 4 * k + (int)grp; // this group's chunk of the trip
+            const uint32_t l = (uint32_t)__shfl((int)len, src, 64);
+            const uint64_t o = (uint64_t)(uint32_t)__shfl((int)(uint32_t)off, src, 64) |
+                               ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off >> 32), src, 64) << 32);
+            const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (c0 + (uint32_t)src + 1u) * p.slot_bytes - l;
+            u32x4 RANS_GLOBAL *dst = reinterpret_cast<u32x4 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + o);
+            const uint32_t n16 = (l + 15u) >> 4; // (0 behind the last chunk)
+            for (uint32_t i = sub; i < n16; i += 16u)
+                dst[i] = *reinterpret_cast<gvec_cptr>(sa + 16ull * i);
+        }
     }
 }
 
@@ -311,7 +329,7 @@ hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t strea
 {
     const uint64_t cap = (uint64_t)num_cus * 8;
     if (p.slot_bytes <= 8192) { // small chunks: 16 lanes each
-        const uint64_t want = (p.nchunks + 15) / 16;
+        const uint64_t want = (p.nchunks + 255) / 256; // a wave per 64 chunks, four waves per block
         const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
         RANS_LAUNCH(k_compact_small, dim3(grid), dim3(256), 0, stream, p);
         return hipGetLastError();
