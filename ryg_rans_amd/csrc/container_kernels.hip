@@ -168,17 +168,48 @@ __global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
             len = p.lengths[mine];
             off = p.offsets[mine];
         }
-#pragma unroll 4
-        for (int k = 0; k < 16; ++k) {
-            const int src = 4 * k + (int)grp; // this group's chunk of the trip
-            const uint32_t l = (uint32_t)__shfl((int)len, src, 64);
-            const uint64_t o = (uint64_t)(uint32_t)__shfl((int)(uint32_t)off, src, 64) |
-                               ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off >> 32), src, 64) << 32);
-            const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (c0 + (uint32_t)src + 1u) * p.slot_bytes - l;
-            u32x4 RANS_GLOBAL *dst = reinterpret_cast<u32x4 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + o);
-            const uint32_t n16 = (l + 15u) >> 4; // (0 behind the last chunk)
-            for (uint32_t i = sub; i < n16; i += 16u)
-                dst[i] = *reinterpret_cast<gvec_cptr>(sa + 16ull * i);
+        // four chunks per group at a time, two pieces of each in flight (512 bytes of a chunk per pass): a wave's trip is
+        // a chain of memory round trips, and with a load -> store pair per piece (the compiler may not move a load above
+        // a store to memory it cannot tell apart) the kernel was bound by that chain, not by any unit: 130 us
+        for (int k0 = 0; k0 < 16; k0 += 4) {
+            uint64_t sa[4], da[4];
+            uint32_t n16[4], most = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int src = 4 * (k0 + q) + (int)grp; // this group's chunk
+                const uint32_t l = (uint32_t)__shfl((int)len, src, 64);
+                const uint64_t o = (uint64_t)(uint32_t)__shfl((int)(uint32_t)off, src, 64) |
+                                   ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off >> 32), src, 64) << 32);
+                sa[q] = reinterpret_cast<uint64_t>(p.scratch) + (c0 + (uint32_t)src + 1u) * p.slot_bytes - l;
+                da[q] = reinterpret_cast<uint64_t>(p.out) + o;
+                n16[q] = (l + 15u) >> 4; // (0 behind the last chunk)
+                most = n16[q] > most ? n16[q] : most;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t m2 = (uint32_t)__shfl_xor((int)most, d, 64);
+                most = m2 > most ? m2 : most;
+            }
+            most = uniform(most);
+            for (uint32_t i0 = 0; i0 < most; i0 += 32u) {
+                u32x4 v[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t i = i0 + 16u * h + sub;
+                        if (i < n16[q])
+                            v[q][h] = *reinterpret_cast<gvec_cptr>(sa[q] + 16ull * i);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t i = i0 + 16u * h + sub;
+                        if (i < n16[q])
+                            *reinterpret_cast<u32x4 RANS_GLOBAL *>(da[q] + 16ull * i) = v[q][h];
+                    }
+            }
         }
     }
 }
