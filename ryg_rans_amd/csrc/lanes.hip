@@ -1914,7 +1914,7 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
 // The staged lane encoder (coalesced symbol loads, whole-line stream stores, fused placement) takes u8 symbols in
 // 16-byte aligned chunks with slots made of whole lines; RANS_AMD_LANES=regwin keeps the per-lane kernel (A/B runs),
 // =staged forces the staged one whatever the batch count (tests).  Returns the waves per block the LDS allows, 0 = no.
-static uint32_t encode_lanes_staged_waves(const EncParams &p, int num_cus)
+static uint32_t encode_lanes_staged_waves(const EncParams &p, int num_cus, uint64_t min_batches_per_cu = 6)
 {
     const size_t table_lds = (size_t)p.nsyms * sizeof(EncRec);
     const int force = lanes_force();
@@ -1926,7 +1926,7 @@ static uint32_t encode_lanes_staged_waves(const EncParams &p, int num_cus)
                         ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 15u) == 0 &&
                         (reinterpret_cast<uintptr_t>(p.scratch) & 15u) == 0 &&
                         // fewer, longer batches: the per-lane kernel's many small blocks hide latency better
-                        (force > 0 || (p.nchunks + 63) / 64 >= (uint64_t)num_cus * 6);
+                        (force > 0 || (p.nchunks + 63) / 64 >= (uint64_t)num_cus * min_batches_per_cu);
     return staged ? sw : 0u;
 }
 
@@ -1936,7 +1936,12 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p_i
     const size_t table_lds = (size_t)p.nsyms * sizeof(EncRec);
     if (table_lds > 128 * 1024)
         return hipErrorInvalidValue;
-    uint32_t sw = encode_lanes_staged_waves(p, num_cus);
+    // (the dedicated 2-way rans64 encoder is worth it from one batch per CU on: 4096-symbol chunks, 1024 batches of
+    //  config 2's 256 MiB, 0.78 ms with the per-lane kernel; with the fused placement the predicate must stay the one
+    //  encode_lanes_fused() gave api.cpp)
+    const bool r64x2_shape = FMT == FMT_R64 && NW == 2 && !p.status && (p.chunk_syms & 63u) == 0 && p.scale_bits >= 7 &&
+                             p.scale_bits <= 16 && p.nsyms <= 256 && (p.n / p.chunk_syms) / 64 >= (uint64_t)num_cus;
+    uint32_t sw = encode_lanes_staged_waves(p, num_cus, r64x2_shape ? 1 : 6);
     const bool staged = sw >= 1;
     if (!staged && p.status)
         return hipErrorInvalidValue; // (api.cpp asks encode_lanes_fused() before it sets up the fused placement)
