@@ -494,11 +494,6 @@ int rans_amd_ways_supported(int format, uint32_t n_ways) { return ways_supported
 static uint64_t encode_slot_bytes(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
 {
     const uint64_t b = rans_amd_chunk_bound(format, (uint32_t)(n < chunk_syms ? n : chunk_syms), n_ways);
-    // RANS_AMD_DEBUG_SLOT=<bytes>: measurement knob -- scratch slots of that size instead of the worst case (how much of
-    // the compaction's time is the sparseness of the slots); streams longer than that overrun their slot
-    static const char *dbg = getenv("RANS_AMD_DEBUG_SLOT");
-    if (dbg && atoi(dbg) >= 64)
-        return ((uint64_t)atoi(dbg) + 63) & ~uint64_t(63);
     return (b + 63) & ~uint64_t(63);
 }
 
