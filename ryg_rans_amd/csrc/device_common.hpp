@@ -424,10 +424,12 @@ struct EncMailbox {
 };
 static_assert(sizeof(EncMailbox) == kEncMailboxBytes, "mailbox layout");
 
-// Every wait of the placement protocol gives up after kSpinLimit polls (seconds; waits are microseconds) and sets a
-// bit of EncParams::flags -- 8: mailbox full, 16: (unused), 32: look-back, 64: wait for an own prefix -- which the
-// host turns into an error: a protocol bug must show up as a failed call, not as a hung GPU.
-constexpr uint32_t kSpinLimit = 1u << 21;
+// Every wait of the placement protocols gives up after kSpinLimit polls and sets a bit of EncParams::flags -- 8: mailbox
+// full, 16: a copier / scanner waiting for its coders, 32: look-back, 64: a coder waiting for its batch's place, 128: a
+// coder waiting for its next unit -- which the host turns into an error: a protocol bug must show up as a failed call,
+// not as a GPU that hangs for ever.  The limit is minutes, not microseconds: a wait is as long as the coding of the
+// largest chunk somebody else is still busy with (a 2^31-symbol chunk of a *_host call keeps one wave busy for seconds).
+constexpr uint32_t kSpinLimit = 1u << 28;
 
 __device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t unit, uint32_t len, uint32_t *flags)
 {
@@ -446,7 +448,8 @@ __device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t unit, uint
 
 // Copier side (whole wave): the next entry in order, {ex = unit + 1, ey = bytes}; false when every one of the block's
 // `producers` coding waves has left its loop and nothing is left to take.
-__device__ __forceinline__ bool mailbox_pop(EncMailbox *mb, uint32_t lane, uint32_t producers, uint32_t &ex, uint32_t &ey)
+__device__ __forceinline__ bool mailbox_pop(EncMailbox *mb, uint32_t lane, uint32_t producers, uint32_t &ex, uint32_t &ey,
+                                            uint32_t *flags)
 {
     uint32_t h = 0;
     if (lane == 0)
@@ -465,8 +468,10 @@ __device__ __forceinline__ bool mailbox_pop(EncMailbox *mb, uint32_t lane, uint3
         if (fin == producers && (int32_t)(tail - h) <= 0)
             return false;
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > 16u * kSpinLimit) // (this wait is as long as a unit takes to code: milliseconds at most)
+        if (++spins > 0xf0000000u) { // (LDS polls, a quarter of a microsecond each)
+            atomicOr(flags, lane == 0 ? 16u : 0u);
             return false;
+        }
     }
     // (every lane writes the same zero: a trailing `if (lane == 0)` invites the compiler to let the other lanes run ahead
     //  into code whose readfirstlane / ballot assumes the whole wave -- see lanes.hip, lanes_scan_batch)

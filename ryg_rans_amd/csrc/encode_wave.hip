@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         if (wave >= waves_per_block) { // ---- copier wave
             for (;;) {
                 uint32_t ex = 0, ey = 0;
-                if (!mailbox_pop(mb, lane, waves_per_block, ex, ey))
+                if (!mailbox_pop(mb, lane, waves_per_block, ex, ey, p.flags))
                     break;
                 const uint64_t chunk = ex - 1u;
                 const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1u) * p.slot_bytes - ey;
