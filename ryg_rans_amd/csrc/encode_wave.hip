@@ -156,6 +156,53 @@ __device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x3 &rec, uin
                  : "vcc", "scc", "memory");
 }
 
+// The same for the byte format (rans_byte.h:62-74 renormalisation, :83-90 / :258-280 update) -- the compiler's version
+// of this sub-step is 33.7 VALU instructions per round, three byte stores with 64-bit address arithmetic each among
+// them.  Record {rcp, cmpl | rshift << 24, bias, x_max} (built in the kernel's prologue from the EncRec table):
+//   v_cmp x2    x >= x_max (one byte leaves), (x >> 8) >= x_max (two bytes leave); x_max = freq << (31 - scale_bits)
+//   s_bcnt1 x2  bytes emitted -> the wave's write offset moves down
+//   v_mbcnt x4  rank among the emitting lanes, both masks: the lane's place (ascending lane = ascending address, the
+//               low byte of a lane at the higher address)
+//   two stores  the two-byte lanes one global_store_short of the swapped low half (v_perm), the one-byte lanes one
+//               global_store_byte -- each under its own exec mask, against the chunk's SGPR base
+//   x / freq    Alverson: mulhi(x, rcp) >> rshift, exact; x' = x + bias + q * cmpl (q < 2^24, cmpl < 2^24: v_mad_u32_u24)
+// 17 VALU + 7 SALU, no v_cndmask, no branch.  s[34:35] holds the two-byte mask.
+__device__ __forceinline__ void enc_byte_full(uint32_t &x, const u32x4 &rec, uint32_t &wp, const uint8_t RANS_GLOBAL *slot,
+                                              uint32_t &worst, uint32_t swap_sel)
+{
+    uint32_t t, r, q, sh, c1, c2;
+    asm volatile("v_cmp_ge_u32_e32 vcc, %[x], %[xm]\n\t"
+                 "v_lshrrev_b32_e32 %[t], 8, %[x]\n\t"
+                 "v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                 "v_cmp_ge_u32_e64 s[34:35], %[t], %[xm]\n\t"
+                 "s_bcnt1_i32_b64 %[c1], vcc\n\t"
+                 "s_bcnt1_i32_b64 %[c2], s[34:35]\n\t"
+                 "s_add_u32 %[c1], %[c1], %[c2]\n\t"
+                 "s_sub_u32 %[wp], %[wp], %[c1]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[r], s34, %[r]\n\t"
+                 "v_mbcnt_hi_u32_b32 %[r], s35, %[r]\n\t"
+                 "v_add_u32_e32 %[r], %[wp], %[r]\n\t"
+                 "v_perm_b32 %[t], %[x], %[x], %[sel]\n\t"
+                 "s_mov_b64 exec, s[34:35]\n\t"
+                 "global_store_short %[r], %[t], %[base]\n\t"
+                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                 "s_andn2_b64 exec, vcc, s[34:35]\n\t"
+                 "global_store_byte %[r], %[x], %[base]\n\t"
+                 "v_lshrrev_b32_e32 %[x], 8, %[x]\n\t"
+                 "s_mov_b64 exec, -1\n\t"
+                 "v_mul_hi_u32 %[q], %[x], %[rcp]\n\t"
+                 "v_lshrrev_b32_e32 %[sh], 24, %[w]\n\t"
+                 "v_lshrrev_b32_e32 %[q], %[sh], %[q]\n\t"
+                 "v_mad_u32_u24 %[q], %[q], %[w], %[x]\n\t"
+                 "v_add_u32_e32 %[x], %[q], %[bias]"
+                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [r] "=&v"(r), [q] "=&v"(q), [sh] "=&v"(sh),
+                   [c1] "=&s"(c1), [c2] "=&s"(c2)
+                 : [rcp] "v"(rec.x), [w] "v"(rec.y), [bias] "v"(rec.z), [xm] "v"(rec.w), [base] "s"(slot), [sel] "v"(swap_sel)
+                 : "vcc", "scc", "memory", "s34", "s35");
+}
+
 constexpr int kEncAliasLdsThreads = 1024; // FMT_ALIAS_LDS: 16 waves share the (up to 160 KiB) tables of a CU
 
 // ---------------------------------------------------------------------------
@@ -254,9 +301,13 @@ __device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chun
     }
 }
 
+// waves per SIMD the fused kernel is compiled for: 8 (64 VGPRs: 4 blocks of 8 waves per CU) with one state per lane, 4 and 2
+// with 2-4 and 8 states per lane -- at 64 VGPRs those spilled 20 to 785 registers (the 512-way rans64 encoder)
+constexpr int enc_fused_waves_per_simd(int K) { return K == 1 ? 8 : (K <= 4 ? 4 : 2); }
+
 template <int FMT, int K, bool FUSED>
 __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (FUSED ? kEncFusedThreads : kEncBlockThreads),
-                                  (FUSED && FMT != FMT_ALIAS_LDS) ? 8 : 1) // fused: 4 blocks of 8 waves per CU, 64 VGPRs
+                                  (FUSED && FMT != FMT_ALIAS_LDS) ? enc_fused_waves_per_simd(K) : 1)
     k_encode(const EncParams p)
 {
     using Tr = FmtTraits<FMT>;
@@ -265,7 +316,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
 
     // word format: the 256 WordEncRec of the full-wave path come first (LDS address = sym << 4),
     // the per-symbol EncRec table of the general path behind them
-    constexpr uint32_t kWordRecBytes = FMT == FMT_WORD ? 256u * (uint32_t)sizeof(WordEncRec) : 0u;
+    // (byte format: 256 records {rcp, cmpl | rshift << 24, bias, x_max} of enc_byte_full, built from the EncRec table below)
+    constexpr uint32_t kWordRecBytes = (FMT == FMT_WORD || FMT == FMT_BYTE) ? 256u * (uint32_t)sizeof(WordEncRec) : 0u;
     if constexpr (FMT == FMT_WORD) {
         if (p.word_enc_recs) { // (absent for alphabets beyond 256 symbols: they never take the full-wave path)
             const uint4 *g = reinterpret_cast<const uint4 *>(p.word_enc_recs);
@@ -292,6 +344,15 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             l[i] = g[i];
         for (uint32_t i = p.nsyms + threadIdx.x; i < 256u; i += blockDim.x)
             l[i] = uint4{0u, 0u, 0u, 0u};
+        if constexpr (FMT == FMT_BYTE) { // EncRec {freq | rshift << 24, bias, rcp, -} -> the full-wave path's records
+            uint4 *f = reinterpret_cast<uint4 *>(smem);
+            for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) {
+                const uint4 r = i < p.nsyms ? g[i] : uint4{0u, 0u, 0u, 0u};
+                const uint32_t freq = r.x & 0xffffffu;
+                f[i] = freq ? uint4{r.z, (((1u << p.scale_bits) - freq) & 0xffffffu) | (r.x & 0xff000000u), r.y, freq << (31u - p.scale_bits)}
+                            : uint4{0u, 0xffffffffu, 0u, 0xffffffffu}; // no frequency: nothing leaves, x stays, v_max sees it
+            }
+        }
     }
     EncMailbox *mb = reinterpret_cast<EncMailbox *>(smem + p.mailbox_off);
     if constexpr (FUSED) {
@@ -446,8 +507,13 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 }
             }
         } else if (fast_rounds) {
-            uint32_t rec_mask = 0xff0u;
+            uint32_t rec_mask = 0xff0u, swap_sel = 0x0c0c0001u; // (v_perm selector: the low two bytes swapped, zeros above)
             asm volatile("" : "+v"(rec_mask)); // keep the mask in a VGPR (a literal operand costs a slower VALU form)
+            asm volatile("" : "+v"(swap_sel));
+            // byte format: the hand-written sub-step needs its records at LDS address 0 and the one model of the launch
+            const bool byte_asm = FMT == FMT_BYTE && lds_at_zero && !adaptive;
+            (void)swap_sel;
+            (void)byte_asm;
             uint32_t cur[4][K], nxt[4][K];
             auto load_super = [&](uint32_t (&dstq)[4][K], uint32_t sg) {
 #pragma unroll
@@ -484,6 +550,22 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                         if (step + 1 < 4 * K)
                             rec = rec_at(step + 1);
                         enc_word_full(x[K - 1 - step % K], now, wp, slot, worst);
+                    }
+                } else if (FMT == FMT_BYTE && byte_asm) {
+                    if constexpr (FMT == FMT_BYTE) { // (the same walk over the 4 K symbols as the word format's)
+                        auto rec_at = [&](int step) {
+                            const int J = 3 - step / K, k = K - 1 - step % K;
+                            const uint32_t at = (J == 0 ? (t[k] << 4) : (t[k] >> (8 * J - 4))) & rec_mask;
+                            return *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>((uintptr_t)at); // table at LDS address 0
+                        };
+                        u32x4 rec = rec_at(0);
+#pragma unroll
+                        for (int step = 0; step < 4 * K; ++step) {
+                            const u32x4 now = rec;
+                            if (step + 1 < 4 * K)
+                                rec = rec_at(step + 1);
+                            enc_byte_full(x[K - 1 - step % K], now, wp, slot, worst, swap_sel);
+                        }
                     }
                 } else {
 #pragma unroll
@@ -558,7 +640,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     const size_t nrecs = p.nsyms < 256 ? 256 : p.nsyms;
     size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
                  : (FMT == FMT_BYTE && p.chunk_freqs) ? (size_t)waves * kAdaptEncWaveLds
-                                                      : nrecs * sizeof(EncRec) + (FMT == FMT_WORD ? 256 * sizeof(WordEncRec) : 0);
+                                                      : nrecs * sizeof(EncRec) + ((FMT == FMT_WORD || FMT == FMT_BYTE) ? 256 * sizeof(WordEncRec) : 0);
     EncParams q = p;
     if (fused) {
         lds = (lds + 15) & ~(size_t)15;
@@ -574,6 +656,10 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     uint64_t per_cu = lds ? (160 * 1024) / lds : 8;
     per_cu = per_cu < 1 ? 1 : per_cu;
     per_cu = per_cu * waves > 32 ? 32 / waves : per_cu;
+    if (fused && FMT != FMT_ALIAS_LDS) { // ... and within the waves per SIMD the kernel's register budget was chosen for
+        const uint64_t fit = (uint64_t)enc_fused_waves_per_simd(K) * 4 / waves;
+        per_cu = per_cu > fit ? (fit ? fit : 1) : per_cu;
+    }
     uint64_t cap = (uint64_t)num_cus * (FMT == FMT_ALIAS_LDS || fused ? per_cu : 8);
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
     if (fused) {
