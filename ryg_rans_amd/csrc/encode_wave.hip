@@ -21,13 +21,53 @@ template <int FMT> struct EncTables {
     const uint16_t *remap16;     // LDS (FMT_ALIAS_LDS)
     uint32_t scale_bits;
     uint32_t nsyms;
+    uint32_t swap_sel; // v_perm selector of enc_renorm_byte_full (kept in a VGPR)
 };
+
+// Renormalisation of the byte-stream formats for a FULL wave (rans_byte.h:62-74: zero, one or two bytes leave the
+// state while x >= x_max), hand-written -- see enc_byte_full below, whose first half this is: two compares give the
+// one-byte and the two-byte mask, four v_mbcnt the lane's place, the two-byte lanes store the swapped low half with one
+// global_store_short, the one-byte lanes one global_store_byte, each under its own exec mask.  12 VALU where the
+// compiler's version (three byte stores with 64-bit address arithmetic each, the byte count by sign tricks) has ~25.
+// A lane that must not emit passes x_max = 0xffffffff.  s[34:35] holds the two-byte mask.
+__device__ __forceinline__ void enc_renorm_byte_full(uint32_t &x, uint32_t x_max, uint32_t &wp, const uint8_t RANS_GLOBAL *slot,
+                                                     uint32_t swap_sel)
+{
+    uint32_t t, r, c1, c2;
+    uint32_t wps = uniform(wp); // (an "s" operand fed from a loop-carried value wants the readfirstlane spelled out)
+    const uint8_t RANS_GLOBAL *base = reinterpret_cast<const uint8_t RANS_GLOBAL *>(uniform64(reinterpret_cast<uint64_t>(slot)));
+    asm volatile("v_cmp_ge_u32_e32 vcc, %[x], %[xm]\n\t"
+                 "v_lshrrev_b32_e32 %[t], 8, %[x]\n\t"
+                 "v_cmp_ge_u32_e64 s[34:35], %[t], %[xm]\n\t"
+                 "s_bcnt1_i32_b64 %[c1], vcc\n\t"
+                 "s_bcnt1_i32_b64 %[c2], s[34:35]\n\t"
+                 "s_add_u32 %[c1], %[c1], %[c2]\n\t"
+                 "s_sub_u32 %[wp], %[wp], %[c1]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[r], s34, %[r]\n\t"
+                 "v_mbcnt_hi_u32_b32 %[r], s35, %[r]\n\t"
+                 "v_add_u32_e32 %[r], %[wp], %[r]\n\t"
+                 "v_perm_b32 %[t], %[x], %[x], %[sel]\n\t"
+                 "s_mov_b64 exec, s[34:35]\n\t"
+                 "global_store_short %[r], %[t], %[base]\n\t"
+                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                 "s_andn2_b64 exec, vcc, s[34:35]\n\t"
+                 "global_store_byte %[r], %[x], %[base]\n\t"
+                 "v_lshrrev_b32_e32 %[x], 8, %[x]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [x] "+v"(x), [wp] "+s"(wps), [t] "=&v"(t), [r] "=&v"(r), [c1] "=&s"(c1), [c2] "=&s"(c2)
+                 : [xm] "v"(x_max), [base] "s"(base), [sel] "v"(swap_sel)
+                 : "vcc", "scc", "memory", "s34", "s35");
+    wp = wps;
+}
 
 // One encoder sub-step for 64 lanes.  `wp` = write cursor (byte offset inside the
 // slot, moves down, wave-uniform).
 // PADDED: the record table holds 256 entries (zero records behind nsyms) and `sym` is a byte, so it
 // indexes the table as it is -- no range select (a v_cndmask costs ~22 issue cycles on gfx950).
-template <int FMT, bool PADDED = false>
+// FULL: all 64 lanes hold a symbol (the byte-stream formats then renormalise with enc_renorm_byte_full).
+template <int FMT, bool PADDED = false, bool FULL = false>
 __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename FmtTraits<FMT>::state_t &x,
                                             uint32_t sym, bool active, uint8_t RANS_GLOBAL *slot, uint32_t &wp,
                                             bool &bad)
@@ -76,6 +116,11 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         // main_alias.cpp:241-250 (alias put).  The low byte is emitted first, i.e.
         // ends up at the higher address.
         const uint32_t x_max = freq << (31u - T.scale_bits);
+        uint32_t y;
+        if constexpr (FULL) {
+            y = x;
+            enc_renorm_byte_full(y, active ? x_max : 0xffffffffu, wp, slot, T.swap_sel);
+        } else {
         const bool e1 = active && x >= x_max;
         const bool e2 = e1 && (x >> 8) >= x_max;
         const uint64_t m1 = __builtin_amdgcn_ballot_w64(e1);
@@ -92,7 +137,8 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         // bytes emitted = [x >= x_max] + [x >> 8 >= x_max] as sign bits (x, x_max < 2^31), then one shift:
         // no selects.  Inactive or invalid lanes may shift by garbage; their result is discarded below.
         const uint32_t nb = ((x_max - 1u - x) >> 31) + ((x_max - 1u - (x >> 8)) >> 31);
-        const uint32_t y = x >> (nb << 3);
+        y = x >> (nb << 3);
+        }
         uint32_t xn;
         if constexpr (FMT == FMT_ALIAS) {
             uint32_t q, rem;
@@ -391,6 +437,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
     T.remap16 = reinterpret_cast<const uint16_t *>(smem + (size_t)nrecs * 8u);
     T.scale_bits = p.scale_bits;
     T.nsyms = p.nsyms;
+    T.swap_sel = 0x0c0c0001u; // (the low two bytes swapped, zeros above)
+    asm volatile("" : "+v"(T.swap_sel));
 
     bool bad = false;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
@@ -497,7 +545,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                         for (int h = 1; h >= 0; --h)
 #pragma unroll
                             for (int k = K - 1; k >= 0; --k)
-                                enc_substep<FMT>(T, x[k], (t[k] >> (16 * h)) & 0xffffu, true, slot, wp, bad);
+                                enc_substep<FMT, false, true>(T, x[k], (t[k] >> (16 * h)) & 0xffffu, true, slot, wp, bad);
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
@@ -572,7 +620,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                     for (int J = 3; J >= 0; --J)
 #pragma unroll
                         for (int k = K - 1; k >= 0; --k)
-                            enc_substep<FMT, true>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
+                            enc_substep<FMT, true, kIsAlias<FMT>>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
                 }
                 }
 #pragma unroll
