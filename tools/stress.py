@@ -57,8 +57,21 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
             data = (rng.integers(0, 2, n) * int(rng.integers(1, K))).astype(dt)
         if len(np.unique(data)) < 2:
             continue
+        if big and rng.integers(0, 3) == 0:  # config 2's shape: the dedicated 2-way rans64 lane decoder / encoder (whole batches
+            fmt, n_ways, K = FMT_R64, 2, 256  #  of 64 full chunks + a tail), any scale_bits with a cum2sym table
+            sb = int(rng.integers(8, 17))
+            chunk = 64 * int(rng.integers(1, 9))
+            n = int(rng.integers(256 * 64 * chunk, 300 * 64 * chunk)) + int(rng.integers(0, 3)) * int(rng.integers(0, chunk))
+            data = (oracle.gen_zipf(n, K=256, s=float(rng.uniform(0.3, 2.5)), seed=int(rng.integers(1, 1 << 30))) if kind != 1
+                    else rng.integers(0, 256, n).astype(np.uint8))
+            dt = np.uint8
         os.environ["RANS_AMD_LANES"] = str(rng.choice(["staged", "regwin", ""]))
-        desc = dict(case=case, fmt=fmt, sb=sb, K=K, n=n, n_ways=n_ways, chunk=chunk, kind=kind, lanes=os.environ["RANS_AMD_LANES"])
+        if rng.integers(0, 2) == 0:  # the lane encoders placing their chunks themselves (scanner wave per block)
+            os.environ["RANS_AMD_LANES_FUSED"] = "1"
+        else:
+            os.environ.pop("RANS_AMD_LANES_FUSED", None)
+        desc = dict(case=case, fmt=fmt, sb=sb, K=K, n=n, n_ways=n_ways, chunk=chunk, kind=kind, lanes=os.environ["RANS_AMD_LANES"],
+                    lanes_fused=os.environ.get("RANS_AMD_LANES_FUSED", ""))
         try:
             counts = oracle.count_freqs(data, K)
             f, _ = oracle.normalize(counts, 1 << sb)
@@ -99,6 +112,7 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
         except Exception as e:  # noqa: BLE001
             fails += 1
             print("EXC", desc, repr(e), flush=True)
+    os.environ.pop("RANS_AMD_LANES_FUSED", None)
     if saved is None:
         os.environ.pop("RANS_AMD_LANES", None)
     else:
