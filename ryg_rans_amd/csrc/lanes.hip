@@ -1029,19 +1029,23 @@ __device__ __forceinline__ void lane_put_staged(typename FmtTraits<FMT>::state_t
 // chunks of a batch can be copied to their place once the total of everything before the batch is known.
 //
 // The unit of the scan is a ROUND OF A BLOCK: its C coding waves take C consecutive batches (one claim of the block's
-// scanner wave, the last wave of the block, on a counter behind the status words), code them, and post their totals
-// in LDS; the scanner adds them up, publishes status[unit] = AGGREGATE | total, looks back over the units before it
-// (decoupled look-back, device_common.hpp; kScanWords * 64 units per step) until it meets a PREFIX, publishes its own
-// PREFIX and leaves every coder the place of its batch in LDS.  A coder copies the batch of round r AFTER it has coded
-// round r + 1 -- the scan of round r has had a whole round's time by then, so nobody waits except at the very end, where
+// scanner wave on a counter behind the status words), code them, and post their totals in LDS; the scanner adds them
+// up, publishes status[unit] = AGGREGATE | total, looks back over the units before it (decoupled look-back,
+// device_common.hpp; kScanWords * 64 units per step) until it meets a PREFIX, publishes its own PREFIX and leaves the
+// place of every coder's batch in LDS; kLaneCopyWaves copier waves -- no LDS of their own, so they come on top of the
+// coding waves the rings allow -- then move the round's batches to the container while the coders are a round ahead.
 // 256 units (one per CU) finish together and one look-back step resolves them all.
 //
-// What this replaced, all of them measured on config 2 (0.39 ms with the two extra kernels): the coding wave placing
-// its own batch at once (0.54: every wave of the first round finishes at the same moment and the prefix travels 64
-// batches per memory round trip); a copier wave per block that scans and copies batch by batch through a mailbox
+// What this replaced, all of them measured on config 2 (0.36-0.40 ms with the two extra kernels): the coding wave
+// placing its own batch at once (0.54: every wave of the first round finishes at the same moment and the prefix travels
+// 64 batches per memory round trip); a copier wave per block that scans and copies batch by batch through a mailbox
 // (0.375-0.52: 6-8 us per batch where the coders deliver one every 8 us); a scanner wave per block working batch by
 // batch while the coders copy (0.40-0.42: with 2816 batches ending together a scanner walks back thousands of status
-// words for each of its 11 batches, one memory round trip per 64 or 256 of them -- as long as coding the round).
+// words for each of its 11 batches); the round-of-a-block units with the coders copying their previous batch (0.42-0.47:
+// the protocol costs 0.01 ms then, the copy 0.13 -- these kernels run 3-4 waves per SIMD, each bound by its own
+// dependency chain, and a wave that spends 40 us per batch in memory round trips is not replaced by anybody).  With
+// the copier waves the fused launch is as fast as the three kernels (0.34-0.37 ms against 0.35-0.37: 11 coding waves in
+// three rounds instead of 16 in two pay for what the copy no longer costs) -- hence still opt-in.
 // Units are claimed in ascending order by running blocks and a scanner waits only for smaller units: the smallest
 // unfinished unit always belongs to a running block.  The copy is quad-cooperative like every other access of these
 // kernels: instruction t moves 64 bytes of the chunk of the quad's lane t (16 bytes per lane, source unaligned),
@@ -1052,26 +1056,25 @@ __device__ __forceinline__ void lane_put_staged(typename FmtTraits<FMT>::state_t
 // and parked lane 0's store behind the loop, for ever (found with the watchdogs below: flags 0x40, every status word
 // still AGGREGATE).  Stores that one lane would do are done by all of them with the same value.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kLaneCopiers = 1;   // scanner waves per block (on top of the coding waves the LDS allows, <= 16 in all)
-constexpr int kLaneCopyDepth = 2;
+constexpr uint32_t kLaneCopyWaves = 3; // copier waves per block
+constexpr uint32_t kLaneCopiers = 1 + kLaneCopyWaves; // scanner + copier waves (on top of the coding waves, <= 16 in all)
+constexpr int kLaneCopyDepth = 4;
 constexpr int kScanWords = 4;
 
 struct LaneRounds { // the block's control words in LDS (EncParams::mailbox_off), zero at kernel start; index = round & 1
-    uint32_t unit[2];     // unit claimed for the round ...
-    uint32_t unit_seq[2]; // ... valid when this is round + 1
+    // (units: round & 3 -- the scanner names round r + 1's unit while a copier may still be busy with round r - 1)
+    uint32_t unit[4];     // unit claimed for the round ...
+    uint32_t unit_seq[4]; // ... valid when this is round + 1
     uint32_t posted[2];   // coding waves that have posted their total
     uint32_t base_seq[2]; // bases[] valid when this is round + 1
+    uint32_t copied[2];   // copier waves that are through with the round
     uint32_t totals[2][16];
     unsigned long long bases[2][16];
 };
 static_assert(sizeof(LaneRounds) <= kEncMailboxBytes, "LaneRounds must fit the LDS reserved for the placement");
 
 struct LaneCoder { // a coding wave's view
-    uint32_t round;      // rounds begun
-    bool have_prev;      // a batch coded and not yet copied
-    uint32_t prev_round; // its round
-    uint64_t prev_batch;
-    uint32_t prev_len;   // this lane's chunk of it
+    uint32_t round; // rounds begun
 };
 
 // poll an LDS word until it has the value (whole wave; gives up after kSpinLimit polls and says so in flags)
@@ -1093,9 +1096,9 @@ __device__ __forceinline__ uint64_t lanes_round_begin(const EncParams &p, LaneRo
                                                       uint32_t coders, uint32_t lane)
 {
     const uint32_t r = cs.round;
-    if (!lanes_wait_lds(&ctl->unit_seq[r & 1u], r + 1u, p.flags, 128u, lane))
+    if (!lanes_wait_lds(&ctl->unit_seq[r & 3u], r + 1u, p.flags, 128u, lane))
         return ~0ull;
-    const uint64_t first = p.batch_begin + (uint64_t)uniform(*(volatile uint32_t *)&ctl->unit[r & 1u]) * coders;
+    const uint64_t first = p.batch_begin + (uint64_t)uniform(*(volatile uint32_t *)&ctl->unit[r & 3u]) * coders;
     if (first >= p.batch_end)
         return ~0ull;
     return first + wave < p.batch_end ? first + wave : ~0ull - 1u;
@@ -1163,39 +1166,44 @@ __device__ __forceinline__ void lanes_copy_batch(const EncParams &p, uint64_t ba
     }
 }
 
-// coding wave: the batch of an earlier round goes to its place (its base is in LDS since the scan of that round)
-__device__ __forceinline__ void lanes_copy_prev(const EncParams &p, LaneRounds *ctl, LaneCoder &cs, uint32_t wave, uint32_t lane)
-{
-    if (!cs.have_prev)
-        return;
-    cs.have_prev = false;
-    const uint32_t r = cs.prev_round;
-    if (!(p.debug & 2u) && !lanes_wait_lds(&ctl->base_seq[r & 1u], r + 1u, p.flags, 64u, lane))
-        return;
-    const volatile uint32_t *b = reinterpret_cast<const volatile uint32_t *>(&ctl->bases[r & 1u][wave]);
-    const unsigned long long base = (unsigned long long)uniform(b[0]) | ((unsigned long long)uniform(b[1]) << 32);
-    lanes_copy_batch(p, cs.prev_batch, cs.prev_len, base, lane);
-}
-
-// coding wave, end of a round: post the total (len: this lane's chunk, 0 without one; batch = ~0 - 1: no batch this
-// round), copy the batch of the round before, remember this one
+// coding wave, end of a round: post the total (len: this lane's chunk, 0 without one)
 __device__ __forceinline__ void lanes_round_end(const EncParams &p, LaneRounds *ctl, LaneCoder &cs, uint32_t wave, uint32_t lane,
                                                 uint64_t batch, uint32_t len)
 {
+    (void)batch;
     const uint32_t r = cs.round;
     uint32_t sum = (len + 15u) & ~15u;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1)
         sum += (uint32_t)__shfl_xor((int)sum, d, 64);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every flushed line of the batch has left the wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // lengths[] and every flushed line of the batch have left the wave
     *(volatile uint32_t *)&ctl->totals[r & 1u][wave] = sum; // (every lane, the same value)
     atomicAdd(&ctl->posted[r & 1u], lane == 0 ? 1u : 0u);
-    lanes_copy_prev(p, ctl, cs, wave, lane);
-    cs.have_prev = batch != ~0ull - 1u;
-    cs.prev_round = r;
-    cs.prev_batch = batch;
-    cs.prev_len = len;
     cs.round = r + 1u;
+}
+
+// copier wave number k of the block: when the places of a round's batches are known, the batches k, k + kLaneCopyWaves,
+// ... of the round go to the container
+__device__ __forceinline__ void lanes_copier(const EncParams &p, LaneRounds *ctl, uint32_t k, uint32_t lane, uint32_t coders)
+{
+    for (uint32_t r = 0;; ++r) {
+        if (!lanes_wait_lds(&ctl->unit_seq[r & 3u], r + 1u, p.flags, 128u, lane))
+            return;
+        const uint64_t first = p.batch_begin + (uint64_t)uniform(*(volatile uint32_t *)&ctl->unit[r & 3u]) * coders;
+        if (first >= p.batch_end)
+            return;
+        if (!lanes_wait_lds(&ctl->base_seq[r & 1u], r + 1u, p.flags, 64u, lane))
+            return;
+        for (uint32_t w = k; w < coders && first + w < p.batch_end; w += kLaneCopyWaves) {
+            const volatile uint32_t *b = reinterpret_cast<const volatile uint32_t *>(&ctl->bases[r & 1u][w]);
+            const unsigned long long base = (unsigned long long)uniform(b[0]) | ((unsigned long long)uniform(b[1]) << 32);
+            const uint64_t chunk = (first + w) * 64u + lane;
+            // (written by a wave of this CU before it posted its total, read through L2)
+            const uint32_t len = chunk < p.nchunks ? __hip_atomic_load(p.lengths + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            lanes_copy_batch(p, first + w, len, base, lane);
+        }
+        atomicAdd(&ctl->copied[r & 1u], lane == 0 ? 1u : 0u);
+    }
 }
 
 // the scanner wave's life
@@ -1215,8 +1223,8 @@ __device__ __forceinline__ void lanes_scanner(const EncParams &p, LaneRounds *ct
     *(volatile uint32_t *)&ctl->unit_seq[0] = 1u;
     for (uint32_t r = 0; u < nunits; ++r) {
         const uint32_t un = claim(); // the coders find their next unit as soon as they are through with this one
-        *(volatile uint32_t *)&ctl->unit[(r + 1u) & 1u] = un;
-        *(volatile uint32_t *)&ctl->unit_seq[(r + 1u) & 1u] = r + 2u;
+        *(volatile uint32_t *)&ctl->unit[(r + 1u) & 3u] = un;
+        *(volatile uint32_t *)&ctl->unit_seq[(r + 1u) & 3u] = r + 2u;
         if (!lanes_wait_lds(&ctl->posted[r & 1u], coders, p.flags, 16u, lane))
             return;
         const uint32_t mine = *(volatile uint32_t *)&ctl->totals[r & 1u][slot];
@@ -1291,6 +1299,11 @@ __device__ __forceinline__ void lanes_scanner(const EncParams &p, LaneRounds *ct
         }
         __hip_atomic_store(p.status + gu, kStPrefix | (base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (every lane)
         const unsigned long long place = base + incl - t; // of coder `lane`'s batch
+        if (r >= 2u) { // the copiers are through with round r - 2, whose places these words still hold
+            if (!lanes_wait_lds(&ctl->copied[r & 1u], kLaneCopyWaves, p.flags, 16u, lane))
+                return;
+            *(volatile uint32_t *)&ctl->copied[r & 1u] = 0u;
+        }
         volatile uint32_t *b = reinterpret_cast<volatile uint32_t *>(&ctl->bases[r & 1u][slot]);
         b[0] = (uint32_t)place; // (lanes >= 15 all write slot 15)
         b[1] = (uint32_t)(place >> 32);
@@ -1321,8 +1334,11 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
     const bool fused = p.status != nullptr;
     const uint32_t waves_per_block = (blockDim.x >> 6) - (fused ? kLaneCopiers : 0u); // coding waves
     LaneRounds *ctl = reinterpret_cast<LaneRounds *>(smem + p.mailbox_off);
-    if (fused && wave >= waves_per_block) { // ---- copier wave
-        lanes_scanner(p, ctl, lane, waves_per_block);
+    if (fused && wave >= waves_per_block) { // ---- the scanner wave and the copier waves
+        if (wave == waves_per_block)
+            lanes_scanner(p, ctl, lane, waves_per_block);
+        else
+            lanes_copier(p, ctl, wave - waves_per_block - 1u, lane, waves_per_block);
         return;
     }
     uint8_t *rows = smem + p.nsyms * (uint32_t)sizeof(EncRec) + wave * kEncWaveLds;
@@ -1332,7 +1348,7 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
     const uint32_t slot_lines = (uint32_t)(p.slot_bytes / kLaneLine);
 
     bool bad = false;
-    LaneCoder cs{0, false, 0, 0, 0};
+    LaneCoder cs{0};
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
     for (uint64_t batch_v = p.batch_begin + (uint64_t)blockIdx.x * waves_per_block + wave;; batch_v += total_waves) {
         if (fused) { // the block's scanner hands out the rounds
@@ -1463,8 +1479,6 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0)
         atomicOr(p.flags, 1u);
-    if (fused)
-        lanes_copy_prev(p, ctl, cs, wave, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1605,8 +1619,11 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
             atomicOr(p.flags, 4u);
         return;
     }
-    if (fused && wave >= waves_per_block) { // ---- copier wave
-        lanes_scanner(p, ctl, lane, waves_per_block);
+    if (fused && wave >= waves_per_block) { // ---- the scanner wave and the copier waves
+        if (wave == waves_per_block)
+            lanes_scanner(p, ctl, lane, waves_per_block);
+        else
+            lanes_copier(p, ctl, wave - waves_per_block - 1u, lane, waves_per_block);
         return;
     }
     const uint32_t ringbase = kR64EncTable + wave * kR64EncRing; // LDS byte offset, 8 KiB aligned
@@ -1623,7 +1640,7 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
     const uint32_t slot_lines = (uint32_t)(p.slot_bytes / kLaneLine);
     const uint32_t nblocks = p.chunk_syms >> 6;
     uint32_t worst = 0;
-    LaneCoder cs{0, false, 0, 0, 0};
+    LaneCoder cs{0};
 
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
     for (uint64_t batch_v = p.batch_begin + (uint64_t)blockIdx.x * waves_per_block + wave;; batch_v += total_waves) {
@@ -1717,8 +1734,6 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
     }
     if (__builtin_amdgcn_ballot_w64(worst >= (1u << p.scale_bits)) != 0 && lane == 0)
         atomicOr(p.flags, 1u);
-    if (fused)
-        lanes_copy_prev(p, ctl, cs, wave, lane);
 }
 
 // Lane-per-stream encoder, second generation: symbols arrive as 16-byte per-lane loads
