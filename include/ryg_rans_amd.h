@@ -101,6 +101,10 @@ typedef struct rans_amd_model rans_amd_model; /* immutable after creation */
 /* ---- library / context ------------------------------------------------- */
 
 int rans_amd_version(void);
+/* Bit 0 (RANS_AMD_BUILD_MEASURE): this is the -DRANS_AMD_MEASURE build -- it reads the RANS_AMD_* experiment knobs from
+ * the environment, some of which drop stores or skip copies.  0 for the library that ships: it reads no environment. */
+#define RANS_AMD_BUILD_MEASURE 1u
+unsigned rans_amd_build_flags(void);
 const char *rans_amd_status_string(int status);
 /* Text of the most recent failure on this thread ("" if none). */
 const char *rans_amd_last_error(void);
@@ -114,6 +118,24 @@ int rans_amd_ctx_create(int device, rans_amd_ctx **out_ctx);
 int rans_amd_ctx_destroy(rans_amd_ctx *ctx);
 /* Drop cached device workspaces (encode scratch). */
 int rans_amd_ctx_trim(rans_amd_ctx *ctx);
+
+/* Kernel-family choices of a context.  Every setting produces the same bytes -- the alternatives exist because
+ * they were measured against each other and the tests run all of them; the defaults are the fast
+ * ones.  The library reads no environment variable: this call is the only way to change what it launches.
+ * (Knobs that change what a kernel WRITES -- dropped stores, skipped copies, for the experiments DESIGN.md quotes --
+ * exist only in the separate -DRANS_AMD_MEASURE build, never in this library.) */
+enum rans_amd_option {
+    RANS_AMD_OPT_LANE_KERNELS = 0,         /* narrow interleaves (N = 1, 2, 4, 8): 0 = automatic (default), 1 = the staged
+                                              generation only, 2 = the per-lane register-window generation */
+    RANS_AMD_OPT_LANE_FUSED_PLACEMENT = 1, /* 1 = the lane-per-chunk encoders place their chunks themselves (default 0:
+                                              layout + compaction kernels behind them) */
+    RANS_AMD_OPT_FUSED_PLACEMENT = 2,      /* 0 = wave-per-chunk encoders followed by layout + compaction kernels
+                                              (default 1: the coding kernel places its chunks itself) */
+    RANS_AMD_OPT_DUAL_DECODE = 3           /* 64-way alias decoders: 1 = two chunks per wavefront for the models whose tables
+                                              leave room for one block per CU only (default), 0 = always one chunk per
+                                              wavefront, 2 = two chunks per wavefront whenever the tables fit */
+};
+int rans_amd_ctx_set_option(rans_amd_ctx *ctx, int option, int value);
 
 /* ---- model building (SymbolStats, main.cpp:49-129) ---------------------- */
 
@@ -134,7 +156,8 @@ int rans_amd_normalize_freqs(uint32_t *freqs, uint32_t *cum_freqs, uint32_t nsym
 /* Build every host/device table the given format needs from NORMALISED
  * frequencies (sum == 1<<scale_bits) and upload them.
  *   BYTE : cum2sym[M] + RansDecSymbol/RansEncSymbol per symbol   (scale_bits <= 16)
- *   WORD : RansWordTables slots                                  (scale_bits == 12, nsyms <= 256)
+ *   WORD : RansWordTables slots                                  (scale_bits == 12, nsyms <= 4096; u16 symbols
+ *          beyond 256 -- rans_word_sse41.h:41 fixes 256, the stream format does not depend on the alphabet)
  *   R64  : cum2sym[M] + Rans64Dec/EncSymbol                      (scale_bits 7..16: table decoder; 1..6 and
  *          17..31: no 2^scale_bits table, the kernels search the cumulative frequencies -- same stream, slower)
  *   ALIAS: divider/slot_adjust/slot_freqs/sym_id (+alias_remap)  (nsyms a power of two dividing M)

@@ -549,6 +549,38 @@ int orc_encode_chunked(int fmt, const orc_model *m, const void *syms, size_t n, 
     return rc;
 }
 
+/* Compare the chunks [c0, c1) of somebody else's container with this oracle's own streams for the same symbols:
+ * returns -1 when every chunk has the oracle's length and bytes, the index of the first chunk that differs
+ * otherwise, -2 on a bad argument.  No shared state: ranges may be compared from several threads at once (that is
+ * how the full-size GPU containers -- 32768 chunks of a 1 GiB shard -- are checked chunk by chunk in seconds). */
+int64_t orc_compare_chunks(int fmt, const orc_model *m, const void *syms, size_t n, int sym_bytes, uint32_t n_ways,
+                           size_t chunk_syms, uint64_t c0, uint64_t c1, const uint8_t *container,
+                           const uint64_t *offsets, const uint32_t *lengths)
+{
+    if (chunk_syms == 0 || c0 > c1)
+        return -2;
+    size_t nchunks = (n + chunk_syms - 1) / chunk_syms;
+    if (c1 > nchunks)
+        return -2;
+    size_t bound = orc_stream_bound(fmt, chunk_syms < n ? chunk_syms : n, n_ways);
+    uint8_t *tmp = (uint8_t *)malloc(bound);
+    if (!tmp)
+        return -2;
+    int64_t bad = -1;
+    for (uint64_t c = c0; c < c1; c++) {
+        size_t first = (size_t)c * chunk_syms;
+        size_t cnt = n - first < chunk_syms ? n - first : chunk_syms;
+        size_t len = 0;
+        int rc = orc_encode(fmt, m, (const uint8_t *)syms + first * sym_bytes, cnt, sym_bytes, n_ways, tmp, bound, &len);
+        if (rc || len != lengths[c] || memcmp(tmp + bound - len, container + offsets[c], len) != 0) {
+            bad = (int64_t)c;
+            break;
+        }
+    }
+    free(tmp);
+    return bad;
+}
+
 int orc_decode_chunked(int fmt, const orc_model *m, const uint8_t *container,
                        const uint64_t *offsets, const uint32_t *lengths, size_t n, int sym_bytes,
                        uint32_t n_ways, size_t chunk_syms, void *out)

@@ -90,6 +90,11 @@ int orc_encode_chunked(int fmt, const orc_model *m, const void *syms, size_t n, 
                        uint32_t n_ways, size_t chunk_syms, size_t align,
                        uint8_t *out, size_t cap, uint64_t *offsets, uint32_t *lengths,
                        size_t *out_total);
+/* Chunks [c0, c1) of a container against the oracle's own streams for them: -1 = all equal (length and bytes), else
+ * the first differing chunk; -2 = bad argument.  Thread-safe. */
+int64_t orc_compare_chunks(int fmt, const orc_model *m, const void *syms, size_t n, int sym_bytes, uint32_t n_ways,
+                           size_t chunk_syms, uint64_t c0, uint64_t c1, const uint8_t *container,
+                           const uint64_t *offsets, const uint32_t *lengths);
 int orc_decode_chunked(int fmt, const orc_model *m, const uint8_t *container,
                        const uint64_t *offsets, const uint32_t *lengths, size_t n, int sym_bytes,
                        uint32_t n_ways, size_t chunk_syms, void *out);

@@ -21,6 +21,9 @@ LIB_PATH = os.environ.get("RANS_AMD_LIB") or os.path.join(_HERE, "lib", "libryg_
 FMT_BYTE, FMT_WORD, FMT_R64, FMT_ALIAS = 0, 1, 2, 3
 FORMAT_NAMES = {FMT_BYTE: "byte", FMT_WORD: "word", FMT_R64: "r64", FMT_ALIAS: "alias"}
 
+OPT_LANE_KERNELS, OPT_LANE_FUSED_PLACEMENT, OPT_FUSED_PLACEMENT, OPT_DUAL_DECODE = range(4)
+LANE_KERNELS = {"auto": 0, "staged": 1, "regwin": 2}
+
 OK, E_ARG, E_MODEL, E_SPACE, E_CORRUPT, E_UNSUPPORTED, E_HIP, E_NOMEM = range(8)
 
 (TAB_FREQS, TAB_CUM_FREQS, TAB_CUM2SYM, TAB_WORD_SLOTS, TAB_ALIAS_DIVIDER, TAB_ALIAS_SLOT_ADJUST,
@@ -28,8 +31,8 @@ OK, E_ARG, E_MODEL, E_SPACE, E_CORRUPT, E_UNSUPPORTED, E_HIP, E_NOMEM = range(8)
 
 # every symbol include/ryg_rans_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "rans_amd_version", "rans_amd_status_string", "rans_amd_last_error", "rans_amd_device_count",
-    "rans_amd_ctx_create", "rans_amd_ctx_destroy", "rans_amd_ctx_trim",
+    "rans_amd_version", "rans_amd_build_flags", "rans_amd_status_string", "rans_amd_last_error", "rans_amd_device_count",
+    "rans_amd_ctx_create", "rans_amd_ctx_destroy", "rans_amd_ctx_trim", "rans_amd_ctx_set_option",
     "rans_amd_count_freqs_host", "rans_amd_count_freqs", "rans_amd_normalize_freqs",
     "rans_amd_model_create", "rans_amd_model_destroy", "rans_amd_model_format", "rans_amd_model_scale_bits",
     "rans_amd_model_nsyms", "rans_amd_model_sym_bytes", "rans_amd_model_table",
@@ -82,12 +85,14 @@ def _load():
     u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     sig = {
         "rans_amd_version": (i32, []),
+        "rans_amd_build_flags": (u32, []),
         "rans_amd_status_string": (C.c_char_p, [i32]),
         "rans_amd_last_error": (C.c_char_p, []),
         "rans_amd_device_count": (i32, []),
         "rans_amd_ctx_create": (i32, [i32, C.POINTER(vp)]),
         "rans_amd_ctx_destroy": (i32, [vp]),
         "rans_amd_ctx_trim": (i32, [vp]),
+        "rans_amd_ctx_set_option": (i32, [vp, i32, i32]),
         "rans_amd_count_freqs_host": (i32, [vp, u64, i32, u32, u32p]),
         "rans_amd_count_freqs": (i32, [vp, vp, u64, i32, u32, u32p, vp]),
         "rans_amd_normalize_freqs": (i32, [u32p, u32p, u32, u32]),
@@ -212,6 +217,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, option, value):
+        """rans_amd_ctx_set_option: kernel-family choices (all produce the same bytes)."""
+        _check(_lib.rans_amd_ctx_set_option(self._h, int(option), int(value)), "ctx_set_option")
 
     # -- measurement
     def set_timing(self, on=True):

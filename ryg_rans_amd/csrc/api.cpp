@@ -94,6 +94,8 @@ struct rans_amd_ctx {
     bool timing = false;
     bool dec_timed = false, enc_timed = false;
     uint32_t launch_seq = 0; // selects one of kWorkSlots chunk counters at d_words + 256
+    uint32_t variant = 0;    // kVar* bits (rans_amd_ctx_set_option)
+    bool unfused = false;    // RANS_AMD_OPT_FUSED_PLACEMENT = 0: k_encode + k_layout + k_compact
     const char *last_kernel = "";
     const char *last_enc_kernel = ""; // the coding kernel of the last encode call
     bool last_enc_fused = false;      // ... and whether it placed its chunks itself (no k_layout / k_compact)
@@ -114,7 +116,8 @@ struct rans_amd_model {
     void *d_word_enc = nullptr;
     void *d_remap = nullptr;
     void *d_alias_recs8 = nullptr, *d_alias_remap16 = nullptr; // alias encoder's LDS tables, when they fit
-    uint32_t table0_bytes = 0, table1_bytes = 0;
+    void *d_dual0 = nullptr, *d_dual1 = nullptr; // alias: the tables of the two-chunks-per-wave decoder (FMT_ALIAS2)
+    uint32_t table0_bytes = 0, table1_bytes = 0, dual0_bytes = 0, dual1_bytes = 0;
 };
 
 namespace {
@@ -177,6 +180,8 @@ uint32_t state_bytes(int format) { return format == RANS_AMD_FMT_R64 ? 8u : 4u; 
 extern "C" {
 
 int rans_amd_version(void) { return RANS_AMD_VERSION; }
+
+unsigned rans_amd_build_flags(void) { return kMeasureBuild ? RANS_AMD_BUILD_MEASURE : 0u; }
 
 const char *rans_amd_status_string(int status)
 {
@@ -267,6 +272,8 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx)
     if (!ctx)
         return fail(RANS_AMD_E_ARG, "ctx is NULL");
     DeviceGuard guard(ctx->device);
+    // host_mu before mu: the order the *_host wrappers take them in (they hold host_mu across the nested call)
+    std::lock_guard<std::mutex> host_lock(ctx->host_mu);
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->scratch.release();
     ctx->lengths.release();
@@ -278,6 +285,35 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx)
     ctx->host_idx.release();
     ctx->trace.release();
     return RANS_AMD_OK;
+}
+
+int rans_amd_ctx_set_option(rans_amd_ctx *ctx, int option, int value)
+{
+    if (!ctx)
+        return fail(RANS_AMD_E_ARG, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    switch (option) {
+    case RANS_AMD_OPT_LANE_KERNELS:
+        if (value < 0 || value > 2)
+            return fail(RANS_AMD_E_ARG, "set_option: RANS_AMD_OPT_LANE_KERNELS takes 0 (auto), 1 (staged) or 2 (register window)");
+        ctx->variant &= ~(kVarLanesStaged | kVarLanesRegwin);
+        ctx->variant |= value == 1 ? kVarLanesStaged : value == 2 ? kVarLanesRegwin : 0u;
+        return RANS_AMD_OK;
+    case RANS_AMD_OPT_LANE_FUSED_PLACEMENT:
+        ctx->variant = value ? (ctx->variant | kVarLanesFused) : (ctx->variant & ~kVarLanesFused);
+        return RANS_AMD_OK;
+    case RANS_AMD_OPT_FUSED_PLACEMENT:
+        ctx->unfused = value == 0;
+        return RANS_AMD_OK;
+    case RANS_AMD_OPT_DUAL_DECODE:
+        if (value < 0 || value > 2)
+            return fail(RANS_AMD_E_ARG, "set_option: RANS_AMD_OPT_DUAL_DECODE takes 0 (never), 1 (automatic) or 2 (whenever the tables fit)");
+        ctx->variant &= ~(kVarNoDual | kVarDualAlways);
+        ctx->variant |= value == 0 ? kVarNoDual : value == 2 ? kVarDualAlways : 0u;
+        return RANS_AMD_OK;
+    default:
+        return fail(RANS_AMD_E_ARG, "set_option: unknown option");
+    }
 }
 
 /* ---- model ------------------------------------------------------------ */
@@ -397,6 +433,13 @@ int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_fr
         }
         if (rc == RANS_AMD_OK)
             rc = upload(h.alias_remap.data(), h.alias_remap.size() * 4, &m->d_remap);
+        if (rc == RANS_AMD_OK && !h.alias2_halves.empty()) {
+            m->dual0_bytes = (uint32_t)(h.alias2_halves.size() * sizeof(AliasHalf));
+            m->dual1_bytes = (uint32_t)h.alias2_own.size();
+            rc = upload(h.alias2_halves.data(), m->dual0_bytes, &m->d_dual0);
+            if (rc == RANS_AMD_OK)
+                rc = upload(h.alias2_own.data(), m->dual1_bytes, &m->d_dual1);
+        }
         if (rc == RANS_AMD_OK && !h.alias_remap16.empty()) {
             rc = upload(h.alias_recs8.data(), h.alias_recs8.size() * 8, &m->d_alias_recs8);
             if (rc == RANS_AMD_OK)
@@ -430,7 +473,8 @@ int rans_amd_model_destroy(rans_amd_model *m)
         return RANS_AMD_OK;
     if (m->device >= 0) { // not m->ctx->device: a model may outlive its context
         DeviceGuard guard(m->device);
-        for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_word_enc, m->d_remap, m->d_alias_recs8, m->d_alias_remap16})
+        for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_word_enc, m->d_remap, m->d_alias_recs8, m->d_alias_remap16,
+                        m->d_dual0, m->d_dual1})
             if (p)
                 (void)hipFree(p);
     }
@@ -554,10 +598,10 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     // The wave-per-chunk encoders place and copy their chunks themselves (EncParams::status; encode_wave.hip
     // place_and_copy): no k_layout / k_compact.  The lane-per-chunk encoders (N = 1, 2, 4, 8 with many chunks) and the
     // 160 KiB alias model keep the three-kernel path.
-    // RANS_AMD_ENCODE_UNFUSED=1: A/B knob.
-    static const bool unfused_env = getenv("RANS_AMD_ENCODE_UNFUSED") != nullptr;
-    // RANS_AMD_ALIAS_L2=1: A/B knob, the general alias encoder (alias_remap gathered from L2)
-    static const bool alias_l2 = getenv("RANS_AMD_ALIAS_L2") != nullptr;
+    // (context option RANS_AMD_OPT_FUSED_PLACEMENT = 0 restores the three-kernel path)
+    const bool unfused_env = ctx->unfused;
+    // RANS_AMD_ALIAS_L2=1 (measure build): A/B knob, the general alias encoder (alias_remap gathered from L2)
+    static const bool alias_l2 = measure_knob("RANS_AMD_ALIAS_L2") != nullptr;
     const int enc_format = model->host.r64_search ? kKernelFormatR64Search
                            : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
                            : (format == RANS_AMD_FMT_ALIAS && model->d_alias_remap16 && !alias_l2) ? kKernelFormatAliasLds
@@ -571,10 +615,12 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     ep.slot_bytes = slot;
     ep.nsyms = model->host.nsyms;
     ep.sym_bytes = (uint32_t)model->host.sym_bytes;
+    ep.scale_bits = model->host.scale_bits;
+    ep.variant = ctx->variant;
     const bool lanes = encode_uses_lanes(enc_format, nchunks, n_ways);
-    // RANS_AMD_LANES_FUSED=1 (read at every call): the lane encoders place their chunks themselves as well -- bit-exact,
+    // context option RANS_AMD_OPT_LANE_FUSED_PLACEMENT: the lane encoders place their chunks themselves as well -- bit-exact,
     // tested, and on config 2 no faster than k_layout + k_compact_small behind them (lanes.hip says why), hence opt-in
-    const bool lanes_fused_env = getenv("RANS_AMD_LANES_FUSED") != nullptr;
+    const bool lanes_fused_env = (ctx->variant & kVarLanesFused) != 0;
     const bool fused = nchunks > 0 && nchunks < (1ull << 31) && !unfused_env &&
                        (lanes ? lanes_fused_env && encode_lanes_can_fuse(enc_format, ep, ctx->num_cus)
                               : encode_fused_fits(enc_format, model->host.nsyms, model->host.scale_bits));
@@ -609,7 +655,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         ep.sym_bytes = (uint32_t)model->host.sym_bytes;
         ep.flags = ctx->d_enc_flags();
         {
-            static const char *dbg = getenv("RANS_AMD_ENC_DEBUG");
+            static const char *dbg = measure_knob("RANS_AMD_ENC_DEBUG"); // (measure build only: output wrong by construction)
             ep.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
         }
         if (fused) {
@@ -721,7 +767,7 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         dp.err_count = ctx->d_err();
         // dynamic chunk hand-out: a 4-byte counter zeroed in stream order ahead of the kernel
         // A/B knob (RANS_AMD_STATIC_SCHED=1 restores static striding).
-        static const bool static_sched = getenv("RANS_AMD_STATIC_SCHED") != nullptr;
+        static const bool static_sched = measure_knob("RANS_AMD_STATIC_SCHED") != nullptr;
         // Counters form a ring of 64 slots (all zero at context creation); launch i uses slot
         // i % 64 and re-zeroes slot (i + 32) % 64 from inside the kernel, so no memset node is
         // needed and up to 32 decode launches of one context may be in flight at once.
@@ -735,15 +781,16 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
                 return wrc;
             dp.wave_scratch = static_cast<uint8_t *>(ctx->wave_scratch.ptr);
         }
-        static const char *debug_env = getenv("RANS_AMD_DEBUG"); // measurement knobs, see kernels.h
+        static const char *debug_env = measure_knob("RANS_AMD_DEBUG"); // (measure build only, see kernels.h)
         dp.debug = debug_env ? (uint32_t)strtoul(debug_env, nullptr, 0) : 0u;
+        dp.variant = ctx->variant;
         if (!static_sched && nchunks < 0xffffffffull) {
             unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);
             const uint32_t per_slot = kWorkSlotWords;
             dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * per_slot;
             dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * per_slot;
             // the slot's last line: first wave start / last wave end of the launch (rans_amd_launch_spans)
-            static const bool no_span = getenv("RANS_AMD_NO_SPAN") != nullptr; // A/B: cost of the span record
+            static const bool no_span = measure_knob("RANS_AMD_NO_SPAN") != nullptr; // A/B: cost of the span record
             if (!no_span) {
                 dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
                 dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
@@ -751,7 +798,7 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         }
         // wave clocks (rans_amd_set_timing(ctx, 2)) and the debug timeline (RANS_AMD_TRACE=<file>): per-wave
         // start/end ticks, XCD, shader cycles and rounds, read back after a sync
-        static const char *trace_path = getenv("RANS_AMD_TRACE");
+        static const char *trace_path = measure_knob("RANS_AMD_TRACE");
         const bool want_trace = trace_path || ctx->wave_clocks_on;
         const size_t trace_words = (size_t)kTraceWords * 2u * 16u * (size_t)ctx->num_cus;
         dp.trace = nullptr;
@@ -764,9 +811,31 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         }
         if (ctx->timing)
             HIP_TRY(hipEventRecord(ctx->ev[0], s));
-        const int dec_format = model->host.r64_search ? kKernelFormatR64Search
-                               : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
-                                                                                           : format;
+        int dec_format = model->host.r64_search ? kKernelFormatR64Search
+                         : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
+                                                                                     : format;
+        // 64-way alias streams with at least a pair of chunks: two chunks per wave, tables in the FMT_ALIAS2 form
+        // (decode_dual.hip).  u8 symbols are stored a dword per lane: 4-byte aligned chunks of output.
+        // Only models whose tables leave no room for a second block per CU: with two blocks, eight waves per SIMD and one
+        // chunk each are faster than four with two (decode_dual.hip).
+        const bool one_block_per_cu = 2u * ((size_t)((model->table0_bytes + 15u) & ~15u) + ((model->table1_bytes + 15u) & ~15u) +
+                                            (size_t)(kDecBlockThreads / 64) * kRingStride) > 160u * 1024u;
+        const bool dual_always = (ctx->variant & kVarDualAlways) != 0;
+        if (format == RANS_AMD_FMT_ALIAS && model->d_dual0 && n_ways == 64 && nchunks >= 2 && !(ctx->variant & kVarNoDual) &&
+            (one_block_per_cu || dual_always) && decode_dual_fits(model->dual0_bytes, model->dual1_bytes) && !dp.trace &&
+            ((reinterpret_cast<uintptr_t>(d_out) | ((uintptr_t)chunk_syms * dp.sym_bytes)) & 3u) == 0) {
+            dp.table0 = model->d_dual0;
+            dp.table1 = model->d_dual1;
+            dp.table0_bytes = model->dual0_bytes;
+            dp.table1_bytes = model->dual1_bytes;
+            dec_format = model->host.alias2_wide ? kKernelFormatAlias2W : kKernelFormatAlias2;
+        }
+        // (measure build, RANS_AMD_BYTE_DUAL=1: the byte format through the same kernel -- A/B runs)
+        static const bool byte_dual = measure_knob("RANS_AMD_BYTE_DUAL") != nullptr;
+        if (byte_dual && dec_format == RANS_AMD_FMT_BYTE && n_ways == 64 && nchunks >= 2 && !(ctx->variant & kVarNoDual) &&
+            decode_dual_fits(dp.table0_bytes, dp.table1_bytes) && !dp.trace &&
+            ((reinterpret_cast<uintptr_t>(d_out) | (uintptr_t)chunk_syms) & 3u) == 0)
+            dec_format = kKernelFormatByteDual;
         HIP_TRY(launch_decode(dec_format, dp, ctx->num_cus, s, &ctx->last_kernel));
         // the launch that uses slot i zeroes slot i + 32: move on only once it really is in the stream,
         // or a later launch would start from a counter nobody reset
@@ -855,6 +924,8 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         return fail(RANS_AMD_E_ARG, "encode_adaptive: NULL argument or chunk_syms == 0");
     if (scale_bits < 8 || scale_bits > 12)
         return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive: scale_bits must be 8..12 (a chunk's tables live in one wave's LDS)");
+    if ((reinterpret_cast<uintptr_t>(d_chunk_freqs) & 7u) != 0) // (the kernels read a row with 8-byte loads per lane)
+        return fail(RANS_AMD_E_ARG, "encode_adaptive: d_chunk_freqs must be 8-byte aligned");
     if (!ways_supported(RANS_AMD_FMT_BYTE, n_ways))
         return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive: n_ways must be in 1..512");
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0)
@@ -938,7 +1009,7 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         cp.flags = ctx->d_enc_flags();
         HIP_TRY(launch_compact(cp, ctx->num_cus, s));
     }
-    if (ctx->timing) {
+    if (ctx->timing && nchunks) { // (ev[2] is recorded in front of the coding kernel, which an empty input does not launch)
         HIP_TRY(hipEventRecord(ctx->ev[3], s));
         ctx->enc_timed = true;
     }
@@ -965,6 +1036,8 @@ int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_
         return fail(RANS_AMD_E_ARG, "decode_adaptive: NULL argument or chunk_syms == 0");
     if (scale_bits < 8 || scale_bits > 12)
         return fail(RANS_AMD_E_UNSUPPORTED, "decode_adaptive: scale_bits must be 8..12");
+    if ((reinterpret_cast<uintptr_t>(d_chunk_freqs) & 7u) != 0)
+        return fail(RANS_AMD_E_ARG, "decode_adaptive: d_chunk_freqs must be 8-byte aligned");
     if (!ways_supported(RANS_AMD_FMT_BYTE, n_ways))
         return fail(RANS_AMD_E_UNSUPPORTED, "decode_adaptive: n_ways must be in 1..512");
     if ((reinterpret_cast<uintptr_t>(d_container) & 15u) != 0)

@@ -41,7 +41,16 @@ constexpr int FMT_WORD16 = 6;
 // cum2sym + symbol records of its chunk in its own LDS region from the chunk's 256 normalised frequencies
 // (scale_bits <= 12: 4 KiB + 2 KiB per wave), so the tables are addressed through per-wave pointers.
 constexpr int FMT_BYTEA = 7;
-template <int FMT> constexpr bool kIsByteStream = (FMT == FMT_BYTE || FMT == FMT_ALIAS || FMT == FMT_ALIAS_LDS || FMT == FMT_BYTEA);
+// Internal kernel formats of the two-chunks-per-wave DECODER (decode_dual.hip) for alias models: the half-bucket
+// record is {sym | (M - freq) << 16, adjust} -- the update x' = x - adjust - (M - freq) * (x >> scale_bits) needs
+// neither x mod M nor a mask on the frequency, and the low half IS the symbol a 16-bit store writes -- and the divider
+// is held as the bucket's own-slot count (main_alias.cpp:209 `divider[i] = i * tgt + h0`, here h0 alone), one byte per
+// bucket at LDS address 0 (FMT_ALIAS2, M / nsyms <= 255) or two (FMT_ALIAS2W).
+constexpr int FMT_ALIAS2 = 8;
+constexpr int FMT_ALIAS2W = 9;
+template <int FMT> constexpr bool kIsAlias2 = (FMT == FMT_ALIAS2 || FMT == FMT_ALIAS2W);
+template <int FMT> constexpr bool kIsByteStream = (FMT == FMT_BYTE || FMT == FMT_ALIAS || FMT == FMT_ALIAS_LDS || FMT == FMT_BYTEA ||
+                                                   kIsAlias2<FMT>);
 template <int FMT> constexpr bool kIsWord = (FMT == FMT_WORD || FMT == FMT_WORD16);
 
 // OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
@@ -84,6 +93,8 @@ template <> struct FmtTraits<FMT_R64> {
 template <> struct FmtTraits<FMT_R64S> : FmtTraits<FMT_R64> {};
 template <> struct FmtTraits<FMT_ALIAS_LDS> : FmtTraits<FMT_ALIAS> {};
 template <> struct FmtTraits<FMT_BYTEA> : FmtTraits<FMT_BYTE> {};
+template <> struct FmtTraits<FMT_ALIAS2> : FmtTraits<FMT_ALIAS> {};
+template <> struct FmtTraits<FMT_ALIAS2W> : FmtTraits<FMT_ALIAS> {};
 template <> struct FmtTraits<FMT_WORD16> : FmtTraits<FMT_WORD> {
     static constexpr int kSymByte = 0; // dec_step returns the symbol itself
 };
@@ -152,6 +163,8 @@ template <int FMT> struct DecTables {
     // VGPR copies of mask / scale_bits / bucket_shift: a VALU and/shift with an SGPR operand issues in
     // 4.7 cycles, with VGPR operands in 2.7 (profiles/r01_ubench.log)
     uint32_t maskv, sbv, bshiftv;
+    uint32_t lmaskv;       // alias: (M / nsyms) - 1, the mask of a slot's position inside its bucket
+    uint32_t log2n;        // alias: log2(nsyms)
 
     __device__ __forceinline__ void init(const uint8_t *table0, const uint8_t *table1, uint32_t sb, uint32_t log2nsyms)
     {
@@ -164,6 +177,9 @@ template <int FMT> struct DecTables {
         maskv = mask;
         sbv = sb;
         bshiftv = bucket_shift;
+        log2n = log2nsyms;
+        lmaskv = (1u << (bucket_shift & 31u)) - 1u;
+        asm volatile("v_mov_b32 %0, %0" : "+v"(lmaskv));
         asm volatile("v_mov_b32 %0, %0" : "+v"(mask12v)); // opaque: keep them in VGPRs
         asm volatile("v_mov_b32 %0, %0" : "+v"(maskv));
         asm volatile("v_mov_b32 %0, %0" : "+v"(sbv));
@@ -229,6 +245,22 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s]; // {freq, start}
         x = (uint64_t)r.x * (x >> T.scale_bits) + (cf - r.y);
         return s;
+    } else if constexpr (kIsAlias2<FMT>) {
+        // main_alias.cpp:252-267 with the tables of FMT_ALIAS2: t1 (own-slot counts) sits at LDS address 0.
+        // bucket = xm >> (sb - log2 nsyms) straight from x; "xm < divider[bucket]" is "position in bucket < own count"
+        const uint32_t bucket = __builtin_amdgcn_ubfe(x, T.bucket_shift, T.log2n);
+        uint32_t own;
+        if constexpr (FMT == FMT_ALIAS2)
+            own = lds0_u8(bucket);
+        else
+            own = *reinterpret_cast<RANS_LDS const uint16_t *>((uintptr_t)(bucket * 2u));
+        const uint32_t d = (x & T.lmaskv) - own;                       // negative: the bucket's own symbol (half 2b + 1)
+        const uint32_t half = __builtin_amdgcn_alignbit(bucket, d, 31); // 2 * bucket + (d >> 31)
+        const uint2 e = reinterpret_cast<const uint2 *>(T.t0)[half];   // {sym | (M - freq) << 16, adjust}
+        // freq * (x >> sb) + xm - adjust with xm = x - (x >> sb) * M: x - adjust - (M - freq) * (x >> sb); M - freq is a
+        // 16-bit value (freq >= 1 for every half a state can select) and x >> sb < 2^23: one 24-bit multiply
+        x = x - e.y - __umul24(e.x >> 16, x >> T.sbv);
+        return e.x;
     } else {
         // main_alias.cpp:252-267; the subtraction wraps in 32 bits on purpose
         const uint32_t xm = x & T.maskv;

@@ -16,20 +16,30 @@ bool ways_supported(int format, uint32_t n_ways)
 // one chunk per wave
 hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name)
 {
+    if (format == kKernelFormatAlias2 || format == kKernelFormatAlias2W) // (api.cpp has checked the shape)
+        return launch_decode_dual(format, p, num_cus, stream, kernel_name);
+    if (format == kKernelFormatByteDual)
+        return launch_decode_dual((int)RANS_AMD_FMT_BYTE, p, num_cus, stream, kernel_name);
     if (format != kKernelFormatR64Search && format != kKernelFormatWord16 && format != kKernelFormatByteAdaptive &&
         lanes_applicable(p.nchunks, p.n_ways))
         return launch_decode_lanes(format, p, num_cus, stream, kernel_name);
     return launch_decode_wave(format, p, num_cus, stream, kernel_name);
 }
 
-// fused placement needs a mailbox behind the tables in LDS: the alias tables of a 16-bit model over 4096 symbols
-// fill the CU's 160 KiB to the last byte (config 4 keeps the three-kernel path)
+// fused placement needs a mailbox behind the tables in LDS (encode_wave.hip launch_encode_t computes the same sizes and
+// rejects what does not fit): the alias tables of a 16-bit model over 4096 symbols fill the CU's 160 KiB to the last
+// byte (config 4 keeps the three-kernel path), and so do 16-byte records for 8192 symbols against the 128 KiB the
+// other kernels may use -- those shapes take k_encode + k_layout + k_compact.
 bool encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits)
 {
-    if (format != kKernelFormatAliasLds)
-        return true;
     const size_t nrecs = nsyms < 256 ? 256 : nsyms;
-    return nrecs * 8 + ((size_t)2 << scale_bits) + 16 + kEncMailboxBytes <= 160 * 1024;
+    if (format == kKernelFormatAliasLds)
+        return nrecs * 8 + ((size_t)2 << scale_bits) + 16 + kEncMailboxBytes <= 160 * 1024;
+    if (format == kKernelFormatByteAdaptive) // (per-wave tables; never fused, see api.cpp)
+        return false;
+    const bool word_recs = format == (int)RANS_AMD_FMT_WORD || format == (int)RANS_AMD_FMT_BYTE;
+    const size_t tables = nrecs * 16 + (word_recs ? 256 * 16 : 0);
+    return ((tables + 15) & ~(size_t)15) + kEncMailboxBytes <= 128 * 1024;
 }
 
 // true when launch_encode hands this shape to the lane-per-chunk encoders (no fused placement there)

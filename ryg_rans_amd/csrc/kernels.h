@@ -3,10 +3,31 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
 namespace rans_amd {
+
+// Measurement knobs.  The shipped library reads NO environment variable: every A/B switch and every knob that changes
+// what a kernel writes (dropped stores, skipped copies -- the experiments DESIGN.md quotes) exists only in the
+// -DRANS_AMD_MEASURE build (`make measure` -> libryg_rans_amd_measure.so, loaded through RANS_AMD_LIB by the tools).
+// Alternatives that produce the same bytes and that the tests exercise are context options (rans_amd_ctx_set_option).
+#ifdef RANS_AMD_MEASURE
+constexpr bool kMeasureBuild = true;
+inline const char *measure_knob(const char *name) { return getenv(name); }
+#else
+constexpr bool kMeasureBuild = false;
+inline const char *measure_knob(const char *) { return nullptr; }
+#endif
+
+// DecParams::variant / EncParams::variant: kernel-family choices of the context (rans_amd_ctx_set_option)
+constexpr uint32_t kVarLanesStaged = 1u;   // lane-per-chunk kernels: the staged generation only
+constexpr uint32_t kVarLanesRegwin = 2u;   // ... the first generation (per-lane register window)
+constexpr uint32_t kVarLanesFused = 4u;    // lane-per-chunk encoders place their chunks themselves
+constexpr uint32_t kVarNoDual = 8u;        // alias decoders: always one chunk per wave (k_decode)
+constexpr uint32_t kVarDualAlways = 16u;   // ... two chunks per wave (k_decode_dual) whenever the tables fit, not only when
+                                           //     they leave no room for a second block per CU
 
 // Per-wave LDS stream window (see decode_wave.hip "stream window").
 constexpr uint32_t kRingBytes = 2048;   // two 1 KiB blocks
@@ -34,6 +55,12 @@ constexpr int kKernelFormatWord16 = 6;
 // Kernel-side format number of the byte-format DECODER with one model per chunk (device_common.hpp FMT_BYTEA):
 // DecParams::chunk_freqs holds u16[256] per chunk; no table0/table1.
 constexpr int kKernelFormatByteAdaptive = 7;
+// Kernel-side format numbers of the two-chunks-per-wave alias DECODER (device_common.hpp FMT_ALIAS2 / FMT_ALIAS2W):
+// DecParams::table0 = {sym | (M - freq) << 16, adjust} per half bucket, table1 = own-slot count per bucket (u8 / u16).
+constexpr int kKernelFormatAlias2 = 8;
+constexpr int kKernelFormatAlias2W = 9;
+// The byte format (tables as for RANS_AMD_FMT_BYTE) through the two-chunks-per-wave decoder.
+constexpr int kKernelFormatByteDual = 10;
 constexpr uint32_t kTraceWords = 5;      // per-wave record of DecParams::trace
 
 struct DecParams {
@@ -58,8 +85,9 @@ struct DecParams {
     unsigned int *work_counter_reset; // a counter slot of a LATER launch that this launch zeroes
     const uint16_t *chunk_freqs;      // FMT_BYTEA: normalised frequencies, u16[256] per chunk (else NULL)
     uint8_t *wave_scratch;            // one 64-byte line per resident wave (marker stores of the window refills), or NULL
-    uint32_t debug;                   // measurement knobs (RANS_AMD_DEBUG): bit 0 = drop the symbol stores of the
-                                      // 64-way word decoders (their descriptor gets zero records)
+    uint32_t debug;                   // RANS_AMD_MEASURE builds only (RANS_AMD_DEBUG): bit 0 = drop the symbol stores of
+                                      // the 64-way word decoders (their descriptor gets zero records); else 0
+    uint32_t variant;                 // kVar* bits
     unsigned long long *span;         // this launch's {max of ~(wave start), max of wave end} in 100 MHz ticks, or NULL
     unsigned long long *span_reset;   // the span record of a LATER launch that this launch zeroes
     unsigned long long *trace;        // wave clocks: per wave kTraceWords words {start, end (100 MHz ticks), xcc,
@@ -103,7 +131,8 @@ struct EncParams {
     // after it share one status array, in stream order.
     uint64_t batch_begin, batch_end, unit_base; // set by the launcher
     uint32_t claim_slot;
-    uint32_t debug;             // measurement knobs (RANS_AMD_ENC_DEBUG): bit 0 = the lane encoders' fused placement skips the copy
+    uint32_t variant;           // kVar* bits
+    uint32_t debug;             // RANS_AMD_MEASURE builds only (RANS_AMD_ENC_DEBUG): bit 0 = the lane encoders' fused placement skips the copy
                                 //   itself, bit 1 = ... does not wait for a batch's place (uses 0); output is wrong by construction
 };
 #ifndef RANS_FUSED_THREADS
@@ -138,6 +167,7 @@ struct CompactParams {
 // All launchers return hipSuccess or the launch error; they never synchronise.
 hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name);
 hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **kernel_names);
+bool decode_dual_fits(uint32_t table0_bytes, uint32_t table1_bytes); // LDS room for two stream windows per wave (decode_dual.hip)
 bool encode_uses_lanes(int format, uint64_t nchunks, uint32_t n_ways);
 bool encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits);
 bool encode_lanes_can_fuse(int format, const EncParams &p, int num_cus); // lane-per-chunk encoders: see launchers.hpp

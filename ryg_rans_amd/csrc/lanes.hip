@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
                 r[j] = req[16 * j + grp]; // LDS ops of one wave execute in order: sees the writes above
                 v[j] = u32x4{0u, 0u, 0u, 0u};
                 uint64_t a = cbase + rb + (r[j] & ~(kLaneLine - 1u)) + part * 16u;
-                if (p.debug & 2u) // measurement only: every refill hits the same (cached) line
+                if (kMeasureBuild && (p.debug & 2u)) // measurement only: every refill hits the same (cached) line
                     a = cbase + part * 16u;
                 if ((r[j] & 1u) && a < glimit)
                     v[j] = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(a));
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
                     q3 = decode16();
                 // (every valid lane has its 64 symbols here; lanes without a chunk carry zeros)
                 quad_transpose(q0, q1, q2, q3, lane);
-                const uint32_t o = (p.debug & 4u) ? (i0 & 64u) : i0;
+                const uint32_t o = (kMeasureBuild && (p.debug & 4u)) ? (i0 & 64u) : i0;
                 if (vq[0])
                     *reinterpret_cast<u32x4 RANS_GLOBAL *>(at[0] + o) = q0;
                 if (vq[1])
@@ -1144,7 +1144,7 @@ __device__ __forceinline__ void lanes_copy_batch(const EncParams &p, uint64_t ba
         const uint32_t o = (uint32_t)__shfl_xor((int)most, d, 64);
         most = o > most ? o : most;
     }
-    most = (p.debug & 1u) ? 0u : uniform(most);
+    most = (kMeasureBuild && (p.debug & 1u)) ? 0u : uniform(most);
     for (uint32_t i0 = 0; i0 < most; i0 += 4u * kLaneCopyDepth) {
         u32x4 v[4][kLaneCopyDepth];
 #pragma unroll
@@ -1818,22 +1818,19 @@ __global__ void __launch_bounds__(256) k_encode_lanes16(const EncParams p)
         atomicOr(p.flags, 1u);
 }
 
-// RANS_AMD_LANES=staged | regwin: pin the lane-per-stream kernel generation (tests, A/B runs); read at
-// every launch so one process can exercise both
-static int lanes_force()
+// Context option RANS_AMD_OPT_LANE_KERNELS (kVarLanesStaged / kVarLanesRegwin in Params::variant): pin the
+// lane-per-stream kernel generation (tests run both; every generation writes the same bytes)
+static int lanes_force(uint32_t variant)
 {
-    const char *e = getenv("RANS_AMD_LANES");
-    if (!e)
-        return 0;
-    return e[0] == 's' ? 1 : (e[0] == 'r' ? -1 : 0);
+    return (variant & kVarLanesStaged) ? 1 : ((variant & kVarLanesRegwin) ? -1 : 0);
 }
 
 template <int FMT, int NW>
 hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
     const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
-    // RANS_AMD_LANES=regwin: the per-lane register window this kernel replaced (>= 4x over-fetch)
-    const int force = lanes_force();
+    // kVarLanesRegwin: the per-lane register window this kernel replaced (>= 4x over-fetch)
+    const int force = lanes_force(p.variant);
     const bool reg_window = force < 0;
     // staged kernel: the tables are shared by the block, every wave adds kLaneWaveLds of rings, so one
     // large block per CU keeps the most waves resident (rans64, 14 bits: 15 waves; 4-wave blocks: 12)
@@ -1856,7 +1853,7 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
     if constexpr (FMT == FMT_R64 && NW == 2) {
         // third generation for the reference's own 2-way rans64 layout (config 2): full 64-symbol trips only; a ragged
         // last chunk is decoded by the staged kernel in a second launch
-        static const bool off = getenv("RANS_AMD_NO_R64X2") != nullptr;
+        static const bool off = measure_knob("RANS_AMD_NO_R64X2") != nullptr;
         const bool aligned = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 63u) == 0 &&
                              (reinterpret_cast<uintptr_t>(p.container) & 15u) == 0;
         if (!off && force == 0 && staged && aligned && p.nchunks >= 64 && !p.trace) {
@@ -1932,7 +1929,7 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
 static uint32_t encode_lanes_staged_waves(const EncParams &p, int num_cus, uint64_t min_batches_per_cu = 6)
 {
     const size_t table_lds = (size_t)p.nsyms * sizeof(EncRec);
-    const int force = lanes_force();
+    const int force = lanes_force(p.variant);
     // (room for the scanner wave and the control words of the fused placement, whether or not this launch uses them)
     const size_t fixed_lds = table_lds + 16 + kEncMailboxBytes;
     uint32_t sw = fixed_lds + kEncWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - fixed_lds) / kEncWaveLds) : 0;
@@ -1970,9 +1967,9 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p_i
         if constexpr (FMT == FMT_R64 && NW == 2) {
             // the reference's 2-way rans64 layout (config 2) on its own kernel: whole batches of full chunks; what is
             // left (fewer than 64 chunks, the last one perhaps ragged) goes through the staged kernel below
-            static const bool off = getenv("RANS_AMD_NO_R64X2_ENC") != nullptr;
+            static const bool off = measure_knob("RANS_AMD_NO_R64X2_ENC") != nullptr;
             const uint64_t full_batches = (p.n / p.chunk_syms) / 64;
-            if (!off && lanes_force() == 0 && (p.chunk_syms & 63u) == 0 && p.scale_bits >= 7 && p.scale_bits <= 16 &&
+            if (!off && lanes_force(p.variant) == 0 && (p.chunk_syms & 63u) == 0 && p.scale_bits >= 7 && p.scale_bits <= 16 &&
                 p.nsyms <= 256 && full_batches >= (uint64_t)num_cus) {
                 // 8 KiB of table + 8 KiB of ring per coding wave (+ the scanner wave and its LDS words when it places the chunks)
                 uint32_t sw3 = p.status ? 16 - kLaneCopiers : 16;

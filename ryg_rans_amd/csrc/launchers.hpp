@@ -37,6 +37,9 @@ inline hipError_t allow_large_lds(const void *kernel, int bytes, std::atomic<uin
 hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name);
 hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **name);
 
+// two chunks per wave, 64-way, byte-stream formats (decode_dual.hip); format: kKernelFormatAlias2[W] or RANS_AMD_FMT_BYTE
+hipError_t launch_decode_dual(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name);
+
 // lane-per-stream kernels (N = 1, 2, 4, 8 with at least kLaneKernelMinChunks chunks): lanes.hip
 constexpr uint64_t kLaneKernelMinChunks = 64;
 inline bool lanes_applicable(uint64_t nchunks, uint32_t n_ways)

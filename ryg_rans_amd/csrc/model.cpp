@@ -375,14 +375,40 @@ int HostModel::build_alias()
     alias_recs8.clear();
     alias_remap16.clear();
     const size_t nrecs = ns < 256 ? 256 : ns;
+    // decoder tables of the two-chunks-per-wave kernel
+    alias2_halves.clear();
+    alias2_own.clear();
+    alias2_wide = tgt > 255;
+    bool fits16 = ns >= 2 && tgt <= 0xffffu;
+    for (uint32_t f : slot_freqs)
+        fits16 = fits16 && f <= 0xffffu;
+    if (fits16) {
+        alias2_halves.resize(2 * (size_t)ns);
+        for (size_t h = 0; h < alias2_halves.size(); ++h) // (M - 0 = 65536 for a half no state can select: any value)
+            alias2_halves[h] = AliasHalf{sym_id[h] | (((M - slot_freqs[h]) & 0xffffu) << 16), slot_adjust[h]};
+        alias2_own.assign(alias2_wide ? 2 * (size_t)ns : (size_t)ns, 0);
+        for (uint32_t b = 0; b < ns; ++b) {
+            const uint32_t own = divider[b] - b * tgt;
+            if (alias2_wide) {
+                alias2_own[2 * (size_t)b] = (uint8_t)own;
+                alias2_own[2 * (size_t)b + 1] = (uint8_t)(own >> 8);
+            } else {
+                alias2_own[b] = (uint8_t)own;
+            }
+        }
+    }
+    // (only symbols the encoder can meet constrain the record width: an unused symbol at the end of a 16-bit
+    //  alphabet has cum == 65536 and a record nobody reads)
     bool narrow = true;
     for (uint32_t s = 0; s < ns; ++s)
-        narrow = narrow && freqs[s] <= 0xffffu && cum[s] <= 0xffffu;
+        narrow = narrow && (freqs[s] == 0 || (freqs[s] <= 0xffffu && cum[s] <= 0xffffu));
     if (narrow && nrecs * 8 + ((size_t)2 << scale_bits) <= 160 * 1024) {
         alias_recs8.assign(nrecs, 0);
         for (uint32_t s = 0; s < ns; ++s) {
             const uint32_t f = freqs[s];
             const uint32_t rcp = f <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / f);
+            if (f == 0)
+                continue; // zero record
             alias_recs8[s] = (uint64_t)(f | (cum[s] << 16)) | ((uint64_t)rcp << 32);
         }
         alias_remap16.resize(alias_remap.size());

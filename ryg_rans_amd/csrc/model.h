@@ -119,6 +119,13 @@ struct HostModel {
     // {freq | start << 16, floor(2^32 / freq)} per symbol (zero records up to 256) and alias_remap as u16
     std::vector<uint64_t> alias_recs8;
     std::vector<uint16_t> alias_remap16;
+    // FMT_ALIAS, decoder tables of the two-chunks-per-wave kernel (device_common.hpp FMT_ALIAS2): per half bucket
+    // {sym | (M - freq) << 16, adjust}; per bucket the number of slots its own symbol keeps -- divider[b] - b * tgt,
+    // main_alias.cpp:209 -- as u8 (tgt <= 255) or, alias2_wide, as u16.  Empty when the model cannot take that
+    // form (a single bucket, or a 65536-wide symbol).
+    std::vector<AliasHalf> alias2_halves;
+    std::vector<uint8_t> alias2_own;
+    bool alias2_wide = false;
 
     // Returns a rans_amd_status.
     int build(int format, const uint32_t *norm_freqs, uint32_t nsyms, uint32_t scale_bits);

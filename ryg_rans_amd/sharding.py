@@ -35,12 +35,13 @@ class ShardRecord:
         return [self.elapsed_s, self.symbols, self.stream_bytes, self.kernel_ms, self.ok]
 
 
-def gather_records(rec, device="cpu"):
-    """all_gather of one ShardRecord per rank (5 doubles = 40 bytes each)."""
+def gather_records(rec, device="cpu", force=False):
+    """all_gather of one ShardRecord per rank (5 doubles = 40 bytes each).  force: run the collective in a one-rank
+    group as well (bench.py --force-dist: the RCCL call path of the N-GPU run on one GPU)."""
     import torch
     import torch.distributed as dist
     t = torch.tensor(rec.to_list(), dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, t)
         rows = torch.stack(parts).cpu().tolist()

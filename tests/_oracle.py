@@ -88,6 +88,9 @@ class Oracle:
                                            C.POINTER(C.c_size_t)]
         lib.orc_decode_chunked.argtypes = [C.c_int, C.POINTER(OrcModel), u8p, u64p, u32p, C.c_size_t, C.c_int,
                                            C.c_uint32, C.c_size_t, C.c_void_p]
+        lib.orc_compare_chunks.argtypes = [C.c_int, C.POINTER(OrcModel), C.c_void_p, C.c_size_t, C.c_int, C.c_uint32,
+                                           C.c_size_t, C.c_uint64, C.c_uint64, u8p, u64p, u32p]
+        lib.orc_compare_chunks.restype = C.c_int64
         lib.orc_gen_zipf.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_double, C.c_uint64]
         lib.orc_gen_zipf.restype = None
         self.lib = lib
@@ -164,6 +167,65 @@ class Oracle:
         if rc:
             raise ValueError("orc_decode_chunked rc=%d" % rc)
         return out
+
+    # ---- whole containers, threaded over the host cores (ctypes releases the GIL; the C functions share nothing)
+    @staticmethod
+    def host_threads(limit=64):
+        try:
+            return max(1, min(limit, len(os.sched_getaffinity(0))))
+        except AttributeError:
+            return max(1, min(limit, os.cpu_count() or 1))
+
+    def compare_container(self, fmt, model, syms, n_ways, chunk_syms, container, offs, lens, threads=None):
+        """EVERY chunk of `container` (index offs / lens) against this oracle's stream for the same symbols.
+        Returns (chunks compared, index of the first differing chunk or -1)."""
+        from concurrent.futures import ThreadPoolExecutor
+        syms = np.ascontiguousarray(syms)
+        container = np.ascontiguousarray(container, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = syms.size
+        nchunks = (n + chunk_syms - 1) // chunk_syms
+        assert lens.size >= nchunks and offs.size >= nchunks
+        assert nchunks == 0 or int(offs[nchunks - 1]) + int(lens[nchunks - 1]) <= container.size
+        threads = threads or self.host_threads()
+        per = max(1, (nchunks + threads * 4 - 1) // (threads * 4))
+        ranges = [(c, min(nchunks, c + per)) for c in range(0, nchunks, per)]
+
+        def run(rg):
+            return int(self.lib.orc_compare_chunks(fmt, model.ptr, _ptr(syms), n, syms.dtype.itemsize, n_ways, chunk_syms,
+                                                   rg[0], rg[1], _ptr(container, u8p), _ptr(offs, u64p), _ptr(lens, u32p)))
+        with ThreadPoolExecutor(threads) as ex:
+            res = [r for r in ex.map(run, ranges) if r != -1]
+        return nchunks, (min(res) if res else -1)
+
+    def encode_chunked_mt(self, fmt, model, syms, n_ways, chunk_syms, align=16, threads=None):
+        """encode_chunked over ranges of whole chunks in parallel, stitched: the same container, offsets and lengths."""
+        from concurrent.futures import ThreadPoolExecutor
+        syms = np.ascontiguousarray(syms)
+        n = syms.size
+        nchunks = (n + chunk_syms - 1) // chunk_syms
+        threads = threads or self.host_threads()
+        per = max(1, (nchunks + threads * 2 - 1) // (threads * 2))
+        starts = list(range(0, nchunks, per))
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(lambda c: self.encode_chunked(fmt, model, syms[c * chunk_syms:(c + per) * chunk_syms],
+                                                              n_ways, chunk_syms, align), starts))
+        offs = np.zeros(nchunks + 1, dtype=np.uint64)
+        lens = np.zeros(nchunks, dtype=np.uint32)
+        pos = 0
+        bases = []
+        for c, (cont, o, ln) in zip(starts, parts):
+            pos = (pos + align - 1) // align * align
+            bases.append(pos)
+            offs[c:c + ln.size] = o[:ln.size] + np.uint64(pos)
+            lens[c:c + ln.size] = ln
+            pos += cont.size
+        offs[nchunks] = pos
+        out = np.zeros(pos, dtype=np.uint8)
+        for b, (cont, _, _) in zip(bases, parts):
+            out[b:b + cont.size] = cont
+        return out, offs, lens
 
     def gen_zipf(self, n, K=256, s=1.0, seed=1):
         dtype = np.uint8 if K <= 256 else np.uint16

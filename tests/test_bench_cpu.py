@@ -40,8 +40,8 @@ def test_book1_fixture_decodes_to_the_corpus(oracle):
 
 
 def test_index_check_rejects_a_wrong_index(oracle):
-    """bench.oracle_check_chunks: the sampled-chunk comparison really compares (a flipped byte or a shifted
-    offset fails it)."""
+    """bench.oracle_check_chunks really compares: every chunk by default (threaded orc_compare_chunks), a sample on
+    request; a flipped byte in ANY chunk or a shifted offset fails it."""
     import pytest
     import torch
 
@@ -55,16 +55,41 @@ def test_index_check_rejects_a_wrong_index(oracle):
            "d_syms": torch.from_numpy(data), "cont": torch.from_numpy(cont.copy()),
            "offs": torch.from_numpy(offs.astype(np.int64)), "lens": torch.from_numpy(lens.astype(np.int32)),
            "total": int(cont.size)}
-    assert bench.oracle_check_chunks(art, want=8) >= 5
+    assert bench.oracle_check_chunks(art) == len(lens)
+    assert bench.oracle_check_chunks(art, sample=8) >= 5
+    for chunk in range(len(lens)):  # the full comparison sees a flipped bit wherever it is
+        bad = dict(art)
+        c = cont.copy()
+        c[int(offs[chunk]) + int(lens[chunk]) - 1] ^= 1
+        bad["cont"] = torch.from_numpy(c)
+        with pytest.raises(AssertionError):
+            bench.oracle_check_chunks(bad)
     bad = dict(art)
     c = cont.copy()
     c[int(offs[0]) + 300] ^= 1
     bad["cont"] = torch.from_numpy(c)
     with pytest.raises(AssertionError):
-        bench.oracle_check_chunks(bad, want=8)
+        bench.oracle_check_chunks(bad, sample=8)
     bad = dict(art)
     o = offs.astype(np.int64).copy()
     o[3] += 16
     bad["offs"] = torch.from_numpy(o)
     with pytest.raises(AssertionError):
-        bench.oracle_check_chunks(bad, want=8)
+        bench.oracle_check_chunks(bad)
+
+
+def test_threaded_oracle_container_equals_the_serial_one(oracle):
+    """Oracle.encode_chunked_mt (ranges of whole chunks in parallel, stitched) == encode_chunked, and
+    compare_container reports the first differing chunk."""
+    from _oracle import FMT_ALIAS, FMT_R64, FMT_WORD
+    data = oracle.gen_zipf(300001, K=256, s=1.0, seed=5)
+    for fmt, sb, ways, chunk in ((FMT_WORD, 12, 64, 4096), (FMT_R64, 14, 2, 512), (FMT_ALIAS, 16, 64, 1000)):
+        om = oracle.model_for(data, 256, sb, with_alias=(fmt == FMT_ALIAS))
+        cont, offs, lens = oracle.encode_chunked(fmt, om, data, ways, chunk, align=16)
+        c2, o2, l2 = oracle.encode_chunked_mt(fmt, om, data, ways, chunk, align=16, threads=3)
+        assert np.array_equal(cont, c2) and np.array_equal(offs, o2) and np.array_equal(lens, l2)
+        assert oracle.compare_container(fmt, om, data, ways, chunk, cont, offs, lens, threads=3) == (len(lens), -1)
+        c3 = cont.copy()
+        c3[int(offs[17]) + 5] ^= 0x80
+        c3[int(offs[40]) + 5] ^= 0x80
+        assert oracle.compare_container(fmt, om, data, ways, chunk, c3, offs, lens, threads=3) == (len(lens), 17)

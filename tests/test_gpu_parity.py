@@ -394,16 +394,15 @@ def test_many_chunks_layout(gpu, oracle):
 
 
 @pytest.mark.parametrize("generation", ["staged", "regwin", "staged+fused"])
-def test_lane_kernels_both_generations(gpu, oracle, generation, monkeypatch):
+def test_lane_kernels_both_generations(gpu, oracle, generation):
     """Narrow interleaves (N = 1, 2, 4, 8): the wave-cooperative staged kernels and the per-lane
-    register-window kernels they replaced, pinned through RANS_AMD_LANES, every format, ragged last
-    chunk, chunk sizes that are and are not multiples of 16 / 64, against the oracle byte for byte."""
-    R, ctx, torch = gpu
-    monkeypatch.setenv("RANS_AMD_LANES", generation.split("+")[0])
-    if generation.endswith("+fused"):  # the staged encoders placing their chunks themselves (no k_layout / k_compact_small)
-        monkeypatch.setenv("RANS_AMD_LANES_FUSED", "1")
-    else:
-        monkeypatch.delenv("RANS_AMD_LANES_FUSED", raising=False)
+    register-window kernels they replaced, pinned through the context option RANS_AMD_OPT_LANE_KERNELS, every format,
+    ragged last chunk, chunk sizes that are and are not multiples of 16 / 64, against the oracle byte for byte."""
+    R, _, torch = gpu
+    ctx = R.Context(0)  # (its own context: the options must not leak into the other tests)
+    ctx.set_option(R.OPT_LANE_KERNELS, R.LANE_KERNELS[generation.split("+")[0]])
+    # "+fused": the staged encoders placing their chunks themselves (no k_layout / k_compact_small)
+    ctx.set_option(R.OPT_LANE_FUSED_PLACEMENT, int(generation.endswith("+fused")))
     data = oracle.gen_zipf(200000 + 37, K=256, s=1.0, seed=17)
     d_syms = torch.from_numpy(data).cuda()
     for fmt, sb in FORMATS:
@@ -750,18 +749,16 @@ def test_rans64_two_way_lane_kernel(gpu, oracle):
 
 
 @pytest.mark.parametrize("placement", ["kernels", "fused"])
-def test_rans64_two_way_lane_encoder(gpu, oracle, placement, monkeypatch):
+def test_rans64_two_way_lane_encoder(gpu, oracle, placement):
     """BASELINE config 2's encoder: k_encode_lanes_r64x2 (whole batches of 64 full chunks) + the staged kernel for the
     rest, with k_layout / k_compact_small behind them (the default) and placing their chunks themselves
-    (RANS_AMD_LANES_FUSED: scanner wave per block, decoupled look-back over the blocks' rounds): every chunk, the
+    (RANS_AMD_OPT_LANE_FUSED_PLACEMENT: scanner wave per block, decoupled look-back over the blocks' rounds): every chunk, the
     index and the total against the oracle, for scale_bits at both ends of the cum2sym range, a ragged tail, models
     with frequency-1 symbols and a single-symbol model; a symbol outside the model is reported."""
-    R, ctx, torch = gpu
-    if placement == "fused":
-        monkeypatch.setenv("RANS_AMD_LANES_FUSED", "1")
-    else:
-        monkeypatch.delenv("RANS_AMD_LANES_FUSED", raising=False)
+    R, _, torch = gpu
     fused = placement == "fused"
+    ctx = R.Context(0)
+    ctx.set_option(R.OPT_LANE_FUSED_PLACEMENT, int(fused))
     rng = np.random.default_rng(11)
     n = 1600 * 64 * 64 + 64 * 33 + 17  # 1600 full batches of 64-symbol chunks, 33 full chunks and a ragged one behind
     zipf = oracle.gen_zipf(n, K=256, s=1.0, seed=29)
@@ -810,3 +807,85 @@ def test_rans64_two_way_lane_encoder(gpu, oracle, placement, monkeypatch):
     with pytest.raises(R.RansAmdError) as e:
         ctx.encode(gm, torch.from_numpy(bad).cuda(), 2, 64)
     assert e.value.status == R.E_MODEL
+
+
+def _decode_oracle_container(R, ctx, torch, gm, want, offs, lens, n, n_ways, chunk, sync=True):
+    d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
+    return ctx.decode(gm, d_cont, want.size, torch.from_numpy(offs.astype(np.int64)).cuda(),
+                      torch.from_numpy(lens.astype(np.int32)).cuda(), n, n_ways, chunk, sync=sync)
+
+
+def test_dual_chunk_alias_decoder(gpu, oracle):
+    """SURVEY 8(f)4, "two chunks per wave" (the reference's own trick, main_simd.cpp:313-325): k_decode_dual takes 64-way
+    alias containers of at least two chunks.  ORACLE-made containers over 4096 symbols (config 4: u16 symbols, own-slot
+    counts as bytes), 256 symbols at 16 bits (bucket width 256: counts as u16) and small alphabets, with an even and an
+    odd number of chunks, a ragged last chunk, chunk sizes that do and do not fill whole groups of rounds -- decoded by
+    the dual kernel and, with the context option off, by the one-chunk-per-wave kernel; both must give the input.
+    Damaged streams and index entries are counted, chunk by chunk, and never decoded out of bounds."""
+    R, _, torch = gpu
+    ctx = R.Context(0)
+    cases = [(4096, 16, 8192, 8192 * 7 + 4097), (4096, 16, 2048, 2048 * 10), (4096, 12, 1024, 1024 * 9 + 1),
+             (256, 16, 4096, 4096 * 12 + 77), (256, 12, 512, 512 * 33), (16, 8, 256, 256 * 5 + 255), (2, 9, 768, 768 * 4),
+             (4096, 16, 8192 + 64, (8192 + 64) * 4), (256, 14, 4096, 4096 * 2)]
+    for K, sb, chunk, n in cases:
+        data = oracle.gen_zipf(n, K=K, s=1.0, seed=K + sb)
+        view = data if K <= 256 else data.view(np.int16)
+        om, gm = _models(R, ctx, oracle, FMT_ALIAS, sb, data, nsyms=K)
+        want, offs, lens = oracle.encode_chunked(FMT_ALIAS, om, data, 64, chunk, align=16)
+        ctx.set_option(R.OPT_DUAL_DECODE, 1)  # automatic: the dual kernel where the tables allow one block per CU only
+        out = _decode_oracle_container(R, ctx, torch, gm, want, offs, lens, n, 64, chunk)
+        assert ctx.last_decode_kernel() == ("k_decode_dual<alias>" if K >= 4096 else "k_decode<alias>"), (K, sb, chunk)
+        assert np.array_equal(out.cpu().numpy(), view), (K, sb, chunk)
+        ctx.set_option(R.OPT_DUAL_DECODE, 0)
+        out = _decode_oracle_container(R, ctx, torch, gm, want, offs, lens, n, 64, chunk)
+        assert ctx.last_decode_kernel() == "k_decode<alias>", (K, sb, chunk)
+        assert np.array_equal(out.cpu().numpy(), view), (K, sb, chunk)
+        ctx.set_option(R.OPT_DUAL_DECODE, 2)  # whenever the tables fit: every model of this test
+        out = _decode_oracle_container(R, ctx, torch, gm, want, offs, lens, n, 64, chunk)
+        assert ctx.last_decode_kernel() == "k_decode_dual<alias>", (K, sb, chunk)
+        assert np.array_equal(out.cpu().numpy(), view), (K, sb, chunk)
+        # the GPU encoder's container through the dual decoder as well
+        cont, d_offs, d_lens, total = ctx.encode(gm, torch.from_numpy(view).cuda(), 64, chunk)
+        assert total == want.size
+        out = ctx.decode(gm, cont, total, d_offs, d_lens, n, 64, chunk)
+        assert ctx.last_decode_kernel() == "k_decode_dual<alias>"
+        assert np.array_equal(out.cpu().numpy(), view), (K, sb, chunk)
+    # damage: a flipped stream byte in chunks 2 and 5 (one in each half of a pair), a misaligned index entry, a length
+    # beyond the container -- each is counted, the rest of the container still decodes
+    K, sb, chunk, n = 4096, 16, 4096, 4096 * 8
+    data = oracle.gen_zipf(n, K=K, s=1.0, seed=5)
+    om, gm = _models(R, ctx, oracle, FMT_ALIAS, sb, data, nsyms=K)
+    want, offs, lens = oracle.encode_chunked(FMT_ALIAS, om, data, 64, chunk, align=16)
+    bad = want.copy()
+    for c in (2, 5):
+        bad[int(offs[c]) + 64 * 4 + 100] ^= 0x5a
+    with pytest.raises(R.RansAmdError) as e:
+        _decode_oracle_container(R, ctx, torch, gm, bad, offs, lens, n, 64, chunk)
+    assert e.value.status == R.E_CORRUPT
+    out = _decode_oracle_container(R, ctx, torch, gm, bad, offs, lens, n, 64, chunk, sync=False)
+    assert ctx.decode_errors() == 2
+    got = out.cpu().numpy().view(np.uint16)
+    for c in (0, 1, 3, 4, 6, 7):
+        assert np.array_equal(got[c * chunk:(c + 1) * chunk], data[c * chunk:(c + 1) * chunk]), c
+    offs2, lens2 = offs.copy(), lens.copy()
+    offs2[3] += 4            # not 16-byte aligned: rejected
+    lens2[6] = want.size     # runs past the container: rejected
+    out = _decode_oracle_container(R, ctx, torch, gm, want, offs2, lens2, n, 64, chunk, sync=False)
+    assert ctx.decode_errors() == 2
+    got = out.cpu().numpy().view(np.uint16)
+    for c in (0, 1, 2, 4, 5, 7):  # the partner of a rejected chunk is decoded on its own
+        assert np.array_equal(got[c * chunk:(c + 1) * chunk], data[c * chunk:(c + 1) * chunk]), c
+    ctx.close()
+
+
+def test_headline_configuration_runs_the_headline_kernel(gpu, oracle):
+    """A dispatch regression from k_decode_word64 to the general k_decode<word> would keep every parity test green and
+    cost 2.5 %: the 64-way word format with u8 symbols and aligned output must run the hand-scheduled kernel."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(32768 * 5 + 100, K=256, s=1.0, seed=2)
+    om, gm = _models(R, ctx, oracle, FMT_WORD, 12, data)
+    for chunk in (32768, 16384, 4096):
+        want, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, 64, chunk, align=16)
+        out = _decode_oracle_container(R, ctx, torch, gm, want, offs, lens, data.size, 64, chunk)
+        assert ctx.last_decode_kernel() == "k_decode_word64", ctx.last_decode_kernel()
+        assert np.array_equal(out.cpu().numpy(), data)

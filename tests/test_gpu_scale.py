@@ -2,12 +2,13 @@
 
 The small-size parity tests compare every byte with the oracle; here the inputs are the full configurations
 of BASELINE.json -- C3: 1 GiB, word format, 64-way; C2: 256 MiB, rans64, 2-way; C4: 512 Mi u16 symbols, alias
-tables over 4096 symbols, 64-way -- and what is compared with the CPU oracle is a SAMPLE of the container the
-GPU encoder produced: 64 pseudo-random chunks plus the first, last and the ones around the 8192-chunk blocks of
-the offset scan are re-encoded by the oracle and must be byte-identical, and the whole index must be the
-prefix sum of its 16-byte aligned lengths (bench.oracle_check_chunks, the same check bench.py reports as
-`oracle_chunks_checked`).  A symmetric encoder/decoder bug that only shows at scale -- several rounds of the
-persistent grid, the multi-block offset scan, 32-bit overflow somewhere -- cannot pass this.
+tables over 4096 symbols, 64-way -- and what is compared with the CPU oracle is the WHOLE container the GPU encoder
+produced: every chunk is re-encoded by the oracle (threaded over the host cores, oracle/rans_oracle.c
+orc_compare_chunks) and must have the oracle's length and bytes, and the whole index must be the prefix sum of its
+16-byte aligned lengths (bench.oracle_check_chunks, the same check bench.py reports as `oracle_chunks_checked`) -- the
+reference compares all bytes too (main_simd.cpp:340-343).  The decoders are then fed a container the ORACLE made from
+the same symbols (Oracle.encode_chunked_mt), so that nothing they read was written by the GPU encoder.  A symmetric
+encoder/decoder bug, in any chunk, at any size, cannot pass this.
 
 book1 goes through the GPU as well: the committed 64-way word stream, written by the
 unmodified reference, is decoded on the GPU to the corpus (sha256 pinned), and the GPU encoder reproduces all
@@ -60,7 +61,7 @@ def test_bench_generator_equals_oracle_on_gpu(gpu, oracle):
     ("C4", FMT_ALIAS, 16, 4096, 64, 32768, 29),
     ("byte-64", FMT_BYTE, 14, 256, 64, 32768, 30),
 ])
-def test_full_size_sampled_chunks_equal_oracle(gpu, name, fmt, sb, K, ways, chunk, log2n):
+def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways, chunk, log2n):
     R, ctx, torch = gpu
     import bench
     n = 1 << log2n
@@ -72,16 +73,21 @@ def test_full_size_sampled_chunks_equal_oracle(gpu, name, fmt, sb, K, ways, chun
     cont, offs, lens, total = ctx.encode(gm, d_syms, ways, chunk)
     art = {"fmt": fmt, "sb": sb, "K": K, "ways": ways, "chunk": chunk, "n": n, "freqs": freqs, "d_syms": d_syms,
            "cont": cont, "offs": offs, "lens": lens, "total": total}
-    checked = bench.oracle_check_chunks(art, want=64)
-    assert checked >= 64
+    # 1. EVERY chunk of the GPU encoder's container == the oracle's stream for it; the index == prefix sums
+    assert bench.oracle_check_chunks(art) == (n + chunk - 1) // chunk
     out = ctx.decode(gm, cont, total, offs, lens, n, ways, chunk)
     assert torch.equal(out, d_syms)
-    # and the decoder reads an ORACLE-made chunk spliced into the container: replace chunk 1 by the oracle's
-    # bytes for it (they are equal, so this is the identity -- checked above) and chunk 0's stream by a
-    # corrupted copy, which must be flagged
+    if name == "C3":
+        assert ctx.last_decode_kernel() == "k_decode_word64"
+    if name == "C4":
+        assert ctx.last_decode_kernel() == "k_decode_dual<alias>"
+    del out
+    # 2. the decoder on a container made by the ORACLE alone (host, threaded), not by the GPU encoder
+    assert bench.decode_oracle_container(torch, R, ctx, gm, art, "cuda")
+    # 3. a corrupted chunk is flagged (or at least does not decode to the input)
     bad = cont.clone()
     bad[int(offs[0].item()) + int(lens[0].item()) // 2] ^= 0x10
-    out2 = torch.empty_like(out)
+    out2 = torch.empty_like(d_syms)
     ctx.decode(gm, bad, total, offs, lens, n, ways, chunk, d_out=out2, sync=False)
     assert ctx.decode_errors() >= 1 or not torch.equal(out2, d_syms)
 

@@ -23,7 +23,7 @@ def test_random_parity_sweep(seed, oracle):
 def test_random_parity_sweep_big(oracle):
     """The same with inputs of millions of symbols mixed in: several rounds of every persistent grid, and every third
     case in BASELINE config 2's shape (2-way rans64, whole batches of 64 full chunks + a tail) so that the dedicated
-    lane decoder / encoder and both placements of the lane encoders (RANS_AMD_LANES_FUSED) are drawn."""
+    lane decoder / encoder and both placements of the lane encoders (RANS_AMD_OPT_LANE_FUSED_PLACEMENT) are drawn."""
     import torch
     assert torch.cuda.is_available()
     import stress

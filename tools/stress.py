@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle parity sweep (run on the GPU box): random format, scale_bits, alphabet
-skew, n, N, chunk size, buffer misalignment and lane-kernel generation; every case checks
+skew, n, N, chunk size, buffer misalignment and kernel-family options of the context; every case checks
   * GPU encode == oracle encode (lengths, offsets, every chunk's bytes),
   * GPU decode of the ORACLE container == input, GPU decode of its own container == input.
     python tools/stress.py [--cases 300] [--seed 1]
@@ -24,7 +24,6 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
     oracle = oracle or Oracle()
     ctx = ctx or R.Context(0)
     fails = 0
-    saved = os.environ.get("RANS_AMD_LANES")
     for case in range(cases):
         fmt = int(rng.choice([FMT_WORD, FMT_BYTE, FMT_R64, FMT_ALIAS]))
         sb = {FMT_WORD: 12, FMT_BYTE: int(rng.integers(8, 17)), FMT_R64: int(rng.integers(8, 17)),
@@ -33,7 +32,8 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
         if big and rng.integers(0, 8) == 0:  # now and then: enough chunks for several rounds of every persistent grid
             n = int(rng.integers(3_000_000, 7_000_000))
         n_ways = int(rng.choice([1, 2, 4, 8, 64, 128, 256, 512, int(rng.integers(1, 513))]))
-        chunk = int(rng.choice([n + 5, 16 * int(rng.integers(1, 300)), int(rng.integers(1, 5000)), 64 * int(rng.integers(1, 64))]))
+        chunk = int(rng.choice([n + 5, 16 * int(rng.integers(1, 300)), int(rng.integers(1, 5000)), 64 * int(rng.integers(1, 64)),
+                                256 * int(rng.integers(1, 40))]))
         kind = int(rng.integers(0, 4))
         # alphabet: mostly 256 byte symbols; sometimes smaller, for alias a power of two, and
         # occasionally the 4096-symbol u16 alphabet of BASELINE config 4
@@ -65,13 +65,17 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
             data = (oracle.gen_zipf(n, K=256, s=float(rng.uniform(0.3, 2.5)), seed=int(rng.integers(1, 1 << 30))) if kind != 1
                     else rng.integers(0, 256, n).astype(np.uint8))
             dt = np.uint8
-        os.environ["RANS_AMD_LANES"] = str(rng.choice(["staged", "regwin", ""]))
-        if rng.integers(0, 2) == 0:  # the lane encoders placing their chunks themselves (scanner wave per block)
-            os.environ["RANS_AMD_LANES_FUSED"] = "1"
-        else:
-            os.environ.pop("RANS_AMD_LANES_FUSED", None)
-        desc = dict(case=case, fmt=fmt, sb=sb, K=K, n=n, n_ways=n_ways, chunk=chunk, kind=kind, lanes=os.environ["RANS_AMD_LANES"],
-                    lanes_fused=os.environ.get("RANS_AMD_LANES_FUSED", ""))
+        # kernel-family options of the context (every setting writes the same bytes): lane-kernel generation, the lane
+        # encoders placing their chunks themselves (scanner wave per block), wave encoders with / without fused placement,
+        # byte-stream decoders with two chunks per wave or one
+        lanes = str(rng.choice(["staged", "regwin", "auto"]))
+        lanes_fused, wave_fused, dual = int(rng.integers(0, 2)), int(rng.integers(0, 4) != 0), int(rng.integers(0, 3))
+        ctx.set_option(R.OPT_LANE_KERNELS, R.LANE_KERNELS[lanes])
+        ctx.set_option(R.OPT_LANE_FUSED_PLACEMENT, lanes_fused)
+        ctx.set_option(R.OPT_FUSED_PLACEMENT, wave_fused)
+        ctx.set_option(R.OPT_DUAL_DECODE, dual)
+        desc = dict(case=case, fmt=fmt, sb=sb, K=K, n=n, n_ways=n_ways, chunk=chunk, kind=kind, lanes=lanes,
+                    lanes_fused=lanes_fused, wave_fused=wave_fused, dual=dual)
         try:
             counts = oracle.count_freqs(data, K)
             f, _ = oracle.normalize(counts, 1 << sb)
@@ -112,11 +116,8 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
         except Exception as e:  # noqa: BLE001
             fails += 1
             print("EXC", desc, repr(e), flush=True)
-    os.environ.pop("RANS_AMD_LANES_FUSED", None)
-    if saved is None:
-        os.environ.pop("RANS_AMD_LANES", None)
-    else:
-        os.environ["RANS_AMD_LANES"] = saved
+    for opt, val in ((R.OPT_LANE_KERNELS, 0), (R.OPT_LANE_FUSED_PLACEMENT, 0), (R.OPT_FUSED_PLACEMENT, 1), (R.OPT_DUAL_DECODE, 1)):
+        ctx.set_option(opt, val)
     return fails
 
 
