@@ -1,0 +1,238 @@
+// examples/multi_gpu.cpp -- the multi-GPU shape of the decode path for a C/C++ caller: one host thread
+// and one rans_amd_ctx per visible device, every device owns an independent shard (no payload crosses xGMI), and the
+// ONLY communication is one RCCL all-gather of a 40-byte record per rank -- {elapsed s, symbols, stream bytes, kernel
+// ms, ok} -- after which rank 0 prints the per-rank table and the whole-job rate (work = sum over ranks, time = max
+// over ranks: weak scaling).  The same protocol as bench.py + ryg_rans_amd/sharding.py, without Python or torch.
+// The reference has no multi-device code (its only caller shape is main_simd.cpp:131-349); this is what replaces
+// "run the loop of main_simd.cpp:313-332 on every core".
+//
+//   hipcc -O2 -Iinclude examples/multi_gpu.cpp -Lryg_rans_amd/lib -lryg_rans_amd -lrccl -lpthread \
+//         -Wl,-rpath,$PWD/ryg_rans_amd/lib -o build/multi_gpu
+//   build/multi_gpu [devices (default: all)] [log2 symbols per device (default 26)] [steps (default 10)]
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include "ryg_rans_amd.h"
+
+namespace {
+
+struct ShardRecord { // (ryg_rans_amd/sharding.py ShardRecord, as five doubles)
+    double elapsed_s, symbols, stream_bytes, kernel_ms, ok;
+};
+
+// Zipf(256, s = 1) bytes, splitmix64 counter based (element i: state = seed + (i + 1) * golden), inverse
+// CDF over the double running sums -- the generator bench.py and the oracle use, so rank r's shard here IS rank r's
+// shard there (seed = r + 1).
+void gen_zipf(uint8_t *out, size_t n, uint64_t seed)
+{
+    double cdf[256], run = 0.0;
+    for (int k = 0; k < 256; ++k) {
+        run += 1.0 / std::pow((double)(k + 1), 1.0);
+        cdf[k] = run;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t z = seed + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0) * run;
+        const int k = (int)(std::upper_bound(cdf, cdf + 256, u) - cdf);
+        out[i] = (uint8_t)(k > 255 ? 255 : k);
+    }
+}
+
+struct Rank {
+    int device = 0;
+    int world = 1;
+    uint64_t n = 0;
+    int steps = 10;
+    ncclComm_t comm = nullptr;
+    std::vector<ShardRecord> gathered; // filled on every rank by the all-gather
+    int rc = 0;
+    char msg[256] = "";
+};
+
+#define R_CHECK(call)                                                                                      \
+    do {                                                                                                   \
+        int rc__ = (call);                                                                                 \
+        if (rc__ != RANS_AMD_OK) {                                                                         \
+            snprintf(r.msg, sizeof r.msg, "%s -> %s (%s)", #call, rans_amd_status_string(rc__), rans_amd_last_error()); \
+            r.rc = 1;                                                                                      \
+            goto done;                                                                                     \
+        }                                                                                                  \
+    } while (0)
+#define R_HIP(call)                                                                       \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            snprintf(r.msg, sizeof r.msg, "%s -> %s", #call, hipGetErrorString(e__));    \
+            r.rc = 1;                                                                     \
+            goto done;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+void run_rank(Rank &r)
+{
+    const uint32_t n_ways = 64, chunk = 32768, scale_bits = 12;
+    const uint64_t n = r.n;
+    rans_amd_ctx *ctx = nullptr;
+    rans_amd_model *model = nullptr;
+    uint8_t *d_in = nullptr, *d_out = nullptr, *d_cont = nullptr;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_len = nullptr;
+    double *d_rec = nullptr, *d_all = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ShardRecord rec = {0, 0, 0, 0, 0};
+    std::vector<uint8_t> shard(n), back(n);
+    {
+        if (hipSetDevice(r.device) != hipSuccess) { // (the device of THIS thread; the library switches to its context's
+            snprintf(r.msg, sizeof r.msg, "hipSetDevice(%d) failed", r.device); //  device inside every call anyway)
+            r.rc = 1;
+            goto done;
+        }
+        gen_zipf(shard.data(), n, (uint64_t)r.device + 1); // independent shard: seed = rank + 1
+        R_CHECK(rans_amd_ctx_create(r.device, &ctx));       // one context per device
+        R_HIP(hipStreamCreate(&stream));
+        R_HIP(hipEventCreate(&ev0));
+        R_HIP(hipEventCreate(&ev1));
+        const uint64_t nchunks = rans_amd_num_chunks(n, chunk);
+        const uint64_t cap = rans_amd_encode_bound(RANS_AMD_FMT_WORD, n, n_ways, chunk);
+        R_HIP(hipMalloc((void **)&d_in, n + 256));
+        R_HIP(hipMalloc((void **)&d_out, n + 256));
+        R_HIP(hipMalloc((void **)&d_cont, cap + 256));
+        R_HIP(hipMalloc((void **)&d_off, 8 * (nchunks + 1)));
+        R_HIP(hipMalloc((void **)&d_len, 4 * nchunks));
+        R_HIP(hipMalloc((void **)&d_rec, sizeof(ShardRecord)));
+        R_HIP(hipMalloc((void **)&d_all, sizeof(ShardRecord) * (size_t)r.world));
+        R_HIP(hipMemcpy(d_in, shard.data(), n, hipMemcpyHostToDevice));
+        uint32_t freqs[256];
+        R_CHECK(rans_amd_build_model_o0(ctx, RANS_AMD_FMT_WORD, d_in, n, 1, 256, scale_bits, freqs, &model, stream));
+        uint64_t total = 0, bad = 0;
+        R_CHECK(rans_amd_encode(ctx, model, d_in, n, n_ways, chunk, d_cont, cap, d_off, d_len, &total, stream));
+        // warm-up, then `steps` timed decodes of the whole shard (device resident in, device resident out)
+        for (int i = 0; i < 3; ++i)
+            R_CHECK(rans_amd_decode(ctx, model, d_cont, total, d_off, d_len, n, n_ways, chunk, d_out, nullptr, stream));
+        R_HIP(hipStreamSynchronize(stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        R_HIP(hipEventRecord(ev0, stream));
+        for (int i = 0; i < r.steps; ++i)
+            R_CHECK(rans_amd_decode(ctx, model, d_cont, total, d_off, d_len, n, n_ways, chunk, d_out, nullptr, stream));
+        R_HIP(hipEventRecord(ev1, stream));
+        R_HIP(hipStreamSynchronize(stream));
+        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        float ms = 0;
+        R_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        const int drc = rans_amd_decode_errors(ctx, &bad, stream);
+        R_HIP(hipMemcpy(back.data(), d_out, n, hipMemcpyDeviceToHost));
+        const bool same = drc == RANS_AMD_OK && bad == 0 && memcmp(back.data(), shard.data(), n) == 0;
+        rec = ShardRecord{elapsed, (double)n, (double)total, ms / r.steps, same ? 1.0 : 0.0};
+    }
+done:
+    // Every rank reaches the collective, whatever happened above (a rank that failed reports ok = 0): an all-gather
+    // somebody skips would hang the others.  40 bytes per rank over RCCL; it doubles as the end barrier.
+    if (d_rec && d_all && stream) {
+        (void)hipMemcpyAsync(d_rec, &rec, sizeof rec, hipMemcpyHostToDevice, stream);
+        const ncclResult_t nr = ncclAllGather(d_rec, d_all, sizeof(ShardRecord) / sizeof(double), ncclDouble, r.comm, stream);
+        r.gathered.resize((size_t)r.world);
+        if (nr == ncclSuccess && hipMemcpyAsync(r.gathered.data(), d_all, sizeof(ShardRecord) * (size_t)r.world,
+                                                hipMemcpyDeviceToHost, stream) == hipSuccess &&
+            hipStreamSynchronize(stream) == hipSuccess) {
+            // gathered[] now holds every rank's record
+        } else {
+            snprintf(r.msg, sizeof r.msg, "ncclAllGather -> %s", ncclGetErrorString(nr));
+            r.rc = 1;
+            r.gathered.clear();
+        }
+    } else if (!r.rc) {
+        r.rc = 1;
+    }
+    if (model)
+        rans_amd_model_destroy(model);
+    if (ctx)
+        rans_amd_ctx_destroy(ctx);
+    for (void *p : {(void *)d_in, (void *)d_out, (void *)d_cont, (void *)d_off, (void *)d_len, (void *)d_rec, (void *)d_all})
+        if (p)
+            (void)hipFree(p);
+    if (ev0)
+        (void)hipEventDestroy(ev0);
+    if (ev1)
+        (void)hipEventDestroy(ev1);
+    if (stream)
+        (void)hipStreamDestroy(stream);
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    const int visible = rans_amd_device_count();
+    if (visible <= 0) {
+        fprintf(stderr, "no HIP device: this library has no CPU path\n");
+        return 1;
+    }
+    int world = argc > 1 ? atoi(argv[1]) : visible;
+    world = world < 1 ? 1 : (world > visible ? visible : world);
+    const int log2n = argc > 2 ? atoi(argv[2]) : 26;
+    const int steps = argc > 3 ? atoi(argv[3]) : 10;
+
+    std::vector<int> devs((size_t)world);
+    for (int i = 0; i < world; ++i)
+        devs[(size_t)i] = i;
+    std::vector<ncclComm_t> comms((size_t)world);
+    const ncclResult_t nr = ncclCommInitAll(comms.data(), world, devs.data()); // one process, one communicator per device
+    if (nr != ncclSuccess) {
+        fprintf(stderr, "ncclCommInitAll -> %s\n", ncclGetErrorString(nr));
+        return 1;
+    }
+    std::vector<Rank> ranks((size_t)world);
+    std::vector<std::thread> threads;
+    for (int i = 0; i < world; ++i) {
+        ranks[(size_t)i].device = i;
+        ranks[(size_t)i].world = world;
+        ranks[(size_t)i].n = 1ull << log2n;
+        ranks[(size_t)i].steps = steps;
+        ranks[(size_t)i].comm = comms[(size_t)i];
+        threads.emplace_back(run_rank, std::ref(ranks[(size_t)i]));
+    }
+    for (auto &t : threads)
+        t.join();
+    for (auto &c : comms)
+        ncclCommDestroy(c);
+
+    int rc = 0;
+    for (const Rank &r : ranks)
+        if (r.rc) {
+            fprintf(stderr, "rank %d: %s\n", r.device, r.msg);
+            rc = 1;
+        }
+    const std::vector<ShardRecord> &all = ranks[0].gathered; // what RANK 0 received through RCCL
+    if (all.size() != (size_t)world)
+        return 1;
+    double max_elapsed = 0, syms = 0;
+    bool all_ok = true;
+    printf("rank  symbols      stream bytes  kernel ms  decoded GB/s  ok\n");
+    for (size_t i = 0; i < all.size(); ++i) {
+        const ShardRecord &s = all[i];
+        printf("%4zu  %11.0f  %12.0f  %9.4f  %12.1f  %s\n", i, s.symbols, s.stream_bytes, s.kernel_ms,
+               s.symbols / s.kernel_ms / 1e6, s.ok == 1.0 ? "yes" : "NO");
+        max_elapsed = std::max(max_elapsed, s.elapsed_s);
+        syms += s.symbols;
+        all_ok = all_ok && s.ok == 1.0;
+    }
+    printf("{\"n_gpus\": %d, \"steps\": %d, \"value\": %.2f, \"unit\": \"GB/s\", \"ms_per_step\": %.4f, \"scaling\": \"weak\", "
+           "\"bit_exact_roundtrip\": %s, \"records_gathered_by\": \"ncclAllGather\"}\n",
+           world, steps, syms * steps / max_elapsed / 1e9, max_elapsed / steps * 1e3, all_ok ? "true" : "false");
+    puts(all_ok && !rc ? "decode ok!" : "ERROR: bad decoder!");
+    return all_ok && !rc ? 0 : 2;
+}

@@ -234,6 +234,60 @@ class Oracle:
         return out
 
 
+HOST_SIMD_SO = os.path.join(ORACLE_DIR, "libhost_simd.so")
+
+
+class HostSimd:
+    """oracle/host_simd.cpp: pinned-thread timing harness for CPU decoders + the AVX-512 word decoder of
+    include/ryg_rans_amd/compat/rans_word_avx512.h (bench.py's cpu_baseline leg and its tests only)."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(HOST_SIMD_SO)
+
+    def __init__(self):
+        if not os.path.exists(HOST_SIMD_SO):
+            build_checkers()
+        lib = C.CDLL(HOST_SIMD_SO)
+        lib.host_has_avx512.restype = C.c_int
+        lib.host_decode_word_avx512x2.argtypes = [u32p, u8p, C.c_size_t, u8p]
+        lib.host_cpu_order.argtypes = [C.POINTER(C.c_int), C.c_int]
+        lib.host_time_threads.argtypes = [C.c_void_p, u32p, u8p, u64p, C.c_uint32, C.c_size_t, u8p, C.c_uint32, C.c_uint32,
+                                          C.c_int]
+        lib.host_time_threads.restype = C.c_double
+        self.lib = lib
+
+    def has_avx512(self):
+        return bool(self.lib.host_has_avx512())
+
+    def cpu_order(self):
+        buf = (C.c_int * 4096)()
+        n = self.lib.host_cpu_order(buf, 4096)
+        return [int(buf[i]) for i in range(n)]
+
+    def physical_cores(self):
+        """Number of distinct cores among the CPUs this process may use (the first block of cpu_order)."""
+        seen = set()
+        for c in self.cpu_order():
+            try:
+                first = int(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read()
+                            .replace("-", ",").split(",")[0])
+            except (OSError, ValueError):
+                first = c
+            seen.add(first)
+        return max(1, len(seen))
+
+    def decode_word_avx512x2(self, freqs, stream, n):
+        """A 32-way word stream by two 16-lane vectors; the stream gets its 32 bytes of padding here."""
+        f = np.ascontiguousarray(freqs, dtype=np.uint32)
+        padded = np.concatenate([np.ascontiguousarray(stream, dtype=np.uint8), np.zeros(64, np.uint8)])
+        out = np.zeros(n, dtype=np.uint8)
+        rc = self.lib.host_decode_word_avx512x2(_ptr(f, u32p), _ptr(padded, u8p), n, _ptr(out, u8p))
+        if rc:
+            raise ValueError("host_decode_word_avx512x2 rc=%d" % rc)
+        return out
+
+
 class Ref:
     """The unmodified reference behind a C ABI (oracle/ref_driver.cpp)."""
 

@@ -121,3 +121,27 @@ def test_avx2_word_decoder_extension(oracle):
             assert lib.compat_decode_avx2(_p(f, C.c_uint32), _p(cum, C.c_uint32), _p(padded, C.c_uint8), want.size,
                                           n, _p(out, C.c_uint8)) == 0, n
             assert np.array_equal(out, d), n
+
+
+def test_avx512_word_decoder_extension(oracle):
+    """rans_word_avx512.h (16 lanes per vector, vpexpandd renormalisation, one gather per 16 symbols from a 4-byte packed
+    slot record) decodes 32-way word streams made by the oracle -- i.e. by the reference's encoder loop with 8 -> 32
+    lanes -- for lengths with and without a tail round, and on models with frequency-1 symbols."""
+    from _oracle import FMT_WORD, HostSimd
+    hs = HostSimd()
+    if not hs.has_avx512():
+        pytest.skip("host CPU has no AVX-512")
+    rng = np.random.default_rng(5)
+    for n in (1, 31, 32, 33, 1000, 65536 + 17, 300001):
+        data = oracle.gen_zipf(n, K=256, s=1.1, seed=n)
+        f, _ = oracle.normalize(oracle.count_freqs(np.concatenate([data, np.arange(256, dtype=np.uint8)]), 256), 4096)
+        om = oracle.model(f, 12)
+        stream = oracle.encode(FMT_WORD, om, data, 32)
+        assert np.array_equal(hs.decode_word_avx512x2(f, stream, n), data), n
+    data = rng.integers(0, 256, 50000).astype(np.uint8)  # flat model: every frequency 16
+    f, _ = oracle.normalize(oracle.count_freqs(data, 256), 4096)
+    stream = oracle.encode(FMT_WORD, oracle.model(f, 12), data, 32)
+    assert np.array_equal(hs.decode_word_avx512x2(f, stream, data.size), data)
+    # the pinning order lists every usable CPU once
+    order = hs.cpu_order()
+    assert sorted(order) == sorted(os.sched_getaffinity(0))

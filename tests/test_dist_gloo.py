@@ -95,3 +95,38 @@ def test_two_ranks_decode_real_shards_on_one_gpu():
     slow = max(pr["elapsed_ms_per_step"])
     assert d["value"] == pytest.approx(2 * (1 << 26) / (slow * 1e-3) / 1e9, rel=0.02)
     assert "cpu_baseline" not in d and "configs" not in d  # rank-0-at-N=1 legs stay out of multi-rank lines
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_runs_rccl_on_one_gpu():
+    """bench.py --force-dist: torch.distributed over the nccl backend (RCCL) with a single rank -- init_process_group
+    with device_id, both barriers and the on-device all_gather of the record execute on real RCCL on this box, so the
+    N-GPU call path is not dead code until an 8-GPU node shows up."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1", "--log2n", "26",
+           "--prewarm-ms", "0", "--no-configs", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["bit_exact_roundtrip"] is True and d["headline"] is True and d["knobs"] == {}
+    assert d["distributed"] == {"initialised": True, "backend": "nccl", "records_gathered_on": "device (RCCL)"}
+
+
+@pytest.mark.gpu
+def test_bench_refuses_knobs_on_a_headline_run():
+    """A stray RANS_AMD_* variable (another library build, an experiment knob) must not ride through the judged line:
+    without --measure the run stops before it measures anything."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANS_AMD_DEBUG="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--log2n", "22"], capture_output=True,
+                         text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode != 0 and "not a headline run" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -263,6 +263,23 @@ def test_native_cpp_example(gpu):
         assert out.returncode == 0 and "decode ok!" in out.stdout, (fmt, out.stdout, out.stderr)
 
 
+def test_native_multi_gpu_example(gpu):
+    """examples/multi_gpu.cpp (built by __graft_entry__.build()): one host thread and one context per device, independent
+    shards, and RCCL itself -- ncclCommInitAll + ncclAllGather of the 40-byte per-rank records, through rccl.h, no
+    torch -- run on the devices this box has (one): the collective of the N-GPU run executes at least here."""
+    import json
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "build", "multi_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("build/multi_gpu not built")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, "8", "24", "5"], capture_output=True, text=True, timeout=600, env=env)  # (8: clipped to what is visible)
+    assert out.returncode == 0 and "decode ok!" in out.stdout, (out.stdout, out.stderr)
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] >= 1 and line["bit_exact_roundtrip"] is True and line["records_gathered_by"] == "ncclAllGather"
+    assert line["value"] > 0
+
+
 def test_unaligned_buffers_and_streams(gpu, oracle):
     """Symbol buffers at odd addresses take the element-wise paths; containers must be 16-byte
     aligned (E_ARG otherwise); work on a non-default HIP stream."""
