@@ -257,6 +257,21 @@ def decode_oracle_container(torch, R, ctx, model, art, device):
     return bool(torch.equal(out, art["d_syms"])) and bad == 0 and cont.size == art["total"]
 
 
+def cpu_quota_cores():
+    """CPU time this process tree may use per wall second, in cores (cgroup v2 cpu.max / v1 cfs quota), or None."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(d_syms, freqs, n):
     """CPU decode of the same data on this box's host cores, threads PINNED (one per physical core first, SMT siblings
     after): the reference's own fastest decoder -- SSE4.1, two 4-lane vectors on 8-way streams, main_simd.cpp:313-332
@@ -274,7 +289,11 @@ def cpu_baseline(d_syms, freqs, n):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = cores
-    max_threads = max(1, usable)
+    # A container's CFS quota (cgroup cpu.max) can be far below the CPUs its affinity mask shows: threads beyond it are
+    # throttled, not run -- round 2's sweep "fell" from 32 to 256 threads on a 256-CPU box for exactly that reason, pinned
+    # or not.  The sweep stops at the quota; both numbers are reported.
+    quota = cpu_quota_cores()
+    max_threads = max(1, usable if quota is None else min(usable, int(math.ceil(quota))))
     shard = min(1 << 22, n // max_threads)       # 4 Mi symbols per shard (cache friendly: this measures the decoder)
     shard -= shard % 32
     orc = Oracle()
@@ -353,7 +372,8 @@ def cpu_baseline(d_syms, freqs, n):
            "sample": "%d x %d MiB shards from the start of rank 0's data, each its own N-way word stream, one PINNED "
                      "pthread per shard (physical cores first, then SMT siblings), thread counts %s swept for every "
                      "decoder, fastest (decoder, threads) reported" % (max_threads, shard >> 20, cands),
-           "decoders": report, "host_cpus": cores, "usable_cpus": usable, "physical_cores": physical}
+           "decoders": report, "host_cpus": cores, "usable_cpus": usable, "physical_cores": physical,
+           "cpu_quota_cores": quota}
     if ref is not None:
         r0 = report[0]
         res["reference_value"] = r0["best_GBps"]
