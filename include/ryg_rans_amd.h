@@ -131,9 +131,12 @@ enum rans_amd_option {
                                               layout + compaction kernels behind them) */
     RANS_AMD_OPT_FUSED_PLACEMENT = 2,      /* 0 = wave-per-chunk encoders followed by layout + compaction kernels
                                               (default 1: the coding kernel places its chunks itself) */
-    RANS_AMD_OPT_DUAL_DECODE = 3           /* 64-way alias decoders: 1 = two chunks per wavefront for the models whose tables
+    RANS_AMD_OPT_DUAL_DECODE = 3,          /* 64-way alias decoders: 1 = two chunks per wavefront for the models whose tables
                                               leave room for one block per CU only (default), 0 = always one chunk per
                                               wavefront, 2 = two chunks per wavefront whenever the tables fit */
+    RANS_AMD_OPT_ENC_SCRATCH_RING = 4      /* 1 = the fused wave encoders code into a ring of scratch slots per coding
+                                              wave, reused once drained (half the workspace of a large encode, 2-4 %
+                                              slower); default 0: one scratch slot per chunk */
 };
 int rans_amd_ctx_set_option(rans_amd_ctx *ctx, int option, int value);
 

@@ -96,6 +96,7 @@ struct rans_amd_ctx {
     uint32_t launch_seq = 0; // selects one of kWorkSlots chunk counters at d_words + 256
     uint32_t variant = 0;    // kVar* bits (rans_amd_ctx_set_option)
     bool unfused = false;    // RANS_AMD_OPT_FUSED_PLACEMENT = 0: k_encode + k_layout + k_compact
+    bool scratch_ring = false; // RANS_AMD_OPT_ENC_SCRATCH_RING = 1
     const char *last_kernel = "";
     const char *last_enc_kernel = ""; // the coding kernel of the last encode call
     bool last_enc_fused = false;      // ... and whether it placed its chunks itself (no k_layout / k_compact)
@@ -304,6 +305,9 @@ int rans_amd_ctx_set_option(rans_amd_ctx *ctx, int option, int value)
         return RANS_AMD_OK;
     case RANS_AMD_OPT_FUSED_PLACEMENT:
         ctx->unfused = value == 0;
+        return RANS_AMD_OK;
+    case RANS_AMD_OPT_ENC_SCRATCH_RING:
+        ctx->scratch_ring = value != 0;
         return RANS_AMD_OK;
     case RANS_AMD_OPT_DUAL_DECODE:
         if (value < 0 || value > 2)
@@ -590,9 +594,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     const uint64_t slot = encode_slot_bytes(format, n, n_ways, chunk_syms);
     if (slot > 0xfffffff0ull) // chunk stream lengths and in-slot cursors are 32-bit
         return fail(RANS_AMD_E_UNSUPPORTED, "encode: chunk_syms too large (a chunk's stream must stay below 4 GiB)");
-    int rc = ctx->scratch.reserve((size_t)(nchunks * slot + 64));
-    if (rc)
-        return rc;
+    int rc = RANS_AMD_OK;
     HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
 
     // The wave-per-chunk encoders place and copy their chunks themselves (EncParams::status; encode_wave.hip
@@ -624,6 +626,16 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     const bool fused = nchunks > 0 && nchunks < (1ull << 31) && !unfused_env &&
                        (lanes ? lanes_fused_env && encode_lanes_can_fuse(enc_format, ep, ctx->num_cus)
                               : encode_fused_fits(enc_format, model->host.nsyms, model->host.scale_bits));
+    // Scratch: one worst-case slot per chunk, or -- context option RANS_AMD_OPT_ENC_SCRATCH_RING, fused wave encoders
+    // only -- a small ring of slots per coding wave (kernels.h kEncRingSlots): half the workspace for a 1 GiB shard, and
+    // measured 2-4 % slower, hence opt-in.
+    const uint64_t ring_waves = (uint64_t)ctx->num_cus * kEncRingMaxWavesPerCu;
+    const bool ring = fused && !lanes && ctx->scratch_ring && slot <= kEncRingMaxSlotBytes && nchunks > ring_waves * kEncRingSlots;
+    rc = ctx->scratch.reserve((size_t)((ring ? ring_waves * kEncRingSlots : nchunks) * slot + 64));
+    if (rc)
+        return rc;
+    ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr);
+    ep.ring_slots = ring ? kEncRingSlots : 0u;
     if (fused) {
         // (wave encoders: a word per chunk; lane encoders: a word per round of a block, at most one per batch of 64
         //  chunks; then the claim counters)
@@ -642,7 +654,6 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         ep.nchunks = nchunks;
         ep.chunk_syms = chunk_syms;
         ep.n_ways = n_ways;
-        ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr);
         ep.slot_bytes = slot;
         ep.lengths = d_lengths;
         ep.enc_recs = model->d_enc;
@@ -712,7 +723,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
             return fail(RANS_AMD_E_SPACE, "encode: container does not fit out_cap");
         if (flags & 4u) // (a kernel that addresses its LDS tables by raw offsets found them elsewhere: never code on that)
             return fail(RANS_AMD_E_HIP, "encode: internal error (dynamic LDS does not start at offset 0)");
-        if (flags & ~7u) { // a wait of the fused placement gave up (device_common.hpp kSpinLimit): the container is not valid
+        if (flags & ~7u) { // a wait of the fused placement gave up (256: a coder waiting for its scratch slot) (device_common.hpp kSpinLimit): the container is not valid
             char msg[160];
             snprintf(msg, sizeof msg, "encode: internal error (placement protocol timed out, flags 0x%x)", flags);
             return fail(RANS_AMD_E_HIP, msg);
@@ -942,28 +953,10 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
     if (nchunks) {
-        // 1. count_freqs per chunk on the GPU (main.cpp:59-66, one wave per chunk)
-        rc = ctx->hist.reserve((size_t)nchunks * 256u * 4u);
-        if (rc)
-            return rc;
-        uint32_t *d_counts = static_cast<uint32_t *>(ctx->hist.ptr);
-        HIP_TRY(launch_histogram_chunks(d_syms, n, chunk_syms, nchunks, d_counts, ctx->num_cus, s));
-        std::vector<uint32_t> counts((size_t)nchunks * 256u);
-        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        // 2. normalize_freqs per chunk on the host, exactly the reference's (main.cpp:75-129); u16 each
-        std::vector<uint16_t> freqs16(counts.size());
-        uint32_t cum[257];
-        for (uint64_t c = 0; c < nchunks; ++c) {
-            uint32_t *f = &counts[(size_t)c * 256u];
-            rc = normalize_freqs(f, cum, 256, 1u << scale_bits);
-            if (rc)
-                return fail(rc, "encode_adaptive: normalize_freqs failed for a chunk");
-            for (int i = 0; i < 256; ++i)
-                freqs16[(size_t)c * 256u + i] = (uint16_t)f[i]; // <= 4096
-        }
-        HIP_TRY(hipMemcpyAsync(d_chunk_freqs, freqs16.data(), freqs16.size() * 2, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s)); // (freqs16 is about to go out of scope)
+        // 1 + 2. count_freqs and normalize_freqs per chunk ON THE DEVICE (main.cpp:59-129, one wave per chunk; the
+        // arithmetic of model.cpp normalize_freqs): the rows go straight into d_chunk_freqs -- no copy to the host, no
+        // synchronisation, the call is asynchronous like the rest of the ABI
+        HIP_TRY(launch_chunk_models(d_syms, n, chunk_syms, nchunks, scale_bits, d_chunk_freqs, ctx->d_enc_flags(), ctx->num_cus, s));
         // 3. encode: every wave builds the records of the chunk it codes
         if (ctx->timing)
             HIP_TRY(hipEventRecord(ctx->ev[2], s));
@@ -1021,7 +1014,7 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         HIP_TRY(hipStreamSynchronize(s));
         *h_total_bytes = total;
         if (flags & 1u)
-            return fail(RANS_AMD_E_MODEL, "encode_adaptive: a symbol without a slot was met (internal error)");
+            return fail(RANS_AMD_E_MODEL, "encode_adaptive: a chunk's counts could not be normalised, or a symbol without a slot was met");
         if (flags & 2u)
             return fail(RANS_AMD_E_SPACE, "encode_adaptive: container does not fit out_cap");
     }

@@ -372,16 +372,34 @@ hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t strea
 }
 
 // ---------------------------------------------------------------------------
-// count_freqs (main.cpp:59-66) per CHUNK: one wave per chunk of u8 symbols, 256 counters in the wave's LDS,
-// written out as u32[256] per chunk (the model of every chunk is built from these).
+// One model per CHUNK, built where the symbols are: one wave per chunk of u8 symbols counts them
+// (count_freqs, main.cpp:59-66; 256 counters in the wave's LDS) and normalises the counts to 1 << scale_bits exactly
+// as SymbolStats::normalize_freqs does (main.cpp:75-129; the width-based restatement of model.cpp normalize_freqs):
+//   edge[s]  = target * (counts[0] + .. + counts[s]) / total          (64-bit product, truncating division)
+//   width[s] = edge[s] - edge[s-1]
+//   every symbol that occurs but got width 0, in ascending order, takes one slot from the narrowest symbol wider than
+//   1 (lowest index on ties) -- a sequential repair: one wave-wide arg-min per squeezed symbol.
+// Lane l owns symbols 4l .. 4l+3 (the layout adapt_load_cum reads); the result is u16[256] per chunk.  A chunk that
+// cannot be normalised (more distinct symbols than slots) sets bit 0 of *flags.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_histogram_chunks(const uint8_t *syms, uint64_t n, uint32_t chunk_syms,
-                                                          uint64_t nchunks, uint32_t *counts)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_chunk_models(const uint8_t *syms, uint64_t n, uint32_t chunk_syms, uint64_t nchunks,
+                                                      uint32_t scale_bits, uint16_t *chunk_freqs, uint32_t *flags)
 {
     __shared__ uint32_t hist[4][256];
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x >> 6);
     uint32_t *h = hist[wave];
+    const uint32_t target = 1u << scale_bits;
     const uint64_t total_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     for (uint64_t c = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < nchunks; c += total_waves) {
         const uint64_t first = c * chunk_syms;
@@ -402,21 +420,75 @@ __global__ void __launch_bounds__(256) k_histogram_chunks(const uint8_t *syms, u
         for (uint32_t i = body + lane; i < nsym; i += 64u)
             atomicAdd(&h[src[i]], 1u);
         // (LDS operations of one wave execute in order: the reads below see every lane's increments)
-        uint32_t *out = counts + c * 256u;
+        uint32_t cnt[4], width[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            out[lane + 64 * i] = h[lane + 64 * i];
+            cnt[i] = h[4u * lane + i];
+        // inclusive running sums in symbol order; the total is the chunk's symbol count
+        const uint32_t own = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        uint32_t incl = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+            incl += lane >= (uint32_t)d ? t : 0u;
+        }
+        uint32_t run = incl - own;
+        uint32_t edge[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            run += cnt[i];
+            edge[i] = (uint32_t)(((uint64_t)target * run) / nsym); // (nsym >= 1: a chunk holds at least one symbol)
+        }
+        uint32_t prev = (uint32_t)__shfl_up((int)edge[3], 1, 64);
+        prev = lane ? prev : 0u;
+        width[0] = edge[0] - prev;
+        width[1] = edge[1] - edge[0];
+        width[2] = edge[2] - edge[1];
+        width[3] = edge[3] - edge[2];
+        // repair, in ascending symbol order
+        bool failed = false;
+        for (;;) {
+            uint32_t mine = 256u; // this lane's lowest squeezed symbol
+#pragma unroll
+            for (int i = 3; i >= 0; --i)
+                mine = (cnt[i] != 0u && width[i] == 0u) ? 4u * lane + (uint32_t)i : mine;
+            const uint32_t s = wave_min_u32(mine);
+            if (s >= 256u)
+                break;
+            uint32_t key = 0xffffffffu; // (width << 8 | symbol) of this lane's narrowest symbol wider than 1
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                const uint32_t k = (width[i] << 8) | (4u * lane + (uint32_t)i);
+                key = (width[i] > 1u && k < key) ? k : key;
+            }
+            const uint32_t best = wave_min_u32(key);
+            if (best == 0xffffffffu) { // nobody can give a slot away
+                failed = true;
+                break;
+            }
+            const uint32_t victim = best & 0xffu;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                width[i] -= (4u * lane + (uint32_t)i == victim) ? 1u : 0u;
+                width[i] = (4u * lane + (uint32_t)i == s) ? 1u : width[i];
+            }
+        }
+        if (failed && lane == 0)
+            atomicOr(flags, 1u);
+        // u16 x 4 per lane = 8 bytes at 8 * lane (adapt_load_cum's layout)
+        const u32x2 packed = {width[0] | (width[1] << 16), width[2] | (width[3] << 16)};
+        *reinterpret_cast<u32x2 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(chunk_freqs) + c * 512u + 8u * lane) = packed;
     }
 }
 
-hipError_t launch_histogram_chunks(const void *syms, uint64_t n, uint32_t chunk_syms, uint64_t nchunks, uint32_t *d_counts,
-                                   int num_cus, hipStream_t stream)
+hipError_t launch_chunk_models(const void *syms, uint64_t n, uint32_t chunk_syms, uint64_t nchunks, uint32_t scale_bits,
+                               uint16_t *d_chunk_freqs, uint32_t *d_flags, int num_cus, hipStream_t stream)
 {
     const uint64_t want = (nchunks + 3) / 4;
     const uint64_t cap = (uint64_t)num_cus * 8;
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
-    RANS_LAUNCH(k_histogram_chunks, dim3(grid), dim3(256), 0, stream, static_cast<const uint8_t *>(syms), n, chunk_syms, nchunks,
-                d_counts);
+    RANS_LAUNCH(k_chunk_models, dim3(grid), dim3(256), 0, stream, static_cast<const uint8_t *>(syms), n, chunk_syms, nchunks,
+                scale_bits, d_chunk_freqs, d_flags);
     return hipGetLastError();
 }
 

@@ -456,20 +456,44 @@ struct EncMailbox {
 };
 static_assert(sizeof(EncMailbox) == kEncMailboxBytes, "mailbox layout");
 
-// Every wait of the placement protocols gives up after kSpinLimit polls and sets a bit of EncParams::flags -- 8: mailbox
-// full, 16: a copier / scanner waiting for its coders, 32: look-back, 64: a coder waiting for its batch's place, 128: a
-// coder waiting for its next unit -- which the host turns into an error: a protocol bug must show up as a failed call,
-// not as a GPU that hangs for ever.  The limit is minutes, not microseconds: a wait is as long as the coding of the
-// largest chunk somebody else is still busy with (a 2^31-symbol chunk of a *_host call keeps one wave busy for seconds).
-constexpr uint32_t kSpinLimit = 1u << 28;
+// Every wait of the placement protocols gives up after kWaitSeconds of WALL time (the 100 MHz clock, read every 256th
+// poll) and sets a bit of EncParams::flags -- 8: mailbox full, 16: a copier / scanner waiting for its coders, 32:
+// look-back, 64: a coder waiting for its batch's place, 128: a coder waiting for its next unit, 256: a coder waiting for
+// its scratch slot -- which the host turns into an error: a protocol bug must show up as a failed call, not as a GPU
+// that hangs for ever.  Half a minute, not microseconds: a wait is as long as the coding of the largest chunk somebody
+// else is still busy with (a 2^31-symbol chunk of a *_host call keeps one wave busy for seconds).  (Rounds 1-2 counted
+// polls, 2^28 of them: between 25 seconds and nine minutes depending on what a poll costs -- a protocol bug in round 3
+// held a GPU box for a quarter of an hour.)
+constexpr unsigned long long kWaitTicks = 30ull * 100000000ull;
+constexpr uint32_t kProtocolErrorBits = ~7u; // EncParams::flags: everything but bad symbol / no space / LDS layout
+struct SpinWatch {
+    unsigned long long t0 = 0;
+    uint32_t polls = 0;
+    // true when the wait should be abandoned: it has lasted kWaitTicks, or some other wait of this launch has given up
+    // already (its flag is set: the launch has failed, and nobody should sit through the timeout a second time --
+    // a failed look-back would otherwise cost every chunk behind it another half minute)
+    __device__ __forceinline__ bool expired(const uint32_t *flags)
+    {
+        if ((++polls & 255u) != 0u)
+            return false;
+        if (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kProtocolErrorBits)
+            return true;
+        const unsigned long long t = wall_clock64();
+        if (t0 == 0) {
+            t0 = t;
+            return false;
+        }
+        return t - t0 > kWaitTicks;
+    }
+};
 
 __device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t unit, uint32_t len, uint32_t *flags)
 {
     const uint32_t i = atomicAdd(&mb->tail, 1u) & 63u;
     volatile uint2 *e = &mb->entries[i];
-    uint32_t spins = 0;
+    SpinWatch watch;
     while (e->x != 0u) { // (64 entries for at most 15 encoders: the copier would have to be 4 units per encoder behind)
-        if (++spins > kSpinLimit) {
+        if (watch.expired(flags)) {
             atomicOr(flags, 8u);
             break;
         }
@@ -488,7 +512,7 @@ __device__ __forceinline__ bool mailbox_pop(EncMailbox *mb, uint32_t lane, uint3
         h = atomicAdd(&mb->claim, 1u);
     h = uniform(h);
     volatile uint2 *e = &mb->entries[h & 63u];
-    for (uint32_t spins = 0;;) {
+    for (SpinWatch watch;;) {
         const unsigned long long ev = *reinterpret_cast<volatile unsigned long long *>(e);
         ex = uniform((uint32_t)ev);
         ey = uniform((uint32_t)(ev >> 32));
@@ -500,7 +524,7 @@ __device__ __forceinline__ bool mailbox_pop(EncMailbox *mb, uint32_t lane, uint3
         if (fin == producers && (int32_t)(tail - h) <= 0)
             return false;
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > 0xf0000000u) { // (LDS polls, a quarter of a microsecond each)
+        if (watch.expired(flags)) { // (an idle copier polls for as long as its block codes: the clock restarts with every entry)
             atomicOr(flags, lane == 0 ? 16u : 0u);
             return false;
         }

@@ -34,12 +34,12 @@ bool encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits)
 {
     const size_t nrecs = nsyms < 256 ? 256 : nsyms;
     if (format == kKernelFormatAliasLds)
-        return nrecs * 8 + ((size_t)2 << scale_bits) + 16 + kEncMailboxBytes <= 160 * 1024;
+        return nrecs * 8 + ((size_t)2 << scale_bits) + 16 + kEncFusedLdsBytes <= 160 * 1024;
     if (format == kKernelFormatByteAdaptive) // (per-wave tables; never fused, see api.cpp)
         return false;
     const bool word_recs = format == (int)RANS_AMD_FMT_WORD || format == (int)RANS_AMD_FMT_BYTE;
     const size_t tables = nrecs * 16 + (word_recs ? 256 * 16 : 0);
-    return ((tables + 15) & ~(size_t)15) + kEncMailboxBytes <= 128 * 1024;
+    return ((tables + 15) & ~(size_t)15) + kEncFusedLdsBytes <= 128 * 1024;
 }
 
 // true when launch_encode hands this shape to the lane-per-chunk encoders (no fused placement there)

@@ -278,7 +278,7 @@ __device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chun
 {
     const unsigned long long alen = (len + 15u) & ~15u;
     unsigned long long base = 0;
-    uint32_t spins = 0;
+    SpinWatch watch;
     for (uint64_t j = chunk;;) { // status[j-1], status[j-2], ... are still to be added
         unsigned long long st = kStPrefix; // virtual predecessor of chunk 0: an inclusive prefix of 0
         if (lane < j)
@@ -288,7 +288,7 @@ __device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chun
         const uint32_t first_pref = pref ? (uint32_t)__builtin_ctzll(pref) : 64u;
         const uint64_t need = first_pref >= 63u ? ~0ull : ((2ull << first_pref) - 1ull); // lanes 0 .. first_pref
         if ((ready & need) != need) { // a predecessor in that range has not finished its chunk yet
-            if (++spins > kSpinLimit) { // (never seen; a protocol error must not hang the GPU)
+            if (watch.expired(p.flags)) { // (a protocol error must not hang the GPU)
                 if (lane == 0)
                     atomicOr(p.flags, 32u);
                 break;
@@ -401,8 +401,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         }
     }
     EncMailbox *mb = reinterpret_cast<EncMailbox *>(smem + p.mailbox_off);
+    // scratch ring: drained[w] = chunks of coding wave w that the copier has moved out of their slots.  Raw LDS address,
+    // explicit DS instructions on both sides: the protocol must not depend on how the compiler threads a lane-0 branch
+    // through the code around it
+    const uint32_t drained_lds = (uint32_t)(uintptr_t)(RANS_LDS uint8_t *)(smem + p.mailbox_off + kEncMailboxBytes);
     if constexpr (FUSED) {
-        if (threadIdx.x < kEncMailboxBytes / 4u)
+        if (threadIdx.x < kEncFusedLdsBytes / 4u)
             reinterpret_cast<uint32_t *>(mb)[threadIdx.x] = 0u;
     }
     __syncthreads();
@@ -421,8 +425,20 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 if (!mailbox_pop(mb, lane, waves_per_block, ex, ey, p.flags))
                     break;
                 const uint64_t chunk = ex - 1u;
-                const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1u) * p.slot_bytes - ey;
-                place_and_copy(p, chunk, sa, ey, lane);
+                if (p.ring_slots) { // entry: length | slot of the ring << 26 | coding wave << 28
+                    const uint32_t len = ey & 0x3ffffffu, j = (ey >> 26) & 3u, w = ey >> 28;
+                    const uint64_t slot = ((uint64_t)blockIdx.x * waves_per_block + w) * p.ring_slots + j;
+                    // a ring slot is read again and again, each time with another chunk's bytes in it: whatever this CU's
+                    // vector L1 still holds of the slot's previous occupant must go (the coders' stores are in L2)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    place_and_copy(p, chunk, reinterpret_cast<uint64_t>(p.scratch) + (slot + 1u) * p.slot_bytes - len, len, lane);
+                    // the copy's loads have returned (its stores could not have been issued otherwise): the slot is free.
+                    // (every lane executes the add, lane 0 with 1 and the others with 0)
+                    asm volatile("ds_add_u32 %0, %1" ::"v"(drained_lds + 4u * w), "v"(lane == 0 ? 1u : 0u) : "memory");
+                } else {
+                    const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1u) * p.slot_bytes - ey;
+                    place_and_copy(p, chunk, sa, ey, lane);
+                }
             }
             return;
         }
@@ -447,8 +463,27 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
     const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
     const uint32_t in_lane_off = (lane & 3u) * N + (lane & ~3u);
 
+    uint32_t coded = 0; // chunks this wave has coded (scratch ring: chunk number `coded` goes into slot coded % R)
     for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave;; chunk_v += total_waves) {
         if constexpr (FUSED) {
+            // scratch ring: the slot about to be reused must have been drained -- BEFORE the claim, so that a claimed chunk
+            // is always in the hands of a running wave (the forward-progress argument above: the copier that drains this
+            // wave's old chunk waits only for chunks smaller than ones its own block has claimed, and those are being coded)
+            if (p.ring_slots && coded >= p.ring_slots) {
+                SpinWatch watch;
+                for (;;) {
+                    uint32_t got_drained;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(got_drained) : "v"(drained_lds + 4u * wave) : "memory");
+                    if (uniform(got_drained) + p.ring_slots > coded)
+                        break;
+                    if (watch.expired(p.flags)) {
+                        if (lane == 0)
+                            atomicOr(p.flags, 256u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
             // ascending claims, one counter per pool of blocks (a 64-byte line each, behind the status words; pool q
             // hands out the chunks c with c % npools == q): a single counter retires ~90 claims per microsecond
             const uint32_t npools = gridDim.x < kWorkPools ? gridDim.x : kWorkPools;
@@ -464,8 +499,11 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         const uint64_t first = chunk * p.chunk_syms;
         const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
         const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + first * p.sym_bytes;
-        uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + chunk * p.slot_bytes;
+        const uint32_t ring_j = (FUSED && p.ring_slots) ? coded % p.ring_slots : 0u;
+        const uint64_t slot_no = (FUSED && p.ring_slots) ? ((uint64_t)blockIdx.x * waves_per_block + wave) * p.ring_slots + ring_j : chunk;
+        uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + uniform64(slot_no) * p.slot_bytes;
         uint32_t wp = (uint32_t)p.slot_bytes;
+        ++coded;
 
         if (adaptive) // this chunk's model -> this wave's records (RansEncSymbolInit per chunk, main.cpp:159-162)
             adapt_build_enc(p.chunk_freqs + chunk * 256u, p.scale_bits, lane, const_cast<uint4 *>(T.recs));
@@ -665,7 +703,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                                    __HIP_MEMORY_SCOPE_AGENT);
                 // (the copier will overwrite that word with the PREFIX: it must not learn of the chunk before the store is done)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a workgroup-scope fence emits no wait for global stores on this target)
-                mailbox_push(mb, (uint32_t)chunk, len, p.flags);
+                mailbox_push(mb, (uint32_t)chunk, p.ring_slots ? (len | (ring_j << 26) | (wave << 28)) : len, p.flags);
             }
         }
     }
@@ -693,7 +731,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     if (fused) {
         lds = (lds + 15) & ~(size_t)15;
         q.mailbox_off = (uint32_t)lds;
-        lds += kEncMailboxBytes;
+        lds += kEncFusedLdsBytes;
     }
     const size_t lds_cap = FMT == FMT_ALIAS_LDS ? 160 * 1024 : 128 * 1024;
     if (lds > lds_cap || (FMT == FMT_WORD && !p.word_enc_recs && p.sym_bytes == 1) ||

@@ -124,6 +124,8 @@ struct EncParams {
     uint8_t *out;               // fused: the container
     uint64_t out_cap;
     uint32_t mailbox_off;       // fused: LDS byte offset of the block's mailbox (set by the launcher)
+    uint32_t ring_slots;        // fused wave encoders: 0 = scratch holds one slot per CHUNK (slot of chunk c at c * slot_bytes);
+                                // R > 0 = one ring of R slots per CODING WAVE (wave g's slots at (g * R + j) * slot_bytes)
     // Lane-per-chunk encoders (lanes.hip), fused: a launch codes the batches (64 chunks each) [batch_begin, batch_end)
     // of the nchunks chunks; status holds one word per UNIT -- the C batches the C coding waves of a block take in one
     // round -- numbered from unit_base, then (from word ceil(nchunks / 64) on) claim counters on a 64-byte line each,
@@ -144,6 +146,20 @@ struct EncParams {
 constexpr uint32_t kEncFusedThreads = RANS_FUSED_THREADS; // 7 encoder waves + 1 copier wave; 4 blocks per CU
 constexpr uint32_t kEncFusedCopiers16 = RANS_FUSED_COPIERS16; // copier waves of a 16-wave block
 constexpr uint32_t kEncMailboxBytes = 16 + 64 * 8;
+// Wave-per-chunk encoders, fused placement: behind the mailbox, one "drained" counter per coding wave of the block (the
+// scratch ring protocol, EncParams::ring_slots)
+constexpr uint32_t kEncDrainBytes = 64;
+constexpr uint32_t kEncFusedLdsBytes = kEncMailboxBytes + kEncDrainBytes;
+// Scratch ring of the fused wave encoders: every coding wave owns kEncRingSlots worst-case slots and codes its chunks
+// into them in turn (a slot is reused once the block's copier has moved its previous occupant to the container), so the
+// scratch a launch touches is (coding waves) x (slots) x (stream of a chunk) instead of the whole container once more --
+// small enough to stay in the 256 MiB Infinity Cache, which is what takes the second trip through HBM out of the encoders.
+#ifndef RANS_ENC_RING_SLOTS
+#define RANS_ENC_RING_SLOTS 2
+#endif
+constexpr uint32_t kEncRingSlots = RANS_ENC_RING_SLOTS;
+constexpr uint32_t kEncRingMaxWavesPerCu = 32;          // resident waves of a CU: upper bound of the coding waves
+constexpr uint64_t kEncRingMaxSlotBytes = 1ull << 26;   // mailbox entries of the ring protocol keep 26 bits of length
 
 struct LayoutParams {
     const uint32_t *lengths;
@@ -177,9 +193,10 @@ hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t strea
 hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
                             uint32_t *d_flags, int num_cus, hipStream_t stream);
 
-// per-chunk histograms of u8 symbols: d_counts[nchunks][256]
-hipError_t launch_histogram_chunks(const void *syms, uint64_t n, uint32_t chunk_syms, uint64_t nchunks, uint32_t *d_counts,
-                                   int num_cus, hipStream_t stream);
+// per-chunk models of u8 symbols, built on the device: count + normalise to 1 << scale_bits (main.cpp:59-129 per chunk),
+// d_chunk_freqs[nchunks][256] as u16; bit 0 of *d_flags when a chunk cannot be normalised
+hipError_t launch_chunk_models(const void *syms, uint64_t n, uint32_t chunk_syms, uint64_t nchunks, uint32_t scale_bits,
+                               uint16_t *d_chunk_freqs, uint32_t *d_flags, int num_cus, hipStream_t stream);
 // (format, n_ways) combinations with a kernel.
 bool ways_supported(int format, uint32_t n_ways);
 

@@ -1077,13 +1077,13 @@ struct LaneCoder { // a coding wave's view
     uint32_t round; // rounds begun
 };
 
-// poll an LDS word until it has the value (whole wave; gives up after kSpinLimit polls and says so in flags)
+// poll an LDS word until it has the value (whole wave; gives up after kWaitTicks and says so in flags)
 __device__ __forceinline__ bool lanes_wait_lds(volatile uint32_t *word, uint32_t value, uint32_t *flags, uint32_t flag_bit, uint32_t lane)
 {
-    for (uint32_t spins = 0;; ++spins) {
+    for (SpinWatch watch;;) {
         if (uniform(*word) == value)
             return true;
-        if (spins > kSpinLimit) {
+        if (watch.expired(flags)) {
             atomicOr(flags, lane == 0 ? flag_bit : 0u);
             return false;
         }
@@ -1240,7 +1240,7 @@ __device__ __forceinline__ void lanes_scanner(const EncParams &p, LaneRounds *ct
         const uint64_t gu = p.unit_base + u;
         __hip_atomic_store(p.status + gu, kStAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (every lane)
         unsigned long long base = 0;
-        uint32_t spins = 0;
+        SpinWatch watch;
         for (uint64_t j = gu;;) { // status[j-1], status[j-2], ... are still to be added
             unsigned long long st[kScanWords];
             uint64_t ready[kScanWords], pref[kScanWords];
@@ -1274,7 +1274,7 @@ __device__ __forceinline__ void lanes_scanner(const EncParams &p, LaneRounds *ct
                 }
             }
             if (!all_ready) { // a unit in that range is still being coded
-                if (++spins > kSpinLimit) { // (never seen; a protocol error must not hang the GPU)
+                if (watch.expired(p.flags)) { // (a protocol error must not hang the GPU)
                     atomicOr(p.flags, lane == 0 ? 32u : 0u);
                     break;
                 }

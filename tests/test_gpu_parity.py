@@ -906,3 +906,27 @@ def test_headline_configuration_runs_the_headline_kernel(gpu, oracle):
         out = _decode_oracle_container(R, ctx, torch, gm, want, offs, lens, data.size, 64, chunk)
         assert ctx.last_decode_kernel() == "k_decode_word64", ctx.last_decode_kernel()
         assert np.array_equal(out.cpu().numpy(), data)
+
+
+def test_fused_encoder_scratch_ring(gpu, oracle):
+    """Context option RANS_AMD_OPT_ENC_SCRATCH_RING: the fused wave encoders code into a ring of scratch slots per coding
+    wave (kernels.h kEncRingSlots), reused once the block's copier has drained them -- taken when there are more chunks
+    than ring slots.  Forty thousand small chunks make every wave go round its ring several times; the container must be
+    the oracle's, byte for byte, index and all.  (The 1 GiB shape runs in test_gpu_scale.)"""
+    R, _, torch = gpu
+    ctx = R.Context(0)
+    ctx.set_option(R.OPT_ENC_SCRATCH_RING, 1)
+    for fmt, sb, chunk in ((FMT_WORD, 12, 128), (FMT_BYTE, 14, 192), (FMT_R64, 14, 64 * 3)):
+        n = chunk * 40000 + 77
+        data = oracle.gen_zipf(n, K=256, s=1.0, seed=chunk)
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        want, offs, lens = oracle.encode_chunked_mt(fmt, om, data, 64, chunk, align=16)
+        for _ in range(2):  # (a second launch reuses the context's status words and scratch)
+            cont, d_offs, d_lens, total = ctx.encode(gm, torch.from_numpy(data).cuda(), 64, chunk)
+            assert ctx.last_encode_kernel()[1] is True
+            assert total == want.size
+            assert np.array_equal(d_offs.cpu().numpy().astype(np.uint64), offs)
+            assert np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens)
+            assert oracle.compare_container(fmt, om, data, 64, chunk, cont[:total].cpu().numpy(), offs, lens) == (len(lens), -1)
+        out = ctx.decode(gm, cont, total, d_offs, d_lens, n, 64, chunk)
+        assert np.array_equal(out.cpu().numpy(), data)

@@ -84,7 +84,18 @@ def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways
     del out
     # 2. the decoder on a container made by the ORACLE alone (host, threaded), not by the GPU encoder
     assert bench.decode_oracle_container(torch, R, ctx, gm, art, "cuda")
-    # 3. a corrupted chunk is flagged (or at least does not decode to the input)
+    # 3. the encoder with its scratch ring (RANS_AMD_OPT_ENC_SCRATCH_RING; wave-per-chunk encoders): the same container
+    if ways == 64 and fmt != FMT_ALIAS:
+        ctx2 = R.Context(0)
+        ctx2.set_option(R.OPT_ENC_SCRATCH_RING, 1)
+        gm2 = ctx2.model(fmt, freqs, sb)
+        cont_r, offs_r, lens_r, total_r = ctx2.encode(gm2, d_syms, ways, chunk)
+        assert total_r == total and torch.equal(offs_r, offs) and torch.equal(lens_r, lens)
+        art_r = dict(art, cont=cont_r)
+        assert bench.oracle_check_chunks(art_r) == (n + chunk - 1) // chunk
+        del cont_r, gm2
+        ctx2.close()
+    # 4. a corrupted chunk is flagged (or at least does not decode to the input)
     bad = cont.clone()
     bad[int(offs[0].item()) + int(lens[0].item()) // 2] ^= 0x10
     out2 = torch.empty_like(d_syms)

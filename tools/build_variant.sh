@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_variant.sh <name> <file.hip> <extra hipcc flags...> -- build/libexp_<name>.so: the library with ONE kernel
+# tools/build_variant.sh <name> <file.hip|file.cpp> <extra hipcc flags...> -- build/libexp_<name>.so: the library with ONE kernel
 # file recompiled with extra flags (experiment knobs are -D macros), the other objects taken from build/obj
 set -e
 NAME=$1; FILE=$2; shift 2
@@ -10,7 +10,7 @@ if [ -n "$MEASURE" ]; then make -s measure >/dev/null; O=../../build/obj_measure
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-const-variable --offload-arch=gfx950 "$@" -c $FILE -o $O/variant_$NAME.o
 OBJS=""
 for f in decode_wave decode_dual encode_wave lanes container_kernels dispatch api model container; do
-  if [ "$f.hip" = "$FILE" ]; then OBJS="$OBJS $O/variant_$NAME.o"; else OBJS="$OBJS $O/$f.o"; fi
+  if [ "$f.hip" = "$FILE" ] || [ "$f.cpp" = "$FILE" ]; then OBJS="$OBJS $O/variant_$NAME.o"; else OBJS="$OBJS $O/$f.o"; fi
 done
 /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -shared -o ../../build/libexp_$NAME.so $OBJS -Wl,-rpath,/opt/rocm/lib
 echo built build/libexp_$NAME.so

@@ -74,6 +74,7 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
         ctx.set_option(R.OPT_LANE_FUSED_PLACEMENT, lanes_fused)
         ctx.set_option(R.OPT_FUSED_PLACEMENT, wave_fused)
         ctx.set_option(R.OPT_DUAL_DECODE, dual)
+        ctx.set_option(R.OPT_ENC_SCRATCH_RING, int(rng.integers(0, 2)))
         desc = dict(case=case, fmt=fmt, sb=sb, K=K, n=n, n_ways=n_ways, chunk=chunk, kind=kind, lanes=lanes,
                     lanes_fused=lanes_fused, wave_fused=wave_fused, dual=dual)
         try:
@@ -116,7 +117,8 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
         except Exception as e:  # noqa: BLE001
             fails += 1
             print("EXC", desc, repr(e), flush=True)
-    for opt, val in ((R.OPT_LANE_KERNELS, 0), (R.OPT_LANE_FUSED_PLACEMENT, 0), (R.OPT_FUSED_PLACEMENT, 1), (R.OPT_DUAL_DECODE, 1)):
+    for opt, val in ((R.OPT_LANE_KERNELS, 0), (R.OPT_LANE_FUSED_PLACEMENT, 0), (R.OPT_FUSED_PLACEMENT, 1), (R.OPT_DUAL_DECODE, 1),
+                     (R.OPT_ENC_SCRATCH_RING, 0)):
         ctx.set_option(opt, val)
     return fails
 
