@@ -28,7 +28,7 @@ template <int MODE> __global__ void __launch_bounds__(1024) k_slot(uint32_t *out
     for (int it = 0; it < ITERS; ++it) {
         a = a * 1103515245u + 12345u;
         const uint32_t slot = (a >> 10) & 4095u;
-        if constexpr (MODE == 0 || MODE >= 3) { // b64 gather (MODE >= 3: second copy for the upper half wave)
+        if constexpr (MODE == 0 || (MODE >= 3 && MODE <= 5)) { // b64 gather (MODE 3..5: second copy for the upper half wave)
             uint64_t v;
             asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(slot * 8u + base));
             asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
