@@ -170,36 +170,68 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 #ifndef RANS_ENC_STORE // (experiment knob: -DRANS_ENC_STORE='""' drops the stream stores of the word encoder)
 #define RANS_ENC_STORE "global_store_short %[t], %[x], %[base]\n\t"
 #endif
-typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x3 &rec, uint32_t &wp,
-                                              const uint8_t RANS_GLOBAL *slot, uint32_t &worst)
+// rec = WordEncRec {m', cmpl | bias << 12 | sh << 27} (model.h; eight bytes: one ds_read_b64).  SMALL: no frequency of the
+// model exceeds 2048, the renormalised state is below 2^31 and q = mulhi(x, m') >> sh is exact (Alverson,
+// rans_byte.h:201-243): 14 VALU.  Otherwise the round-up method of Granlund & Montgomery for 32-bit dividends,
+// t = mulhi(x, m'); q = (t + ((x - t) >> 1)) >> sh: 17 VALU.  (Round 2's 16-byte record needed 15 and no unpacking, and
+// lost twice as many LDS cycles to the bank conflicts of its gather: the LDS, not the VALU, bounds this kernel.)
+template <bool SMALL>
+__device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x2 &rec, uint32_t &wp,
+                                              const uint8_t RANS_GLOBAL *slot, uint32_t &worst, uint32_t m12)
 {
-    uint32_t t, q, sh, cnt;
-    asm volatile("v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
-                 "v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
-                 "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
-                 "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                 "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
-                 "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
-                 "s_mov_b64 exec, vcc\n\t"
-                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                 "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
-                 RANS_ENC_STORE
-                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                 "s_mov_b64 exec, -1\n\t"
-                 "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
-                 "v_lshrrev_b32_e32 %[sh], 24, %[w]\n\t"
-                 "v_sub_u32_e32 %[t], %[x], %[q]\n\t"
-                 "v_lshrrev_b32_e32 %[t], 1, %[t]\n\t"
-                 "v_add_u32_e32 %[q], %[q], %[t]\n\t"
-                 "v_lshrrev_b32_e32 %[q], %[sh], %[q]\n\t"
-                 "v_mad_u32_u24 %[q], %[q], %[w], %[x]\n\t"
-                 "v_add_u32_e32 %[x], %[q], %[bias]"
-                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [sh] "=&v"(sh),
-                   [cnt] "=&s"(cnt)
-                 : [m] "v"(rec.x), [w] "v"(rec.y), [bias] "v"(rec.z), [base] "s"(slot)
-                 : "vcc", "scc", "memory");
+    uint32_t t, q, c, cnt;
+    if constexpr (SMALL) {
+        asm volatile("v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                     "v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
+                     "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
+                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                     "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
+                     "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
+                     "s_mov_b64 exec, vcc\n\t"
+                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
+                     RANS_ENC_STORE
+                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
+                     "v_lshrrev_b32_e32 %[t], 27, %[w]\n\t"
+                     "v_and_b32_e32 %[c], %[m12], %[w]\n\t"
+                     "v_lshrrev_b32_e32 %[q], %[t], %[q]\n\t"
+                     "v_bfe_u32 %[t], %[w], 12, 13\n\t"
+                     "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
+                     "v_add_u32_e32 %[x], %[q], %[t]"
+                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
+                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12), [base] "s"(slot)
+                     : "vcc", "scc", "memory");
+    } else {
+        asm volatile("v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                     "v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
+                     "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
+                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                     "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
+                     "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
+                     "s_mov_b64 exec, vcc\n\t"
+                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
+                     RANS_ENC_STORE
+                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
+                     "v_sub_u32_e32 %[t], %[x], %[q]\n\t"
+                     "v_lshrrev_b32_e32 %[t], 1, %[t]\n\t"
+                     "v_add_u32_e32 %[q], %[q], %[t]\n\t"
+                     "v_lshrrev_b32_e32 %[t], 27, %[w]\n\t"
+                     "v_and_b32_e32 %[c], %[m12], %[w]\n\t"
+                     "v_lshrrev_b32_e32 %[q], %[t], %[q]\n\t"
+                     "v_bfe_u32 %[t], %[w], 12, 13\n\t"
+                     "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
+                     "v_add_u32_e32 %[x], %[q], %[t]"
+                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
+                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12), [base] "s"(slot)
+                     : "vcc", "scc", "memory");
+    }
 }
 
 // The same for the byte format (rans_byte.h:62-74 renormalisation, :83-90 / :258-280 update) -- the compiler's version
@@ -211,12 +243,13 @@ __device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x3 &rec, uin
 //               low byte of a lane at the higher address)
 //   two stores  the two-byte lanes one global_store_short of the swapped low half (v_perm), the one-byte lanes one
 //               global_store_byte -- each under its own exec mask, against the chunk's SGPR base
-//   x / freq    Alverson: mulhi(x, rcp) >> rshift, exact; x' = x + bias + q * cmpl (q < 2^24, cmpl < 2^24: v_mad_u32_u24)
-// 17 VALU + 7 SALU, no v_cndmask, no branch.  s[34:35] holds the two-byte mask.
+//   x / freq    Alverson: mulhi(x, rcp) >> rshift, exact (the shift takes its count from the record's top byte: SDWA);
+//               x' = x + bias + q * cmpl (q < 2^24, cmpl < 2^24: v_mad_u32_u24)
+// 16 VALU + 7 SALU, no v_cndmask, no branch.  s[34:35] holds the two-byte mask.
 __device__ __forceinline__ void enc_byte_full(uint32_t &x, const u32x4 &rec, uint32_t &wp, const uint8_t RANS_GLOBAL *slot,
                                               uint32_t &worst, uint32_t swap_sel)
 {
-    uint32_t t, r, q, sh, c1, c2;
+    uint32_t t, r, q, c1, c2;
     asm volatile("v_cmp_ge_u32_e32 vcc, %[x], %[xm]\n\t"
                  "v_lshrrev_b32_e32 %[t], 8, %[x]\n\t"
                  "v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
@@ -239,11 +272,10 @@ __device__ __forceinline__ void enc_byte_full(uint32_t &x, const u32x4 &rec, uin
                  "v_lshrrev_b32_e32 %[x], 8, %[x]\n\t"
                  "s_mov_b64 exec, -1\n\t"
                  "v_mul_hi_u32 %[q], %[x], %[rcp]\n\t"
-                 "v_lshrrev_b32_e32 %[sh], 24, %[w]\n\t"
-                 "v_lshrrev_b32_e32 %[q], %[sh], %[q]\n\t"
+                 "v_lshrrev_b32_sdwa %[q], %[w], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
                  "v_mad_u32_u24 %[q], %[q], %[w], %[x]\n\t"
                  "v_add_u32_e32 %[x], %[q], %[bias]"
-                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [r] "=&v"(r), [q] "=&v"(q), [sh] "=&v"(sh),
+                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [r] "=&v"(r), [q] "=&v"(q),
                    [c1] "=&s"(c1), [c2] "=&s"(c2)
                  : [rcp] "v"(rec.x), [w] "v"(rec.y), [bias] "v"(rec.z), [xm] "v"(rec.w), [base] "s"(slot), [sel] "v"(swap_sel)
                  : "vcc", "scc", "memory", "s34", "s35");
@@ -363,12 +395,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
     // word format: the 256 WordEncRec of the full-wave path come first (LDS address = sym << 4),
     // the per-symbol EncRec table of the general path behind them
     // (byte format: 256 records {rcp, cmpl | rshift << 24, bias, x_max} of enc_byte_full, built from the EncRec table below)
-    constexpr uint32_t kWordRecBytes = (FMT == FMT_WORD || FMT == FMT_BYTE) ? 256u * (uint32_t)sizeof(WordEncRec) : 0u;
+    constexpr uint32_t kWordRecBytes = (FMT == FMT_WORD || FMT == FMT_BYTE) ? 256u * 16u : 0u; // (word: 2 KiB of it in use)
     if constexpr (FMT == FMT_WORD) {
         if (p.word_enc_recs) { // (absent for alphabets beyond 256 symbols: they never take the full-wave path)
-            const uint4 *g = reinterpret_cast<const uint4 *>(p.word_enc_recs);
+            const uint4 *g = reinterpret_cast<const uint4 *>(p.word_enc_recs); // 256 records of 8 bytes
             uint4 *l = reinterpret_cast<uint4 *>(smem);
-            for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x)
+            for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x)
                 l[i] = g[i];
         }
     }
@@ -594,6 +626,13 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             }
         } else if (fast_rounds) {
             uint32_t rec_mask = 0xff0u, swap_sel = 0x0c0c0001u; // (v_perm selector: the low two bytes swapped, zeros above)
+            uint32_t rec_mask8 = 0x7f8u, m12v = 0xfffu; // (word format: 8-byte records)
+            asm volatile("" : "+v"(rec_mask8));
+            asm volatile("" : "+v"(m12v));
+            if (kMeasureBuild && (p.debug & 4u)) // measurement only: every lane reads record 0 -- what the bank conflicts of the
+                rec_mask = rec_mask8 = 0u;       // record gather cost; the output is wrong by construction
+            (void)rec_mask8;
+            (void)m12v;
             asm volatile("" : "+v"(rec_mask)); // keep the mask in a VGPR (a literal operand costs a slower VALU form)
             asm volatile("" : "+v"(swap_sel));
             // byte format: the hand-written sub-step needs its records at LDS address 0 and the one model of the launch
@@ -626,17 +665,29 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                     // a scheduling barrier for the compiler)
                     auto rec_at = [&](int step) { // step 0 = (J 3, k K-1), descending
                         const int J = 3 - step / K, k = K - 1 - step % K;
-                        const uint32_t at = (J == 0 ? (t[k] << 4) : (t[k] >> (8 * J - 4))) & rec_mask;
-                        return *reinterpret_cast<const __attribute__((address_space(3))) u32x3 *>((uintptr_t)at); // table at LDS address 0
+                        const uint32_t at = (J == 0 ? (t[k] << 3) : (t[k] >> (8 * J - 3))) & rec_mask8;
+                        return *reinterpret_cast<const __attribute__((address_space(3))) u32x2 *>((uintptr_t)at); // table at LDS address 0
                     };
-                    u32x3 rec = rec_at(0);
+                    u32x2 rec = rec_at(0);
+                    wp = uniform(wp); // (asm results count as divergent: say what they are, or the "s" operands below get VGPRs)
+                    if (p.word_small) { // (wave-uniform: one scalar branch per four rounds)
 #pragma unroll
-                    for (int step = 0; step < 4 * K; ++step) {
-                        const u32x3 now = rec;
-                        if (step + 1 < 4 * K)
-                            rec = rec_at(step + 1);
-                        enc_word_full(x[K - 1 - step % K], now, wp, slot, worst);
+                        for (int step = 0; step < 4 * K; ++step) {
+                            const u32x2 now = rec;
+                            if (step + 1 < 4 * K)
+                                rec = rec_at(step + 1);
+                            enc_word_full<true>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
+                        }
+                    } else {
+#pragma unroll
+                        for (int step = 0; step < 4 * K; ++step) {
+                            const u32x2 now = rec;
+                            if (step + 1 < 4 * K)
+                                rec = rec_at(step + 1);
+                            enc_word_full<false>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
+                        }
                     }
+                    wp = uniform(wp);
                 } else if (FMT == FMT_BYTE && byte_asm) {
                     if constexpr (FMT == FMT_BYTE) { // (the same walk over the 4 K symbols as the word format's)
                         auto rec_at = [&](int step) {
@@ -669,7 +720,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             }
         }
 
-        if (worst > 0x0fffffffu)
+        if (worst > (FMT == FMT_WORD ? 0x7fffffffu : 0x0fffffffu)) // (a symbol without a record: all ones in the word v_max tracks)
             bad = true;
         // flush: lane N-1 first, i.e. lane 0's state ends up first in memory
         // (main.cpp:244-245, main_simd.cpp:298-299)
@@ -726,7 +777,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     const size_t nrecs = p.nsyms < 256 ? 256 : p.nsyms;
     size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
                  : (FMT == FMT_BYTE && p.chunk_freqs) ? (size_t)waves * kAdaptEncWaveLds
-                                                      : nrecs * sizeof(EncRec) + ((FMT == FMT_WORD || FMT == FMT_BYTE) ? 256 * sizeof(WordEncRec) : 0);
+                                                      : nrecs * sizeof(EncRec) + ((FMT == FMT_WORD || FMT == FMT_BYTE) ? 256 * 16 : 0);
     EncParams q = p;
     if (fused) {
         lds = (lds + 15) & ~(size_t)15;

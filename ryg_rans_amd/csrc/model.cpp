@@ -2,6 +2,7 @@
 #include "model.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/ryg_rans_amd.h"
@@ -257,19 +258,32 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
                                          : WordSlot{freqs[s], (slot - cum[s]) | (s << 16)};
         }
         word_enc_recs.clear(); // (the full-wave encoder path and its 256 records are for byte symbols)
+        word_small = true;
+        for (uint32_t s = 0; s < ns; ++s)
+            word_small = word_small && freqs[s] <= 2048u;
+#ifdef RANS_AMD_MEASURE // (A/B runs: the round-up reciprocals whatever the model)
+        if (getenv("RANS_AMD_WORD_NO_SMALL"))
+            word_small = false;
+#endif
         if (ns <= 256)
-            word_enc_recs.assign(256, WordEncRec{0u, 0xffffffffu, 0u, 0u});
+            word_enc_recs.assign(256, WordEncRec{0u, 0xffffffffu});
+        auto pack = [](uint32_t cmpl, uint32_t bias, uint32_t sh) { return cmpl | (bias << 12) | (sh << 27); };
         for (uint32_t s = 0; s < ns && ns <= 256; ++s) {
             const uint32_t f = freqs[s];
             if (f == 0)
                 continue;
-            if (f == 1) {
-                word_enc_recs[s] = WordEncRec{0xffffffffu, M - 1, cum[s] + M - 1, 0u};
+            if (f == 1) { // q = x - 1 either way: mulhi(x, 2^32 - 1) = x - 1, no shift; bias = start + M - 1 (13 bits)
+                word_enc_recs[s] = WordEncRec{0xffffffffu, pack(M - 1, cum[s] + M - 1, 0)};
                 continue;
             }
             const uint32_t l = ceil_log2(f);
-            const uint64_t mprime = (((uint64_t)1 << 32) * (((uint64_t)1 << l) - f)) / f + 1;
-            word_enc_recs[s] = WordEncRec{(uint32_t)mprime, (M - f) | ((l - 1) << 24), cum[s], 0u};
+            if (word_small) { // x < 2^31 after renormalisation: Alverson (rans_byte.h:201-243), q = mulhi(x, rcp) >> (l - 1)
+                const uint32_t rcp = (uint32_t)((((uint64_t)1 << (l + 31)) + f - 1) / f);
+                word_enc_recs[s] = WordEncRec{rcp, pack(M - f, cum[s], l - 1)};
+            } else {
+                const uint64_t mprime = (((uint64_t)1 << 32) * (((uint64_t)1 << l) - f)) / f + 1;
+                word_enc_recs[s] = WordEncRec{(uint32_t)mprime, pack(M - f, cum[s], l - 1)};
+            }
         }
     }
     if (fmt == RANS_AMD_FMT_ALIAS) {

@@ -83,12 +83,21 @@ struct EncRec {
 // (q = x - 1) with bias = start + 4095, cmpl = 4095 -- the same identity rans_byte.h:186-199 uses.
 // The renormalisation test x >= freq << 20 (rans_word_sse41.h:85) is the carry of
 // x + (cmpl << 20): (4096 - freq) << 20 = 2^32 - (freq << 20).
+// Round 3: 8 bytes, read with one ds_read_b64.  The gather of 64 random records is what the LDS charges the encoder for:
+// 16-byte records cost 9.7 LDS-array cycles per wave instruction on Zipf(256) symbols (ds_read_b128: four groups of 16
+// lanes, a record covers four banks), 8-byte records 4.9 (two groups of 32 lanes, two banks each) -- bank model of
+// MI355X_MICROARCH "LDS", and measured: every lane reading record 0 took the 1 GiB encode from 0.80 to 0.51 ms
+// (profiles/r03_encoder_bound.md).  The fields are taken apart with VALU instructions, which this kernel has to spare.
+//   mprime   reciprocal: word_small (no frequency above 2048: the renormalised state is below 2^31) -> Alverson,
+//            ceil(2^(31 + ceil(log2 freq)) / freq), q = mulhi(x, mprime) >> sh exact (rans_byte.h:201-243); otherwise the
+//            round-up method above
+//   packed   cmpl (bits 0..11) | bias (bits 12..24) | sh (bits 27..31); packed << 20 is cmpl << 20 = 2^32 - (freq << 20),
+//            the addend whose carry out of x is the renormalisation test (rans_word_sse41.h:85).  No record: 0xffffffff.
 struct WordEncRec {
     uint32_t mprime;
-    uint32_t cmpl_sh; // cmpl (bits 0..23, feeds v_mad_u32_u24 directly) | sh << 24
-    uint32_t bias;
-    uint32_t pad;
+    uint32_t packed;
 };
+static_assert(sizeof(WordEncRec) == 8, "one ds_read_b64");
 
 int count_freqs_host(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *freqs);
 int normalize_freqs(uint32_t *freqs, uint32_t *cum, uint32_t nsyms, uint32_t target_total);
@@ -115,6 +124,7 @@ struct HostModel {
     std::vector<AliasHalf> alias_halves; // [2*nsyms]        FMT_ALIAS
     std::vector<EncRec> enc_recs;       // [nsyms]          all formats
     std::vector<WordEncRec> word_enc_recs; // [256]         FMT_WORD
+    bool word_small = false;               // FMT_WORD: no frequency above 2048 -> Alverson reciprocals in word_enc_recs
     // FMT_ALIAS, when 2 M + 8 max(nsyms, 256) bytes fit in LDS: the encoder's tables in their LDS form --
     // {freq | start << 16, floor(2^32 / freq)} per symbol (zero records up to 256) and alias_remap as u16
     std::vector<uint64_t> alias_recs8;

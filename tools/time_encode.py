@@ -38,9 +38,12 @@ def main():
         f, _ = R.normalize_freqs(ctx.count_freqs_device(d, nsyms), 1 << sb)
         m = ctx.model(fmt, f, sb)
         cont, offs, lens, total = ctx.encode(m, d, ways, a.chunk)
-        out = ctx.decode(m, cont, total, offs, lens, n, ways, a.chunk)
-        ok = bool(torch.equal(out, d))
-        del out
+        try:  # (measurement builds with output-changing knobs: the container may be garbage)
+            out = ctx.decode(m, cont, total, offs, lens, n, ways, a.chunk)
+            ok = bool(torch.equal(out, d))
+            del out
+        except R.RansAmdError:
+            ok = False
         kern = ctx.last_encode_kernel()
         for r in range(a.rounds):
             for _ in range(30):
