@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: 64-way interleaved rANS decode (word format) of
-synthetic order-0 byte streams, one 1 GiB shard per GPU (BASELINE.json configs[2] / [4]).
+synthetic order-0 byte streams, one 1 GiB shard per GPU (BASELINE.json configs[2] / [4]), 16 Ki-symbol chunks.
 
   python bench.py                                  # 1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -48,7 +48,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=30, help="symbols per GPU = 2^log2n (default 1 GiB)")
     ap.add_argument("--ways", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=32768, help="symbols per independent chunk stream")
+    ap.add_argument("--chunk", type=int, default=16384,
+                    help="symbols per independent chunk stream (16 Ki since round 3: the tail of a launch -- waves that finish "
+                         "between 0.8 and 1.0 of its duration -- is shorter with smaller chunks; measured -1.2 to -1.7 %% kernel time "
+                         "against 32 Ki on three boxes for 0.8 %% more stream bytes, DESIGN 4.1)")
     ap.add_argument("--format", default="word", choices=["word", "byte", "r64", "alias"])
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (reference timing + oracle checks)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
@@ -393,7 +396,7 @@ def kernel_source_tag():
     """sha256 (first 16 hex digits) of the sources the decode kernel is built from: a committed PMC traffic
     measurement is quoted only when it was taken on this very kernel."""
     h = hashlib.sha256()
-    for f in ("decode_wave.hip", "device_common.hpp", "kernels.h"):
+    for f in ("decode_wave.hip", "decode_common.hpp", "device_common.hpp", "kernels.h"):
         with open(os.path.join(ROOT, "ryg_rans_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -589,8 +592,8 @@ def main():
         # (tools/profile.sh -> tools/summarize_profile.py -> profiles/<tag>_traffic.json); PMC passes cannot
         # share a process with the timed run, so a committed measurement is quoted only when it was taken on
         # this workload AND on the kernel sources of this checkout (its `kernel_source_tag`), else null.
-        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r02_traffic.json"))
-        default_workload = (args.format == "word" and args.ways == 64 and args.chunk == 32768 and args.log2n == 30)
+        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r03_traffic.json"))
+        default_workload = (args.format == "word" and args.ways == 64 and args.chunk == 16384 and args.log2n == 30)
         if os.path.exists(tj) and default_workload:
             try:
                 t = json.load(open(tj))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/pmc.sh <tag> -- SQ/LDS counter passes over the bench decode kernel (run via gpurun).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"

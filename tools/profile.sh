@@ -5,7 +5,7 @@
 #   <tag>_pmc_{fetch,write}/  separate PMC passes for HBM traffic (FETCH_SIZE / WRITE_SIZE)
 # Summaries are copied into profiles/ by tools/summarize_profile.py afterwards.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"

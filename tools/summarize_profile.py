@@ -29,7 +29,7 @@ def short_name(name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
