@@ -58,7 +58,7 @@ def main():
         for r in range(a.rounds):
             for v, val in VARIANTS.items():
                 ctx.set_option(R.OPT_DUAL_DECODE, val)
-                for _ in range(40):  # settle the clocks on this kernel
+                for _ in range(min(40, 2 * a.launches)):  # settle the clocks on this kernel
                     ctx.decode(m, cont, total, offs, lens, n, ways, chunk, d_out=out, sync=False)
                 torch.cuda.synchronize()
                 ms = []

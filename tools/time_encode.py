@@ -46,7 +46,7 @@ def main():
             ok = False
         kern = ctx.last_encode_kernel()
         for r in range(a.rounds):
-            for _ in range(30):
+            for _ in range(min(30, 2 * a.launches)):
                 ctx.encode(m, d, ways, a.chunk, d_out=cont, sync=False, d_offsets=offs, d_lengths=lens)
             torch.cuda.synchronize()
             ms = []
