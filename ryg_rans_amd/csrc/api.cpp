@@ -118,6 +118,7 @@ struct rans_amd_model {
     void *d_remap = nullptr;
     void *d_alias_recs8 = nullptr, *d_alias_remap16 = nullptr; // alias encoder's LDS tables, when they fit
     void *d_dual0 = nullptr, *d_dual1 = nullptr; // alias: the tables of the two-chunks-per-wave decoder (FMT_ALIAS2)
+    void *d_packed = nullptr;                    // rans64: 4-byte slot records (HostModel::r64_packed), when the model has them
     uint32_t table0_bytes = 0, table1_bytes = 0, dual0_bytes = 0, dual1_bytes = 0;
 };
 
@@ -419,6 +420,8 @@ int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_fr
             m->table1_bytes = (uint32_t)(h.sym_recs.size() * sizeof(SymRec));
             rc = upload(h.sym_recs.data(), m->table1_bytes, &m->d_table1);
         }
+        if (rc == RANS_AMD_OK && !h.r64_packed.empty())
+            rc = upload(h.r64_packed.data(), h.r64_packed.size() * 4, &m->d_packed);
         break;
     }
     case RANS_AMD_FMT_ALIAS:
@@ -478,7 +481,7 @@ int rans_amd_model_destroy(rans_amd_model *m)
     if (m->device >= 0) { // not m->ctx->device: a model may outlive its context
         DeviceGuard guard(m->device);
         for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_word_enc, m->d_remap, m->d_alias_recs8, m->d_alias_remap16,
-                        m->d_dual0, m->d_dual1})
+                        m->d_dual0, m->d_dual1, m->d_packed})
             if (p)
                 (void)hipFree(p);
     }
@@ -768,6 +771,8 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         dp.table1 = model->d_table1 ? model->d_table1 : model->d_table0;
         dp.table0_bytes = model->table0_bytes;
         dp.table1_bytes = model->table1_bytes;
+        dp.packed = model->d_packed;
+        dp.packed_bytes = model->d_packed ? (uint32_t)(model->host.r64_packed.size() * 4) : 0u;
         dp.scale_bits = model->host.scale_bits;
         dp.log2nsyms = model->host.log2nsyms;
         if (model->host.r64_search) { // log2 of the padded cum table

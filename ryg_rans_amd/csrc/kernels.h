@@ -77,6 +77,8 @@ struct DecParams {
     const void *table1; // byte/r64: SymRec[nsyms];  alias: divider u32[nsyms]
     uint32_t table0_bytes;
     uint32_t table1_bytes;
+    const void *packed;    // rans64, cum2sym decoders: 4-byte slot records {freq:12 | slot - start:12 | sym:8} [M], or NULL
+    uint32_t packed_bytes; //   (models whose largest frequency is below 4096; the 2-way lane decoder reads them)
     uint32_t scale_bits;
     uint32_t log2nsyms;
     uint32_t sym_bytes;

@@ -497,6 +497,51 @@ constexpr uint32_t kR64WaveLds = 64 * kR64RingStride;
     R64_LOOKUP "v_lshl_or_b32 " PK ", v49, 8, v48\n\t" R64_UPDATE                                                       \
     R64_LOOKUP "v_lshl_or_b32 " PK ", v48, 16, " PK "\n\tv_lshl_or_b32 " PK ", v49, 24, " PK "\n\t" R64_UPDATE
 #define R64_GROUP(P0, P1, P2, P3) R64_QUAD(P0) R64_QUAD(P1) R64_QUAD(P2) R64_QUAD(P3)
+// Round 3, the same pair of symbols with ONE gather each: a 4-byte slot record {freq:12 | slot - start:12 | sym:8} per
+// cumulative slot (the layout rans_word_sse41.h:64-72 uses for the word format, applied to rans64's tables; it holds every
+// model whose largest frequency is below 4096 -- at 14 bits every model whose most probable symbol stays below 25 %), at LDS
+// address 4 * slot.  One LDS round trip per pair of symbols instead of two dependent ones, one gather instead of two
+// (the LDS pipe was 74 % busy, half of it bank conflicts of the two gathers); one more VALU instruction per symbol.
+#define R64P_LOOKUP                                                                                                     \
+    "v_and_b32 v46, %[maskv], v40\n\t"                                                                                  \
+    "v_and_b32 v47, %[maskv], v42\n\t"                                                                                  \
+    "v_lshlrev_b32 v46, 2, v46\n\t"                                                                                     \
+    "v_lshlrev_b32 v47, 2, v47\n\t"                                                                                     \
+    "ds_read_b32 v54, v46\n\t"                                                                                          \
+    "ds_read_b32 v56, v47\n\t"                                                                                          \
+    "v_lshrrev_b64 v[50:51], %[sbv], v[40:41]\n\t"                                                                      \
+    "v_lshrrev_b64 v[52:53], %[sbv], v[42:43]\n\t"
+// PACK: the instruction(s) that put the two symbols (top bytes of v54, v56) into the trip's output dword
+#define R64P_UPDATE(PACK)                                                                                               \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                          \
+    PACK                                                                                                                \
+    "v_and_b32 v48, %[m12v], v54\n\t"                                                                                   \
+    "v_bfe_u32 v58, v54, 12, 12\n\t"                                                                                    \
+    "v_mul_u32_u24 v59, v48, v51\n\t"                                                                                   \
+    "v_mad_u64_u32 v[40:41], vcc, v50, v48, v[58:59]\n\t"                                                               \
+    "v_cmpx_gt_u64 s[36:37], %[kL], v[40:41]\n\t"                                                                       \
+    "v_mov_b32 v41, v40\n\t"                                                                                            \
+    "v_mov_b32 v40, v44\n\t"                                                                                            \
+    "v_mov_b32 v44, v45\n\t"                                                                                            \
+    "v_add_u32 %[cur], 4, %[cur]\n\t"                                                                                   \
+    "s_mov_b64 exec, -1\n\t"                                                                                            \
+    "v_and_b32 v49, %[m12v], v56\n\t"                                                                                   \
+    "v_bfe_u32 v60, v56, 12, 12\n\t"                                                                                    \
+    "v_mul_u32_u24 v61, v49, v53\n\t"                                                                                   \
+    "v_mad_u64_u32 v[42:43], vcc, v52, v49, v[60:61]\n\t"                                                               \
+    "v_cmpx_gt_u64 s[38:39], %[kL], v[42:43]\n\t"                                                                       \
+    "v_mov_b32 v43, v42\n\t"                                                                                            \
+    "v_mov_b32 v42, v44\n\t"                                                                                            \
+    "v_add_u32 %[cur], 4, %[cur]\n\t"                                                                                   \
+    "s_or_b64 exec, s[36:37], s[38:39]\n\t"                                                                             \
+    "v_and_b32 v62, 0x7f, %[cur]\n\t"                                                                                   \
+    "v_add_u32 v62, %[row], v62\n\t"                                                                                    \
+    "ds_read2_b32 v[44:45], v62 offset1:1\n\t"                                                                          \
+    "s_mov_b64 exec, -1\n\t"
+#define R64P_QUAD(PK)                                                                                                   \
+    R64P_LOOKUP R64P_UPDATE("v_perm_b32 " PK ", v56, v54, %[selA]\n\t")                                                 \
+    R64P_LOOKUP R64P_UPDATE("v_perm_b32 v63, v56, v54, %[selB]\n\tv_or_b32 " PK ", " PK ", v63\n\t")
+#define R64P_GROUP(P0, P1, P2, P3) R64P_QUAD(P0) R64P_QUAD(P1) R64P_QUAD(P2) R64P_QUAD(P3)
 // parked pieces -> ring.  Lane 4k+m holds piece m of the line of lane 4k+t (fetch instruction t): it goes to that
 // lane's row, rq0 + 136 t + slot (rq0 = own row - 136 m + 16 m); piece 0 of slot 0 also refreshes the mirror dword.
 #define R64_COMMIT                                                                                                      \
@@ -641,7 +686,7 @@ constexpr uint32_t kR64WaveLds = 64 * kR64RingStride;
         "v62", "v63", "v64", "v65", "v66", "v67", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", \
         "s47", "s50"
 
-__global__ void __launch_bounds__(1024) k_decode_lanes_r64x2(const DecParams p)
+template <bool PACKED> __global__ void __launch_bounds__(1024) k_decode_lanes_r64x2(const DecParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u;
@@ -679,6 +724,9 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_r64x2(const DecParams p)
     asm volatile("v_mov_b32 %0, %0" : "+v"(maskv)); // VGPR copies: a VALU op with an SGPR operand issues slower
     asm volatile("v_mov_b32 %0, %0" : "+v"(sbv));
     asm volatile("v_mov_b32 %0, %0" : "+v"(t1v));
+    uint32_t m12v = 0xfffu;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(m12v));
+    (void)m12v;
     const uint64_t kL = 1ull << 31;
     const uint64_t m0 = 0x1111111111111111ull; // lane 0 of every quad
 
@@ -736,6 +784,43 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_r64x2(const DecParams p)
             win = (uint64_t)w0 | ((uint64_t)w1 << 32);
         }
         uint32_t trips = uniform(p.chunk_syms >> 6);
+        if constexpr (PACKED) {
+        asm volatile("s_mov_b64 s[40:41], 0\n\t"
+                     "s_mov_b64 s[42:43], 0\n\t"
+                     "s_mov_b64 s[44:45], 0\n\t"
+                     "s_mov_b64 s[46:47], 0\n\t"
+                     "s_mov_b32 s50, 0\n\t"
+                     ".Lr64trip_%=:\n\t"
+                     R64_COMMIT
+                     "s_cmp_eq_u32 s50, 0\n\t"
+                     "s_cbranch_scc1 .Lr64first_%=\n\t"
+                     R64_TRANSPOSE R64_STORES
+                     ".Lr64first_%=:\n\t"
+#define R64_BOUNDARY(N)                                                                                                 \
+    "v_sub_u32 v46, %[ld], %[cur]\n\t"                                                                                  \
+    "v_cmp_gt_i32 vcc, 48, v46\n\t"                                                                                     \
+    "s_cbranch_vccz .Lr64ok" N "_%=\n\t"                                                                                \
+    /* side path (some lane is about to starve): everybody with room asks now, and we wait */                          \
+    R64_FETCH R64_COMMIT                                                             \
+    "v_sub_u32 v46, %[ld], %[cur]\n\t"                                                                                  \
+    ".Lr64ok" N "_%=:\n\t" R64_FETCH
+                     R64_BOUNDARY("0") R64P_GROUP("v8", "v9", "v10", "v11")
+                     R64_COMMIT R64_BOUNDARY("1") R64P_GROUP("v12", "v13", "v14", "v15")
+                     R64_COMMIT R64_BOUNDARY("2") R64P_GROUP("v16", "v17", "v18", "v19")
+                     R64_COMMIT R64_BOUNDARY("3") R64P_GROUP("v20", "v21", "v22", "v23")
+                     "s_mov_b32 s50, 1\n\t"
+                     "s_sub_u32 %[trips], %[trips], 1\n\t"
+                     "s_cmp_lg_u32 %[trips], 0\n\t"
+                     "s_cbranch_scc1 .Lr64trip_%=\n\t"
+                     R64_TRANSPOSE R64_STORES
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+{v[40:41]}"(xA), "+{v[42:43]}"(xB), "+{v[44:45]}"(win), [cur] "+v"(cur), [ld] "+v"(ld), [at0] "+v"(at[0]),
+                       [at1] "+v"(at[1]), [at2] "+v"(at[2]), [at3] "+v"(at[3]), [trips] "+s"(trips)
+                     : [maskv] "v"(maskv), [sbv] "v"(sbv), [m12v] "v"(m12v), [selA] "s"(0x0c0c0703u), [selB] "s"(0x07030c0cu), [row] "v"(row), [l16] "v"(l16), [rq0] "v"(rq0),
+                       [kL] "s"(kL), [m0] "s"(m0), [vq0] "s"(vq[0]), [vq1] "s"(vq[1]), [vq2] "s"(vq[2]), [vq3] "s"(vq[3]),
+                       [rsrc] "s"(rsrc4)
+                     : R64_CLOBBERS);
+        } else {
         asm volatile("s_mov_b64 s[40:41], 0\n\t"
                      "s_mov_b64 s[42:43], 0\n\t"
                      "s_mov_b64 s[44:45], 0\n\t"
@@ -771,6 +856,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_r64x2(const DecParams p)
                        [kL] "s"(kL), [m0] "s"(m0), [vq0] "s"(vq[0]), [vq1] "s"(vq[1]), [vq2] "s"(vq[2]), [vq3] "s"(vq[3]),
                        [rsrc] "s"(rsrc4)
                      : R64_CLOBBERS);
+        }
         // RansDec end state: both states back at L, every byte of the chunk consumed (main64.cpp has no check; ours)
         if (valid && (xA != kL || xB != kL || cur - cur0 != len))
             nbad++;
@@ -1858,25 +1944,36 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
                              (reinterpret_cast<uintptr_t>(p.container) & 15u) == 0;
         if (!off && force == 0 && staged && aligned && p.nchunks >= 64 && !p.trace) {
             const uint64_t full = p.n / p.chunk_syms; // chunks with chunk_syms symbols
-            uint32_t sw3 = (uint32_t)((160 * 1024 - table_lds) / kR64WaveLds);
+            // packed slot records (one gather per symbol) where the model has them and at least 8 waves' rings fit beside
+            // the table
+            static const bool no_packed = measure_knob("RANS_AMD_NO_R64_PACKED") != nullptr; // (A/B runs)
+            const size_t packed_lds = (p.packed_bytes + 15u) & ~(size_t)15;
+            const bool packed = p.packed && !no_packed && packed_lds + 8u * kR64WaveLds <= 160 * 1024;
+            const size_t table_lds3 = packed ? packed_lds : table_lds;
+            uint32_t sw3 = (uint32_t)((160 * 1024 - table_lds3) / kR64WaveLds);
             sw3 = sw3 > 16 ? 16 : sw3;
             const uint64_t batches = (full + 63) / 64;
             const uint64_t per_cu = (batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
             const uint64_t rounds = (per_cu + sw3 - 1) / sw3;
             const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
             sw3 = (uint32_t)(even ? even : 1);
-            static std::atomic<uint64_t> lds_ok3{0};
-            if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_decode_lanes_r64x2), 160 * 1024, lds_ok3);
-                e != hipSuccess)
+            auto kern3 = packed ? k_decode_lanes_r64x2<true> : k_decode_lanes_r64x2<false>;
+            static std::atomic<uint64_t> lds_ok3[2] = {{0}, {0}};
+            if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern3), 160 * 1024, lds_ok3[packed]); e != hipSuccess)
                 return e;
             DecParams q = p;
             q.nchunks = full;
             q.n = full * p.chunk_syms;
+            if (packed) { // the kernel stages "table 0" and "table 1": the packed records and nothing
+                q.table0 = p.packed;
+                q.table0_bytes = p.packed_bytes;
+                q.table1_bytes = 0;
+            }
             const uint64_t want_blocks = (batches + sw3 - 1) / sw3;
             const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)num_cus ? want_blocks : (uint64_t)num_cus);
             if (name)
-                *name = "k_decode_lanes_r64x2";
-            RANS_LAUNCH(k_decode_lanes_r64x2, dim3(grid), dim3(64 * sw3), table_lds + (size_t)sw3 * kR64WaveLds, stream, q);
+                *name = packed ? "k_decode_lanes_r64x2<packed slots>" : "k_decode_lanes_r64x2";
+            RANS_LAUNCH(kern3, dim3(grid), dim3(64 * sw3), table_lds3 + (size_t)sw3 * kR64WaveLds, stream, q);
             if (hipError_t e = hipGetLastError(); e != hipSuccess)
                 return e;
             if (full == p.nchunks)

@@ -193,6 +193,20 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
         // entries ns+1.. stay ~0; cum[ns] = M is > every cf as well, so symbol ns is never chosen
     }
 
+    r64_packed.clear();
+    if (fmt == RANS_AMD_FMT_R64 && !r64_search && ns <= 256 && sb <= 14) {
+        bool small = true;
+        for (uint32_t s = 0; s < ns; ++s)
+            small = small && freqs[s] <= 4095u;
+        if (small) {
+            r64_packed.resize(M);
+            for (uint32_t slot = 0; slot < M; ++slot) {
+                const uint32_t s = cum2sym[slot];
+                r64_packed[slot] = freqs[s] | ((slot - cum[s]) << 12) | (s << 24);
+            }
+        }
+    }
+
     // per-symbol records
     sym_recs.resize(ns);
     enc_recs.resize(ns);

@@ -114,6 +114,9 @@ struct HostModel {
     std::vector<uint16_t> cum2sym;  // [M] (exported as u8 when nsyms <= 256); empty for scale_bits > 16
     bool r64_search = false;        // rans64 with scale_bits 1..6 or 17..31: symbol by search, see build()
     std::vector<uint32_t> cum_padded; // r64_search: cum[] padded with ~0 to a power of two
+    // rans64 with a cum2sym table, byte symbols, scale_bits <= 14 and no frequency above 4095: one 4-byte record per slot,
+    // freq | (slot - start) << 12 | sym << 24 (k_decode_lanes_r64x2<packed>: one gather per symbol instead of two)
+    std::vector<uint32_t> r64_packed;
 
     // alias (main_alias.cpp:56-63)
     std::vector<uint32_t> divider, slot_adjust, slot_freqs, sym_id, alias_remap;

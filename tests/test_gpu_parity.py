@@ -699,16 +699,21 @@ def test_rans64_two_way_lane_kernel(gpu, oracle):
     rng = np.random.default_rng(5)
     zipf = oracle.gen_zipf(600000 + 333, K=256, s=1.0, seed=23)
     flat = rng.integers(0, 256, 300000).astype(np.uint8)
+    heavy = np.where(rng.random(300000) < 0.6, 0, rng.integers(0, 256, 300000)).astype(np.uint8)  # one symbol above 50 %
     cases = [(zipf, 14, 512), (zipf, 14, 64), (zipf, 12, 1024), (zipf, 16, 4096), (zipf, 8, 128), (zipf[:64 * 64], 14, 64),
-             (zipf[:70 * 512 + 5], 11, 512), (flat, 14, 512), (flat, 16, 192)]
+             (zipf[:70 * 512 + 5], 11, 512), (flat, 14, 512), (flat, 16, 192), (heavy, 14, 512), (heavy, 12, 256), (heavy, 13, 64)]
     for data, sb, chunk in cases:
         om, gm = _models(R, ctx, oracle, FMT_R64, sb, data)
+        # round 3: models with scale_bits <= 14 and no frequency above 4095 are decoded from 4-byte packed slot records
+        # (one gather per symbol); everything else from cum2sym + {freq, start} as before
+        packed = sb <= 14 and int(gm.freqs.max()) <= 4095
+        kernel = "k_decode_lanes_r64x2<packed slots>" if packed else "k_decode_lanes_r64x2"
         want, offs, lens = oracle.encode_chunked(FMT_R64, om, data, 2, chunk, align=16)
         d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
         d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
         d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
         out = ctx.decode(gm, d_cont, want.size, d_offs, d_lens, data.size, 2, chunk)
-        assert ctx.last_decode_kernel() == "k_decode_lanes_r64x2", ctx.last_decode_kernel()
+        assert ctx.last_decode_kernel() == kernel, (ctx.last_decode_kernel(), sb, chunk)
         assert np.array_equal(out.cpu().numpy(), data), (sb, chunk, data.size)
         d_syms = torch.from_numpy(data).cuda()
         cont, o2, l2, total = ctx.encode(gm, d_syms, 2, chunk)
@@ -746,6 +751,17 @@ def test_rans64_two_way_lane_kernel(gpu, oracle):
                      torch.from_numpy(offs.astype(np.int64)).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda(),
                      rare.size, 2, 256)
     assert ctx.last_decode_kernel() == "k_decode_lanes_r64x2"
+    assert np.array_equal(out.cpu().numpy(), rare)
+    # the same through the packed slot records (12 bits: the frequent symbol's 3841 fits the record's 12-bit field)
+    sb = 12
+    f = np.ones(256, np.uint32)
+    f[0] = (1 << sb) - 255
+    om, gm = oracle.model(f, sb), ctx.model(FMT_R64, f, sb)
+    want, offs, lens = oracle.encode_chunked(FMT_R64, om, rare, 2, 256, align=16)
+    out = ctx.decode(gm, torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda(), want.size,
+                     torch.from_numpy(offs.astype(np.int64)).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda(),
+                     rare.size, 2, 256)
+    assert ctx.last_decode_kernel() == "k_decode_lanes_r64x2<packed slots>"
     assert np.array_equal(out.cpu().numpy(), rare)
     # damage: flipped stream bytes, a length that lies, an offset off its 16-byte grid
     data, sb, chunk = zipf[:128 * 512], 14, 512

@@ -23,6 +23,7 @@ CONFIGS = {
     "alias256": (R.FMT_ALIAS, 16, 256, 64, 32768, 1 << 20),
     "byte": (R.FMT_BYTE, 14, 256, 64, 32768, 1 << 20),
     "word": (R.FMT_WORD, 12, 256, 64, 32768, 1 << 20),
+    "c2": (R.FMT_R64, 14, 256, 2, 512, 1 << 20),
 }
 VARIANTS = {"dual": 2, "single": 0}
 
