@@ -84,6 +84,7 @@ struct rans_amd_ctx {
     DeviceBuffer hist;
     DeviceBuffer layout_sums; // per-block totals of the offset scan (many-chunk containers)
     DeviceBuffer enc_status;  // fused encoder: look-back word per chunk + the claim counters (EncParams::status)
+    DeviceBuffer enc_mailboxes; // fused encoder whose tables fill the LDS: one mailbox per block (EncParams::mailbox_global)
     DeviceBuffer wave_scratch; // one 64-byte line per resident decoder wave (DecParams::wave_scratch)
     DeviceBuffer host_in, host_out, host_idx; // staging of the *_host wrappers, kept between calls (under host_mu)
     std::mutex host_mu;
@@ -255,6 +256,7 @@ int rans_amd_ctx_destroy(rans_amd_ctx *ctx)
     ctx->hist.release();
     ctx->layout_sums.release();
     ctx->enc_status.release();
+    ctx->enc_mailboxes.release();
     ctx->host_in.release();
     ctx->host_out.release();
     ctx->host_idx.release();
@@ -282,6 +284,7 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx)
     ctx->hist.release();
     ctx->layout_sums.release();
     ctx->enc_status.release();
+    ctx->enc_mailboxes.release();
     ctx->host_in.release();
     ctx->host_out.release();
     ctx->host_idx.release();
@@ -626,14 +629,14 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     // context option RANS_AMD_OPT_LANE_FUSED_PLACEMENT: the lane encoders place their chunks themselves as well -- bit-exact,
     // tested, and on config 2 no faster than k_layout + k_compact_small behind them (lanes.hip says why), hence opt-in
     const bool lanes_fused_env = (ctx->variant & kVarLanesFused) != 0;
+    const int fits = lanes ? 0 : encode_fused_fits(enc_format, model->host.nsyms, model->host.scale_bits);
     const bool fused = nchunks > 0 && nchunks < (1ull << 31) && !unfused_env &&
-                       (lanes ? lanes_fused_env && encode_lanes_can_fuse(enc_format, ep, ctx->num_cus)
-                              : encode_fused_fits(enc_format, model->host.nsyms, model->host.scale_bits));
+                       (lanes ? lanes_fused_env && encode_lanes_can_fuse(enc_format, ep, ctx->num_cus) : fits != 0);
     // Scratch: one worst-case slot per chunk, or -- context option RANS_AMD_OPT_ENC_SCRATCH_RING, fused wave encoders
     // only -- a small ring of slots per coding wave (kernels.h kEncRingSlots): half the workspace for a 1 GiB shard, and
     // measured 2-4 % slower, hence opt-in.
     const uint64_t ring_waves = (uint64_t)ctx->num_cus * kEncRingMaxWavesPerCu;
-    const bool ring = fused && !lanes && ctx->scratch_ring && slot <= kEncRingMaxSlotBytes && nchunks > ring_waves * kEncRingSlots;
+    const bool ring = fused && !lanes && fits == 1 && ctx->scratch_ring && slot <= kEncRingMaxSlotBytes && nchunks > ring_waves * kEncRingSlots;
     rc = ctx->scratch.reserve((size_t)((ring ? ring_waves * kEncRingSlots : nchunks) * slot + 64));
     if (rc)
         return rc;
@@ -647,6 +650,14 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         if (rc)
             return rc;
         HIP_TRY(hipMemsetAsync(ctx->enc_status.ptr, 0, status_bytes, s));
+        if (fits == 2) { // the tables fill the LDS: one mailbox per block in global memory
+            const size_t mb_bytes = (size_t)ctx->num_cus * kEncMailboxStride;
+            rc = ctx->enc_mailboxes.reserve(mb_bytes);
+            if (rc)
+                return rc;
+            HIP_TRY(hipMemsetAsync(ctx->enc_mailboxes.ptr, 0, mb_bytes, s));
+            ep.mailbox_global = static_cast<uint8_t *>(ctx->enc_mailboxes.ptr);
+        }
     }
 
     if (ctx->timing)

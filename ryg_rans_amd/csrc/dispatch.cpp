@@ -26,20 +26,22 @@ hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_
     return launch_decode_wave(format, p, num_cus, stream, kernel_name);
 }
 
-// fused placement needs a mailbox behind the tables in LDS (encode_wave.hip launch_encode_t computes the same sizes and
-// rejects what does not fit): the alias tables of a 16-bit model over 4096 symbols fill the CU's 160 KiB to the last
-// byte (config 4 keeps the three-kernel path), and so do 16-byte records for 8192 symbols against the 128 KiB the
-// other kernels may use -- those shapes take k_encode + k_layout + k_compact.
-bool encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits)
+// Fused placement needs a mailbox for the block's coders and copier (encode_wave.hip launch_encode_t computes the same
+// sizes).  It lives behind the tables in LDS where there is room; the alias tables of a 16-bit model over 4096 symbols
+// fill the CU's 160 KiB to the last byte (config 4), and that kernel keeps its mailbox in global memory (round 3; a push
+// and a pop per chunk, 175 us apart: L2 latency does not matter there).  16-byte records for more than 8159 symbols
+// against the 128 KiB the other kernels may use cannot fuse at all (no model of that shape can be created today: its
+// decoder tables do not fit either).
+int encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits)
 {
     const size_t nrecs = nsyms < 256 ? 256 : nsyms;
     if (format == kKernelFormatAliasLds)
-        return nrecs * 8 + ((size_t)2 << scale_bits) + 16 + kEncFusedLdsBytes <= 160 * 1024;
+        return nrecs * 8 + ((size_t)2 << scale_bits) + 16 + kEncFusedLdsBytes <= 160 * 1024 ? 1 : 2;
     if (format == kKernelFormatByteAdaptive) // (per-wave tables; never fused, see api.cpp)
-        return false;
+        return 0;
     const bool word_recs = format == (int)RANS_AMD_FMT_WORD || format == (int)RANS_AMD_FMT_BYTE;
     const size_t tables = nrecs * 16 + (word_recs ? 256 * 16 : 0);
-    return ((tables + 15) & ~(size_t)15) + kEncFusedLdsBytes <= 128 * 1024;
+    return ((tables + 15) & ~(size_t)15) + kEncFusedLdsBytes <= 128 * 1024 ? 1 : 0;
 }
 
 // true when launch_encode hands this shape to the lane-per-chunk encoders (no fused placement there)

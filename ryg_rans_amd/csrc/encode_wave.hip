@@ -432,13 +432,16 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             }
         }
     }
-    EncMailbox *mb = reinterpret_cast<EncMailbox *>(smem + p.mailbox_off);
+    // (the mailbox sits behind the tables in LDS, or -- tables that fill the LDS -- in this block's slot of a global array:
+    //  coders and copier of a block run on one CU, i.e. behind one L2)
+    EncMailbox *mb = p.mailbox_global ? reinterpret_cast<EncMailbox *>(p.mailbox_global + (size_t)blockIdx.x * kEncMailboxStride)
+                                      : reinterpret_cast<EncMailbox *>(smem + p.mailbox_off);
     // scratch ring: drained[w] = chunks of coding wave w that the copier has moved out of their slots.  Raw LDS address,
     // explicit DS instructions on both sides: the protocol must not depend on how the compiler threads a lane-0 branch
     // through the code around it
     const uint32_t drained_lds = (uint32_t)(uintptr_t)(RANS_LDS uint8_t *)(smem + p.mailbox_off + kEncMailboxBytes);
     if constexpr (FUSED) {
-        if (threadIdx.x < kEncFusedLdsBytes / 4u)
+        if (!p.mailbox_global && threadIdx.x < kEncFusedLdsBytes / 4u) // (the global ones are zeroed by the host)
             reinterpret_cast<uint32_t *>(mb)[threadIdx.x] = 0u;
     }
     __syncthreads();
@@ -779,7 +782,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
                  : (FMT == FMT_BYTE && p.chunk_freqs) ? (size_t)waves * kAdaptEncWaveLds
                                                       : nrecs * sizeof(EncRec) + ((FMT == FMT_WORD || FMT == FMT_BYTE) ? 256 * 16 : 0);
     EncParams q = p;
-    if (fused) {
+    if (fused && !p.mailbox_global) {
         lds = (lds + 15) & ~(size_t)15;
         q.mailbox_off = (uint32_t)lds;
         lds += kEncFusedLdsBytes;

@@ -127,6 +127,8 @@ struct EncParams {
     uint8_t *out;               // fused: the container
     uint64_t out_cap;
     uint32_t mailbox_off;       // fused: LDS byte offset of the block's mailbox (set by the launcher)
+    uint8_t *mailbox_global;    // fused, tables that fill the CU's LDS to the last byte (the 4096-symbol, 16-bit alias model):
+                                // one kEncMailboxStride-byte mailbox per block in global memory (zero at launch), else NULL
     uint32_t ring_slots;        // fused wave encoders: 0 = scratch holds one slot per CHUNK (slot of chunk c at c * slot_bytes);
                                 // R > 0 = one ring of R slots per CODING WAVE (wave g's slots at (g * R + j) * slot_bytes)
     // Lane-per-chunk encoders (lanes.hip), fused: a launch codes the batches (64 chunks each) [batch_begin, batch_end)
@@ -153,6 +155,7 @@ constexpr uint32_t kEncMailboxBytes = 16 + 64 * 8;
 // scratch ring protocol, EncParams::ring_slots)
 constexpr uint32_t kEncDrainBytes = 64;
 constexpr uint32_t kEncFusedLdsBytes = kEncMailboxBytes + kEncDrainBytes;
+constexpr uint32_t kEncMailboxStride = 640; // a block's mailbox in global memory (EncParams::mailbox_global): whole 128-byte lines
 // Scratch ring of the fused wave encoders: every coding wave owns kEncRingSlots worst-case slots and codes its chunks
 // into them in turn (a slot is reused once the block's copier has moved its previous occupant to the container), so the
 // scratch a launch touches is (coding waves) x (slots) x (stream of a chunk) instead of the whole container once more --
@@ -188,7 +191,8 @@ hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_
 hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **kernel_names);
 bool decode_dual_fits(uint32_t table0_bytes, uint32_t table1_bytes); // LDS room for two stream windows per wave (decode_dual.hip)
 bool encode_uses_lanes(int format, uint64_t nchunks, uint32_t n_ways);
-bool encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits);
+// 0: the fused placement does not fit; 1: mailbox in the block's LDS; 2: the tables fill the LDS, mailbox in global memory
+int encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits);
 bool encode_lanes_can_fuse(int format, const EncParams &p, int num_cus); // lane-per-chunk encoders: see launchers.hpp
 hipError_t launch_layout(const LayoutParams &p, hipStream_t stream);
 uint32_t layout_blocks(uint64_t nchunks); // blocks (and block_sums entries) launch_layout uses

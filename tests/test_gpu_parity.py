@@ -134,6 +134,9 @@ def test_alias_4096_symbols(gpu, oracle):
             assert np.array_equal(g[a:b], cont[a:b]), "chunk %d differs" % c
         d_out = ctx.decode(gm, g_cont, total, g_offs, g_lens, data.size, n_ways, chunk)
         assert np.array_equal(d_out.cpu().numpy().view(np.uint16), data)
+        # round 3: this model's tables (128 KiB of alias_remap + 32 KiB of records) fill the CU's LDS to the last byte, and the
+        # kernel places its chunks itself all the same -- its mailbox lives in global memory
+        assert ctx.last_encode_kernel() == ("k_encode<alias, LDS remap>", True), ctx.last_encode_kernel()
 
 
 def test_reference_fixtures(gpu):

@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 import ryg_rans_amd as R  # noqa: E402
 from tools.config_sweep import zipf  # noqa: E402
 
-CONFIGS = {"word": (R.FMT_WORD, 12, 256, 64), "byte": (R.FMT_BYTE, 14, 256, 64), "r64": (R.FMT_R64, 14, 256, 64)}
+CONFIGS = {"word": (R.FMT_WORD, 12, 256, 64), "byte": (R.FMT_BYTE, 14, 256, 64), "r64": (R.FMT_R64, 14, 256, 64),
+           "c4": (R.FMT_ALIAS, 16, 4096, 64)}
 
 
 def main():
@@ -26,14 +27,16 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--tag", default="")
     ap.add_argument("--ring", type=int, default=0, help="RANS_AMD_OPT_ENC_SCRATCH_RING")
+    ap.add_argument("--fused", type=int, default=1, help="RANS_AMD_OPT_FUSED_PLACEMENT")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = R.Context(0)
     ctx.set_timing(True)
     ctx.set_option(R.OPT_ENC_SCRATCH_RING, a.ring)
+    ctx.set_option(R.OPT_FUSED_PLACEMENT, a.fused)
     for name in a.configs.split(","):
         fmt, sb, nsyms, ways = CONFIGS[name]
-        n = 1 << a.log2n
+        n = (1 << a.log2n) // (2 if nsyms > 256 else 1)  # (u16 symbols: the same number of bytes)
         d = zipf(n, nsyms, 1, dev)
         f, _ = R.normalize_freqs(ctx.count_freqs_device(d, nsyms), 1 << sb)
         m = ctx.model(fmt, f, sb)
@@ -56,7 +59,7 @@ def main():
                 ms.append(ctx.last_kernel_ms()[1])
             mean = sum(ms) / len(ms)
             print("%-10s %-5s chunk %-6d round %d  mean %.4f ms  min %.4f ms  frac %.4f  %s %s" % (
-                a.tag, name, a.chunk, r, mean, min(ms), (total + n) / mean / 1e6 / 8000.0, kern, "ok" if ok else "MISMATCH"),
+                a.tag, name, a.chunk, r, mean, min(ms), (total + n * d.element_size()) / mean / 1e6 / 8000.0, kern, "ok" if ok else "MISMATCH"),
                 flush=True)
         del d, cont
         torch.cuda.empty_cache()
