@@ -12,11 +12,11 @@ n = 1 << 30
 d = gen_zipf(torch, n, 256, 1.0, 1, dev)
 f, _ = R.normalize_freqs(ctx.count_freqs_device(d, 256), 4096)
 m = ctx.model(R.FMT_WORD, f, 12)
-cont, offs, lens, total = ctx.encode(m, d, 64, 32768)
+cont, offs, lens, total = ctx.encode(m, d, 64, 16384)
 nb = (total + 4095) & ~4095
 
 def t(cont, out):
-    ms, mn = timed_launches(torch, lambda: ctx.decode(m, cont, total, offs, lens, n, 64, 32768, d_out=out, sync=False), 12, 2)
+    ms, mn = timed_launches(torch, lambda: ctx.decode(m, cont, total, offs, lens, n, 64, 16384, d_out=out, sync=False), 12, 2)
     return ms
 
 outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(10)]
