@@ -40,7 +40,9 @@ int encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits)
     if (format == kKernelFormatByteAdaptive) // (per-wave tables; never fused, see api.cpp)
         return 0;
     const bool word_recs = format == (int)RANS_AMD_FMT_WORD || format == (int)RANS_AMD_FMT_BYTE;
-    const size_t tables = nrecs * 16 + (word_recs ? 256 * 16 : 0);
+    size_t tables = nrecs * 16 + (word_recs ? 256 * 16 : 0);
+    if (format == (int)RANS_AMD_FMT_WORD && nrecs == 256) // the staging windows of the word encoder's waves
+        tables += (size_t)(kEncFusedThreads / 64) * kEncStageBytes;
     return ((tables + 15) & ~(size_t)15) + kEncFusedLdsBytes <= 128 * 1024 ? 1 : 0;
 }
 

@@ -167,6 +167,10 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 //   x / freq    round-up reciprocal (model.h, WordEncRec): one v_mul_hi_u32 and four cheap ops,
 //               exact, so no compare/select; x' = x + bias + q * cmpl in one v_mad_u32_u24 + add
 // 15 VALU, no v_cndmask, no branch.  `wp` is the byte offset of the lowest word written so far.
+// (One state per lane -- every 64-way launch -- runs enc_word_full_staged below instead: the words go to LDS first.)
+#ifndef RANS_ENC_STAGE // (experiment knob: -DRANS_ENC_STAGE=0 = the word encoder stores every round's words itself)
+#define RANS_ENC_STAGE 1
+#endif
 #ifndef RANS_ENC_STORE // (experiment knob: -DRANS_ENC_STORE='""' drops the stream stores of the word encoder)
 #define RANS_ENC_STORE "global_store_short %[t], %[x], %[base]\n\t"
 #endif
@@ -230,6 +234,72 @@ __device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x2 &rec, uin
                      "v_add_u32_e32 %[x], %[q], %[t]"
                      : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
                      : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12), [base] "s"(slot)
+                     : "vcc", "scc", "memory");
+    }
+}
+
+// The same with the emitted words staged in LDS: a 2 KiB window per wave that mirrors the low eleven bits of the slot
+// offset (win_base is 2 KiB aligned, so the address is one v_bfi); stage_flush() in the kernel moves what four rounds
+// have produced to memory in whole 16-byte pieces.  One ds_write_b16 per round instead of one global_store_short: the
+// per-round stores were 4.3e7 write requests of 19 bytes on the 1 GiB encode and kept the address unit 87 % busy
+// (profiles/r03_encoder_bound.md); the LDS pipe is 18 % busy since the records are eight bytes.
+template <bool SMALL>
+__device__ __forceinline__ void enc_word_full_staged(uint32_t &x, const u32x2 &rec, uint32_t &wp,
+                                              uint32_t win_mask, uint32_t win_base, uint32_t &worst, uint32_t m12)
+{
+    uint32_t t, q, c, cnt;
+    if constexpr (SMALL) {
+        asm volatile("v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                     "v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
+                     "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
+                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                     "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
+                     "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
+                     "s_mov_b64 exec, vcc\n\t"
+                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
+                     "v_bfi_b32 %[t], %[wm], %[t], %[wb]\n\t"
+                     "ds_write_b16 %[t], %[x]\n\t"
+                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
+                     "v_lshrrev_b32_e32 %[t], 27, %[w]\n\t"
+                     "v_and_b32_e32 %[c], %[m12], %[w]\n\t"
+                     "v_lshrrev_b32_e32 %[q], %[t], %[q]\n\t"
+                     "v_bfe_u32 %[t], %[w], 12, 13\n\t"
+                     "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
+                     "v_add_u32_e32 %[x], %[q], %[t]"
+                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
+                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12), [wm] "v"(win_mask), [wb] "v"(win_base)
+                     : "vcc", "scc", "memory");
+    } else {
+        asm volatile("v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                     "v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
+                     "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
+                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                     "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
+                     "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
+                     "s_mov_b64 exec, vcc\n\t"
+                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
+                     "v_bfi_b32 %[t], %[wm], %[t], %[wb]\n\t"
+                     "ds_write_b16 %[t], %[x]\n\t"
+                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
+                     "v_sub_u32_e32 %[t], %[x], %[q]\n\t"
+                     "v_lshrrev_b32_e32 %[t], 1, %[t]\n\t"
+                     "v_add_u32_e32 %[q], %[q], %[t]\n\t"
+                     "v_lshrrev_b32_e32 %[t], 27, %[w]\n\t"
+                     "v_and_b32_e32 %[c], %[m12], %[w]\n\t"
+                     "v_lshrrev_b32_e32 %[q], %[t], %[q]\n\t"
+                     "v_bfe_u32 %[t], %[w], 12, 13\n\t"
+                     "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
+                     "v_add_u32_e32 %[x], %[q], %[t]"
+                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
+                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12), [wm] "v"(win_mask), [wb] "v"(win_base)
                      : "vcc", "scc", "memory");
     }
 }
@@ -642,6 +712,41 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             const bool byte_asm = FMT == FMT_BYTE && lds_at_zero && !adaptive;
             (void)swap_sel;
             (void)byte_asm;
+            // word format, one state per lane: stream staging (enc_word_full_staged).  Invariant between groups of four
+            // rounds: memory holds the stream from wp up; what a flush writes below wp (< 16 bytes, whatever the window
+            // held) is written again, correctly, by the next flush, and at the end by the state flush.
+            constexpr bool kStage = RANS_ENC_STAGE && FMT == FMT_WORD && K == 1;
+            uint32_t win_mask = kEncStageBytes - 1u, win_base = kWordRecBytes + 256u * (uint32_t)sizeof(EncRec) + wave * kEncStageBytes;
+            asm volatile("" : "+v"(win_mask));
+            asm volatile("" : "+v"(win_base));
+            const __attribute__((address_space(3))) uint8_t *win =
+                reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)win_base);
+            if (kStage && (wp & 15u)) { // the tail rounds have stored words themselves: the piece that holds wp goes into the window
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane < 4u) {
+                    const uint32_t at = (wp & ~15u) + 4u * lane;
+                    const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t RANS_GLOBAL *>(slot + at));
+                    *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(win_base + (at & (kEncStageBytes - 1u)))) = v;
+                }
+            }
+            // [wp, wp_old) -> memory, in whole 16-byte pieces.  Sixteen rounds emit at most 13 words per lane (a symbol adds
+            // at most 12 bits to a state of 16..32 bits, a word takes 16 out): 1664 bytes, within the window, and at most
+            // 106 pieces -- two passes of the wave, the second one rarely has any lanes (the average is 50 pieces).
+            auto stage_flush = [&](uint32_t wp_old) {
+                const uint32_t hi = (wp_old + 15u) & ~15u, lo = wp & ~15u;
+                const int32_t a = (int32_t)hi - 16 * (int32_t)(lane + 1u);
+                auto piece = [&](int32_t at) {
+                    if (at >= (int32_t)lo) {
+                        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(win + ((uint32_t)at & (kEncStageBytes - 1u)));
+                        *reinterpret_cast<u32x4 RANS_GLOBAL *>(const_cast<uint8_t RANS_GLOBAL *>(slot) + (uint32_t)at) = v;
+                    }
+                };
+                piece(a);
+                if (hi - lo > 1024u) // (wave-uniform)
+                    piece(a - 1024);
+            };
+            (void)stage_flush;
+            (void)win;
             uint32_t cur[4][K], nxt[4][K];
             auto load_super = [&](uint32_t (&dstq)[4][K], uint32_t sg) {
 #pragma unroll
@@ -656,6 +761,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             while (sg-- > 0) {
                 if (sg > 0)
                     load_super(nxt, sg - 1);
+                const uint32_t wp_super = uniform(wp);
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     uint32_t t[K];
@@ -679,7 +785,10 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                             const u32x2 now = rec;
                             if (step + 1 < 4 * K)
                                 rec = rec_at(step + 1);
-                            enc_word_full<true>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
+                            if constexpr (kStage)
+                                enc_word_full_staged<true>(x[K - 1 - step % K], now, wp, win_mask, win_base, worst, m12v);
+                            else
+                                enc_word_full<true>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
                         }
                     } else {
 #pragma unroll
@@ -687,7 +796,10 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                             const u32x2 now = rec;
                             if (step + 1 < 4 * K)
                                 rec = rec_at(step + 1);
-                            enc_word_full<false>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
+                            if constexpr (kStage)
+                                enc_word_full_staged<false>(x[K - 1 - step % K], now, wp, win_mask, win_base, worst, m12v);
+                            else
+                                enc_word_full<false>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
                         }
                     }
                     wp = uniform(wp);
@@ -715,6 +827,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                             enc_substep<FMT, true, kIsAlias<FMT>>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
                 }
                 }
+                if constexpr (kStage)
+                    stage_flush(wp_super);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -781,6 +895,8 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
                  : (FMT == FMT_BYTE && p.chunk_freqs) ? (size_t)waves * kAdaptEncWaveLds
                                                       : nrecs * sizeof(EncRec) + ((FMT == FMT_WORD || FMT == FMT_BYTE) ? 256 * 16 : 0);
+    if (RANS_ENC_STAGE && FMT == FMT_WORD && K == 1 && p.sym_bytes == 1 && nrecs == 256)
+        lds += (size_t)waves * kEncStageBytes; // stream staging windows (2 KiB aligned: 4 + 4 KiB of tables in front)
     EncParams q = p;
     if (fused && !p.mailbox_global) {
         lds = (lds + 15) & ~(size_t)15;

@@ -155,6 +155,9 @@ constexpr uint32_t kEncMailboxBytes = 16 + 64 * 8;
 // scratch ring protocol, EncParams::ring_slots)
 constexpr uint32_t kEncDrainBytes = 64;
 constexpr uint32_t kEncFusedLdsBytes = kEncMailboxBytes + kEncDrainBytes;
+// word encoder, one state per lane: the emitted words of sixteen rounds are staged in a window of LDS per wave
+// (encode_wave.hip, enc_word_full_staged); the windows follow the 8 KiB of record tables
+constexpr uint32_t kEncStageBytes = 2048;
 constexpr uint32_t kEncMailboxStride = 640; // a block's mailbox in global memory (EncParams::mailbox_global): whole 128-byte lines
 // Scratch ring of the fused wave encoders: every coding wave owns kEncRingSlots worst-case slots and codes its chunks
 // into them in turn (a slot is reused once the block's copier has moved its previous occupant to the container), so the
