@@ -40,6 +40,30 @@ def test_version_and_status_strings():
     assert R.lib().rans_amd_status_string(99) == b"unknown status"
 
 
+def test_shipped_library_is_not_the_measure_build():
+    """The library the package loads reads no environment: RANS_AMD_BUILD_MEASURE is clear (bench.py refuses a headline
+    run on a build that has it), and the measure build, when present, says what it is."""
+    assert R.lib().rans_amd_build_flags() == 0
+    measure = os.path.join(os.path.dirname(R.LIB_PATH), "libryg_rans_amd_measure.so")
+    if os.path.exists(measure):
+        m = C.CDLL(measure)
+        m.rans_amd_build_flags.restype = C.c_uint32
+        assert m.rans_amd_build_flags() & 1  # RANS_AMD_BUILD_MEASURE
+    # the product sources read the environment only inside measure_knob() / #ifdef RANS_AMD_MEASURE
+    for fn in ("api.cpp", "dispatch.cpp", "lanes.hip", "encode_wave.hip", "decode_wave.hip", "decode_dual.hip"):
+        text = open(os.path.join(ROOT, "ryg_rans_amd", "csrc", fn)).read()
+        assert "getenv(" not in text, fn
+
+
+def test_set_option_checks_its_arguments():
+    assert R.lib().rans_amd_ctx_set_option(None, R.OPT_DUAL_DECODE, 1) == R.E_ARG
+    assert b"ctx is NULL" in R.lib().rans_amd_last_error()
+    header = open(os.path.join(ROOT, "include", "ryg_rans_amd.h")).read()
+    for name in ("LANE_KERNELS", "LANE_FUSED_PLACEMENT", "FUSED_PLACEMENT", "DUAL_DECODE", "ENC_SCRATCH_RING"):
+        m = re.search(r"RANS_AMD_OPT_%s\s*=\s*(\d+)" % name, header)
+        assert m and int(m.group(1)) == getattr(R, "OPT_" + name), name
+
+
 def test_no_cpu_fallback():
     """Without a GPU the context cannot be created and nothing can be encoded/decoded."""
     import torch
