@@ -363,6 +363,15 @@ def test_word_encoder_full_wave_path_extremes(gpu, oracle):
     cases.append(("powers of two", f, rng.choice(13, n, p=f[:13] / 4096.0).astype(np.uint8)))
     f = np.ones(256, np.uint32); f[3] = 4096 - 255
     cases.append(("3841 + 255 x 1", f, rng.choice(256, n, p=f / 4096.0).astype(np.uint8)))
+    # twelve bits per symbol, every symbol: 1536 bytes per sixteen rounds of a wave -- the staged words need both passes
+    # of the flush (encode_wave.hip stage_flush); and the other end, a stream of almost nothing but flushed states
+    rare = rng.integers(0, 255, n).astype(np.uint8)
+    rare[rare >= 3] += 1
+    cases.append(("255 x 1 only", f, rare))
+    cases.append(("3841 only", f, np.full(n, 3, np.uint8)))
+    mixed = rare.copy()
+    mixed[(np.arange(n) // 2048) % 2 == 0] = 3  # bursts: pieces of every size, flushes with nothing to write
+    cases.append(("bursts", f, mixed))
     f = np.zeros(256, np.uint32); f[10] = 2049; f[11] = 2047
     cases.append(("2049/2047", f, rng.integers(10, 12, n).astype(np.uint8)))
     f = np.zeros(256, np.uint32); f[:5] = [3, 5, 7, 4081 - 1365, 1365]
@@ -371,7 +380,9 @@ def test_word_encoder_full_wave_path_extremes(gpu, oracle):
         om = oracle.model(f, 12)
         gm = ctx.model(FMT_WORD, f, 12)
         d = torch.from_numpy(data).cuda()
-        for n_ways, chunk in ((64, 8192), (128, 16384), (256, 32768), (64, n)):
+        # (64-way with ragged chunks: rounds beyond the last full sixteen store their words themselves, the staging
+        #  window is then primed with the 16-byte piece the write offset stands in)
+        for n_ways, chunk in ((64, 8192), (128, 16384), (256, 32768), (64, n), (64, 5000), (64, 1031), (64, 2048 + 64 * 7 + 5)):
             want, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, n_ways, chunk, align=16)
             cont, d_offs, d_lens, total = ctx.encode(gm, d, n_ways, chunk)
             assert total == want.size, (name, n_ways)
