@@ -218,6 +218,10 @@ class Context:
         except Exception:
             pass
 
+    def trim(self):
+        """rans_amd_ctx_trim: frees the workspaces the context keeps between calls (they come back on demand)."""
+        _check(_lib.rans_amd_ctx_trim(self._h), "ctx_trim")
+
     def set_option(self, option, value):
         """rans_amd_ctx_set_option: kernel-family choices (all produce the same bytes)."""
         _check(_lib.rans_amd_ctx_set_option(self._h, int(option), int(value)), "ctx_set_option")

@@ -98,6 +98,7 @@ struct rans_amd_ctx {
     uint32_t variant = 0;    // kVar* bits (rans_amd_ctx_set_option)
     bool unfused = false;    // RANS_AMD_OPT_FUSED_PLACEMENT = 0: k_encode + k_layout + k_compact
     bool scratch_ring = false; // RANS_AMD_OPT_ENC_SCRATCH_RING = 1
+    size_t scratch_shift = 0, status_shift = 0; // measure build: where in their allocations the two start (placement sweeps)
     const char *last_kernel = "";
     const char *last_enc_kernel = ""; // the coding kernel of the last encode call
     bool last_enc_fused = false;      // ... and whether it placed its chunks itself (no k_layout / k_compact)
@@ -291,6 +292,22 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx)
     ctx->trace.release();
     return RANS_AMD_OK;
 }
+
+#ifdef RANS_AMD_MEASURE
+// Measure build only (not in the header, not in the shipped library): where the encoder's workspaces lie, and a byte
+// offset (a multiple of 256) for each inside its allocation -- tools/dbg_enc_placement.py sweeps them.
+extern "C" __attribute__((visibility("default"))) unsigned long long rans_amd_measure_ptr(rans_amd_ctx *ctx, int which)
+{
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return which == 0 ? (unsigned long long)(uintptr_t)ctx->scratch.ptr + ctx->scratch_shift
+                      : (unsigned long long)(uintptr_t)ctx->enc_status.ptr + ctx->status_shift;
+}
+extern "C" __attribute__((visibility("default"))) void rans_amd_measure_shift(rans_amd_ctx *ctx, int which, unsigned long long bytes)
+{
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (which == 0 ? ctx->scratch_shift : ctx->status_shift) = (size_t)bytes & ~(size_t)255;
+}
+#endif
 
 int rans_amd_ctx_set_option(rans_amd_ctx *ctx, int option, int value)
 {
@@ -637,19 +654,19 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     // measured 2-4 % slower, hence opt-in.
     const uint64_t ring_waves = (uint64_t)ctx->num_cus * kEncRingMaxWavesPerCu;
     const bool ring = fused && !lanes && fits == 1 && ctx->scratch_ring && slot <= kEncRingMaxSlotBytes && nchunks > ring_waves * kEncRingSlots;
-    rc = ctx->scratch.reserve((size_t)((ring ? ring_waves * kEncRingSlots : nchunks) * slot + 64));
+    rc = ctx->scratch.reserve((size_t)((ring ? ring_waves * kEncRingSlots : nchunks) * slot + 64) + ctx->scratch_shift);
     if (rc)
         return rc;
-    ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr);
+    ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr) + ctx->scratch_shift;
     ep.ring_slots = ring ? kEncRingSlots : 0u;
     if (fused) {
         // (wave encoders: a word per chunk; lane encoders: a word per round of a block, at most one per batch of 64
         //  chunks; then the claim counters)
         const size_t status_bytes = (size_t)(nchunks + 8u * kWorkPools) * 8;
-        rc = ctx->enc_status.reserve(status_bytes);
+        rc = ctx->enc_status.reserve(status_bytes + ctx->status_shift);
         if (rc)
             return rc;
-        HIP_TRY(hipMemsetAsync(ctx->enc_status.ptr, 0, status_bytes, s));
+        HIP_TRY(hipMemsetAsync(static_cast<uint8_t *>(ctx->enc_status.ptr) + ctx->status_shift, 0, status_bytes, s));
         if (fits == 2) { // the tables fill the LDS: one mailbox per block in global memory
             const size_t mb_bytes = (size_t)ctx->num_cus * kEncMailboxStride;
             rc = ctx->enc_mailboxes.reserve(mb_bytes);
@@ -685,7 +702,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
             ep.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
         }
         if (fused) {
-            ep.status = static_cast<unsigned long long *>(ctx->enc_status.ptr);
+            ep.status = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(ctx->enc_status.ptr) + ctx->status_shift);
             ep.offsets = d_offsets;
             ep.out = static_cast<uint8_t *>(d_out);
             ep.out_cap = out_cap;
@@ -710,7 +727,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         HIP_TRY(launch_layout(lp, s));
         if (nchunks) {
             CompactParams cp;
-            cp.scratch = static_cast<const uint8_t *>(ctx->scratch.ptr);
+            cp.scratch = ep.scratch;
             cp.slot_bytes = slot;
             cp.lengths = d_lengths;
             cp.offsets = d_offsets;

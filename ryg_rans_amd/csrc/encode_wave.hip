@@ -238,14 +238,14 @@ __device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x2 &rec, uin
     }
 }
 
-// The same with the emitted words staged in LDS: a 2 KiB window per wave that mirrors the low eleven bits of the slot
-// offset (win_base is 2 KiB aligned, so the address is one v_bfi); stage_flush() in the kernel moves what four rounds
-// have produced to memory in whole 16-byte pieces.  One ds_write_b16 per round instead of one global_store_short: the
-// per-round stores were 4.3e7 write requests of 19 bytes on the 1 GiB encode and kept the address unit 87 % busy
-// (profiles/r03_encoder_bound.md); the LDS pipe is 18 % busy since the records are eight bytes.
+// The same with the emitted words staged in LDS: `wp` is an LDS address here, the write pointer into the wave's 2 KiB
+// window (one ds_write_b16 per round instead of one global_store_short: the per-round stores were 4.3e7 write requests
+// of 19 bytes on the 1 GiB encode and kept the address unit 87 % busy, profiles/r03_encoder_bound.md; the LDS pipe is 18 %
+// busy since the records are eight bytes).  stage_flush() in the kernel moves what sixteen rounds have produced to memory
+// in whole 16-byte pieces and sets the pointer back to the top of the window, so it never wraps.
 template <bool SMALL>
 __device__ __forceinline__ void enc_word_full_staged(uint32_t &x, const u32x2 &rec, uint32_t &wp,
-                                              uint32_t win_mask, uint32_t win_base, uint32_t &worst, uint32_t m12)
+                                              uint32_t &worst, uint32_t m12)
 {
     uint32_t t, q, c, cnt;
     if constexpr (SMALL) {
@@ -259,7 +259,6 @@ __device__ __forceinline__ void enc_word_full_staged(uint32_t &x, const u32x2 &r
                      "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
                      "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
                      "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
-                     "v_bfi_b32 %[t], %[wm], %[t], %[wb]\n\t"
                      "ds_write_b16 %[t], %[x]\n\t"
                      "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
                      "s_mov_b64 exec, -1\n\t"
@@ -271,7 +270,7 @@ __device__ __forceinline__ void enc_word_full_staged(uint32_t &x, const u32x2 &r
                      "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
                      "v_add_u32_e32 %[x], %[q], %[t]"
                      : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12), [wm] "v"(win_mask), [wb] "v"(win_base)
+                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12)
                      : "vcc", "scc", "memory");
     } else {
         asm volatile("v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
@@ -284,7 +283,6 @@ __device__ __forceinline__ void enc_word_full_staged(uint32_t &x, const u32x2 &r
                      "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
                      "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
                      "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
-                     "v_bfi_b32 %[t], %[wm], %[t], %[wb]\n\t"
                      "ds_write_b16 %[t], %[x]\n\t"
                      "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
                      "s_mov_b64 exec, -1\n\t"
@@ -299,7 +297,7 @@ __device__ __forceinline__ void enc_word_full_staged(uint32_t &x, const u32x2 &r
                      "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
                      "v_add_u32_e32 %[x], %[q], %[t]"
                      : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12), [wm] "v"(win_mask), [wb] "v"(win_base)
+                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12)
                      : "vcc", "scc", "memory");
     }
 }
@@ -699,12 +697,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             }
         } else if (fast_rounds) {
             uint32_t rec_mask = 0xff0u, swap_sel = 0x0c0c0001u; // (v_perm selector: the low two bytes swapped, zeros above)
-            uint32_t rec_mask8 = 0x7f8u, m12v = 0xfffu; // (word format: 8-byte records)
-            asm volatile("" : "+v"(rec_mask8));
+            uint32_t k3v = 3u, m12v = 0xfffu; // (word format: 8-byte records)
+            asm volatile("" : "+v"(k3v)); // (SDWA takes no literal; a VGPR operand is also the faster VALU form)
             asm volatile("" : "+v"(m12v));
             if (kMeasureBuild && (p.debug & 4u)) // measurement only: every lane reads record 0 -- what the bank conflicts of the
-                rec_mask = rec_mask8 = 0u;       // record gather cost; the output is wrong by construction
-            (void)rec_mask8;
+                rec_mask = 0u, k3v = 31u;        // record gather cost; the output is wrong by construction
+            (void)k3v;
             (void)m12v;
             asm volatile("" : "+v"(rec_mask)); // keep the mask in a VGPR (a literal operand costs a slower VALU form)
             asm volatile("" : "+v"(swap_sel));
@@ -716,37 +714,43 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             // rounds: memory holds the stream from wp up; what a flush writes below wp (< 16 bytes, whatever the window
             // held) is written again, correctly, by the next flush, and at the end by the state flush.
             constexpr bool kStage = RANS_ENC_STAGE && FMT == FMT_WORD && K == 1;
-            uint32_t win_mask = kEncStageBytes - 1u, win_base = kWordRecBytes + 256u * (uint32_t)sizeof(EncRec) + wave * kEncStageBytes;
-            asm volatile("" : "+v"(win_mask));
-            asm volatile("" : "+v"(win_base));
-            const __attribute__((address_space(3))) uint8_t *win =
-                reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)win_base);
+            // The window: LDS [win_base, win_base + 2048).  Its last 16 bytes are the piece of the slot the write offset stands
+            // in (what lies above the offset there was produced before and is in memory already); a super-group of sixteen
+            // rounds writes downwards from win_top = win_base + 2032 + (wp & 15), at most 1664 bytes (13 words per lane: a
+            // symbol adds at most 12 bits to a state of 16..32 bits, a word takes 16 out), so LDS address and slot offset
+            // stay congruent modulo 16 and nothing wraps.
+            const uint32_t win_base = kWordRecBytes + 256u * (uint32_t)sizeof(EncRec) + wave * kEncStageBytes;
+            constexpr uint32_t kTopPiece = kEncStageBytes - 16u;
+            auto lds_u32x4 = [](uint32_t at) { return reinterpret_cast<__attribute__((address_space(3))) u32x4 *>((uintptr_t)at); };
             if (kStage && (wp & 15u)) { // the tail rounds have stored words themselves: the piece that holds wp goes into the window
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane < 4u) {
-                    const uint32_t at = (wp & ~15u) + 4u * lane;
-                    const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t RANS_GLOBAL *>(slot + at));
-                    *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(win_base + (at & (kEncStageBytes - 1u)))) = v;
+                    const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t RANS_GLOBAL *>(slot + (wp & ~15u) + 4u * lane));
+                    *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(win_base + kTopPiece + 4u * lane)) = v;
                 }
             }
-            // [wp, wp_old) -> memory, in whole 16-byte pieces.  Sixteen rounds emit at most 13 words per lane (a symbol adds
-            // at most 12 bits to a state of 16..32 bits, a word takes 16 out): 1664 bytes, within the window, and at most
-            // 106 pieces -- two passes of the wave, the second one rarely has any lanes (the average is 50 pieces).
-            auto stage_flush = [&](uint32_t wp_old) {
-                const uint32_t hi = (wp_old + 15u) & ~15u, lo = wp & ~15u;
+            // LDS [lp, top) -> slot [wp - (top - lp), wp), in whole 16-byte pieces: at most 106 of them -- two passes of the
+            // wave, the second one rarely has any lanes (the average is 50 pieces).  What a piece holds below the new write
+            // offset is whatever the window held: it is written again, correctly, by the next flush, and at the end by the
+            // state flush (same wave, same address: in order).  The lowest piece then becomes the window's top piece.
+            auto stage_flush = [&](uint32_t top, uint32_t lp) {
+                const uint32_t hi = (top + 15u) & ~15u, lo = lp & ~15u;
+                const uint32_t to_slot = wp - top; // (wraps; congruent to 0 modulo 16)
                 const int32_t a = (int32_t)hi - 16 * (int32_t)(lane + 1u);
                 auto piece = [&](int32_t at) {
                     if (at >= (int32_t)lo) {
-                        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(win + ((uint32_t)at & (kEncStageBytes - 1u)));
-                        *reinterpret_cast<u32x4 RANS_GLOBAL *>(const_cast<uint8_t RANS_GLOBAL *>(slot) + (uint32_t)at) = v;
+                        const u32x4 v = *lds_u32x4((uint32_t)at);
+                        *reinterpret_cast<u32x4 RANS_GLOBAL *>(const_cast<uint8_t RANS_GLOBAL *>(slot) + ((uint32_t)at + to_slot)) = v;
+                        if ((uint32_t)at == lo)
+                            *lds_u32x4(win_base + kTopPiece) = v;
                     }
                 };
                 piece(a);
                 if (hi - lo > 1024u) // (wave-uniform)
                     piece(a - 1024);
+                wp -= top - lp;
             };
             (void)stage_flush;
-            (void)win;
             uint32_t cur[4][K], nxt[4][K];
             auto load_super = [&](uint32_t (&dstq)[4][K], uint32_t sg) {
 #pragma unroll
@@ -761,7 +765,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             while (sg-- > 0) {
                 if (sg > 0)
                     load_super(nxt, sg - 1);
-                const uint32_t wp_super = uniform(wp);
+                const uint32_t win_top = win_base + kTopPiece + (uniform(wp) & 15u);
+                uint32_t lp = win_top; // (staged path: the coding loop moves this LDS pointer, stage_flush() sets wp)
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     uint32_t t[K];
@@ -774,11 +779,20 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                     // a scheduling barrier for the compiler)
                     auto rec_at = [&](int step) { // step 0 = (J 3, k K-1), descending
                         const int J = 3 - step / K, k = K - 1 - step % K;
-                        const uint32_t at = (J == 0 ? (t[k] << 3) : (t[k] >> (8 * J - 3))) & rec_mask8;
+                        uint32_t at; // byte J of t[k], times the eight bytes of a record: one SDWA shift
+                        if (J == 3)
+                            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(at) : "v"(k3v), "v"(t[k]));
+                        else if (J == 2)
+                            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(at) : "v"(k3v), "v"(t[k]));
+                        else if (J == 1)
+                            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(at) : "v"(k3v), "v"(t[k]));
+                        else
+                            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(at) : "v"(k3v), "v"(t[k]));
                         return *reinterpret_cast<const __attribute__((address_space(3))) u32x2 *>((uintptr_t)at); // table at LDS address 0
                     };
                     u32x2 rec = rec_at(0);
                     wp = uniform(wp); // (asm results count as divergent: say what they are, or the "s" operands below get VGPRs)
+                    lp = uniform(lp);
                     if (p.word_small) { // (wave-uniform: one scalar branch per four rounds)
 #pragma unroll
                         for (int step = 0; step < 4 * K; ++step) {
@@ -786,7 +800,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                             if (step + 1 < 4 * K)
                                 rec = rec_at(step + 1);
                             if constexpr (kStage)
-                                enc_word_full_staged<true>(x[K - 1 - step % K], now, wp, win_mask, win_base, worst, m12v);
+                                enc_word_full_staged<true>(x[K - 1 - step % K], now, lp, worst, m12v);
                             else
                                 enc_word_full<true>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
                         }
@@ -797,12 +811,13 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                             if (step + 1 < 4 * K)
                                 rec = rec_at(step + 1);
                             if constexpr (kStage)
-                                enc_word_full_staged<false>(x[K - 1 - step % K], now, wp, win_mask, win_base, worst, m12v);
+                                enc_word_full_staged<false>(x[K - 1 - step % K], now, lp, worst, m12v);
                             else
                                 enc_word_full<false>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
                         }
                     }
                     wp = uniform(wp);
+                    lp = uniform(lp);
                 } else if (FMT == FMT_BYTE && byte_asm) {
                     if constexpr (FMT == FMT_BYTE) { // (the same walk over the 4 K symbols as the word format's)
                         auto rec_at = [&](int step) {
@@ -828,7 +843,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 }
                 }
                 if constexpr (kStage)
-                    stage_flush(wp_super);
+                    stage_flush(win_top, uniform(lp));
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll

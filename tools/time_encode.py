@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--placements", type=int, default=1, help="repeat with the container and the scratch re-allocated elsewhere")
     ap.add_argument("--ring", type=int, default=0, help="RANS_AMD_OPT_ENC_SCRATCH_RING")
     ap.add_argument("--fused", type=int, default=1, help="RANS_AMD_OPT_FUSED_PLACEMENT")
     a = ap.parse_args()
@@ -40,27 +41,42 @@ def main():
         d = zipf(n, nsyms, 1, dev)
         f, _ = R.normalize_freqs(ctx.count_freqs_device(d, nsyms), 1 << sb)
         m = ctx.model(fmt, f, sb)
-        cont, offs, lens, total = ctx.encode(m, d, ways, a.chunk)
-        try:  # (measurement builds with output-changing knobs: the container may be garbage)
-            out = ctx.decode(m, cont, total, offs, lens, n, ways, a.chunk)
-            ok = bool(torch.equal(out, d))
-            del out
-        except R.RansAmdError:
-            ok = False
-        kern = ctx.last_encode_kernel()
-        for r in range(a.rounds):
-            for _ in range(min(30, 2 * a.launches)):
-                ctx.encode(m, d, ways, a.chunk, d_out=cont, sync=False, d_offsets=offs, d_lengths=lens)
-            torch.cuda.synchronize()
-            ms = []
-            for _ in range(a.launches):
-                ctx.encode(m, d, ways, a.chunk, d_out=cont, sync=False, d_offsets=offs, d_lengths=lens)
+        means, pads = [], []
+        for pl in range(a.placements):
+            # timings move by several per cent with where the container and the scratch happen to lie: every placement
+            # frees both, shifts the allocator by an odd amount and allocates them again
+            if pl:
+                del cont, offs, lens
+                ctx.trim()
+                torch.cuda.empty_cache()
+                pads.append(torch.empty((pl * 7 + 3) * (1 << 20) + pl * 4096, dtype=torch.uint8, device=dev))
+            cont, offs, lens, total = ctx.encode(m, d, ways, a.chunk)
+            try:  # (measurement builds with output-changing knobs: the container may be garbage)
+                out = ctx.decode(m, cont, total, offs, lens, n, ways, a.chunk)
+                ok = bool(torch.equal(out, d))
+                del out
+            except R.RansAmdError:
+                ok = False
+            kern = ctx.last_encode_kernel()
+            for r in range(a.rounds):
+                for _ in range(min(30, 2 * a.launches)):
+                    ctx.encode(m, d, ways, a.chunk, d_out=cont, sync=False, d_offsets=offs, d_lengths=lens)
                 torch.cuda.synchronize()
-                ms.append(ctx.last_kernel_ms()[1])
-            mean = sum(ms) / len(ms)
-            print("%-10s %-5s chunk %-6d round %d  mean %.4f ms  min %.4f ms  frac %.4f  %s %s" % (
-                a.tag, name, a.chunk, r, mean, min(ms), (total + n * d.element_size()) / mean / 1e6 / 8000.0, kern, "ok" if ok else "MISMATCH"),
-                flush=True)
+                ms = []
+                for _ in range(a.launches):
+                    ctx.encode(m, d, ways, a.chunk, d_out=cont, sync=False, d_offsets=offs, d_lengths=lens)
+                    torch.cuda.synchronize()
+                    ms.append(ctx.last_kernel_ms()[1])
+                mean = sum(ms) / len(ms)
+                means.append(mean)
+                print("%-10s %-5s chunk %-6d placement %d round %d  mean %.4f ms  min %.4f ms  frac %.4f  %s %s" % (
+                    a.tag, name, a.chunk, pl, r, mean, min(ms), (total + n * d.element_size()) / mean / 1e6 / 8000.0, kern,
+                    "ok" if ok else "MISMATCH"), flush=True)
+        if len(means) > 1:
+            srt = sorted(means)
+            print("%-10s %-5s chunk %-6d SUMMARY over %d: median %.4f  min %.4f  max %.4f" % (
+                a.tag, name, a.chunk, len(srt), srt[len(srt) // 2], srt[0], srt[-1]), flush=True)
+        del pads
         del d, cont
         torch.cuda.empty_cache()
 
