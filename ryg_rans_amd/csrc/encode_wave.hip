@@ -3,6 +3,7 @@
 
 #include "device_common.hpp"
 #include "launchers.hpp"
+#include <type_traits>
 
 namespace rans_amd {
 
@@ -760,6 +761,9 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                         dstq[j][k] = *reinterpret_cast<const uint32_t RANS_GLOBAL *>(
                             src + (uint64_t)(sg * 16u + j * 4u) * N + in_lane_off + k * 64u);
             };
+            // (the loop once per reciprocal method of the word format: a branch inside it costs register copies at every join)
+            auto fast_loop = [&](auto small_tag) {
+            constexpr bool kSmall = decltype(small_tag)::value;
             uint32_t sg = fast_rounds >> 4;
             load_super(cur, sg - 1);
             while (sg-- > 0) {
@@ -793,28 +797,15 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                     u32x2 rec = rec_at(0);
                     wp = uniform(wp); // (asm results count as divergent: say what they are, or the "s" operands below get VGPRs)
                     lp = uniform(lp);
-                    if (p.word_small) { // (wave-uniform: one scalar branch per four rounds)
 #pragma unroll
-                        for (int step = 0; step < 4 * K; ++step) {
-                            const u32x2 now = rec;
-                            if (step + 1 < 4 * K)
-                                rec = rec_at(step + 1);
-                            if constexpr (kStage)
-                                enc_word_full_staged<true>(x[K - 1 - step % K], now, lp, worst, m12v);
-                            else
-                                enc_word_full<true>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
-                        }
-                    } else {
-#pragma unroll
-                        for (int step = 0; step < 4 * K; ++step) {
-                            const u32x2 now = rec;
-                            if (step + 1 < 4 * K)
-                                rec = rec_at(step + 1);
-                            if constexpr (kStage)
-                                enc_word_full_staged<false>(x[K - 1 - step % K], now, lp, worst, m12v);
-                            else
-                                enc_word_full<false>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
-                        }
+                    for (int step = 0; step < 4 * K; ++step) {
+                        const u32x2 now = rec;
+                        if (step + 1 < 4 * K)
+                            rec = rec_at(step + 1);
+                        if constexpr (kStage)
+                            enc_word_full_staged<kSmall>(x[K - 1 - step % K], now, lp, worst, m12v);
+                        else
+                            enc_word_full<kSmall>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
                     }
                     wp = uniform(wp);
                     lp = uniform(lp);
@@ -850,6 +841,11 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                     for (int k = 0; k < K; ++k)
                         cur[j][k] = nxt[j][k];
             }
+            };
+            if (FMT == FMT_WORD && p.word_small)
+                fast_loop(std::true_type{});
+            else
+                fast_loop(std::false_type{});
         }
 
         if (worst > (FMT == FMT_WORD ? 0x7fffffffu : 0x0fffffffu)) // (a symbol without a record: all ones in the word v_max tracks)
