@@ -94,7 +94,15 @@ typedef enum rans_amd_table {
 /* A context owns ONE encode workspace, error counter and work-counter ring: host calls on it are
  * serialised by a mutex, and its asynchronous work must stay on ONE stream at a time (synchronise
  * before switching streams).  Concurrent streams want one context each.  Models are immutable, may be
- * used from any stream, and may be destroyed after the context they were created with. */
+ * used from any stream, and may be destroyed after the context they were created with.
+ *
+ * hipGraph capture: rans_amd_encode / rans_amd_decode (and the _adaptive pair) may be called while `stream` is being
+ * captured -- kernels, memsets and nothing else go into the graph, and a replay does what the call did, on the same
+ * buffers.  Rules: the host result pointer (h_total_bytes / h_bad_chunks) must be NULL (fetch with
+ * rans_amd_encode_status / rans_amd_decode_errors after a replay); the same call must have run once outside the capture
+ * (workspaces are allocated on first use, and nothing may be allocated inside a capture: RANS_AMD_E_ARG says so); the
+ * context must not be trimmed or destroyed while the graph exists; at most 8 captured decode launches of one context
+ * run at the same time; rans_amd_set_timing has no effect on captured launches. */
 typedef struct rans_amd_ctx rans_amd_ctx;     /* one per (process, GPU) and per concurrent stream */
 typedef struct rans_amd_model rans_amd_model; /* immutable after creation */
 
@@ -218,6 +226,11 @@ uint64_t rans_amd_encode_workspace_bytes(int format, uint64_t n, uint32_t n_ways
 int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,
                     uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t out_cap,
                     uint64_t *d_offsets, uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream);
+
+/* Synchronise `stream` and report how the last rans_amd_encode / rans_amd_encode_adaptive of this context ended when it
+ * was called without h_total_bytes (asynchronously, or as a graph node): RANS_AMD_OK, RANS_AMD_E_MODEL (a symbol with
+ * frequency 0), RANS_AMD_E_SPACE (out_cap too small) or RANS_AMD_E_HIP.  The container size is d_offsets[n_chunks]. */
+int rans_amd_encode_status(rans_amd_ctx *ctx, void *stream);
 
 /* Decode a container.  d_out receives n symbols.  Every chunk is checked the way
  * the reference's streams allow (all final states == L, cursor == end of the

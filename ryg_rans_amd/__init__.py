@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "rans_amd_model_create", "rans_amd_model_destroy", "rans_amd_model_format", "rans_amd_model_scale_bits",
     "rans_amd_model_nsyms", "rans_amd_model_sym_bytes", "rans_amd_model_table",
     "rans_amd_num_chunks", "rans_amd_chunk_bound", "rans_amd_encode_bound", "rans_amd_ways_supported",
-    "rans_amd_encode", "rans_amd_decode", "rans_amd_decode_errors",
+    "rans_amd_encode", "rans_amd_encode_status", "rans_amd_decode", "rans_amd_decode_errors",
     "rans_amd_encode_host", "rans_amd_decode_host",
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_encode_kernel", "rans_amd_last_wave_clocks",
     "rans_amd_launch_spans",
@@ -93,6 +93,7 @@ def _load():
         "rans_amd_ctx_destroy": (i32, [vp]),
         "rans_amd_ctx_trim": (i32, [vp]),
         "rans_amd_ctx_set_option": (i32, [vp, i32, i32]),
+        "rans_amd_encode_status": (i32, [vp, vp]),
         "rans_amd_count_freqs_host": (i32, [vp, u64, i32, u32, u32p]),
         "rans_amd_count_freqs": (i32, [vp, vp, u64, i32, u32, u32p, vp]),
         "rans_amd_normalize_freqs": (i32, [u32p, u32p, u32, u32]),
@@ -360,6 +361,10 @@ class Context:
                                              d_out.data_ptr(), C.byref(bad) if sync else None, _torch_stream()),
                "decode_adaptive")
         return d_out
+
+    def encode_status(self):
+        """rans_amd_encode_status: raises what the last asynchronous (sync=False) or graph-replayed encode ended with."""
+        _check(_lib.rans_amd_encode_status(self._h, _torch_stream()), "encode_status")
 
     def decode_errors(self):
         bad = C.c_uint64(0)

@@ -43,6 +43,26 @@ int hip_fail(hipError_t e, const char *where)
             return hip_fail(e__, #expr);                \
     } while (0)
 
+// Stream capture (hipStreamBeginCapture ... EndCapture around calls of this library: the launches become nodes of a
+// hipGraph).  What a captured call may not do is what a graph cannot replay: allocate, wait for the stream, read
+// anything back.  The entry points find out once per call (CaptureScope) and the workspaces refuse to grow meanwhile
+// -- run the call once outside the capture first, the workspaces are kept.
+thread_local bool t_capturing = false;
+struct CaptureScope {
+    bool prev;
+    bool active = false;
+    explicit CaptureScope(hipStream_t s) : prev(t_capturing)
+    {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &st) == hipSuccess) // (the legacy null stream cannot be captured)
+            active = st == hipStreamCaptureStatusActive;
+        else
+            (void)hipGetLastError();
+        t_capturing = active;
+    }
+    ~CaptureScope() { t_capturing = prev; }
+};
+
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
@@ -50,6 +70,8 @@ struct DeviceBuffer {
     {
         if (want <= bytes)
             return RANS_AMD_OK;
+        if (t_capturing)
+            return fail(RANS_AMD_E_ARG, "a workspace would have to grow while the stream is capturing: make the same call once outside the capture first");
         if (ptr)
             (void)hipFree(ptr);
         ptr = nullptr;
@@ -95,6 +117,7 @@ struct rans_amd_ctx {
     bool timing = false;
     bool dec_timed = false, enc_timed = false;
     uint32_t launch_seq = 0; // selects one of kWorkSlots chunk counters at d_words + 256
+    uint32_t capture_seq = 0; // ... and one of the kCaptureSlots behind them for a launch that is being captured into a graph
     uint32_t variant = 0;    // kVar* bits (rans_amd_ctx_set_option)
     bool unfused = false;    // RANS_AMD_OPT_FUSED_PLACEMENT = 0: k_encode + k_layout + k_compact
     bool scratch_ring = false; // RANS_AMD_OPT_ENC_SCRATCH_RING = 1
@@ -125,6 +148,31 @@ struct rans_amd_model {
 };
 
 namespace {
+
+// the encoders' device flags (EncParams::flags) as a status
+int encode_flags_status(uint32_t flags)
+{
+    if (flags & 1u)
+        return fail(RANS_AMD_E_MODEL, "encode: input holds a symbol with frequency 0");
+    if (flags & 2u)
+        return fail(RANS_AMD_E_SPACE, "encode: container does not fit out_cap");
+    if (flags & 4u) // (a kernel that addresses its LDS tables by raw offsets found them elsewhere: never code on that)
+        return fail(RANS_AMD_E_HIP, "encode: internal error (dynamic LDS does not start at offset 0)");
+    if (flags & ~7u) { // a wait of the fused placement gave up (device_common.hpp SpinWatch; 256: a coder waiting for its scratch slot)
+        char msg[160];
+        snprintf(msg, sizeof msg, "encode: internal error (placement protocol timed out, flags 0x%x)", flags);
+        return fail(RANS_AMD_E_HIP, msg);
+    }
+    return RANS_AMD_OK;
+}
+
+// counter slot of a launch that is being captured (kernels.h kCaptureSlots: that many captured launches of one context
+// may run at the same time)
+unsigned int *capture_counters(rans_amd_ctx *ctx)
+{
+    unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);
+    return ring + (size_t)(kWorkSlots + ctx->capture_seq++ % kCaptureSlots) * kWorkSlotWords;
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -233,7 +281,7 @@ int rans_amd_ctx_create(int device, rans_amd_ctx **out_ctx)
         return fail(RANS_AMD_E_NOMEM, "ctx");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const size_t words_bytes = 256 + (size_t)kWorkSlots * kWorkSlotWords * 4;
+    const size_t words_bytes = 256 + (size_t)(kWorkSlots + kCaptureSlots) * kWorkSlotWords * 4;
     e = hipMalloc(reinterpret_cast<void **>(&ctx->d_words), words_bytes);
     if (e == hipSuccess)
         e = hipMemset(ctx->d_words, 0, words_bytes);
@@ -613,6 +661,9 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     DeviceGuard guard(ctx->device);
     std::lock_guard<std::mutex> lock(ctx->mu);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const CaptureScope capture(s);
+    if (capture.active && h_total_bytes)
+        return fail(RANS_AMD_E_ARG, "encode: h_total_bytes must be NULL while the stream is capturing (d_offsets[n_chunks] holds the total)");
 
     const uint64_t slot = encode_slot_bytes(format, n, n_ways, chunk_syms);
     if (slot > 0xfffffff0ull) // chunk stream lengths and in-slot cursors are 32-bit
@@ -677,7 +728,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         }
     }
 
-    if (ctx->timing)
+    if (ctx->timing && !t_capturing)
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
     if (nchunks) {
         ep.syms = static_cast<const uint8_t *>(d_syms);
@@ -737,7 +788,7 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
             HIP_TRY(launch_compact(cp, ctx->num_cus, s));
         }
     }
-    if (ctx->timing) {
+    if (ctx->timing && !t_capturing) {
         HIP_TRY(hipEventRecord(ctx->ev[3], s));
         ctx->enc_timed = true;
     }
@@ -749,19 +800,22 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         HIP_TRY(hipMemcpyAsync(&total, d_offsets + nchunks, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         *h_total_bytes = total;
-        if (flags & 1u)
-            return fail(RANS_AMD_E_MODEL, "encode: input holds a symbol with frequency 0");
-        if (flags & 2u)
-            return fail(RANS_AMD_E_SPACE, "encode: container does not fit out_cap");
-        if (flags & 4u) // (a kernel that addresses its LDS tables by raw offsets found them elsewhere: never code on that)
-            return fail(RANS_AMD_E_HIP, "encode: internal error (dynamic LDS does not start at offset 0)");
-        if (flags & ~7u) { // a wait of the fused placement gave up (256: a coder waiting for its scratch slot) (device_common.hpp kSpinLimit): the container is not valid
-            char msg[160];
-            snprintf(msg, sizeof msg, "encode: internal error (placement protocol timed out, flags 0x%x)", flags);
-            return fail(RANS_AMD_E_HIP, msg);
-        }
+        return encode_flags_status(flags);
     }
     return RANS_AMD_OK;
+}
+
+int rans_amd_encode_status(rans_amd_ctx *ctx, void *stream)
+{
+    if (!ctx)
+        return fail(RANS_AMD_E_ARG, "encode_status: ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t flags = 0;
+    HIP_TRY(hipMemcpyAsync(&flags, ctx->d_enc_flags(), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return encode_flags_status(flags);
 }
 
 /* ---- decode ------------------------------------------------------------- */
@@ -783,6 +837,9 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     DeviceGuard guard(ctx->device);
     std::lock_guard<std::mutex> lock(ctx->mu);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const CaptureScope capture(s);
+    if (capture.active && h_bad_chunks)
+        return fail(RANS_AMD_E_ARG, "decode: h_bad_chunks must be NULL while the stream is capturing (rans_amd_decode_errors after the replay)");
 
     if (nchunks) {
         DecParams dp{};
@@ -832,19 +889,29 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         if (!static_sched && nchunks < 0xffffffffull) {
             unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);
             const uint32_t per_slot = kWorkSlotWords;
-            dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * per_slot;
-            dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * per_slot;
-            // the slot's last line: first wave start / last wave end of the launch (rans_amd_launch_spans)
             static const bool no_span = measure_knob("RANS_AMD_NO_SPAN") != nullptr; // A/B: cost of the span record
-            if (!no_span) {
-                dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
-                dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
+            if (capture.active) {
+                // A launch that becomes a graph node runs again and again with these very arguments: its counters are one
+                // of kCaptureSlots slots of their own, zeroed by a memset node in front of the kernel (so every replay
+                // starts from zero, and the ring of the eager launches never sees a slot a replay has used).
+                dp.work_counter = capture_counters(ctx);
+                HIP_TRY(hipMemsetAsync(dp.work_counter, 0, (size_t)per_slot * 4, s));
+                if (!no_span)
+                    dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
+            } else {
+                dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * per_slot;
+                dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * per_slot;
+                // the slot's last line: first wave start / last wave end of the launch (rans_amd_launch_spans)
+                if (!no_span) {
+                    dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
+                    dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
+                }
             }
         }
         // wave clocks (rans_amd_set_timing(ctx, 2)) and the debug timeline (RANS_AMD_TRACE=<file>): per-wave
         // start/end ticks, XCD, shader cycles and rounds, read back after a sync
         static const char *trace_path = measure_knob("RANS_AMD_TRACE");
-        const bool want_trace = trace_path || ctx->wave_clocks_on;
+        const bool want_trace = (trace_path || ctx->wave_clocks_on) && !capture.active; // (read back after a sync)
         const size_t trace_words = (size_t)kTraceWords * 2u * 16u * (size_t)ctx->num_cus;
         dp.trace = nullptr;
         if (want_trace) {
@@ -854,7 +921,7 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
             dp.trace = static_cast<unsigned long long *>(ctx->trace.ptr);
             HIP_TRY(hipMemsetAsync(dp.trace, 0, trace_words * 8, s));
         }
-        if (ctx->timing)
+        if (ctx->timing && !t_capturing)
             HIP_TRY(hipEventRecord(ctx->ev[0], s));
         int dec_format = model->host.r64_search ? kKernelFormatR64Search
                          : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
@@ -884,9 +951,9 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         HIP_TRY(launch_decode(dec_format, dp, ctx->num_cus, s, &ctx->last_kernel));
         // the launch that uses slot i zeroes slot i + 32: move on only once it really is in the stream,
         // or a later launch would start from a counter nobody reset
-        if (dp.work_counter)
+        if (dp.work_counter && !capture.active)
             ctx->launch_seq++;
-        if (ctx->timing) {
+        if (ctx->timing && !t_capturing) {
             HIP_TRY(hipEventRecord(ctx->ev[1], s));
             ctx->dec_timed = true;
         }
@@ -979,6 +1046,9 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
     DeviceGuard guard(ctx->device);
     std::lock_guard<std::mutex> lock(ctx->mu);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const CaptureScope capture(s);
+    if (capture.active && h_total_bytes)
+        return fail(RANS_AMD_E_ARG, "encode_adaptive: h_total_bytes must be NULL while the stream is capturing");
     const uint64_t slot = encode_slot_bytes(RANS_AMD_FMT_BYTE, n, n_ways, chunk_syms);
     if (slot > 0xfffffff0ull)
         return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive: chunk_syms too large");
@@ -992,7 +1062,7 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         // synchronisation, the call is asynchronous like the rest of the ABI
         HIP_TRY(launch_chunk_models(d_syms, n, chunk_syms, nchunks, scale_bits, d_chunk_freqs, ctx->d_enc_flags(), ctx->num_cus, s));
         // 3. encode: every wave builds the records of the chunk it codes
-        if (ctx->timing)
+        if (ctx->timing && !t_capturing)
             HIP_TRY(hipEventRecord(ctx->ev[2], s));
         EncParams ep{};
         ep.syms = static_cast<const uint8_t *>(d_syms);
@@ -1036,7 +1106,7 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         cp.flags = ctx->d_enc_flags();
         HIP_TRY(launch_compact(cp, ctx->num_cus, s));
     }
-    if (ctx->timing && nchunks) { // (ev[2] is recorded in front of the coding kernel, which an empty input does not launch)
+    if (ctx->timing && !t_capturing && nchunks) { // (ev[2] is recorded in front of the coding kernel, which an empty input does not launch)
         HIP_TRY(hipEventRecord(ctx->ev[3], s));
         ctx->enc_timed = true;
     }
@@ -1073,6 +1143,9 @@ int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_
     DeviceGuard guard(ctx->device);
     std::lock_guard<std::mutex> lock(ctx->mu);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const CaptureScope capture(s);
+    if (capture.active && h_bad_chunks)
+        return fail(RANS_AMD_E_ARG, "decode_adaptive: h_bad_chunks must be NULL while the stream is capturing");
     if (nchunks) {
         DecParams dp{};
         dp.container = static_cast<const uint8_t *>(d_container);
@@ -1089,19 +1162,23 @@ int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_
         dp.sym_bytes = 1;
         dp.err_count = ctx->d_err();
         dp.chunk_freqs = d_chunk_freqs;
-        if (nchunks < 0xffffffffull) {
+        if (nchunks < 0xffffffffull && capture.active) { // (as in rans_amd_decode)
+            dp.work_counter = capture_counters(ctx);
+            HIP_TRY(hipMemsetAsync(dp.work_counter, 0, (size_t)kWorkSlotWords * 4, s));
+            dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
+        } else if (nchunks < 0xffffffffull) {
             unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);
             dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * kWorkSlotWords;
             dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * kWorkSlotWords;
             dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
             dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
         }
-        if (ctx->timing)
+        if (ctx->timing && !t_capturing)
             HIP_TRY(hipEventRecord(ctx->ev[0], s));
         HIP_TRY(launch_decode(kKernelFormatByteAdaptive, dp, ctx->num_cus, s, &ctx->last_kernel));
-        if (dp.work_counter)
+        if (dp.work_counter && !capture.active)
             ctx->launch_seq++;
-        if (ctx->timing) {
+        if (ctx->timing && !t_capturing) {
             HIP_TRY(hipEventRecord(ctx->ev[1], s));
             ctx->dec_timed = true;
         }

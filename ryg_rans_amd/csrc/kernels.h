@@ -39,6 +39,7 @@ constexpr int kDecBlockThreads = 1024; // 16 waves share one table image
 constexpr uint32_t kWorkPools = 8;       // chunk hand-out counters per launch (one per XCD)
 constexpr uint32_t kWorkPoolStride = 16; // in uint32: every counter on its own 64-byte line
 constexpr uint32_t kWorkSlots = 64;      // launches that may reuse the counter ring before wrap
+constexpr uint32_t kCaptureSlots = 8;    // counter slots behind the ring for launches captured into a hipGraph (api.cpp)
 // one ring slot = kWorkPools counters (a 64-byte line each) + one line for the launch's wave span record
 constexpr uint32_t kWorkSlotWords = (kWorkPools + 1) * kWorkPoolStride;
 constexpr int kEncBlockThreads = 256;

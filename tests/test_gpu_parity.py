@@ -960,3 +960,97 @@ def test_fused_encoder_scratch_ring(gpu, oracle):
             assert oracle.compare_container(fmt, om, data, 64, chunk, cont[:total].cpu().numpy(), offs, lens) == (len(lens), -1)
         out = ctx.decode(gm, cont, total, d_offs, d_lens, n, 64, chunk)
         assert np.array_equal(out.cpu().numpy(), data)
+
+
+def test_hip_graph_capture(gpu, oracle):
+    """rans_amd_encode + rans_amd_decode captured into a hipGraph (torch.cuda.graph = hipStreamBeginCapture on the
+    stream the calls are issued on): every replay codes the chunks again -- the container equals the oracle's, the
+    symbols come back -- eager launches before, between and after keep working (the work-counter ring of the eager
+    launches never sees a slot a replay used), and the rules of include/ryg_rans_amd.h are enforced: no host result
+    pointer inside a capture, no workspace growth inside a capture."""
+    import subprocess
+    import sys
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf((1 << 20) + 777, K=256, s=1.0, seed=11)
+    n = data.size
+    d = torch.from_numpy(data).cuda()
+    for fmt, sb, ways, chunk in ((FMT_WORD, 12, 64, 4096), (FMT_BYTE, 14, 64, 8192), (FMT_R64, 14, 2, 512), (FMT_ALIAS, 16, 64, 4096),
+                                 (FMT_WORD, 12, 256, 16384)):
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        want, w_offs, w_lens = oracle.encode_chunked(fmt, om, data, ways, chunk, align=16)
+        # once outside the capture: the workspaces exist afterwards
+        cont, offs, lens, total = ctx.encode(gm, d, ways, chunk)
+        assert total == want.size
+        out = ctx.decode(gm, cont, total, offs, lens, n, ways, chunk)
+        assert torch.equal(out, d)
+        cont2, offs2, lens2, out2 = torch.zeros_like(cont), torch.zeros_like(offs), torch.zeros_like(lens), torch.zeros_like(out)
+        s = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ctx.encode(gm, d, ways, chunk, d_out=cont2, sync=False, d_offsets=offs2, d_lengths=lens2)
+            ctx.decode(gm, cont2, total, offs2, lens2, n, ways, chunk, d_out=out2, sync=False)
+        assert not bool(out2.any())  # capturing ran nothing
+        for rep in range(3):
+            cont2.zero_(); offs2.zero_(); lens2.zero_(); out2.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            ctx.encode_status()
+            assert ctx.decode_errors() == 0
+            nchunks = len(w_lens)
+            assert np.array_equal(offs2.cpu().numpy()[:nchunks].astype(np.int64), w_offs[:nchunks].astype(np.int64)), (fmt, ways, rep)
+            assert np.array_equal(lens2.cpu().numpy()[:nchunks].astype(np.int64), w_lens.astype(np.int64)), (fmt, ways, rep)
+            assert int(offs2[nchunks].item()) == total
+            got = cont2[:total].cpu().numpy()
+            for c in range(len(w_lens)):
+                o, ln = int(w_offs[c]), int(w_lens[c])
+                assert np.array_equal(got[o:o + ln], want[o:o + ln]), (fmt, ways, rep, c)
+            assert torch.equal(out2, d), (fmt, ways, rep)
+            # an eager decode between the replays (the ring moves on; the graph's slot is its own)
+            out.zero_()
+            ctx.decode(gm, cont2, total, offs2, lens2, n, ways, chunk, d_out=out)
+            assert torch.equal(out, d)
+        # more eager launches than the ring has slots, then one more replay
+        for _ in range(70):
+            ctx.decode(gm, cont, total, offs, lens, n, ways, chunk, d_out=out, sync=False)
+        out2.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert ctx.decode_errors() == 0 and torch.equal(out2, d) and torch.equal(out, d)
+        del g
+    # the rules, in a process of its own (a refused call inside a capture must leave this one alone)
+    script = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import ryg_rans_amd as R
+ctx = R.Context(0)
+f = np.zeros(256, np.uint32); f[:4] = [1024, 1024, 1024, 1024]
+m = ctx.model(R.FMT_WORD, f, 12)
+d = torch.randint(0, 4, (1 << 18,), dtype=torch.uint8, device="cuda")
+cap = R.encode_bound(R.FMT_WORD, d.numel(), 64, 4096) + 16
+cont = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+offs = torch.zeros(65, dtype=torch.int64, device="cuda"); lens = torch.zeros(64, dtype=torch.int32, device="cuda")
+codes = []
+s = torch.cuda.Stream()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, stream=s):
+    try:  # no warm-up call: the scratch would have to be allocated inside the capture
+        ctx.encode(m, d, 64, 4096, d_out=cont, sync=False, d_offsets=offs, d_lengths=lens)
+        codes.append(0)
+    except R.RansAmdError as e:
+        codes.append(e.status)
+ctx.encode(m, d, 64, 4096, d_out=cont, d_offsets=offs, d_lengths=lens)
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g2, stream=s):
+    try:  # a host result pointer inside a capture
+        ctx.encode(m, d, 64, 4096, d_out=cont, sync=True, d_offsets=offs, d_lengths=lens)
+        codes.append(0)
+    except R.RansAmdError as e:
+        codes.append(e.status)
+    ctx.encode(m, d, 64, 4096, d_out=cont, sync=False, d_offsets=offs, d_lengths=lens)
+g2.replay(); torch.cuda.synchronize(); ctx.encode_status()
+print("codes", codes, R.E_ARG)
+assert codes == [R.E_ARG, R.E_ARG]
+print("capture rules ok")
+""" % os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "capture rules ok" in r.stdout, r.stdout + r.stderr
