@@ -139,3 +139,69 @@ int compat_sizeof(int which)
     }
 }
 }
+
+// ---- rans_alias_compat.h: the alias coder over the byte stream format, u8 or u16 symbols ----
+#include "rans_alias_compat.h"
+
+extern "C" {
+
+static uint32_t alias_sym(const void *in, int sym_bytes, size_t i)
+{
+    return sym_bytes == 1 ? ((const uint8_t *)in)[i] : ((const uint16_t *)in)[i];
+}
+
+int compat_alias_encode(const uint32_t *freqs, const uint32_t *cum, uint32_t nsyms, uint32_t scale_bits, const void *in,
+                        int sym_bytes, size_t n, uint32_t N, uint8_t *buf, size_t cap, size_t *out_len)
+{
+    RansAliasTable t;
+    if (RansAliasTableInit(&t, freqs, cum, nsyms, scale_bits))
+        return 2;
+    std::vector<RansState> st(N);
+    for (auto &x : st) RansEncInit(&x);
+    uint8_t *p = buf + cap;
+    for (size_t i = n; i-- > 0;) RansEncPutAlias(&st[i % N], &p, &t, alias_sym(in, sym_bytes, i), scale_bits);
+    for (uint32_t l = N; l-- > 0;) RansEncFlush(&st[l], &p);
+    *out_len = (size_t)(buf + cap - p);
+    RansAliasTableFree(&t);
+    return 0;
+}
+
+int compat_alias_decode(const uint32_t *freqs, const uint32_t *cum, uint32_t nsyms, uint32_t scale_bits, const uint8_t *stream,
+                        size_t len, size_t n, uint32_t N, void *out, int sym_bytes)
+{
+    RansAliasTable t;
+    if (RansAliasTableInit(&t, freqs, cum, nsyms, scale_bits))
+        return 2;
+    std::vector<RansState> st(N);
+    uint8_t *p = (uint8_t *)stream;
+    for (auto &x : st) RansDecInit(&x, &p);
+    for (size_t base = 0; base < n; base += N) {
+        uint32_t cnt = n - base < N ? (uint32_t)(n - base) : N;
+        for (uint32_t l = 0; l < cnt; l++) {
+            uint32_t s = RansDecGetAlias(&st[l], &t, scale_bits);
+            if (sym_bytes == 1) ((uint8_t *)out)[base + l] = (uint8_t)s;
+            else ((uint16_t *)out)[base + l] = (uint16_t)s;
+        }
+        for (uint32_t l = 0; l < cnt; l++) RansDecRenorm(&st[l], &p);
+    }
+    RansAliasTableFree(&t);
+    return p == stream + len ? 0 : 3;
+}
+
+// the tables, for comparison with the library's (rans_amd_model_table): divider[n], slot_adjust[2n], slot_freqs[2n],
+// sym_id[2n], alias_remap[M] back to back
+int compat_alias_tables(const uint32_t *freqs, const uint32_t *cum, uint32_t nsyms, uint32_t scale_bits, uint32_t *out)
+{
+    RansAliasTable t;
+    if (RansAliasTableInit(&t, freqs, cum, nsyms, scale_bits))
+        return 2;
+    memcpy(out, t.divider, 4 * (size_t)nsyms); out += nsyms;
+    memcpy(out, t.slot_adjust, 8 * (size_t)nsyms); out += 2 * nsyms;
+    memcpy(out, t.slot_freqs, 8 * (size_t)nsyms); out += 2 * nsyms;
+    memcpy(out, t.sym_id, 8 * (size_t)nsyms); out += 2 * nsyms;
+    memcpy(out, t.alias_remap, 4u << scale_bits);
+    RansAliasTableFree(&t);
+    return 0;
+}
+
+}

@@ -67,6 +67,63 @@ def test_streams_equal_oracle(drv, oracle, fmt, cfmt, sb):
             assert np.array_equal(out, data), (N,)
 
 
+def test_alias_header_equals_oracle_and_library(drv, oracle):
+    """rans_alias_compat.h (the reference keeps its alias coder inside main_alias.cpp:147-267; here it is a header for any
+    power-of-two alphabet): streams equal the oracle's byte for byte -- 256 symbols and the 4096-symbol u16 alphabet of
+    config 4, several scale_bits and interleaves -- and the tables equal the ones the product library builds."""
+    import ryg_rans_amd as R
+    from _oracle import FMT_ALIAS
+    u8p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+    drv.compat_alias_encode.argtypes = [u32p, u32p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_size_t, C.c_uint32, u8p,
+                                        C.c_size_t, C.POINTER(C.c_size_t)]
+    drv.compat_alias_decode.argtypes = [u32p, u32p, C.c_uint32, C.c_uint32, u8p, C.c_size_t, C.c_size_t, C.c_uint32,
+                                        C.c_void_p, C.c_int]
+    drv.compat_alias_tables.argtypes = [u32p, u32p, C.c_uint32, C.c_uint32, u32p]
+    rng = np.random.default_rng(17)
+    cases = [(256, 16, oracle.gen_zipf(60001, K=256, s=1.0, seed=2)),
+             (256, 12, np.minimum(rng.geometric(0.05, 30000) - 1, 255).astype(np.uint8)),
+             (256, 8, rng.integers(0, 256, 5000, dtype=np.uint8)),
+             (16, 10, rng.integers(0, 16, 7001).astype(np.uint8)),
+             (4096, 16, oracle.gen_zipf(90003, K=4096, s=1.0, seed=3)),
+             (4096, 13, rng.integers(0, 4096, 40000).astype(np.uint16))]
+    for nsyms, sb, data in cases:
+        f, cum = oracle.normalize(oracle.count_freqs(data, nsyms), 1 << sb)
+        f = np.ascontiguousarray(f, np.uint32)
+        cum = np.ascontiguousarray(cum, np.uint32)
+        om = oracle.model(f, sb, with_alias=True)
+        # tables: header == library (host-only model, no GPU needed)
+        M = 1 << sb
+        tabs = np.zeros(7 * nsyms + M, np.uint32)
+        assert drv.compat_alias_tables(_p(f, C.c_uint32), _p(cum, C.c_uint32), nsyms, sb, _p(tabs, C.c_uint32)) == 0
+        lm = R.Model(None, FMT_ALIAS, f, sb)
+        sym_dtype = np.uint8 if nsyms <= 256 else np.uint16
+        parts = [lm.table(R.TAB_ALIAS_DIVIDER, np.uint32), lm.table(R.TAB_ALIAS_SLOT_ADJUST, np.uint32),
+                 lm.table(R.TAB_ALIAS_SLOT_FREQS, np.uint32), lm.table(R.TAB_ALIAS_SYM_ID, sym_dtype).astype(np.uint32),
+                 lm.table(R.TAB_ALIAS_REMAP, np.uint32)]
+        assert np.array_equal(tabs, np.concatenate(parts)), (nsyms, sb)
+        for N in (1, 2, 64, 7):
+            want = oracle.encode(FMT_ALIAS, om, data, N)
+            cap = (data.size * 4 + N * 8 + 64) & ~7
+            buf = np.zeros(cap + 16, np.uint8)
+            out_len = C.c_size_t(0)
+            assert drv.compat_alias_encode(_p(f, C.c_uint32), _p(cum, C.c_uint32), nsyms, sb, data.ctypes.data,
+                                           data.dtype.itemsize, data.size, N, _p(buf, C.c_uint8), cap, C.byref(out_len)) == 0
+            assert np.array_equal(buf[cap - out_len.value:cap], want), (nsyms, sb, N)
+            padded = np.concatenate([want, np.zeros(16, np.uint8)])
+            out = np.zeros(data.size, data.dtype)
+            assert drv.compat_alias_decode(_p(f, C.c_uint32), _p(cum, C.c_uint32), nsyms, sb, _p(padded, C.c_uint8), want.size,
+                                           data.size, N, out.ctypes.data, data.dtype.itemsize) == 0
+            assert np.array_equal(out, data), (nsyms, sb, N)
+    # what the builder refuses: an alphabet that is no power of two, frequencies that do not add up
+    f = np.array([1000, 1000, 2096], np.uint32)
+    cum = np.array([0, 1000, 2000, 4096], np.uint32)
+    t = np.zeros(64, np.uint32)
+    assert drv.compat_alias_tables(_p(f, C.c_uint32), _p(cum, C.c_uint32), 3, 12, _p(t, C.c_uint32)) == 2
+    f = np.array([1000, 1000, 1000, 1000], np.uint32)
+    cum = np.array([0, 1000, 2000, 3000, 4000], np.uint32)
+    assert drv.compat_alias_tables(_p(f, C.c_uint32), _p(cum, C.c_uint32), 4, 12, _p(t, C.c_uint32)) == 2
+
+
 def test_reference_mains_build_unchanged_against_compat_headers(book1):
     """The drop-in claim for the per-symbol API: the reference's four sample programs, fed to
     the compiler from stdin (so their own directory is not on the include path), compile
