@@ -41,7 +41,7 @@ int encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits)
         return 0;
     const bool word_recs = format == (int)RANS_AMD_FMT_WORD || format == (int)RANS_AMD_FMT_BYTE;
     size_t tables = nrecs * 16 + (word_recs ? 256 * 16 : 0);
-    if (format == (int)RANS_AMD_FMT_WORD && nrecs == 256) // the staging windows of the word encoder's waves
+    if (word_recs && nrecs == 256) // the staging windows of the word / byte encoder's waves
         tables += (size_t)(kEncFusedThreads / 64) * kEncStageBytes;
     return ((tables + 15) & ~(size_t)15) + kEncFusedLdsBytes <= 128 * 1024 ? 1 : 0;
 }

@@ -350,6 +350,44 @@ __device__ __forceinline__ void enc_byte_full(uint32_t &x, const u32x4 &rec, uin
                  : "vcc", "scc", "memory", "s34", "s35");
 }
 
+// The same with the emitted bytes staged in LDS (`wp` is the LDS write pointer of the wave's window, as in
+// enc_word_full_staged): the two-byte lanes write their bytes with ds_write_b8 + ds_write_b8_d16_hi from one register that
+// holds byte 1 of x in its byte 0 and byte 0 of x in its byte 2 (`split_sel`), the one-byte lanes with one ds_write_b8.
+__device__ __forceinline__ void enc_byte_full_staged(uint32_t &x, const u32x4 &rec, uint32_t &wp, uint32_t &worst, uint32_t split_sel)
+{
+    uint32_t t, r, q, c1, c2;
+    asm volatile("v_cmp_ge_u32_e32 vcc, %[x], %[xm]\n\t"
+                 "v_lshrrev_b32_e32 %[t], 8, %[x]\n\t"
+                 "v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                 "v_cmp_ge_u32_e64 s[34:35], %[t], %[xm]\n\t"
+                 "s_bcnt1_i32_b64 %[c1], vcc\n\t"
+                 "s_bcnt1_i32_b64 %[c2], s[34:35]\n\t"
+                 "s_add_u32 %[c1], %[c1], %[c2]\n\t"
+                 "s_sub_u32 %[wp], %[wp], %[c1]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[r], s34, %[r]\n\t"
+                 "v_mbcnt_hi_u32_b32 %[r], s35, %[r]\n\t"
+                 "v_add_u32_e32 %[r], %[wp], %[r]\n\t"
+                 "v_perm_b32 %[t], %[x], %[x], %[sel]\n\t"
+                 "s_mov_b64 exec, s[34:35]\n\t"
+                 "ds_write_b8 %[r], %[t]\n\t"
+                 "ds_write_b8_d16_hi %[r], %[t] offset:1\n\t"
+                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                 "s_andn2_b64 exec, vcc, s[34:35]\n\t"
+                 "ds_write_b8 %[r], %[x]\n\t"
+                 "v_lshrrev_b32_e32 %[x], 8, %[x]\n\t"
+                 "s_mov_b64 exec, -1\n\t"
+                 "v_mul_hi_u32 %[q], %[x], %[rcp]\n\t"
+                 "v_lshrrev_b32_sdwa %[q], %[w], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+                 "v_mad_u32_u24 %[q], %[q], %[w], %[x]\n\t"
+                 "v_add_u32_e32 %[x], %[q], %[bias]"
+                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [r] "=&v"(r), [q] "=&v"(q),
+                   [c1] "=&s"(c1), [c2] "=&s"(c2)
+                 : [rcp] "v"(rec.x), [w] "v"(rec.y), [bias] "v"(rec.z), [xm] "v"(rec.w), [sel] "v"(split_sel)
+                 : "vcc", "scc", "memory", "s34", "s35");
+}
+
 constexpr int kEncAliasLdsThreads = 1024; // FMT_ALIAS_LDS: 16 waves share the (up to 160 KiB) tables of a CU
 
 // ---------------------------------------------------------------------------
@@ -714,7 +752,15 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             // word format, one state per lane: stream staging (enc_word_full_staged).  Invariant between groups of four
             // rounds: memory holds the stream from wp up; what a flush writes below wp (< 16 bytes, whatever the window
             // held) is written again, correctly, by the next flush, and at the end by the state flush.
-            constexpr bool kStage = RANS_ENC_STAGE && FMT == FMT_WORD && K == 1;
+            constexpr bool kStageW = RANS_ENC_STAGE && FMT == FMT_WORD && K == 1;
+            // (byte format: 16 rounds emit at most (8 + 16 scale_bits) / 8 bytes per lane, 31 at 15 bits: 1984 bytes fit the
+            //  window, the 33 x 64 of 16-bit probabilities do not -- those models keep the per-round stores)
+            constexpr bool kStageB = RANS_ENC_STAGE && FMT == FMT_BYTE && K == 1;
+            const bool stage_b = kStageB && byte_asm && p.scale_bits <= 15u;
+            const bool stage_on = kStageW || stage_b;
+            uint32_t split_sel = 0x0c000c01u; // (v_perm selector: byte 1 of x in byte 0, byte 0 of x in byte 2)
+            asm volatile("" : "+v"(split_sel));
+            (void)split_sel;
             // The window: LDS [win_base, win_base + 2048).  Its last 16 bytes are the piece of the slot the write offset stands
             // in (what lies above the offset there was produced before and is in memory already); a super-group of sixteen
             // rounds writes downwards from win_top = win_base + 2032 + (wp & 15), at most 1664 bytes (13 words per lane: a
@@ -723,7 +769,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             const uint32_t win_base = kWordRecBytes + 256u * (uint32_t)sizeof(EncRec) + wave * kEncStageBytes;
             constexpr uint32_t kTopPiece = kEncStageBytes - 16u;
             auto lds_u32x4 = [](uint32_t at) { return reinterpret_cast<__attribute__((address_space(3))) u32x4 *>((uintptr_t)at); };
-            if (kStage && (wp & 15u)) { // the tail rounds have stored words themselves: the piece that holds wp goes into the window
+            if (stage_on && (wp & 15u)) { // the tail rounds have stored words themselves: the piece that holds wp goes into the window
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane < 4u) {
                     const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t RANS_GLOBAL *>(slot + (wp & ~15u) + 4u * lane));
@@ -763,7 +809,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             };
             // (the loop once per reciprocal method of the word format: a branch inside it costs register copies at every join)
             auto fast_loop = [&](auto small_tag) {
-            constexpr bool kSmall = decltype(small_tag)::value;
+            constexpr bool kSmall = decltype(small_tag)::value; // word: the reciprocal method; byte: staged or not
+            constexpr bool kStage = kStageW || (kStageB && kSmall);
             uint32_t sg = fast_rounds >> 4;
             load_super(cur, sg - 1);
             while (sg-- > 0) {
@@ -817,12 +864,16 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                             return *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>((uintptr_t)at); // table at LDS address 0
                         };
                         u32x4 rec = rec_at(0);
+                        lp = uniform(lp);
 #pragma unroll
                         for (int step = 0; step < 4 * K; ++step) {
                             const u32x4 now = rec;
                             if (step + 1 < 4 * K)
                                 rec = rec_at(step + 1);
-                            enc_byte_full(x[K - 1 - step % K], now, wp, slot, worst, swap_sel);
+                            if constexpr (kStageB && kSmall)
+                                enc_byte_full_staged(x[K - 1 - step % K], now, lp, worst, split_sel);
+                            else
+                                enc_byte_full(x[K - 1 - step % K], now, wp, slot, worst, swap_sel);
                         }
                     }
                 } else {
@@ -842,7 +893,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                         cur[j][k] = nxt[j][k];
             }
             };
-            if (FMT == FMT_WORD && p.word_small)
+            if ((FMT == FMT_WORD && p.word_small) || (FMT == FMT_BYTE && stage_b))
                 fast_loop(std::true_type{});
             else
                 fast_loop(std::false_type{});
@@ -906,8 +957,8 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
                  : (FMT == FMT_BYTE && p.chunk_freqs) ? (size_t)waves * kAdaptEncWaveLds
                                                       : nrecs * sizeof(EncRec) + ((FMT == FMT_WORD || FMT == FMT_BYTE) ? 256 * 16 : 0);
-    if (RANS_ENC_STAGE && FMT == FMT_WORD && K == 1 && p.sym_bytes == 1 && nrecs == 256)
-        lds += (size_t)waves * kEncStageBytes; // stream staging windows (2 KiB aligned: 4 + 4 KiB of tables in front)
+    if (RANS_ENC_STAGE && (FMT == FMT_WORD || (FMT == FMT_BYTE && !p.chunk_freqs)) && K == 1 && p.sym_bytes == 1 && nrecs == 256)
+        lds += (size_t)waves * kEncStageBytes; // stream staging windows (4 + 4 KiB of tables in front)
     EncParams q = p;
     if (fused && !p.mailbox_global) {
         lds = (lds + 15) & ~(size_t)15;
