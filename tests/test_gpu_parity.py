@@ -1054,3 +1054,37 @@ print("capture rules ok")
 """ % os.path.dirname(HERE)
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "capture rules ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_byte_encoder_staging_extremes(gpu, oracle):
+    """The byte encoder's staged sub-step (enc_byte_full_staged, models up to 15 bits) at the edges of its window: every
+    symbol the rarest one (15 bits each: 1920 bytes per sixteen rounds of a wave, the 2 KiB window nearly full, both passes
+    of the flush), nothing but the commonest (flushes with nothing to write), bursts of both, ragged chunks whose tail
+    rounds store for themselves -- and the 16-bit model next to it, which must take the per-round stores."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(23)
+    n = 1 << 17
+    for sb in (15, 14, 9, 16):
+        M = 1 << sb
+        f = np.ones(256, np.uint32)
+        f[3] = M - 255
+        rare = rng.integers(0, 255, n).astype(np.uint8)
+        rare[rare >= 3] += 1
+        common = np.full(n, 3, np.uint8)
+        bursts = rare.copy()
+        bursts[(np.arange(n) // 3000) % 2 == 0] = 3
+        om = oracle.model(f, sb)
+        gm = ctx.model(FMT_BYTE, f, sb)
+        for name, data in (("rare", rare), ("common", common), ("bursts", bursts)):
+            d = torch.from_numpy(data).cuda()
+            for n_ways, chunk in ((64, 8192), (64, n), (64, 5000), (64, 1031), (64, 2048 + 64 * 7 + 5), (128, 16384)):
+                want, offs, lens = oracle.encode_chunked(FMT_BYTE, om, data, n_ways, chunk, align=16)
+                cont, d_offs, d_lens, total = ctx.encode(gm, d, n_ways, chunk)
+                assert total == want.size, (sb, name, n_ways, chunk)
+                assert np.array_equal(d_lens.cpu().numpy().astype(np.int64), lens.astype(np.int64)), (sb, name, n_ways, chunk)
+                got = cont[:total].cpu().numpy()
+                for c in range(len(lens)):
+                    o, ln = int(offs[c]), int(lens[c])
+                    assert np.array_equal(got[o:o + ln], want[o:o + ln]), (sb, name, n_ways, chunk, c)
+                out = ctx.decode(gm, cont, total, d_offs, d_lens, n, n_ways, chunk)
+                assert np.array_equal(out.cpu().numpy(), data), (sb, name, n_ways, chunk)
