@@ -618,10 +618,10 @@ def main():
                 cfgs.append(e)
                 arts.append(a)
                 e, a = measure_config(torch, R, ctx, "C4 alias 4096 symbols 64-way 512 Mi u16 symbols", R.FMT_ALIAS, 16,
-                                      4096, 64, 32768, 29, 1, ks, device)
+                                      4096, 64, args.chunk, 29, 1, ks, device)
                 cfgs.append(e)
                 arts.append(a)
-                e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256)", R.FMT_BYTE, 14, 256, 64, 32768,
+                e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256)", R.FMT_BYTE, 14, 256, 64, args.chunk,
                                       30, 1, ks, device, d_syms=d_syms)
                 cfgs.append(e)
                 arts.append(a)

@@ -60,6 +60,8 @@ def test_bench_generator_equals_oracle_on_gpu(gpu, oracle):
     ("C2", FMT_R64, 14, 256, 2, 512, 28),
     ("C4", FMT_ALIAS, 16, 4096, 64, 32768, 29),
     ("byte-64", FMT_BYTE, 14, 256, 64, 32768, 30),
+    ("C4-16k-chunks", FMT_ALIAS, 16, 4096, 64, 16384, 29),
+    ("byte-64-16k-chunks", FMT_BYTE, 14, 256, 64, 16384, 30),
 ])
 def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways, chunk, log2n):
     R, ctx, torch = gpu
@@ -79,7 +81,7 @@ def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways
     assert torch.equal(out, d_syms)
     if name == "C3":
         assert ctx.last_decode_kernel() == "k_decode_word64"
-    if name == "C4":
+    if name.startswith("C4"):
         assert ctx.last_decode_kernel() == "k_decode_dual<alias>"
     del out
     # 2. the decoder on a container made by the ORACLE alone (host, threaded), not by the GPU encoder
