@@ -739,8 +739,9 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             uint32_t k3v = 3u, m12v = 0xfffu; // (word format: 8-byte records)
             asm volatile("" : "+v"(k3v)); // (SDWA takes no literal; a VGPR operand is also the faster VALU form)
             asm volatile("" : "+v"(m12v));
-            if (kMeasureBuild && (p.debug & 4u)) // measurement only: every lane reads record 0 -- what the bank conflicts of the
-                rec_mask = 0u, k3v = 31u;        // record gather cost; the output is wrong by construction
+            if (kMeasureBuild && (p.debug & 4u)) // measurement only: every lane reads record 0 (word format: or, symbols with bit 0
+                rec_mask = 0u, k3v = 31u;        // set, an address beyond the LDS, which reads zeros) -- what the bank conflicts of
+                                                 // the record gather cost; the output is wrong by construction
             (void)k3v;
             (void)m12v;
             asm volatile("" : "+v"(rec_mask)); // keep the mask in a VGPR (a literal operand costs a slower VALU form)
