@@ -1088,3 +1088,29 @@ def test_byte_encoder_staging_extremes(gpu, oracle):
                     assert np.array_equal(got[o:o + ln], want[o:o + ln]), (sb, name, n_ways, chunk, c)
                 out = ctx.decode(gm, cont, total, d_offs, d_lens, n, n_ways, chunk)
                 assert np.array_equal(out.cpu().numpy(), data), (sb, name, n_ways, chunk)
+
+
+@pytest.mark.parametrize("fmt,sb", [(FMT_WORD, 12), (FMT_BYTE, 14), (FMT_BYTE, 16)])
+def test_staged_encoders_with_the_three_kernel_placement(gpu, oracle, fmt, sb):
+    """RANS_AMD_OPT_FUSED_PLACEMENT = 0 (k_encode + k_layout + k_compact): the coding kernel is the same template with
+    16-wave blocks and no copier -- its LDS staging windows sit behind the same tables -- and must write the same bytes."""
+    R, _, torch = gpu
+    ctx = R.Context(0)
+    ctx.set_option(R.OPT_FUSED_PLACEMENT, 0)
+    try:
+        data = oracle.gen_zipf(700001, K=256, s=1.1, seed=31)
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        d = torch.from_numpy(data).cuda()
+        for n_ways, chunk in ((64, 4096), (64, 5000), (64, 32768), (128, 8192)):
+            want, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+            cont, d_offs, d_lens, total = ctx.encode(gm, d, n_ways, chunk)
+            assert ctx.last_encode_kernel()[1] is False  # not the fused placement
+            assert total == want.size
+            got = cont[:total].cpu().numpy()
+            for c in range(len(lens)):
+                o, ln = int(offs[c]), int(lens[c])
+                assert np.array_equal(got[o:o + ln], want[o:o + ln]), (n_ways, chunk, c)
+            out = ctx.decode(gm, cont, total, d_offs, d_lens, data.size, n_ways, chunk)
+            assert np.array_equal(out.cpu().numpy(), data)
+    finally:
+        ctx.close()
