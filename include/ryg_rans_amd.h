@@ -54,7 +54,9 @@
 extern "C" {
 #endif
 
-#define RANS_AMD_VERSION 100 /* 0.1.0 */
+/* 0.3.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
+ * inside a hipGraph capture (0.3.0).  A caller built against an older header keeps working. */
+#define RANS_AMD_VERSION 300
 
 typedef enum rans_amd_status {
     RANS_AMD_OK = 0,
