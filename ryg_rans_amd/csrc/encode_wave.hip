@@ -755,9 +755,11 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             // held) is written again, correctly, by the next flush, and at the end by the state flush.
             constexpr bool kStageW = RANS_ENC_STAGE && FMT == FMT_WORD && K == 1;
             // (byte format: 16 rounds emit at most (8 + 16 scale_bits) / 8 bytes per lane, 31 at 15 bits: 1984 bytes fit the
-            //  window, the 33 x 64 of 16-bit probabilities do not -- those models keep the per-round stores)
+            //  window, the 33 x 64 of 16-bit probabilities do not -- those models flush every eight rounds: 17 x 64)
             constexpr bool kStageB = RANS_ENC_STAGE && FMT == FMT_BYTE && K == 1;
-            const bool stage_b = kStageB && byte_asm && p.scale_bits <= 15u;
+            const bool stage_b = kStageB && byte_asm && p.scale_bits <= 16u;
+            const bool flush8 = kStageB && p.scale_bits == 16u;
+            (void)flush8;
             const bool stage_on = kStageW || stage_b;
             uint32_t split_sel = 0x0c000c01u; // (v_perm selector: byte 1 of x in byte 0, byte 0 of x in byte 2)
             asm volatile("" : "+v"(split_sel));
@@ -817,7 +819,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             while (sg-- > 0) {
                 if (sg > 0)
                     load_super(nxt, sg - 1);
-                const uint32_t win_top = win_base + kTopPiece + (uniform(wp) & 15u);
+                uint32_t win_top = win_base + kTopPiece + (uniform(wp) & 15u);
                 uint32_t lp = win_top; // (staged path: the coding loop moves this LDS pointer, stage_flush() sets wp)
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
@@ -883,6 +885,13 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
 #pragma unroll
                         for (int k = K - 1; k >= 0; --k)
                             enc_substep<FMT, true, kIsAlias<FMT>>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
+                }
+                if constexpr (kStageB && kStage) { // (16-bit byte models: half a super-group fills the window)
+                    if (j == 2 && flush8) {
+                        stage_flush(win_top, uniform(lp));
+                        win_top = win_base + kTopPiece + (uniform(wp) & 15u);
+                        lp = win_top;
+                    }
                 }
                 }
                 if constexpr (kStage)

@@ -1060,7 +1060,8 @@ def test_byte_encoder_staging_extremes(gpu, oracle):
     """The byte encoder's staged sub-step (enc_byte_full_staged, models up to 15 bits) at the edges of its window: every
     symbol the rarest one (15 bits each: 1920 bytes per sixteen rounds of a wave, the 2 KiB window nearly full, both passes
     of the flush), nothing but the commonest (flushes with nothing to write), bursts of both, ragged chunks whose tail
-    rounds store for themselves -- and the 16-bit model next to it, which must take the per-round stores."""
+    rounds store for themselves -- and the 16-bit model next to it, whose window is flushed every eight rounds (17 x 64
+    bytes; sixteen rounds would be 33 x 64, more than the window)."""
     R, ctx, torch = gpu
     rng = np.random.default_rng(23)
     n = 1 << 17
