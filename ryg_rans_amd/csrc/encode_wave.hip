@@ -23,6 +23,7 @@ template <int FMT> struct EncTables {
     uint32_t scale_bits;
     uint32_t nsyms;
     uint32_t swap_sel; // v_perm selector of enc_renorm_byte_full (kept in a VGPR)
+    uint32_t split_sel; // ... and of enc_renorm_byte_full_staged
 };
 
 // Renormalisation of the byte-stream formats for a FULL wave (rans_byte.h:62-74: zero, one or two bytes leave the
@@ -63,12 +64,45 @@ __device__ __forceinline__ void enc_renorm_byte_full(uint32_t &x, uint32_t x_max
     wp = wps;
 }
 
+// The same with the bytes written into the wave's LDS staging window (`wp` is its LDS write pointer, see
+// enc_word_full_staged / enc_byte_full_staged): split_sel puts byte 1 of x into byte 0 and byte 0 into byte 2.
+__device__ __forceinline__ void enc_renorm_byte_full_staged(uint32_t &x, uint32_t x_max, uint32_t &wp, uint32_t split_sel)
+{
+    uint32_t t, r, c1, c2;
+    uint32_t wps = uniform(wp); // (an "s" operand fed from a loop-carried value wants the readfirstlane spelled out)
+    asm volatile("v_cmp_ge_u32_e32 vcc, %[x], %[xm]\n\t"
+                 "v_lshrrev_b32_e32 %[t], 8, %[x]\n\t"
+                 "v_cmp_ge_u32_e64 s[34:35], %[t], %[xm]\n\t"
+                 "s_bcnt1_i32_b64 %[c1], vcc\n\t"
+                 "s_bcnt1_i32_b64 %[c2], s[34:35]\n\t"
+                 "s_add_u32 %[c1], %[c1], %[c2]\n\t"
+                 "s_sub_u32 %[wp], %[wp], %[c1]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[r], s34, %[r]\n\t"
+                 "v_mbcnt_hi_u32_b32 %[r], s35, %[r]\n\t"
+                 "v_add_u32_e32 %[r], %[wp], %[r]\n\t"
+                 "v_perm_b32 %[t], %[x], %[x], %[sel]\n\t"
+                 "s_mov_b64 exec, s[34:35]\n\t"
+                 "ds_write_b8 %[r], %[t]\n\t"
+                 "ds_write_b8_d16_hi %[r], %[t] offset:1\n\t"
+                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                 "s_andn2_b64 exec, vcc, s[34:35]\n\t"
+                 "ds_write_b8 %[r], %[x]\n\t"
+                 "v_lshrrev_b32_e32 %[x], 8, %[x]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [x] "+v"(x), [wp] "+s"(wps), [t] "=&v"(t), [r] "=&v"(r), [c1] "=&s"(c1), [c2] "=&s"(c2)
+                 : [xm] "v"(x_max), [sel] "v"(split_sel)
+                 : "vcc", "scc", "memory", "s34", "s35");
+    wp = wps;
+}
+
 // One encoder sub-step for 64 lanes.  `wp` = write cursor (byte offset inside the
 // slot, moves down, wave-uniform).
 // PADDED: the record table holds 256 entries (zero records behind nsyms) and `sym` is a byte, so it
 // indexes the table as it is -- no range select (a v_cndmask costs ~22 issue cycles on gfx950).
 // FULL: all 64 lanes hold a symbol (the byte-stream formats then renormalise with enc_renorm_byte_full).
-template <int FMT, bool PADDED = false, bool FULL = false>
+template <int FMT, bool PADDED = false, bool FULL = false, bool STAGED = false> // (STAGED: FULL, and wp is an LDS pointer)
 __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename FmtTraits<FMT>::state_t &x,
                                             uint32_t sym, bool active, uint8_t RANS_GLOBAL *slot, uint32_t &wp,
                                             bool &bad)
@@ -120,7 +154,10 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         uint32_t y;
         if constexpr (FULL) {
             y = x;
-            enc_renorm_byte_full(y, active ? x_max : 0xffffffffu, wp, slot, T.swap_sel);
+            if constexpr (STAGED)
+                enc_renorm_byte_full_staged(y, active ? x_max : 0xffffffffu, wp, T.split_sel);
+            else
+                enc_renorm_byte_full(y, active ? x_max : 0xffffffffu, wp, slot, T.swap_sel);
         } else {
         const bool e1 = active && x >= x_max;
         const bool e2 = e1 && (x >> 8) >= x_max;
@@ -597,6 +634,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
     T.nsyms = p.nsyms;
     T.swap_sel = 0x0c0c0001u; // (the low two bytes swapped, zeros above)
     asm volatile("" : "+v"(T.swap_sel));
+    T.split_sel = 0x0c000c01u; // (byte 1 of x in byte 0, byte 0 of x in byte 2)
+    asm volatile("" : "+v"(T.split_sel));
 
     bool bad = false;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
@@ -758,9 +797,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             //  window, the 33 x 64 of 16-bit probabilities do not -- those models flush every eight rounds: 17 x 64)
             constexpr bool kStageB = RANS_ENC_STAGE && FMT == FMT_BYTE && K == 1;
             const bool stage_b = kStageB && byte_asm && p.scale_bits <= 16u;
-            const bool flush8 = kStageB && p.scale_bits == 16u;
+            // (alias tables in LDS, byte symbols: windows where the launcher found room behind the tables, EncParams::stage_off)
+            constexpr bool kStageA = RANS_ENC_STAGE && FMT == FMT_ALIAS_LDS && K == 1;
+            const bool stage_a = kStageA && p.stage_off != 0u && p.scale_bits <= 16u;
+            const bool flush8 = (kStageB || kStageA) && p.scale_bits == 16u;
             (void)flush8;
-            const bool stage_on = kStageW || stage_b;
+            const bool stage_on = kStageW || stage_b || stage_a;
             uint32_t split_sel = 0x0c000c01u; // (v_perm selector: byte 1 of x in byte 0, byte 0 of x in byte 2)
             asm volatile("" : "+v"(split_sel));
             (void)split_sel;
@@ -769,7 +811,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             // rounds writes downwards from win_top = win_base + 2032 + (wp & 15), at most 1664 bytes (13 words per lane: a
             // symbol adds at most 12 bits to a state of 16..32 bits, a word takes 16 out), so LDS address and slot offset
             // stay congruent modulo 16 and nothing wraps.
-            const uint32_t win_base = kWordRecBytes + 256u * (uint32_t)sizeof(EncRec) + wave * kEncStageBytes;
+            const uint32_t win_base = (FMT == FMT_ALIAS_LDS ? p.stage_off : kWordRecBytes + 256u * (uint32_t)sizeof(EncRec)) + wave * kEncStageBytes;
             constexpr uint32_t kTopPiece = kEncStageBytes - 16u;
             auto lds_u32x4 = [](uint32_t at) { return reinterpret_cast<__attribute__((address_space(3))) u32x4 *>((uintptr_t)at); };
             if (stage_on && (wp & 15u)) { // the tail rounds have stored words themselves: the piece that holds wp goes into the window
@@ -813,7 +855,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             // (the loop once per reciprocal method of the word format: a branch inside it costs register copies at every join)
             auto fast_loop = [&](auto small_tag) {
             constexpr bool kSmall = decltype(small_tag)::value; // word: the reciprocal method; byte: staged or not
-            constexpr bool kStage = kStageW || (kStageB && kSmall);
+            constexpr bool kStage = kStageW || ((kStageB || kStageA) && kSmall);
             uint32_t sg = fast_rounds >> 4;
             load_super(cur, sg - 1);
             while (sg-- > 0) {
@@ -884,9 +926,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                     for (int J = 3; J >= 0; --J)
 #pragma unroll
                         for (int k = K - 1; k >= 0; --k)
-                            enc_substep<FMT, true, kIsAlias<FMT>>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
+                            if constexpr (kStageA && kSmall)
+                                enc_substep<FMT, true, true, true>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, lp, bad);
+                            else
+                                enc_substep<FMT, true, kIsAlias<FMT>>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
                 }
-                if constexpr (kStageB && kStage) { // (16-bit byte models: half a super-group fills the window)
+                if constexpr ((kStageB || kStageA) && kStage) { // (16-bit models: half a super-group fills the window)
                     if (j == 2 && flush8) {
                         stage_flush(win_top, uniform(lp));
                         win_top = win_base + kTopPiece + (uniform(wp) & 15u);
@@ -903,7 +948,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                         cur[j][k] = nxt[j][k];
             }
             };
-            if ((FMT == FMT_WORD && p.word_small) || (FMT == FMT_BYTE && stage_b))
+            if ((FMT == FMT_WORD && p.word_small) || (FMT == FMT_BYTE && stage_b) || (FMT == FMT_ALIAS_LDS && stage_a))
                 fast_loop(std::true_type{});
             else
                 fast_loop(std::false_type{});
@@ -974,6 +1019,14 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
         lds = (lds + 15) & ~(size_t)15;
         q.mailbox_off = (uint32_t)lds;
         lds += kEncFusedLdsBytes;
+    }
+    q.stage_off = 0;
+    if (RANS_ENC_STAGE && FMT == FMT_ALIAS_LDS && K == 1 && p.sym_bytes == 1) { // windows of the coding waves, where there is room
+        const size_t at = (lds + 15) & ~(size_t)15;
+        if (at + (size_t)enc_waves * kEncStageBytes <= 160 * 1024) {
+            q.stage_off = (uint32_t)at;
+            lds = at + (size_t)enc_waves * kEncStageBytes;
+        }
     }
     const size_t lds_cap = FMT == FMT_ALIAS_LDS ? 160 * 1024 : 128 * 1024;
     if (lds > lds_cap || (FMT == FMT_WORD && !p.word_enc_recs && p.sym_bytes == 1) ||

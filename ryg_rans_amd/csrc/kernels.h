@@ -128,6 +128,8 @@ struct EncParams {
     uint8_t *out;               // fused: the container
     uint64_t out_cap;
     uint32_t mailbox_off;       // fused: LDS byte offset of the block's mailbox (set by the launcher)
+    uint32_t stage_off;         // alias encoder with its tables in LDS: byte offset of the coding waves' staging windows, 0 =
+                                // the tables leave no room for them (set by the launcher; word / byte: fixed, behind their tables)
     uint8_t *mailbox_global;    // fused, tables that fill the CU's LDS to the last byte (the 4096-symbol, 16-bit alias model):
                                 // one kEncMailboxStride-byte mailbox per block in global memory (zero at launch), else NULL
     uint32_t ring_slots;        // fused wave encoders: 0 = scratch holds one slot per CHUNK (slot of chunk c at c * slot_bytes);

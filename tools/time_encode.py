@@ -15,7 +15,7 @@ import ryg_rans_amd as R  # noqa: E402
 from tools.config_sweep import zipf  # noqa: E402
 
 CONFIGS = {"word": (R.FMT_WORD, 12, 256, 64), "byte": (R.FMT_BYTE, 14, 256, 64), "r64": (R.FMT_R64, 14, 256, 64),
-           "c4": (R.FMT_ALIAS, 16, 4096, 64)}
+           "c4": (R.FMT_ALIAS, 16, 4096, 64), "alias256": (R.FMT_ALIAS, 16, 256, 64)}
 
 
 def main():
