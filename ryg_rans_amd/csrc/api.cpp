@@ -224,7 +224,6 @@ uint64_t empty_stream(int format, uint32_t n_ways, uint8_t *dst)
     return (uint64_t)n_ways * sbytes;
 }
 
-uint32_t unit_bytes(int format) { return format == RANS_AMD_FMT_WORD ? 2u : format == RANS_AMD_FMT_R64 ? 4u : 1u; }
 uint32_t state_bytes(int format) { return format == RANS_AMD_FMT_R64 ? 8u : 4u; }
 
 } // namespace
