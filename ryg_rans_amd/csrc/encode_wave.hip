@@ -107,6 +107,35 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
                                             uint32_t sym, bool active, uint8_t RANS_GLOBAL *slot, uint32_t &wp,
                                             bool &bad)
 {
+    if constexpr (FMT == FMT_ALIAS_LDS && FULL) {
+        // Full waves of the alias coder with its tables in LDS (main_alias.cpp:241-250), without a single select (a
+        // v_cndmask behind a VALU compare costs several ordinary instructions on this part, and the general form below
+        // has four per symbol):
+        //  * the alphabet is a power of two: a symbol beyond it wraps into the table and the chunk is flagged;
+        //  * a symbol without slots (freq 0) gets x_max = 0xffffffff from a saturating add -- it never emits --
+        //    and is flagged; its lane carries garbage from then on, the call fails with RANS_AMD_E_MODEL;
+        //  * the quotient estimate mulhi(y, floor(2^32 / freq)) is exact or one too small: the correction is a sign mask.
+        // Whatever a lane holds, it emits at most two bytes per round: the slot (2 bytes per symbol) cannot overflow, and
+        // the staged form flushes its window every eight rounds for this format (1024 bytes at most).
+        const uint32_t idx = PADDED ? sym : (sym & (T.nsyms - 1u));
+        const uint2 r8 = reinterpret_cast<const uint2 *>(T.recs)[idx];
+        const uint32_t freq = r8.x & 0xffffu, start = r8.x >> 16, rcp = r8.y;
+        bad = bad || (!PADDED && sym >= T.nsyms) || freq == 0u;
+        const uint32_t k = 31u - T.scale_bits;
+        uint32_t x_max;
+        asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(x_max) : "v"((freq - 1u) << k), "v"(1u << k));
+        uint32_t y = x;
+        if constexpr (STAGED)
+            enc_renorm_byte_full_staged(y, x_max, wp, T.split_sel);
+        else
+            enc_renorm_byte_full(y, x_max, wp, slot, T.swap_sel);
+        const uint32_t q0 = __umulhi(y, rcp);
+        const uint32_t d = y - __umul24(q0, freq) - freq;          // rem0 - freq: negative iff the estimate was exact
+        const uint32_t m = (uint32_t)((int32_t)d >> 31);
+        const uint32_t rem = d + (freq & m), q = q0 + 1u + m;
+        x = (q << T.scale_bits) + T.remap16[(rem + start) & ((1u << T.scale_bits) - 1u)];
+        return;
+    }
     const bool in_alphabet = PADDED || sym < T.nsyms;
     uint4 rec;
     if constexpr (FMT == FMT_ALIAS_LDS) { // 8-byte records: {freq | start << 16, rcp}
@@ -800,7 +829,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             // (alias tables in LDS, byte symbols: windows where the launcher found room behind the tables, EncParams::stage_off)
             constexpr bool kStageA = RANS_ENC_STAGE && FMT == FMT_ALIAS_LDS && K == 1;
             const bool stage_a = kStageA && p.stage_off != 0u && p.scale_bits <= 16u;
-            const bool flush8 = (kStageB || kStageA) && p.scale_bits == 16u;
+            const bool flush8 = kStageA || (kStageB && p.scale_bits == 16u); // (alias: two bytes per lane and round at most, whatever the input)
             (void)flush8;
             const bool stage_on = kStageW || stage_b || stage_a;
             uint32_t split_sel = 0x0c000c01u; // (v_perm selector: byte 1 of x in byte 0, byte 0 of x in byte 2)
