@@ -62,6 +62,11 @@ def test_bench_generator_equals_oracle_on_gpu(gpu, oracle):
     ("byte-64", FMT_BYTE, 14, 256, 64, 32768, 30),
     ("C4-16k-chunks", FMT_ALIAS, 16, 4096, 64, 16384, 29),
     ("byte-64-16k-chunks", FMT_BYTE, 14, 256, 64, 16384, 30),
+    # the wider interleaves and the 64-way rans64 coder at a quarter of the size (several rounds of every persistent grid)
+    ("word-256-way", FMT_WORD, 12, 256, 256, 32768, 28),
+    ("word-128-way", FMT_WORD, 12, 256, 128, 16384, 28),
+    ("r64-64-way", FMT_R64, 14, 256, 64, 16384, 28),
+    ("alias256-64-way", FMT_ALIAS, 16, 256, 64, 16384, 28),
 ])
 def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways, chunk, log2n):
     R, ctx, torch = gpu
