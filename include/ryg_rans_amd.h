@@ -54,9 +54,11 @@
 extern "C" {
 #endif
 
-/* 0.3.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
- * inside a hipGraph capture (0.3.0).  A caller built against an older header keeps working. */
-#define RANS_AMD_VERSION 300
+/* 0.4.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
+ * inside a hipGraph capture (0.3.0); rans_amd_encode_slots + rans_amd_slot_bytes / rans_amd_encode_slots_bound,
+ * rans_amd_container_compact, chunk offsets on any multiple of the format's unit in every decoder (0.4.0).  A caller built
+ * against an older header keeps working. */
+#define RANS_AMD_VERSION 400
 
 typedef enum rans_amd_status {
     RANS_AMD_OK = 0,
@@ -229,12 +231,48 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
                     uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t out_cap,
                     uint64_t *d_offsets, uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream);
 
+/* The same encoder writing every chunk ONCE, in the reference's own buffer convention (rans_byte.h:22-26 "the encoder is
+ * handed the END of the output buffer and moves down"; main.cpp:176-188, main64.cpp:178-190, main_simd.cpp:287-306,
+ * main_alias.cpp:303-315: the stream is [ptr after the flush, end of the buffer)):
+ *
+ *     slot c  =  d_out[c * S, (c + 1) * S),   S = rans_amd_slot_bytes(format, n, n_ways, chunk_syms)
+ *     chunk c's stream  =  the last d_lengths[c] bytes of slot c;   d_offsets[c] = (c + 1) * S - d_lengths[c]
+ *     d_offsets[n_chunks] = n_chunks * S  (the size of the slot container)
+ *
+ * Every chunk's bytes are exactly what rans_amd_encode produces for it (the oracle's stream for that chunk); only WHERE
+ * they lie differs.  rans_amd_encode's compact layout needs every chunk's length before it can place the next one, so its
+ * coding kernels write each stream into scratch and move it once more (a second trip through HBM: 1.9 x the bytes);
+ * here nothing moves -- no scratch, no look-back between workgroups, no copier waves -- and the call is faster by what
+ * the move cost.  The price is capacity: out_cap must be at least rans_amd_encode_slots_bound() = n_chunks * S (S is the
+ * worst case of a chunk: ~2 bytes per symbol, 4 for rans64 -- 2.6 x a typical compact container), checked up front
+ * (RANS_AMD_E_SPACE, nothing launched).  Chunk starts are NOT 16-byte aligned: rans_amd_decode takes them as they are
+ * (any multiple of the format's unit: 1 byte / 2 / 4).  rans_amd_container_compact turns a slot container into the compact
+ * layout (needed before rans_amd_container_pack, or to shrink what is kept). */
+uint64_t rans_amd_slot_bytes(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms);
+uint64_t rans_amd_encode_slots_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms);
+int rans_amd_encode_slots(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,
+                          uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t out_cap,
+                          uint64_t *d_offsets, uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream);
+
+/* Copy the n_chunks streams [d_src + d_src_offsets[c], + d_lengths[c]) -- any layout the decoders accept: a slot
+ * container, a chunk range of another container, chunks in any order -- into the compact layout at d_dst:
+ * d_dst_offsets[c] = sum_{i<c} align16(d_lengths[i]), d_dst_offsets[n_chunks] = end of the last stream (n_chunks + 1
+ * entries).  d_src (src_bytes long) and d_dst (dst_cap) must not overlap.  Asynchronous on `stream` unless h_total_bytes is
+ * given (then: synchronises, stores d_dst_offsets[n_chunks], reports RANS_AMD_E_SPACE when dst_cap was too small --
+ * nothing is copied in that case; rans_amd_encode_status reports the same later for an asynchronous call). */
+int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t src_bytes, const uint64_t *d_src_offsets,
+                               const uint32_t *d_lengths, uint64_t n_chunks, void *d_dst, uint64_t dst_cap,
+                               uint64_t *d_dst_offsets, uint64_t *h_total_bytes, void *stream);
+
 /* Synchronise `stream` and report how the last rans_amd_encode / rans_amd_encode_adaptive of this context ended when it
  * was called without h_total_bytes (asynchronously, or as a graph node): RANS_AMD_OK, RANS_AMD_E_MODEL (a symbol with
  * frequency 0), RANS_AMD_E_SPACE (out_cap too small) or RANS_AMD_E_HIP.  The container size is d_offsets[n_chunks]. */
 int rans_amd_encode_status(rans_amd_ctx *ctx, void *stream);
 
-/* Decode a container.  d_out receives n symbols.  Every chunk is checked the way
+/* Decode a container.  d_out receives n symbols.  Chunk c is the d_lengths[c] bytes at d_container + d_offsets[c];
+ * offsets may be any multiple of the format's renormalisation unit (byte / alias: 1, word: 2, rans64: 4) and need not
+ * ascend -- compact containers (rans_amd_encode), slot containers (rans_amd_encode_slots) and hand-made indexes over
+ * reference streams all decode.  Every chunk is checked the way
  * the reference's streams allow (all final states == L, cursor == end of the
  * chunk's stream, no read past it); failures are counted on the device.  If
  * h_bad_chunks != NULL the call synchronises `stream`, stores the number of
@@ -357,7 +395,8 @@ int rans_amd_last_kernel_ms(rans_amd_ctx *ctx, float *decode_ms, float *encode_m
 /* Name of the dominant device kernel the last decode used (for profile matching). */
 const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx);
 /* Name of the coding kernel the last encode used; *fused_placement (may be NULL) = 1 when that kernel also placed the
- * chunks in the container itself, 0 when the offset scan and the compaction ran as kernels of their own behind it. */
+ * chunks in the container itself, 0 when the offset scan and the compaction ran as kernels of their own behind it, 2 when
+ * there was nothing to place (rans_amd_encode_slots: the chunks stay where they were coded). */
 const char *rans_amd_last_encode_kernel(rans_amd_ctx *ctx, int *fused_placement);
 
 #ifdef __cplusplus

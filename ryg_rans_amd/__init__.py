@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "rans_amd_model_nsyms", "rans_amd_model_sym_bytes", "rans_amd_model_table",
     "rans_amd_num_chunks", "rans_amd_chunk_bound", "rans_amd_encode_bound", "rans_amd_ways_supported",
     "rans_amd_encode", "rans_amd_encode_status", "rans_amd_decode", "rans_amd_decode_errors",
+    "rans_amd_encode_slots", "rans_amd_slot_bytes", "rans_amd_encode_slots_bound", "rans_amd_container_compact",
     "rans_amd_encode_host", "rans_amd_decode_host",
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_encode_kernel", "rans_amd_last_wave_clocks",
     "rans_amd_launch_spans",
@@ -109,6 +110,10 @@ def _load():
         "rans_amd_encode_bound": (u64, [i32, u64, u32, u32]),
         "rans_amd_ways_supported": (i32, [i32, u32]),
         "rans_amd_encode": (i32, [vp, vp, vp, u64, u32, u32, vp, u64, vp, vp, u64p, vp]),
+        "rans_amd_encode_slots": (i32, [vp, vp, vp, u64, u32, u32, vp, u64, vp, vp, u64p, vp]),
+        "rans_amd_slot_bytes": (u64, [i32, u64, u32, u32]),
+        "rans_amd_encode_slots_bound": (u64, [i32, u64, u32, u32]),
+        "rans_amd_container_compact": (i32, [vp, vp, u64, vp, vp, u64, vp, u64, vp, u64p, vp]),
         "rans_amd_decode": (i32, [vp, vp, vp, u64, vp, vp, u64, u32, u32, vp, u64p, vp]),
         "rans_amd_decode_errors": (i32, [vp, u64p, vp]),
         "rans_amd_encode_host": (i32, [vp, vp, vp, u64, u32, vp, u64, u64p]),
@@ -196,6 +201,14 @@ def encode_bound(fmt, n, n_ways, chunk_syms):
     return int(_lib.rans_amd_encode_bound(fmt, n, n_ways, chunk_syms))
 
 
+def slot_bytes(fmt, n, n_ways, chunk_syms):
+    return int(_lib.rans_amd_slot_bytes(fmt, n, n_ways, chunk_syms))
+
+
+def encode_slots_bound(fmt, n, n_ways, chunk_syms):
+    return int(_lib.rans_amd_encode_slots_bound(fmt, n, n_ways, chunk_syms))
+
+
 def ways_supported(fmt, n_ways):
     return bool(_lib.rans_amd_ways_supported(fmt, n_ways))
 
@@ -254,10 +267,16 @@ class Context:
         return _lib.rans_amd_last_decode_kernel(self._h).decode()
 
     def last_encode_kernel(self):
-        """(name of the coding kernel of the last encode, True if it placed the chunks itself)"""
+        """(name of the coding kernel of the last encode, True if no layout / compaction kernels ran behind it)"""
         fused = C.c_int(0)
         name = _lib.rans_amd_last_encode_kernel(self._h, C.byref(fused)).decode()
         return name, bool(fused.value)
+
+    def last_encode_placement(self):
+        """0: layout + compaction kernels behind the coder, 1: the coder placed its chunks itself, 2: slot layout (nothing moved)"""
+        fused = C.c_int(0)
+        _lib.rans_amd_last_encode_kernel(self._h, C.byref(fused))
+        return int(fused.value)
 
     # -- model
     def model(self, fmt, norm_freqs, scale_bits):
@@ -317,6 +336,41 @@ class Context:
                                     d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
                                     C.byref(total) if sync else None, _torch_stream()), "encode")
         return d_out, d_offsets, d_lengths, (total.value if sync else None)
+
+    def encode_slots(self, model, d_syms, n_ways, chunk_syms, d_out=None, sync=True, d_offsets=None, d_lengths=None):
+        """rans_amd_encode_slots: every chunk stays in its slot of slot_bytes() bytes (its stream ends at the slot's end).
+        Returns (d_container, d_offsets, d_lengths, total_bytes = n_chunks * slot)."""
+        import torch
+        n = d_syms.numel()
+        nchunks = num_chunks(n, chunk_syms)
+        cap = encode_slots_bound(model.fmt, n, n_ways, chunk_syms)
+        dev = d_syms.device
+        if d_out is None:
+            d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        if d_offsets is None:
+            d_offsets = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
+        if d_lengths is None:
+            d_lengths = torch.zeros(max(nchunks, 1), dtype=torch.int32, device=dev)
+        total = C.c_uint64(0)
+        _check(_lib.rans_amd_encode_slots(self._h, model._h, d_syms.data_ptr(), n, n_ways, chunk_syms, d_out.data_ptr(),
+                                          d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
+                                          C.byref(total) if sync else None, _torch_stream()), "encode_slots")
+        return d_out, d_offsets, d_lengths, (total.value if sync else None)
+
+    def compact(self, d_src, src_bytes, d_src_offsets, d_lengths, n_chunks, d_dst=None, sync=True):
+        """rans_amd_container_compact: -> (d_dst, d_dst_offsets, total_bytes)."""
+        import torch
+        dev = d_src.device
+        if d_dst is None:
+            cap = int(((d_lengths[:n_chunks].to(torch.int64) + 15) & ~15).sum().item()) + 16 if n_chunks else 16
+            d_dst = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_dst_offsets = torch.zeros(n_chunks + 1, dtype=torch.int64, device=dev)
+        total = C.c_uint64(0)
+        _check(_lib.rans_amd_container_compact(self._h, d_src.data_ptr(), src_bytes, d_src_offsets.data_ptr(),
+                                               d_lengths.data_ptr(), n_chunks, d_dst.data_ptr(), d_dst.numel(),
+                                               d_dst_offsets.data_ptr(), C.byref(total) if sync else None, _torch_stream()),
+               "container_compact")
+        return d_dst, d_dst_offsets, (total.value if sync else None)
 
     def decode(self, model, d_container, container_bytes, d_offsets, d_lengths, n, n_ways, chunk_syms, d_out=None,
                sync=True):

@@ -125,6 +125,7 @@ struct rans_amd_ctx {
     const char *last_kernel = "";
     const char *last_enc_kernel = ""; // the coding kernel of the last encode call
     bool last_enc_fused = false;      // ... and whether it placed its chunks itself (no k_layout / k_compact)
+    bool last_enc_slots = false;      // ... or left them in their slots (rans_amd_encode_slots)
     std::mutex mu;
 
     unsigned long long *d_err() { return reinterpret_cast<unsigned long long *>(d_words); }
@@ -643,9 +644,13 @@ int rans_amd_build_model_o0(rans_amd_ctx *ctx, int format, const void *syms, uin
 
 /* ---- encode ------------------------------------------------------------- */
 
-int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,
-                    uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
-                    uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream)
+} // extern "C"
+
+// rans_amd_encode (slots == false: the compact layout) and rans_amd_encode_slots (slots == true: every chunk stays in the
+// slot it was coded into)
+static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n, uint32_t n_ways,
+                       uint32_t chunk_syms, void *d_out, uint64_t out_cap, uint64_t *d_offsets, uint32_t *d_lengths,
+                       uint64_t *h_total_bytes, void *stream, const bool slots)
 {
     if (!ctx || !model || !d_out || !d_offsets || !d_lengths || (n && !d_syms) || chunk_syms == 0)
         return fail(RANS_AMD_E_ARG, "encode: NULL argument or chunk_syms == 0");
@@ -667,6 +672,8 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     const uint64_t slot = encode_slot_bytes(format, n, n_ways, chunk_syms);
     if (slot > 0xfffffff0ull) // chunk stream lengths and in-slot cursors are 32-bit
         return fail(RANS_AMD_E_UNSUPPORTED, "encode: chunk_syms too large (a chunk's stream must stay below 4 GiB)");
+    if (slots && (nchunks > (~0ull) / slot || out_cap < nchunks * slot)) // (known up front: nothing is launched)
+        return fail(RANS_AMD_E_SPACE, "encode_slots: out_cap is below rans_amd_encode_slots_bound()");
     int rc = RANS_AMD_OK;
     HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
 
@@ -697,17 +704,33 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     // tested, and on config 2 no faster than k_layout + k_compact_small behind them (lanes.hip says why), hence opt-in
     const bool lanes_fused_env = (ctx->variant & kVarLanesFused) != 0;
     const int fits = lanes ? 0 : encode_fused_fits(enc_format, model->host.nsyms, model->host.scale_bits);
-    const bool fused = nchunks > 0 && nchunks < (1ull << 31) && !unfused_env &&
+    const bool fused = !slots && nchunks > 0 && nchunks < (1ull << 31) && !unfused_env &&
                        (lanes ? lanes_fused_env && encode_lanes_can_fuse(enc_format, ep, ctx->num_cus) : fits != 0);
     // Scratch: one worst-case slot per chunk, or -- context option RANS_AMD_OPT_ENC_SCRATCH_RING, fused wave encoders
     // only -- a small ring of slots per coding wave (kernels.h kEncRingSlots): half the workspace for a 1 GiB shard, and
     // measured 2-4 % slower, hence opt-in.
     const uint64_t ring_waves = (uint64_t)ctx->num_cus * kEncRingMaxWavesPerCu;
     const bool ring = fused && !lanes && fits == 1 && ctx->scratch_ring && slot <= kEncRingMaxSlotBytes && nchunks > ring_waves * kEncRingSlots;
-    rc = ctx->scratch.reserve((size_t)((ring ? ring_waves * kEncRingSlots : nchunks) * slot + 64) + ctx->scratch_shift);
-    if (rc)
-        return rc;
-    ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr) + ctx->scratch_shift;
+    if (slots) { // the caller's container is where the chunks are coded: no scratch at all
+        ep.scratch = static_cast<uint8_t *>(d_out);
+        ep.slot_layout = 1u;
+        ep.offsets = d_offsets;
+        if (!lanes && nchunks > 0 && nchunks < (1ull << 32)) { // wave encoders hand their chunks out dynamically
+            const size_t claim_bytes = (size_t)kWorkPools * kWorkPoolStride * 4;
+            rc = ctx->enc_status.reserve(claim_bytes);
+            if (rc)
+                return rc;
+            HIP_TRY(hipMemsetAsync(ctx->enc_status.ptr, 0, claim_bytes, s));
+            ep.claims = static_cast<unsigned int *>(ctx->enc_status.ptr);
+        }
+        if (nchunks == 0)
+            HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, s));
+    } else {
+        rc = ctx->scratch.reserve((size_t)((ring ? ring_waves * kEncRingSlots : nchunks) * slot + 64) + ctx->scratch_shift);
+        if (rc)
+            return rc;
+        ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr) + ctx->scratch_shift;
+    }
     ep.ring_slots = ring ? kEncRingSlots : 0u;
     if (fused) {
         // (wave encoders: a word per chunk; lane encoders: a word per round of a block, at most one per batch of 64
@@ -753,14 +776,16 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         }
         if (fused) {
             ep.status = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(ctx->enc_status.ptr) + ctx->status_shift);
+            ep.claims = reinterpret_cast<unsigned int *>(ep.status + nchunks); // (wave encoders; the lane encoders' scanners count behind their own status words)
             ep.offsets = d_offsets;
             ep.out = static_cast<uint8_t *>(d_out);
             ep.out_cap = out_cap;
         }
         HIP_TRY(launch_encode(enc_format, ep, ctx->num_cus, s, &ctx->last_enc_kernel));
         ctx->last_enc_fused = fused;
+        ctx->last_enc_slots = slots;
     }
-    if (!fused) {
+    if (!fused && !slots) {
         LayoutParams lp;
         lp.lengths = d_lengths;
         lp.offsets = d_offsets;
@@ -776,7 +801,8 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         }
         HIP_TRY(launch_layout(lp, s));
         if (nchunks) {
-            CompactParams cp;
+            CompactParams cp{};
+            cp.src_limit = ~0ull;
             cp.scratch = ep.scratch;
             cp.slot_bytes = slot;
             cp.lengths = d_lengths;
@@ -797,6 +823,89 @@ int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         uint64_t total = 0;
         HIP_TRY(hipMemcpyAsync(&flags, ctx->d_enc_flags(), 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(&total, d_offsets + nchunks, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *h_total_bytes = total;
+        return encode_flags_status(flags);
+    }
+    return RANS_AMD_OK;
+}
+
+extern "C" {
+
+int rans_amd_encode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,
+                    uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
+                    uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream)
+{
+    return encode_impl(ctx, model, d_syms, n, n_ways, chunk_syms, d_out, out_cap, d_offsets, d_lengths, h_total_bytes, stream, false);
+}
+
+int rans_amd_encode_slots(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,
+                          uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
+                          uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream)
+{
+    return encode_impl(ctx, model, d_syms, n, n_ways, chunk_syms, d_out, out_cap, d_offsets, d_lengths, h_total_bytes, stream, true);
+}
+
+uint64_t rans_amd_slot_bytes(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
+{
+    return chunk_syms ? encode_slot_bytes(format, n, n_ways, chunk_syms) : 0;
+}
+
+uint64_t rans_amd_encode_slots_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
+{
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    return nchunks ? nchunks * encode_slot_bytes(format, n, n_ways, chunk_syms) : 16;
+}
+
+int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t src_bytes, const uint64_t *d_src_offsets,
+                               const uint32_t *d_lengths, uint64_t n_chunks, void *d_dst, uint64_t dst_cap,
+                               uint64_t *d_dst_offsets, uint64_t *h_total_bytes, void *stream)
+{
+    if (!ctx || !d_dst || !d_dst_offsets || (n_chunks && (!d_src || !d_src_offsets || !d_lengths)))
+        return fail(RANS_AMD_E_ARG, "container_compact: NULL argument");
+    if (((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst)) & 15u) != 0)
+        return fail(RANS_AMD_E_ARG, "container_compact: d_src and d_dst must be 16-byte aligned");
+    if (d_src == d_dst)
+        return fail(RANS_AMD_E_ARG, "container_compact: the copy is not in place (d_dst must be another buffer)");
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const CaptureScope capture(s);
+    if (capture.active && h_total_bytes)
+        return fail(RANS_AMD_E_ARG, "container_compact: h_total_bytes must be NULL while the stream is capturing");
+    HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
+    LayoutParams lp;
+    lp.lengths = d_lengths;
+    lp.offsets = d_dst_offsets;
+    lp.nchunks = n_chunks;
+    lp.out_cap = dst_cap;
+    lp.flags = ctx->d_enc_flags();
+    lp.block_sums = nullptr;
+    if (layout_blocks(n_chunks) > 1) {
+        int rc = ctx->layout_sums.reserve((size_t)layout_blocks(n_chunks) * 8);
+        if (rc)
+            return rc;
+        lp.block_sums = static_cast<uint64_t *>(ctx->layout_sums.ptr);
+    }
+    HIP_TRY(launch_layout(lp, s));
+    if (n_chunks) {
+        CompactParams cp{};
+        cp.scratch = static_cast<const uint8_t *>(d_src);
+        cp.src_offsets = d_src_offsets;
+        cp.src_limit = (reinterpret_cast<uint64_t>(d_src) + src_bytes + 15u) & ~uint64_t(15);
+        cp.slot_bytes = n_chunks >= 4096 ? 4096 : 1u << 20; // (many chunks: most likely small ones -- 16 lanes per chunk)
+        cp.lengths = d_lengths;
+        cp.offsets = d_dst_offsets;
+        cp.out = static_cast<uint8_t *>(d_dst);
+        cp.nchunks = n_chunks;
+        cp.flags = ctx->d_enc_flags();
+        HIP_TRY(launch_compact(cp, ctx->num_cus, s));
+    }
+    if (h_total_bytes) {
+        uint32_t flags = 0;
+        uint64_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&flags, ctx->d_enc_flags(), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&total, d_dst_offsets + n_chunks, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         *h_total_bytes = total;
         return encode_flags_status(flags);
@@ -1079,6 +1188,7 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         ep.chunk_freqs = d_chunk_freqs;
         HIP_TRY(launch_encode(kKernelFormatByteAdaptive, ep, ctx->num_cus, s, &ctx->last_enc_kernel));
         ctx->last_enc_fused = false;
+        ctx->last_enc_slots = false;
     }
     LayoutParams lp;
     lp.lengths = d_lengths;
@@ -1095,7 +1205,8 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
     }
     HIP_TRY(launch_layout(lp, s));
     if (nchunks) {
-        CompactParams cp;
+        CompactParams cp{};
+        cp.src_limit = ~0ull;
         cp.scratch = static_cast<const uint8_t *>(ctx->scratch.ptr);
         cp.slot_bytes = slot;
         cp.lengths = d_lengths;
@@ -1337,7 +1448,7 @@ const char *rans_amd_last_decode_kernel(rans_amd_ctx *ctx) { return ctx ? ctx->l
 const char *rans_amd_last_encode_kernel(rans_amd_ctx *ctx, int *fused_placement)
 {
     if (fused_placement)
-        *fused_placement = ctx && ctx->last_enc_fused ? 1 : 0;
+        *fused_placement = ctx && ctx->last_enc_slots ? 2 : (ctx && ctx->last_enc_fused ? 1 : 0);
     return ctx ? ctx->last_enc_kernel : "";
 }
 

@@ -125,14 +125,17 @@ __global__ void __launch_bounds__(256) k_compact(const CompactParams p)
     for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave; chunk_v < p.nchunks; chunk_v += total_waves) {
         const uint64_t chunk = uniform64(chunk_v);
         const uint32_t len = uniform(p.lengths[chunk]);
-        const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + (chunk + 1) * p.slot_bytes - len;
+        const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) +
+                            (p.src_offsets ? uniform64(p.src_offsets[chunk]) : (chunk + 1) * p.slot_bytes - len);
         gvec_cptr src = reinterpret_cast<gvec_cptr>(sa & ~uint64_t(15));
         u32x4 RANS_GLOBAL *dst = reinterpret_cast<u32x4 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + p.offsets[chunk]);
         const uint32_t dsh = uniform((uint32_t)(sa & 15u) >> 2), bsh = uniform((uint32_t)(sa & 3u));
         const uint32_t n16 = (len + 15u) >> 4;
         for (uint32_t i = lane; i < n16; i += 64u) {
             const u32x4 a = __builtin_nontemporal_load(src + i);
-            const u32x4 b = __builtin_nontemporal_load(src + i + 1);
+            u32x4 b = {0u, 0u, 0u, 0u}; // (the granule behind the source's last one is not there to be read)
+            if (reinterpret_cast<uint64_t>(src + i + 1) < p.src_limit)
+                b = __builtin_nontemporal_load(src + i + 1);
             u32x4 r;
             switch (dsh) { // wave-uniform
             case 0: r = funnel16<0>(a, b, bsh); break;
@@ -152,6 +155,20 @@ __global__ void __launch_bounds__(256) k_compact(const CompactParams p)
 // chunks -- with every group of 16 lanes fetching its own chunk's pair they were a third of the kernel's
 // vector-memory instructions, and the address path is what bounds it: TA 84 % busy), the groups pick
 // theirs up by ds_bpermute.
+// 16 bytes from any address; what lies at or beyond `limit` reads as zero (the last piece of the last chunk of a
+// caller's buffer: the encoders' scratch has slack and passes no limit)
+__device__ __forceinline__ u32x4 load16_below(uint64_t a, uint64_t limit)
+{
+    if (a + 16u <= limit || a + 16u < a)
+        return *reinterpret_cast<gvec_cptr>(a);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+        if (a + (uint32_t)b < limit)
+            w[b >> 2] |= (uint32_t) * reinterpret_cast<const uint8_t RANS_GLOBAL *>(a + (uint32_t)b) << (8 * (b & 3));
+    return u32x4{w[0], w[1], w[2], w[3]};
+}
+
 __global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
 {
     if (*p.flags & 2u)
@@ -163,10 +180,11 @@ __global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
     for (uint64_t c0 = wave * 64u; c0 < p.nchunks; c0 += waves * 64u) {
         const uint64_t mine = c0 + lane;
         uint32_t len = 0;
-        uint64_t off = 0;
+        uint64_t off = 0, from = 0;
         if (mine < p.nchunks) {
             len = p.lengths[mine];
             off = p.offsets[mine];
+            from = p.src_offsets ? p.src_offsets[mine] : (mine + 1u) * p.slot_bytes - len;
         }
         // four chunks per group at a time, two pieces of each in flight (512 bytes of a chunk per pass): a wave's trip is
         // a chain of memory round trips, and with a load -> store pair per piece (the compiler may not move a load above
@@ -180,7 +198,8 @@ __global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
                 const uint32_t l = (uint32_t)__shfl((int)len, src, 64);
                 const uint64_t o = (uint64_t)(uint32_t)__shfl((int)(uint32_t)off, src, 64) |
                                    ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off >> 32), src, 64) << 32);
-                sa[q] = reinterpret_cast<uint64_t>(p.scratch) + (c0 + (uint32_t)src + 1u) * p.slot_bytes - l;
+                sa[q] = reinterpret_cast<uint64_t>(p.scratch) + ((uint64_t)(uint32_t)__shfl((int)(uint32_t)from, src, 64) |
+                                                                  ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(from >> 32), src, 64) << 32));
                 da[q] = reinterpret_cast<uint64_t>(p.out) + o;
                 n16[q] = (l + 15u) >> 4; // (0 behind the last chunk)
                 most = n16[q] > most ? n16[q] : most;
@@ -199,7 +218,7 @@ __global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
                     for (int h = 0; h < 2; ++h) {
                         const uint32_t i = i0 + 16u * h + sub;
                         if (i < n16[q])
-                            v[q][h] = *reinterpret_cast<gvec_cptr>(sa[q] + 16ull * i);
+                            v[q][h] = load16_below(sa[q] + 16ull * i, p.src_limit);
                     }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)

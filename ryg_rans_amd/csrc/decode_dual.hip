@@ -98,9 +98,11 @@ __device__ __forceinline__ void decode_single(const DecParams &p, const DecTable
     const uint64_t src = cbase + off;
     uint32_t x = *(reinterpret_cast<const uint32_t RANS_GLOBAL *>(src) + lane); // RansDecInit order: lane 0's state first
     StreamWindow W;
-    const uint64_t room = ((p.container_bytes + 15u) & ~uint64_t(15)) - off;
-    const uint32_t climit = (len + 15u) & ~15u;
-    W.open(ring, src, N * Tr::kStateBytes, climit < room ? climit : (uint32_t)room, lane);
+    // (a chunk may start at any byte: the window fetches whole granules from the one that holds its first byte, see k_decode)
+    const uint32_t skip = (uint32_t)off & 15u;
+    const uint64_t room = ((p.container_bytes + 15u) & ~uint64_t(15)) - (off - skip);
+    const uint32_t climit = (skip + len + 15u) & ~15u;
+    W.open(ring, src - skip, skip + N * Tr::kStateBytes, climit < room ? climit : (uint32_t)room, lane);
     const uint32_t rounds = uniform(nsym / N);
     const uint32_t tail = uniform(nsym - rounds * N);
     rounds_done += rounds;
@@ -121,7 +123,7 @@ __device__ __forceinline__ void decode_single(const DecParams &p, const DecTable
         W.checkpoint(lane);
         W.consume(dec_renorm<FMT>(W, x, lane < cnt));
     }
-    const bool all_good = __builtin_amdgcn_ballot_w64(x != Tr::kL) == 0 && W.position() == len;
+    const bool all_good = __builtin_amdgcn_ballot_w64(x != Tr::kL) == 0 && W.position() == skip + len;
     if (!all_good && lane == 0)
         atomicAdd(p.err_count, 1ull);
 }
@@ -209,9 +211,9 @@ __global__ void __launch_bounds__(kDecBlockThreads, 4) k_decode_dual(const DecPa
         const uint64_t off_b = has_b ? uniform64(p.offsets[cb]) : 0ull;
         const uint32_t len_b = has_b ? uniform(p.lengths[cb]) : 0u;
         // off and len come from the caller's index: compare without forming off + len (which can wrap)
-        const bool ok_a = ((off_a & 15u) == 0) && (len_a >= N * Tr::kStateBytes) && (off_a <= p.container_bytes) &&
+        const bool ok_a = (len_a >= N * Tr::kStateBytes) && (off_a <= p.container_bytes) &&
                           (len_a <= p.container_bytes - off_a);
-        const bool ok_b = has_b && ((off_b & 15u) == 0) && (len_b >= N * Tr::kStateBytes) && (off_b <= p.container_bytes) &&
+        const bool ok_b = has_b && (len_b >= N * Tr::kStateBytes) && (off_b <= p.container_bytes) &&
                           (len_b <= p.container_bytes - off_b);
         if ((!ok_a || (has_b && !ok_b)) && lane == 0)
             atomicAdd(p.err_count, (ok_a ? 0ull : 1ull) + ((has_b && !ok_b) ? 1ull : 0ull));
@@ -229,11 +231,13 @@ __global__ void __launch_bounds__(kDecBlockThreads, 4) k_decode_dual(const DecPa
         uint32_t xa = *(reinterpret_cast<const uint32_t RANS_GLOBAL *>(src_a) + lane); // RansDecInit order (main.cpp:261-262)
         uint32_t xb = *(reinterpret_cast<const uint32_t RANS_GLOBAL *>(src_b) + lane);
         StreamWindow Wa, Wb;
+        const uint32_t skip_a = (uint32_t)off_a & 15u, skip_b = (uint32_t)off_b & 15u;
         {
-            const uint64_t room_a = cbytes16 - off_a, room_b = cbytes16 - off_b;
-            const uint32_t cl_a = (len_a + 15u) & ~15u, cl_b = (len_b + 15u) & ~15u;
-            Wa.open(ring_a, src_a, N * Tr::kStateBytes, cl_a < room_a ? cl_a : (uint32_t)room_a, lane);
-            Wb.open(ring_b, src_b, N * Tr::kStateBytes, cl_b < room_b ? cl_b : (uint32_t)room_b, lane);
+            // (byte streams start anywhere: whole granules from the one that holds the chunk's first byte, see k_decode)
+            const uint64_t room_a = cbytes16 - (off_a - skip_a), room_b = cbytes16 - (off_b - skip_b);
+            const uint32_t cl_a = (skip_a + len_a + 15u) & ~15u, cl_b = (skip_b + len_b + 15u) & ~15u;
+            Wa.open(ring_a, src_a - skip_a, skip_a + N * Tr::kStateBytes, cl_a < room_a ? cl_a : (uint32_t)room_a, lane);
+            Wb.open(ring_b, src_b - skip_b, skip_b + N * Tr::kStateBytes, cl_b < room_b ? cl_b : (uint32_t)room_b, lane);
         }
         const uint32_t rounds = uniform(p.chunk_syms / N);
         rounds_done += 2u * rounds;
@@ -280,8 +284,8 @@ __global__ void __launch_bounds__(kDecBlockThreads, 4) k_decode_dual(const DecPa
             }
         }
         // ---- integrity: every state back at L, both cursors exactly at their chunk's end ----
-        const bool good_a = __builtin_amdgcn_ballot_w64(xa != Tr::kL) == 0 && Wa.position() == len_a;
-        const bool good_b = __builtin_amdgcn_ballot_w64(xb != Tr::kL) == 0 && Wb.position() == len_b;
+        const bool good_a = __builtin_amdgcn_ballot_w64(xa != Tr::kL) == 0 && Wa.position() == skip_a + len_a;
+        const bool good_b = __builtin_amdgcn_ballot_w64(xb != Tr::kL) == 0 && Wb.position() == skip_b + len_b;
         if ((!good_a || !good_b) && lane == 0)
             atomicAdd(p.err_count, (good_a ? 0ull : 1ull) + (good_b ? 0ull : 1ull));
     }

@@ -276,8 +276,11 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         uint8_t RANS_GLOBAL *dst = reinterpret_cast<uint8_t RANS_GLOBAL *>(
             reinterpret_cast<uint64_t>(p.out) + first * p.sym_bytes);
 
-        // off and len come from the caller's index: compare without forming off + len (which can wrap)
-        bool ok = ((off & 15u) == 0) && (len >= N * Tr::kStateBytes) && (off <= p.container_bytes) &&
+        // off and len come from the caller's index: compare without forming off + len (which can wrap).  A chunk may
+        // start at any multiple of the format's unit (compact containers start theirs on 16 bytes, the slot layout of
+        // rans_amd_encode_slots ENDS them there): the window fetches whole 16-byte granules from the one that holds the
+        // chunk's first byte, `skip` bytes into it.
+        bool ok = ((off & (Tr::kUnit - 1u)) == 0) && (len >= N * Tr::kStateBytes) && (off <= p.container_bytes) &&
                   (len <= p.container_bytes - off);
         if (!ok) { // wave-uniform
             if (lane == 0)
@@ -313,9 +316,10 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
         StreamWindow W;
         // fetch nothing beyond this chunk's own stream (rounded up to the 16-byte granule) nor beyond the
         // container's last granule
-        const uint64_t room = ((p.container_bytes + 15u) & ~uint64_t(15)) - off;
-        const uint32_t climit = (len + 15u) & ~15u;
-        W.open(ring, src, N * Tr::kStateBytes, climit < room ? climit : (uint32_t)room, lane);
+        const uint32_t skip = (uint32_t)off & 15u;
+        const uint64_t room = ((p.container_bytes + 15u) & ~uint64_t(15)) - (off - skip);
+        const uint32_t climit = (skip + len + 15u) & ~15u;
+        W.open(ring, src - skip, skip + N * Tr::kStateBytes, climit < room ? climit : (uint32_t)room, lane);
 
         const uint32_t rounds = uniform(nsym / N);
         rounds_done += rounds;
@@ -483,7 +487,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 #pragma unroll
         for (int k = 0; k < K; ++k)
             good = good && (x[k] == Tr::kL);
-        const bool all_good = __builtin_amdgcn_ballot_w64(!good) == 0 && W.position() == len;
+        const bool all_good = __builtin_amdgcn_ballot_w64(!good) == 0 && W.position() == skip + len;
         if (!all_good && lane == 0)
             atomicAdd(p.err_count, 1ull);
     }
@@ -519,15 +523,18 @@ constexpr uint32_t kClaimAhead = RANS_CLAIM_AHEAD, kDataAhead = RANS_DATA_AHEAD;
 
 // buffer descriptor of one 64-way word chunk's stream (StreamWindow::stream_rsrc): what may be fetched is the
 // chunk's length rounded up to the 16-byte granule, clipped to the container's last granule
+// (a chunk may start anywhere on a 2-byte boundary: the descriptor starts at the 16-byte granule that holds its first
+//  byte, `off & 15` bytes further down -- see k_decode)
 __device__ __forceinline__ rsrc_t chunk_rsrc(uint64_t cbase, uint64_t cbytes16, uint64_t off, uint32_t len)
 {
     // off and len are wave-uniform (scalar loads); saying so here keeps the descriptor in SGPRs whatever the
     // compiler concluded about the loop-carried copies (a descriptor in VGPRs turns every fetch into a waterfall loop)
     off = uniform64(off);
     len = uniform(len);
-    const uint64_t room = cbytes16 - off;
-    const uint32_t climit = (len + 15u) & ~15u;
-    return StreamWindow::stream_rsrc(cbase + off, 64u * 4u, climit < room ? climit : (uint32_t)room);
+    const uint32_t skip = (uint32_t)off & 15u;
+    const uint64_t room = cbytes16 - (off - skip);
+    const uint32_t climit = (skip + len + 15u) & ~15u;
+    return StreamWindow::stream_rsrc(cbase + (off - skip), skip + 64u * 4u, climit < room ? climit : (uint32_t)room);
 }
 
 __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const DecParams p)
@@ -620,7 +627,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
                          : "memory");                                                       \
             n_off = uniform64(n_off); /* (asm results count as divergent: say what they are) */ \
             n_len = uniform(n_len);                                                         \
-            n_ok = ((n_off & 15u) == 0) && (n_len >= N * Tr::kStateBytes) && (n_off <= p.container_bytes) && \
+            n_ok = ((n_off & 1u) == 0) && (n_len >= N * Tr::kStateBytes) && (n_off <= p.container_bytes) && \
                    (n_len <= p.container_bytes - n_off);                                    \
             if (n_ok) {                                                                     \
                 n_x = *(reinterpret_cast<const uint32_t RANS_GLOBAL *>(cbase + n_off) + lane); \
@@ -643,9 +650,10 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
         // (everything about the chunk is wave-uniform by construction; saying so keeps it, and the descriptors
         // built from it, in SGPRs whatever the compiler concluded about the loop-carried n_* copies)
         const uint64_t c_idx = uniform64(n_idx);
-        const uint32_t c_len = uniform(n_len);
+        const uint32_t c_skip = uniform((uint32_t)n_off & 15u);
+        const uint32_t c_len = uniform(n_len) + c_skip; // (where the cursor must end up, counted from the first granule)
         StreamWindow W;
-        W.install(ring, chunk_rsrc(cbase, cbytes16, n_off, n_len), N * Tr::kStateBytes, lane, n_b0, n_b1);
+        W.install(ring, chunk_rsrc(cbase, cbytes16, n_off, n_len), c_skip + N * Tr::kStateBytes, lane, n_b0, n_b1);
 #ifdef RANS_TOUCH_AHEAD
         {
             const uint64_t sa = cbase + uniform64(n_off) + N * Tr::kStateBytes;

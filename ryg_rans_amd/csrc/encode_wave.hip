@@ -556,13 +556,20 @@ __device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chun
 // with 2-4 and 8 states per lane -- at 64 VGPRs those spilled 20 to 785 registers (the 512-way rans64 encoder)
 constexpr int enc_fused_waves_per_simd(int K) { return K == 1 ? 8 : (K <= 4 ? 4 : 2); }
 
-template <int FMT, int K, bool FUSED>
-__global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (FUSED ? kEncFusedThreads : kEncBlockThreads),
-                                  (FUSED && FMT != FMT_ALIAS_LDS) ? enc_fused_waves_per_simd(K) : 1)
+// MODE 0: static chunk striding into scratch slots (k_layout + k_compact follow; or, with EncParams::slot_layout, nothing
+//         follows: the slots ARE the container).
+// MODE 1: fused placement -- dynamic chunk claims, the last wave(s) of a block copy the finished streams to their place.
+// MODE 2: slot layout -- dynamic chunk claims, every wave codes, a chunk stays in its slot (EncParams::slot_layout):
+//         what the reference does with each of its buffers (main.cpp:176-188), every stream byte written exactly once.
+template <int FMT, int K, int MODE>
+__global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (MODE != 0 ? kEncFusedThreads : kEncBlockThreads),
+                                  (MODE != 0 && FMT != FMT_ALIAS_LDS) ? enc_fused_waves_per_simd(K) : 1)
     k_encode(const EncParams p)
 {
     using Tr = FmtTraits<FMT>;
     using state_t = typename Tr::state_t;
+    constexpr bool FUSED = MODE == 1;
+    constexpr bool DYNAMIC = MODE != 0; // chunks are claimed from EncParams::claims
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     // word format: the 256 WordEncRec of the full-wave path come first (LDS address = sym << 4),
@@ -675,11 +682,11 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
 
     uint32_t coded = 0; // chunks this wave has coded (scratch ring: chunk number `coded` goes into slot coded % R)
     for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave;; chunk_v += total_waves) {
-        if constexpr (FUSED) {
+        if constexpr (DYNAMIC) {
             // scratch ring: the slot about to be reused must have been drained -- BEFORE the claim, so that a claimed chunk
             // is always in the hands of a running wave (the forward-progress argument above: the copier that drains this
             // wave's old chunk waits only for chunks smaller than ones its own block has claimed, and those are being coded)
-            if (p.ring_slots && coded >= p.ring_slots) {
+            if (FUSED && p.ring_slots && coded >= p.ring_slots) {
                 SpinWatch watch;
                 for (;;) {
                     uint32_t got_drained;
@@ -700,7 +707,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             const uint32_t pool = blockIdx.x % npools;
             uint32_t got = 0;
             if (lane == 0)
-                got = atomicAdd(reinterpret_cast<unsigned int *>(p.status + p.nchunks + 8u * pool), 1u);
+                got = atomicAdd(p.claims + kWorkPoolStride * pool, 1u);
             chunk_v = (uint64_t)uniform(got) * npools + pool;
         }
         if (chunk_v >= p.nchunks)
@@ -1010,6 +1017,11 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         const uint32_t len = (uint32_t)p.slot_bytes - wp;
         if (lane == 0)
             p.lengths[chunk] = len;
+        if (p.slot_layout && lane == 0) { // the slot is the chunk's place: the stream is [slot end - len, slot end)
+            p.offsets[chunk] = chunk * p.slot_bytes + wp;
+            if (chunk + 1 == p.nchunks)
+                p.offsets[p.nchunks] = p.nchunks * p.slot_bytes;
+        }
         if constexpr (FUSED) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // every lane's stream stores have reached L2
             if (lane == 0) {
@@ -1034,7 +1046,9 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
 template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num_cus, hipStream_t stream)
 {
     const bool fused = p.status != nullptr;
-    const uint32_t threads = FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (fused ? kEncFusedThreads : kEncBlockThreads);
+    const bool slots = !fused && p.slot_layout && p.claims; // MODE 2: dynamic claims, no copiers
+    const bool dynamic = fused || slots;
+    const uint32_t threads = FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (dynamic ? kEncFusedThreads : kEncBlockThreads);
     const uint32_t waves = threads / 64;
     const uint32_t enc_waves = fused ? waves - (waves >= 16 ? kEncFusedCopiers16 : 1) : waves;
     const size_t nrecs = p.nsyms < 256 ? 256 : p.nsyms;
@@ -1066,21 +1080,29 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     uint64_t per_cu = lds ? (160 * 1024) / lds : 8;
     per_cu = per_cu < 1 ? 1 : per_cu;
     per_cu = per_cu * waves > 32 ? 32 / waves : per_cu;
-    if (fused && FMT != FMT_ALIAS_LDS) { // ... and within the waves per SIMD the kernel's register budget was chosen for
+    if (dynamic && FMT != FMT_ALIAS_LDS) { // ... and within the waves per SIMD the kernel's register budget was chosen for
         const uint64_t fit = (uint64_t)enc_fused_waves_per_simd(K) * 4 / waves;
         per_cu = per_cu > fit ? (fit ? fit : 1) : per_cu;
     }
-    uint64_t cap = (uint64_t)num_cus * (FMT == FMT_ALIAS_LDS || fused ? per_cu : 8);
+    uint64_t cap = (uint64_t)num_cus * (FMT == FMT_ALIAS_LDS || dynamic ? per_cu : 8);
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
     if (fused) {
-        auto kern = k_encode<FMT, K, true>;
+        auto kern = k_encode<FMT, K, 1>;
         static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
         if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), (int)lds_cap, lds_ok); e != hipSuccess)
             return e;
         RANS_LAUNCH(kern, dim3(grid), dim3(threads), lds, stream, q);
         return hipGetLastError();
     }
-    auto kern = k_encode<FMT, K, false>;
+    if (slots) {
+        auto kern = k_encode<FMT, K, 2>;
+        static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
+        if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), (int)lds_cap, lds_ok); e != hipSuccess)
+            return e;
+        RANS_LAUNCH(kern, dim3(grid), dim3(threads), lds, stream, q);
+        return hipGetLastError();
+    }
+    auto kern = k_encode<FMT, K, 0>;
     static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), (int)lds_cap, lds_ok); e != hipSuccess)
         return e;

@@ -144,6 +144,13 @@ struct EncParams {
     uint32_t variant;           // kVar* bits
     uint32_t debug;             // RANS_AMD_MEASURE builds only (RANS_AMD_ENC_DEBUG): bit 0 = the lane encoders' fused placement skips the copy
                                 //   itself, bit 1 = ... does not wait for a batch's place (uses 0); output is wrong by construction
+    // Slot layout (rans_amd_encode_slots): the chunks STAY where they are coded -- `scratch` is the caller's container, chunk
+    // c's stream ends at the end of slot c exactly as the reference's encoder ends at the end of its buffer
+    // (rans_byte.h:22-26, main.cpp:176-188), and the coding kernel writes offsets[c] = c * slot_bytes + (slot_bytes - len)
+    // beside lengths[c]: every stream crosses HBM once, no look-back, no copier waves, no k_layout / k_compact.
+    uint32_t slot_layout;       // 1 = that; `offsets` is then set and `status` is NULL
+    unsigned int *claims;       // wave encoders with dynamic chunk hand-out (fused placement, slot layout): kWorkPools claim
+                                // counters on a 64-byte line each, zero at launch
 };
 #ifndef RANS_FUSED_THREADS
 #define RANS_FUSED_THREADS 512
@@ -184,6 +191,11 @@ struct LayoutParams {
 
 struct CompactParams {
     const uint8_t *scratch;
+    // where chunk c's stream starts in `scratch`: NULL = at the end of its slot ((c + 1) * slot_bytes - lengths[c], the
+    // encoders' scratch); else src_offsets[c] (rans_amd_container_compact: any layout the decoders take), and nothing at
+    // or beyond address src_limit (16-byte aligned end of the source buffer) is read
+    const uint64_t *src_offsets;
+    uint64_t src_limit; // ~0 = no limit (the encoders' scratch carries slack)
     uint64_t slot_bytes;
     const uint32_t *lengths;
     const uint64_t *offsets;

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
         const uint64_t first = chunk * p.chunk_syms;
         // region base: the line of the batch's first chunk (lane 0 always holds a chunk)
         const uint64_t rb = wave_min_offset(off, valid) & ~uint64_t(kLaneLine - 1);
-        if (valid && ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
+        if (valid && ((off & (Tr::kUnit - 1u)) != 0 || len < NW * Tr::kStateBytes || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
                       off - rb >= (1u << 30))) {
             nbad++;
             valid = false;
@@ -742,7 +742,7 @@ template <bool PACKED> __global__ void __launch_bounds__(1024) k_decode_lanes_r6
         const uint64_t off = valid ? p.offsets[chunk] : 0;
         const uint32_t len = valid ? p.lengths[chunk] : 0;
         const uint64_t rb = wave_min_offset(off, valid) & ~uint64_t(kLaneLine - 1);
-        if (valid && ((off & 15u) != 0 || len < 16u || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
+        if (valid && ((off & 3u) != 0 || len < 16u || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
                       off - rb >= (1u << 30))) {
             nbad++;
             valid = false;
@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(256) k_decode_lanes(const DecParams p)
         const uint32_t len = p.lengths[chunk];
         const uint64_t first = chunk * p.chunk_syms;
         const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
-        if ((off & 15u) != 0 || len < NW * Tr::kStateBytes || off > p.container_bytes || len > p.container_bytes - off) {
+        if ((off & (Tr::kUnit - 1u)) != 0 || len < NW * Tr::kStateBytes || off > p.container_bytes || len > p.container_bytes - off) {
             nbad++;
             continue;
         }
@@ -1047,6 +1047,16 @@ __device__ __forceinline__ void lane_put(typename FmtTraits<FMT>::state_t &x, ui
 // ---------------------------------------------------------------------------
 constexpr uint32_t kEncRowStride = 80; // 64 symbol bytes, rows 16-byte aligned, 20 dwords apart
 constexpr uint32_t kEncWaveLds = 64 * kEncRowStride + 64 * kLaneRingStride + 64 * 4;
+
+// slot layout (EncParams::slot_layout): the chunk stays in its slot, its stream is [slot end - len, slot end)
+__device__ __forceinline__ void lanes_publish_slot(const EncParams &p, uint64_t chunk, uint32_t len)
+{
+    if (p.slot_layout) {
+        p.offsets[chunk] = (chunk + 1u) * p.slot_bytes - len;
+        if (chunk + 1 == p.nchunks)
+            p.offsets[p.nchunks] = p.nchunks * p.slot_bytes;
+    }
+}
 
 template <int FMT> struct LaneOut {
     uint8_t *row;  // this lane's output ring in LDS
@@ -1557,6 +1567,7 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
                 }
             }
             p.lengths[chunk] = (uint32_t)p.slot_bytes - O.w;
+            lanes_publish_slot(p, chunk, (uint32_t)p.slot_bytes - O.w);
         }
         flush(true);
         flush(true);
@@ -1813,6 +1824,7 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
         const uint32_t in_ring = pending(); // <= 63 + 16
         const uint32_t len = (uint32_t)p.slot_bytes - (flushed * kLaneLine - in_ring);
         p.lengths[chunk0 + lane] = len;
+        lanes_publish_slot(p, chunk0 + lane, len);
         flush(in_ring > 0u); // the line(s) that hold anything; what lies below the stream start in the lowest one is never read
         flush(in_ring > 64u);
         if (fused)
@@ -1899,6 +1911,7 @@ __global__ void __launch_bounds__(256) k_encode_lanes16(const EncParams p)
             }
         }
         p.lengths[chunk] = (uint32_t)((slot + p.slot_bytes) - wp);
+        lanes_publish_slot(p, chunk, (uint32_t)((slot + p.slot_bytes) - wp));
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane_id() == 0)
         atomicOr(p.flags, 1u);

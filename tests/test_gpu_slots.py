@@ -1,0 +1,229 @@
+"""Slot layout (rans_amd_encode_slots), chunk offsets on any unit boundary, rans_amd_container_compact (-m gpu).
+
+The reference hands its encoder the END of a buffer and finds the stream at [ptr after the flush, buffer end)
+(rans_byte.h:22-26, main.cpp:176-188).  rans_amd_encode_slots does that once per chunk: chunk c's stream is the last
+lengths[c] bytes of slot c -- written once, never moved.  Checked here, against the CPU oracle:
+
+  * every chunk's bytes in its slot == the oracle's stream of that chunk, for every format and kernel family (wave
+    encoders of 64..512 lanes, lane encoders of 1..8, the 2-way rans64 kernel, u16 symbols, the 4096-symbol alias
+    model), offsets[c] == (c + 1) * slot - lengths[c];
+  * the slot container decodes as it is (its chunk starts are not 16-byte aligned) with every decoder family;
+  * rans_amd_container_compact of it == the oracle's compact container == rans_amd_encode's output, byte for byte;
+  * decoders take hand-made indexes whose chunks start on every residue modulo 16 (reference streams packed
+    back to back, in reverse order, with odd gaps).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from _oracle import FMT_ALIAS, FMT_BYTE, FMT_R64, FMT_WORD
+
+UNIT = {FMT_BYTE: 1, FMT_ALIAS: 1, FMT_WORD: 2, FMT_R64: 4}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    import ryg_rans_amd as R
+    ctx = R.Context(0)
+    yield R, ctx, torch
+    ctx.close()
+
+
+def _models(ctx, oracle, fmt, sb, data, nsyms=256):
+    f, _ = oracle.normalize(oracle.count_freqs(data, nsyms), 1 << sb)
+    return oracle.model(f, sb, with_alias=(fmt == FMT_ALIAS)), ctx.model(fmt, f, sb)
+
+
+def _dev(torch, data):
+    return torch.from_numpy(data.view(np.int16) if data.dtype == np.uint16 else data).cuda()
+
+
+def _check_slots(R, ctx, torch, oracle, fmt, om, gm, data, n_ways, chunk, want_kernel=None):
+    cont, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+    nchunks = len(lens)
+    d_syms = _dev(torch, data)
+    slot = R.slot_bytes(fmt, data.size, n_ways, chunk)
+    assert slot % 64 == 0 and slot >= R.chunk_bound(fmt, min(chunk, data.size), n_ways)
+    g_cont, g_offs, g_lens, total = ctx.encode_slots(gm, d_syms, n_ways, chunk)
+    assert total == nchunks * slot == R.encode_slots_bound(fmt, data.size, n_ways, chunk)
+    assert ctx.last_encode_placement() == 2
+    if want_kernel:
+        assert ctx.last_encode_kernel()[0] == want_kernel, ctx.last_encode_kernel()
+    go, gl = g_offs.cpu().numpy().astype(np.uint64), g_lens.cpu().numpy().astype(np.uint32)
+    assert np.array_equal(gl, lens)
+    assert np.array_equal(go[:-1], (np.arange(nchunks, dtype=np.uint64) + 1) * np.uint64(slot) - gl)
+    assert int(go[-1]) == nchunks * slot
+    g = g_cont.cpu().numpy()
+    for c in range(nchunks):
+        a, b = int(go[c]), int(go[c]) + int(gl[c])
+        assert b == (c + 1) * slot
+        assert np.array_equal(g[a:b], cont[int(offs[c]):int(offs[c]) + int(lens[c])]), "chunk %d differs from the oracle" % c
+    # the slot container decodes as it is
+    out = ctx.decode(gm, g_cont, total, g_offs, g_lens, data.size, n_ways, chunk)
+    assert torch.equal(out, d_syms)
+    # compaction == the oracle's container == rans_amd_encode's
+    d_dst, d_doffs, ctotal = ctx.compact(g_cont, total, g_offs, g_lens, nchunks)
+    assert ctotal == cont.size
+    assert np.array_equal(d_doffs.cpu().numpy().astype(np.uint64), offs)
+    c2 = d_dst.cpu().numpy()
+    for c in range(nchunks):
+        a, b = int(offs[c]), int(offs[c]) + int(lens[c])
+        assert np.array_equal(c2[a:b], cont[a:b]), "compacted chunk %d differs" % c
+    e_cont, e_offs, e_lens, etotal = ctx.encode(gm, d_syms, n_ways, chunk)
+    assert etotal == ctotal and torch.equal(e_offs, d_doffs)
+    return g_cont, g_offs, g_lens, total
+
+
+@pytest.mark.parametrize("fmt,sb", [(FMT_WORD, 12), (FMT_BYTE, 14), (FMT_BYTE, 16), (FMT_R64, 14), (FMT_ALIAS, 16), (FMT_ALIAS, 12)])
+@pytest.mark.parametrize("n_ways,chunk", [(64, 4096), (64, 5000), (256, 16384), (128, 4096), (512, 8192), (33, 1000),
+                                          (2, 512), (1, 1000), (4, 2048), (8, 4096), (2, 4095)])
+def test_slot_layout_every_chunk_matches_oracle(gpu, oracle, fmt, sb, n_ways, chunk):
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(300000, K=256, s=1.0, seed=1)
+    om, gm = _models(ctx, oracle, fmt, sb, data)
+    _check_slots(R, ctx, torch, oracle, fmt, om, gm, data, n_ways, chunk)
+
+
+def test_slot_layout_kernels_of_the_bench_configs(gpu, oracle):
+    """The four shapes bench.py times, small: which coding kernel ran, and that no placement kernel did."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(64 * 16384 + 777, K=256, s=1.0, seed=1)
+    om, gm = _models(ctx, oracle, FMT_WORD, 12, data)
+    _check_slots(R, ctx, torch, oracle, FMT_WORD, om, gm, data, 64, 16384, "k_encode<word>")
+    om, gm = _models(ctx, oracle, FMT_BYTE, 14, data)
+    _check_slots(R, ctx, torch, oracle, FMT_BYTE, om, gm, data, 64, 16384, "k_encode<byte>")
+    d2 = oracle.gen_zipf(512 * 64 * 300 + 100, K=256, s=1.0, seed=2)  # >= one batch of 64 chunks per CU + a ragged tail
+    om, gm = _models(ctx, oracle, FMT_R64, 14, d2)
+    _check_slots(R, ctx, torch, oracle, FMT_R64, om, gm, d2, 2, 512, "k_encode_lanes_r64x2")
+    d4 = oracle.gen_zipf(24 * 16384 + 5, K=4096, s=1.0, seed=1)
+    om, gm = _models(ctx, oracle, FMT_ALIAS, 16, d4, nsyms=4096)
+    _check_slots(R, ctx, torch, oracle, FMT_ALIAS, om, gm, d4, 64, 16384, "k_encode<alias, LDS remap>")
+
+
+def test_slot_layout_word_u16_symbols_and_lane_generations(gpu, oracle):
+    R, ctx, torch = gpu
+    d16 = oracle.gen_zipf(150001, K=1000, s=1.0, seed=5)
+    f, _ = oracle.normalize(oracle.count_freqs(d16, 1024), 4096)
+    om, gm = oracle.model(f, 12), ctx.model(FMT_WORD, f, 12)
+    _check_slots(R, ctx, torch, oracle, FMT_WORD, om, gm, d16, 64, 8192)
+    data = oracle.gen_zipf(200000, K=256, s=1.0, seed=9)
+    for opt in (1, 2, 0):  # staged generation, per-lane register windows, automatic
+        ctx.set_option(R.OPT_LANE_KERNELS, opt)
+        try:
+            for fmt, sb in ((FMT_BYTE, 14), (FMT_WORD, 12), (FMT_R64, 14)):
+                om, gm = _models(ctx, oracle, fmt, sb, data)
+                _check_slots(R, ctx, torch, oracle, fmt, om, gm, data, 2, 512)
+        finally:
+            ctx.set_option(R.OPT_LANE_KERNELS, 0)
+
+
+def test_slot_layout_capacity_is_checked_up_front(gpu, oracle):
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(100000, K=256, s=1.0, seed=1)
+    om, gm = _models(ctx, oracle, FMT_WORD, 12, data)
+    need = R.encode_slots_bound(FMT_WORD, data.size, 64, 4096)
+    small = torch.empty(need - 16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.encode_slots(gm, _dev(torch, data), 64, 4096, d_out=small)
+    assert e.value.status == R.E_SPACE
+    # an empty input: no chunks, offsets[0] = 0
+    empty = torch.empty(0, dtype=torch.uint8, device="cuda")
+    _, offs, _, total = ctx.encode_slots(gm, empty, 64, 4096)
+    assert total == 0 and int(offs[0]) == 0
+
+
+@pytest.mark.parametrize("fmt,sb,n_ways,chunk", [(FMT_WORD, 12, 64, 4096), (FMT_WORD, 12, 128, 4096), (FMT_BYTE, 14, 64, 4096),
+                                                 (FMT_BYTE, 14, 33, 1000), (FMT_R64, 14, 64, 4096), (FMT_ALIAS, 16, 64, 4096),
+                                                 (FMT_R64, 14, 2, 512), (FMT_WORD, 12, 2, 512), (FMT_BYTE, 14, 4, 1024),
+                                                 (FMT_R64, 14, 1, 1000), (FMT_ALIAS, 12, 8, 2048)])
+def test_decoders_take_chunks_on_every_unit_boundary(gpu, oracle, fmt, sb, n_ways, chunk):
+    """Reference streams packed back to back (no padding), in reverse order, and with a sliding gap: chunk starts hit
+    every residue modulo 16 the format's unit allows.  Every decoder family (option sweeps as well)."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(300000, K=256, s=1.0, seed=4)
+    om, gm = _models(ctx, oracle, fmt, sb, data)
+    cont, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+    nchunks, unit = len(lens), UNIT[fmt]
+    streams = [cont[int(offs[c]):int(offs[c]) + int(lens[c])] for c in range(nchunks)]
+    layouts = []
+    # 1. back to back
+    o = np.concatenate([[0], np.cumsum(lens.astype(np.uint64))])[:-1]
+    layouts.append(("packed", o))
+    # 2. reverse order, packed
+    r = np.zeros(nchunks, dtype=np.uint64)
+    at = 0
+    for c in range(nchunks - 1, -1, -1):
+        r[c] = at
+        at += int(lens[c])
+    layouts.append(("reversed", r))
+    # 3. a gap of (c mod 16) units in front of chunk c
+    g = np.zeros(nchunks, dtype=np.uint64)
+    at = 0
+    for c in range(nchunks):
+        at += unit * (c % 16)
+        g[c] = at
+        at += int(lens[c])
+    layouts.append(("gaps", g))
+    seen = set()
+    for name, lo in layouts:
+        size = int(max(int(lo[c]) + int(lens[c]) for c in range(nchunks)))
+        buf = np.full(size + 64, 0xA5, dtype=np.uint8)
+        for c in range(nchunks):
+            buf[int(lo[c]):int(lo[c]) + int(lens[c])] = streams[c]
+        seen |= {int(v) % 16 for v in lo}
+        d_cont = torch.from_numpy(buf).cuda()
+        d_offs = torch.from_numpy(lo.astype(np.int64)).cuda()
+        d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+        sweeps = [(None, None)]
+        if n_ways <= 8:
+            sweeps = [(R.OPT_LANE_KERNELS, v) for v in (0, 1, 2)]
+        elif fmt == FMT_ALIAS:
+            sweeps = [(R.OPT_DUAL_DECODE, v) for v in (1, 0, 2)]
+        for opt, val in sweeps:
+            if opt is not None:
+                ctx.set_option(opt, val)
+            try:
+                out = ctx.decode(gm, d_cont, size, d_offs, d_lens, data.size, n_ways, chunk)
+                assert np.array_equal(out.cpu().numpy(), data), (name, opt, val, ctx.last_decode_kernel())
+            finally:
+                if opt is not None:
+                    ctx.set_option(opt, 1 if opt == R.OPT_DUAL_DECODE else 0)
+        # an offset off the unit grid is refused chunk by chunk, never read
+        if unit > 1:
+            bad = lo.copy()
+            bad[1] += 1
+            with pytest.raises(R.RansAmdError) as e:
+                ctx.decode(gm, d_cont, size, torch.from_numpy(bad.astype(np.int64)).cuda(), d_lens, data.size, n_ways, chunk)
+            assert e.value.status == R.E_CORRUPT
+    assert len(seen) >= 16 // unit - 1, seen
+
+
+def test_compact_a_chunk_range_and_a_reordered_index(gpu, oracle):
+    """rans_amd_container_compact takes any source index: a sub-range of a container, chunks in another order."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(200000, K=256, s=1.0, seed=6)
+    om, gm = _models(ctx, oracle, FMT_WORD, 12, data)
+    chunk, n_ways = 4096, 64
+    cont, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, n_ways, chunk, align=16)
+    nchunks = len(lens)
+    d_cont = torch.from_numpy(np.concatenate([cont, np.zeros(16, np.uint8)])).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+    lo, hi = 5, nchunks - 3
+    d_dst, d_doffs, total = ctx.compact(d_cont, cont.size, d_offs[lo:], d_lens[lo:], hi - lo)
+    want_offs = R.offsets_from_lengths(lens[lo:hi])
+    assert np.array_equal(d_doffs.cpu().numpy().astype(np.uint64), want_offs) and total == int(want_offs[-1])
+    got = d_dst.cpu().numpy()
+    for c in range(lo, hi):
+        a = int(want_offs[c - lo])
+        assert np.array_equal(got[a:a + int(lens[c])], cont[int(offs[c]):int(offs[c]) + int(lens[c])])
+    out = ctx.decode(gm, d_dst, total, d_doffs, d_lens[lo:], (hi - lo) * chunk, n_ways, chunk)
+    assert np.array_equal(out.cpu().numpy(), data[lo * chunk:hi * chunk])
+    # too small a destination is reported, nothing is copied
+    tiny = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.compact(d_cont, cont.size, d_offs, d_lens, nchunks, d_dst=tiny)
+    assert e.value.status == R.E_SPACE and int(tiny.sum()) == 0
