@@ -3,8 +3,9 @@
 synthetic order-0 byte streams, one 1 GiB shard per GPU (BASELINE.json configs[2] / [4]), 16 Ki-symbol chunks.
 
   python bench.py                                  # 1 GPU
+  python bench.py --gpus N --steps K --warmup W    # N GPUs of this node: spawns its own N ranks (torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W     # ... or is launched as N ranks by somebody else
 
 A "step" = one pass of the decode hot path over the whole shard (device-resident
 container -> device-resident symbols).  Per rank: generate Zipf(256, s=1) bytes on
@@ -20,9 +21,11 @@ launch / its average duration measured with HIP events on the launch stream, vs 
 8 TB/s HBM peak.  `clocks` = shader clock and per-wave clocks per 64-symbol round measured
 by the kernel itself in one extra instrumented launch.  `configs` (N=1 only) = the other
 BASELINE configurations and the encoders, each timed over back-to-back launches in this same
-run.  `cpu_baseline` (N=1 only) = the reference's own fastest decoder (SSE4.1 8-way,
+run: decode, encode into the slot layout (rans_amd_encode_slots: every stream written once) and
+into the compact layout, each with the reference's own CPU loop of that format timed on this
+box beside it.  `cpu_baseline` (N=1 only) = the reference's own fastest decoder (SSE4.1 8-way,
 oracle/_ref) on this box's host cores over a bounded sample of the same data; the same CPU
-leg re-encodes sampled chunks of every container with the oracle and compares the bytes.
+leg re-encodes EVERY chunk of every container with the oracle and compares the bytes.
 """
 import argparse
 import hashlib
@@ -169,6 +172,22 @@ def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, st
     enc_kernels = enc_kernel + (" (places its chunks itself)" if enc_fused else " + k_layout + k_compact*")
     # (bytes between chunks are alignment padding nobody writes: compare index and sizes, not the raw buffers)
     same_container = bool(torch.equal(offs2, offs)) and bool(torch.equal(lens2, lens))
+    del cont2
+    # slot layout (rans_amd_encode_slots): every chunk written once, where it was coded -- what the reference does with
+    # each of its buffers (main.cpp:176-188).  Encoder timed, the slot container decoded as it is (timed as well: its
+    # chunk starts are not 16-byte aligned and it is 2.6 x as large), and every chunk of it goes to the oracle check.
+    s_cont, s_offs, s_lens, s_total = ctx.encode_slots(model, d_syms, ways, chunk)
+    slot = R.slot_bytes(fmt, n, ways, chunk)
+    s_enc_ms, s_enc_min = timed_launches(
+        torch, lambda: ctx.encode_slots(model, d_syms, ways, chunk, d_out=s_cont, sync=False, d_offsets=s_offs, d_lengths=s_lens),
+        steps, 2)
+    ctx.encode_status()
+    s_kernel = ctx.last_encode_kernel()[0]
+    slots_ok = ctx.last_encode_placement() == 2 and bool(torch.equal(s_lens, lens))
+    out.zero_()
+    s_dec_ms, s_dec_min = timed_launches(
+        torch, lambda: ctx.decode(model, s_cont, s_total, s_offs, s_lens, n, ways, chunk, d_out=out, sync=False), steps, 2)
+    slots_ok = slots_ok and ctx.decode_errors() == 0 and bool(torch.equal(out, d_syms))
     alg = n * sym_bytes + total
     entry = {
         "name": name, "format": R.FORMAT_NAMES[fmt], "scale_bits": sb, "alphabet": K, "n_ways": ways, "chunk_syms": chunk,
@@ -177,13 +196,25 @@ def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, st
         "decode": {"kernel": kernel, "ms_mean": round(dec_ms, 4), "ms_min": round(dec_min, 4), "launches": steps,
                    "decoded_GBps": round(n * sym_bytes / dec_ms / 1e6, 1),
                    "achieved_GBps": round(alg / dec_ms / 1e6, 1), "frac": round(alg / dec_ms / 1e6 / HBM_PEAK_GBPS, 4)},
-        "encode": {"kernels": enc_kernels, "ms_mean": round(enc_ms, 4), "ms_min": round(enc_min, 4),
-                   "launches": steps, "input_GBps": round(n * sym_bytes / enc_ms / 1e6, 1),
-                   "achieved_GBps": round(alg / enc_ms / 1e6, 1), "frac": round(alg / enc_ms / 1e6 / HBM_PEAK_GBPS, 4)},
-        "bit_exact_roundtrip": exact and same_container,
+        # `encode`: the slot layout -- one write per stream, as the reference writes its buffers; `encode_compact`: the
+        # compact container of rans_amd_encode (chunk c at the sum of the aligned lengths before it: the coder's stream goes
+        # through scratch and is moved once more)
+        "encode": {"layout": "slots (rans_amd_encode_slots: chunk c = the last lengths[c] bytes of slot c, written once)",
+                   "kernels": s_kernel + " (nothing to place: no scratch, no copier waves, no layout / compaction kernel)",
+                   "ms_mean": round(s_enc_ms, 4), "ms_min": round(s_enc_min, 4), "launches": steps,
+                   "input_GBps": round(n * sym_bytes / s_enc_ms / 1e6, 1), "achieved_GBps": round(alg / s_enc_ms / 1e6, 1),
+                   "frac": round(alg / s_enc_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                   "slot_bytes": slot, "container_bytes": s_total},
+        "encode_compact": {"layout": "compact (rans_amd_encode)", "kernels": enc_kernels, "ms_mean": round(enc_ms, 4),
+                           "ms_min": round(enc_min, 4), "launches": steps, "input_GBps": round(n * sym_bytes / enc_ms / 1e6, 1),
+                           "achieved_GBps": round(alg / enc_ms / 1e6, 1), "frac": round(alg / enc_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+        "decode_slots": {"kernel": ctx.last_decode_kernel(), "ms_mean": round(s_dec_ms, 4), "ms_min": round(s_dec_min, 4),
+                         "launches": steps, "frac": round(alg / s_dec_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+        "bit_exact_roundtrip": exact and same_container and slots_ok,
     }
     art = {"fmt": fmt, "sb": sb, "K": K, "ways": ways, "chunk": chunk, "n": n, "freqs": freqs, "d_syms": d_syms,
-           "cont": cont, "offs": offs, "lens": lens, "total": total, "entry": entry}
+           "cont": cont, "offs": offs, "lens": lens, "total": total, "entry": entry,
+           "slots": {"cont": s_cont, "offs": s_offs, "lens": s_lens, "total": s_total, "slot": slot}}
     return entry, art
 
 
@@ -204,11 +235,18 @@ def oracle_check_chunks(art, sample=0):
     lens = lens32.astype(np.uint64)
     offs = art["offs"].cpu().numpy().astype(np.uint64)
     nchunks = (n + chunk - 1) // chunk
-    aligned = (lens + np.uint64(15)) & ~np.uint64(15)
-    want_offs = np.zeros(nchunks + 1, dtype=np.uint64)
-    want_offs[1:] = np.cumsum(aligned[:nchunks])
-    want_offs[nchunks] = want_offs[nchunks - 1] + lens[nchunks - 1]
-    assert np.array_equal(offs, want_offs), "chunk index differs from the prefix sums of its lengths"
+    if art.get("slot"):  # slot layout (rans_amd_encode_slots): chunk c is the last lens[c] bytes of slot c
+        slot = np.uint64(art["slot"])
+        want_offs = np.zeros(nchunks + 1, dtype=np.uint64)
+        want_offs[:nchunks] = (np.arange(nchunks, dtype=np.uint64) + np.uint64(1)) * slot - lens[:nchunks]
+        want_offs[nchunks] = np.uint64(nchunks) * slot
+        assert np.array_equal(offs, want_offs), "slot index differs from (c + 1) * slot - length"
+    else:
+        aligned = (lens + np.uint64(15)) & ~np.uint64(15)
+        want_offs = np.zeros(nchunks + 1, dtype=np.uint64)
+        want_offs[1:] = np.cumsum(aligned[:nchunks])
+        want_offs[nchunks] = want_offs[nchunks - 1] + lens[nchunks - 1]
+        assert np.array_equal(offs, want_offs), "chunk index differs from the prefix sums of its lengths"
     assert int(offs[nchunks]) == art["total"]
     om = orc.model(art["freqs"], art["sb"], with_alias=(fmt == FMT_ALIAS))
     syms, cont = art["d_syms"], art["cont"]
@@ -392,6 +430,67 @@ def cpu_baseline(d_syms, freqs, n):
     return res
 
 
+_CPU_BASELINE_CACHE = {}
+
+
+def config_cpu_baseline(art):
+    """The reference's OWN loop of this configuration's format beside its GPU numbers (SURVEY 8(d) "CPU baseline"):
+    rans_byte 2-way (main.cpp:226-246 / 259-280), rans64 2-way (main64.cpp:228-248 / 261-282), alias 2-way
+    (main_alias.cpp:353-373 / 386-405; 4096 symbols: the same loop over the sed-widened model of oracle/_ref), word 8-way
+    with its SSE4.1 decoder (main_simd.cpp:287-300 / 313-332) -- through oracle/_ref (the unmodified reference compiled
+    here), encode AND decode, timed with timer() and __rdtsc() exactly where the mains put them.  Sample: the first
+    256 MiB of the configuration's own symbols as 16 MiB shards; one shard on one pinned thread (the reference as shipped:
+    clocks/symbol), then one shard per thread on as many pinned threads as the CPU quota allows."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from _oracle import FMT_ALIAS, HostSimd, Ref
+    if not Ref.available():
+        return {"value": None, "kind": "reference", "sample": "oracle/_ref not built on this box"}
+    ref = Ref()
+    if not ref.has_loop2():
+        return {"value": None, "kind": "reference", "sample": "oracle/_ref predates ref_time_loop2_mt"}
+    fmt, K, sb, n = art["fmt"], art["K"], art["sb"], art["n"]
+    which = 12 if (fmt == FMT_ALIAS and K == 4096) else fmt
+    key = (which, K, sb, art["d_syms"].data_ptr())
+    if key in _CPU_BASELINE_CACHE:  # (the wider interleaves of the word format share the headline's data and reference loop)
+        return _CPU_BASELINE_CACHE[key]
+    if K not in (256, 4096) or (K == 4096 and fmt != FMT_ALIAS):
+        return {"value": None, "kind": "reference", "sample": "the reference has no loop for this alphabet"}
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cpu_quota_cores()
+    max_threads = max(1, usable if quota is None else min(usable, int(math.ceil(quota))))
+    cpus = HostSimd().cpu_order() if HostSimd.available() else []
+    n_per = 1 << 24
+    max_threads = max(1, min(max_threads, n // n_per, 16))
+    host = art["d_syms"][:max_threads * n_per].cpu().numpy()
+    if host.dtype == np.int16:
+        host = host.view(np.uint16)
+    sym_bytes = host.dtype.itemsize
+    one = ref.time_loop2(which, art["freqs"], sb, host, n_per, 1, cpus)[0]
+    many = ref.time_loop2(which, art["freqs"], sb, host, n_per, max_threads, cpus)
+    ok = one["ok"] and all(t["ok"] for t in many)
+    enc_wall = max(t["enc_s"] for t in many)  # the passes start together (barrier): wall time = the slowest thread
+    dec_wall = max(t["dec_s"] for t in many)
+    loops = {0: "rans_byte.h 2-way, main.cpp:226-246 / 259-280", 1: "rans_word_sse41.h 8-way, scalar encode main_simd.cpp:287-300 / "
+             "SSE4.1 decode main_simd.cpp:313-332", 2: "rans64.h 2-way, main64.cpp:228-248 / 261-282",
+             3: "alias lookup over rans_byte.h 2-way, main_alias.cpp:353-373 / 386-405",
+             12: "alias lookup 2-way, main_alias.cpp:353-373 / 386-405 with LOG2NSYMS 12 and u16 symbols (the sed edits of SURVEY 8(c))"}
+    gb = n_per * sym_bytes / 1e9
+    _CPU_BASELINE_CACHE[key] = res = {
+        "kind": "reference", "unit": "GB/s (uncompressed)", "loop": loops[which], "decode_ok": ok,
+        "value": round(max_threads * gb / dec_wall, 3), "cores": max_threads,
+        "decode": {"single_thread_GBps": round(gb / one["dec_s"], 4), "single_thread_clocks_per_symbol": round(one["dec_clocks"] / n_per, 2),
+                   "threads": max_threads, "all_threads_GBps": round(max_threads * gb / dec_wall, 3)},
+        "encode": {"single_thread_GBps": round(gb / one["enc_s"], 4), "single_thread_clocks_per_symbol": round(one["enc_clocks"] / n_per, 2),
+                   "threads": max_threads, "all_threads_GBps": round(max_threads * gb / enc_wall, 3)},
+        "stream_bytes_per_symbol": round(one["stream_bytes"] / n_per, 5),
+        "sample": "first %d MiB of this configuration's symbols as %d shards of 16 Mi symbols; one shard on one pinned thread, then one "
+                  "shard per pinned thread on %d threads (CPU quota %s, %d usable CPUs)"
+                  % ((max_threads * n_per * sym_bytes) >> 20, max_threads, max_threads, quota, usable),
+    }
+    return res
+
+
 def kernel_source_tag():
     """sha256 (first 16 hex digits) of the sources the decode kernel is built from: a committed PMC traffic
     measurement is quoted only when it was taken on this very kernel."""
@@ -400,6 +499,34 @@ def kernel_source_tag():
         with open(os.path.join(ROOT, "ryg_rans_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def spawn_ranks(args, visible):
+    """Re-run this script as N ranks of one node (torch.distributed.run, rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+    n = args.gpus if args.all_on_device is not None else max(1, min(args.gpus, visible))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv, skip = [], False
+    for a in sys.argv[1:]:  # the same arguments, --gpus replaced by the clamped count
+        if skip:
+            skip = False
+            continue
+        if a == "--gpus":
+            skip = True
+            continue
+        if a.startswith("--gpus="):
+            continue
+        argv.append(a)
+    env = dict(os.environ, BENCH_GPUS_REQUESTED=str(args.gpus), BENCH_GPUS_VISIBLE=str(visible), BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n == 1:  # one visible GPU: the plain single-process run, the line carries the request
+        return subprocess.call([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + argv, env=env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n)] + argv
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -421,11 +548,16 @@ def main():
     if (knobs or measure_build or debug_args) and not args.measure:
         sys.exit("bench.py: RANS_AMD_* variables %s / measure build %s / --debug-* %s: not a headline run (pass --measure to "
                  "run it as a measurement)" % (sorted(knobs), measure_build, debug_args))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` started plainly: spawn the N ranks ourselves -- one process per GPU under
+        # torch.distributed.run on the loopback interface, exactly the command the docstring shows -- and hand its
+        # output through.  N is clamped to the GPUs this node shows (the line says so: gpus_requested / gpus_visible);
+        # --all-on-device (dry runs: every rank on one GPU, gloo for the records) is not clamped.
+        sys.exit(spawn_ranks(args, torch.cuda.device_count()))
+    if args.gpus != world:
+        sys.exit("bench.py --gpus %d inside a %d-rank launch: the launcher's --nproc-per-node and --gpus must agree"
+                 % (args.gpus, world))
     gpu_index = local_rank if args.all_on_device is None else args.all_on_device
     torch.cuda.set_device(gpu_index)
     device = torch.device("cuda", gpu_index)
@@ -550,12 +682,26 @@ def main():
             "prewarm_ms": args.prewarm_ms,
             "per_rank": {"kernel_ms": [round(r.kernel_ms, 4) for r in records],
                          "elapsed_ms_per_step": [round(r.elapsed_s / args.steps * 1e3, 4) for r in records],
-                         "stream_bytes": [int(r.stream_bytes) for r in records]},
+                         "stream_bytes": [int(r.stream_bytes) for r in records],
+                         # every rank's own kernel against its own GPU's peak
+                         "roofline_frac": [round((r.symbols + r.stream_bytes) / (r.kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                           for r in records]},
+            "launch": {"self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1",
+                       "gpus_requested": int(os.environ.get("BENCH_GPUS_REQUESTED", args.gpus)),
+                       "gpus_visible": int(os.environ.get("BENCH_GPUS_VISIBLE", torch.cuda.device_count())),
+                       "all_on_device": args.all_on_device},
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "kernel": ctx.last_decode_kernel(), "kernel_ms_avg": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": n + total,
+                # the job: algorithmic bytes of ALL ranks over the slowest rank's kernel time, against N GPUs' peak (at N = 1
+                # this is `frac`); achieved / peak / frac above are rank 0's kernel on rank 0's GPU
+                "frac_job": round(sum(r.symbols + r.stream_bytes for r in records) / (max(r.kernel_ms for r in records) * 1e-3)
+                                  / 1e9 / (len(records) * HBM_PEAK_GBPS), 4),
+                "achieved_job": round(sum(r.symbols + r.stream_bytes for r in records) / (max(r.kernel_ms for r in records) * 1e-3)
+                                      / 1e9, 1),
+                "peak_job": len(records) * HBM_PEAK_GBPS,
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
                 # what a launch spends inside its wavefronts (first wave start .. last wave end, mean over the timed
                 # launches of rank 0); the rest of kernel_ms_avg is dispatch, the hand-over between back-to-back
@@ -613,6 +759,8 @@ def main():
                 e, a = measure_config(torch, R, ctx, "C3 word 64-way 1 GiB (encoder of the headline config)", R.FMT_WORD, 12,
                                       256, args.ways, args.chunk, args.log2n, 1, ks, device, d_syms=d_syms)
                 cfgs.append(e)
+                arts[0]["entry"] = e  # (the headline's own artefacts: container checked below, CPU loop timed beside it)
+                arts[0]["slots"] = a["slots"]
                 e, a = measure_config(torch, R, ctx, "C2 rans64 2-way 256 MiB Zipf(256)", R.FMT_R64, 14, 256, 2, 512, 28, 1,
                                       ks, device)
                 cfgs.append(e)
@@ -625,6 +773,12 @@ def main():
                                       30, 1, ks, device, d_syms=d_syms)
                 cfgs.append(e)
                 arts.append(a)
+                # "64-way and wider" (north_star): two and four states per lane over the headline's data
+                for wide in (128, 256):
+                    e, a = measure_config(torch, R, ctx, "word %d-way 1 GiB Zipf(256) (%d states per lane)" % (wide, wide // 64),
+                                          R.FMT_WORD, 12, 256, wide, args.chunk, args.log2n, 1, ks, device, d_syms=d_syms)
+                    cfgs.append(e)
+                    arts.append(a)
             except Exception as e:  # noqa: BLE001
                 cfgs.append({"error": repr(e)})
             result["configs"] = cfgs
@@ -640,6 +794,12 @@ def main():
                     if a["entry"] is not None:
                         a["entry"]["oracle_chunks_checked"] = checked[key]
                         a["entry"]["oracle_chunks_total"] = (a["n"] + a["chunk"] - 1) // a["chunk"]
+                    if a.get("slots"):  # ... and every chunk of the slot container the write-once encoder left behind
+                        sl = a["slots"]
+                        a["entry"]["oracle_chunks_checked_slots"] = oracle_check_chunks(
+                            dict(a, cont=sl["cont"], offs=sl["offs"], lens=sl["lens"], total=sl["total"], slot=sl["slot"]),
+                            args.oracle_sample)
+                        del sl["cont"]
                 result["oracle_chunks_checked"] = checked["%s/%d-way/%d" % (args.format, args.ways, args.chunk)]
                 result["oracle_chunks_total"] = (n + args.chunk - 1) // args.chunk
                 result["oracle_chunks_checked_all"] = checked
@@ -652,6 +812,15 @@ def main():
                 result["oracle_chunks_checked"] = 0
                 result["oracle_check_error"] = repr(e)
                 all_ok = False
+            t_cb = time.perf_counter()
+            for a in arts:  # the reference's own loop of every configuration's format, on this box, beside its GPU numbers
+                if a["entry"] is None:
+                    continue
+                try:
+                    a["entry"]["cpu_baseline"] = config_cpu_baseline(a)
+                except Exception as e:  # noqa: BLE001
+                    a["entry"]["cpu_baseline"] = {"value": None, "kind": "reference", "sample": "failed: %r" % (e,)}
+            result["config_cpu_baselines_s"] = round(time.perf_counter() - t_cb, 2)
             try:
                 result["cpu_baseline"] = cpu_baseline(d_syms, freqs, n)
             except Exception as e:  # noqa: BLE001

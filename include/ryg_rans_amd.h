@@ -56,7 +56,8 @@ extern "C" {
 
 /* 0.4.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
  * inside a hipGraph capture (0.3.0); rans_amd_encode_slots + rans_amd_slot_bytes / rans_amd_encode_slots_bound,
- * rans_amd_container_compact, chunk offsets on any multiple of the format's unit in every decoder (0.4.0).  A caller built
+ * rans_amd_container_compact, rans_amd_container_slice, chunk offsets on any multiple of the format's unit in every decoder
+ * (0.4.0).  A caller built
  * against an older header keeps working. */
 #define RANS_AMD_VERSION 400
 
@@ -284,6 +285,20 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
                     uint64_t container_bytes, const uint64_t *d_offsets, const uint32_t *d_lengths,
                     uint64_t n, uint32_t n_ways, uint32_t chunk_syms, void *d_out,
                     uint64_t *h_bad_chunks, void *stream);
+/* Decoding a chunk RANGE [lo, hi) of a container (shard g of G owns chunks [g C / G, (g + 1) C / G)):
+ * chunks are independent and the index is per chunk, so
+ *
+ *     rans_amd_decode(ctx, model, d_container, container_bytes, d_offsets + lo, d_lengths + lo,
+ *                     n_range, n_ways, chunk_syms, (char *)d_out + lo * chunk_syms * sym_bytes, ...)
+ *
+ * with n_range = min(n, hi * chunk_syms) - lo * chunk_syms decodes exactly those chunks (only the container's LAST
+ * chunk may be shorter than chunk_syms, and it may only be the last chunk of a range).  A rank that holds only ITS bytes of
+ * the payload asks rans_amd_container_slice (host arrays in, host arrays out) for them: it receives the byte range
+ * [*byte_begin, *byte_end) that covers the range's streams (*byte_begin 16-byte aligned) and hi - lo + 1 offsets
+ * relative to *byte_begin -- copy that byte range to the device, pass it with the rebased offsets and d_lengths + lo. */
+int rans_amd_container_slice(const uint64_t *offsets, const uint32_t *lengths, uint64_t n_chunks, uint64_t lo, uint64_t hi,
+                             uint64_t *byte_begin, uint64_t *byte_end, uint64_t *rebased_offsets);
+
 /* Synchronise `stream` and return (and reset) the failed-chunk count accumulated
  * by asynchronous rans_amd_decode calls on this context. */
 int rans_amd_decode_errors(rans_amd_ctx *ctx, uint64_t *h_bad_chunks, void *stream);

@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "rans_amd_num_chunks", "rans_amd_chunk_bound", "rans_amd_encode_bound", "rans_amd_ways_supported",
     "rans_amd_encode", "rans_amd_encode_status", "rans_amd_decode", "rans_amd_decode_errors",
     "rans_amd_encode_slots", "rans_amd_slot_bytes", "rans_amd_encode_slots_bound", "rans_amd_container_compact",
+    "rans_amd_container_slice",
     "rans_amd_encode_host", "rans_amd_decode_host",
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_encode_kernel", "rans_amd_last_wave_clocks",
     "rans_amd_launch_spans",
@@ -114,6 +115,7 @@ def _load():
         "rans_amd_slot_bytes": (u64, [i32, u64, u32, u32]),
         "rans_amd_encode_slots_bound": (u64, [i32, u64, u32, u32]),
         "rans_amd_container_compact": (i32, [vp, vp, u64, vp, vp, u64, vp, u64, vp, u64p, vp]),
+        "rans_amd_container_slice": (i32, [u64p, u32p, u64, u64, u64, u64p, u64p, u64p]),
         "rans_amd_decode": (i32, [vp, vp, vp, u64, vp, vp, u64, u32, u32, vp, u64p, vp]),
         "rans_amd_decode_errors": (i32, [vp, u64p, vp]),
         "rans_amd_encode_host": (i32, [vp, vp, vp, u64, u32, vp, u64, u64p]),
@@ -468,6 +470,19 @@ def offsets_from_lengths(lengths):
     _check(_lib.rans_amd_offsets_from_lengths(lengths.ctypes.data_as(C.POINTER(C.c_uint32)), lengths.size,
                                               offs.ctypes.data_as(C.POINTER(C.c_uint64))), "offsets_from_lengths")
     return offs
+
+
+def container_slice(offsets, lengths, lo, hi):
+    """rans_amd_container_slice: chunk range [lo, hi) of an index (host arrays) -> (byte_begin, byte_end, rebased offsets
+    [hi - lo + 1]): the bytes a rank must hold and where its chunks lie in them."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    out = np.zeros(max(1, hi - lo + 1), dtype=np.uint64)
+    b, e = C.c_uint64(0), C.c_uint64(0)
+    _check(_lib.rans_amd_container_slice(offsets.ctypes.data_as(C.POINTER(C.c_uint64)), lengths.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         lengths.size, lo, hi, C.byref(b), C.byref(e), out.ctypes.data_as(C.POINTER(C.c_uint64))),
+           "container_slice")
+    return b.value, e.value, out
 
 
 def pack_container(fmt, norm_freqs, scale_bits, n_symbols, n_ways, chunk_syms, lengths, payload):

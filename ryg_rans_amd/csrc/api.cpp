@@ -699,6 +699,10 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
     ep.sym_bytes = (uint32_t)model->host.sym_bytes;
     ep.scale_bits = model->host.scale_bits;
     ep.variant = ctx->variant;
+    // Watchdog of the placement protocols: half a minute plus what one wave may legitimately need for the call's largest
+    // chunk -- a lane codes a symbol in well under a microsecond, and min(n_ways, 64) lanes share a chunk (a 2^31-symbol
+    // chunk of a 1-way stream: the waits for it may last as long as it does).
+    ep.wait_ticks = 30ull * 100000000ull + ((uint64_t)chunk_syms / (n_ways < 64u ? n_ways : 64u)) * 100ull;
     const bool lanes = encode_uses_lanes(enc_format, nchunks, n_ways);
     // context option RANS_AMD_OPT_LANE_FUSED_PLACEMENT: the lane encoders place their chunks themselves as well -- bit-exact,
     // tested, and on config 2 no faster than k_layout + k_compact_small behind them (lanes.hip says why), hence opt-in

@@ -80,6 +80,32 @@ int rans_amd_offsets_from_lengths(const uint32_t *lengths, uint64_t n_chunks, ui
     return RANS_AMD_OK;
 }
 
+int rans_amd_container_slice(const uint64_t *offsets, const uint32_t *lengths, uint64_t n_chunks, uint64_t lo, uint64_t hi,
+                             uint64_t *byte_begin, uint64_t *byte_end, uint64_t *rebased_offsets)
+{
+    if (!offsets || !lengths || !byte_begin || !byte_end || !rebased_offsets || lo > hi || hi > n_chunks)
+        return RANS_AMD_E_ARG;
+    if (lo == hi) { // an empty range: an empty container
+        *byte_begin = *byte_end = lo < n_chunks ? (offsets[lo] & ~uint64_t(15)) : 0;
+        rebased_offsets[0] = 0;
+        return RANS_AMD_OK;
+    }
+    uint64_t b = ~uint64_t(0), e = 0;
+    for (uint64_t c = lo; c < hi; ++c) { // (offsets need not ascend: the range's extent is the hull of its streams)
+        if (offsets[c] > ~uint64_t(0) - lengths[c])
+            return RANS_AMD_E_CORRUPT;
+        b = offsets[c] < b ? offsets[c] : b;
+        e = offsets[c] + lengths[c] > e ? offsets[c] + lengths[c] : e;
+    }
+    b &= ~uint64_t(15); // whole 16-byte granules: the slice starts as aligned as the container does
+    for (uint64_t c = lo; c < hi; ++c)
+        rebased_offsets[c - lo] = offsets[c] - b;
+    rebased_offsets[hi - lo] = e - b;
+    *byte_begin = b;
+    *byte_end = e;
+    return RANS_AMD_OK;
+}
+
 uint64_t rans_amd_container_bytes(const rans_amd_container_info *info)
 {
     if (!info_sane(info))

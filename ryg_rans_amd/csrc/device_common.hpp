@@ -464,11 +464,16 @@ static_assert(sizeof(EncMailbox) == kEncMailboxBytes, "mailbox layout");
 // else is still busy with (a 2^31-symbol chunk of a *_host call keeps one wave busy for seconds).  (Rounds 1-2 counted
 // polls, 2^28 of them: between 25 seconds and nine minutes depending on what a poll costs -- a protocol bug in round 3
 // held a GPU box for a quarter of an hour.)
+// The limit travels with the launch (EncParams::wait_ticks): api.cpp adds to the half minute what ONE wave may legitimately
+// need for the largest chunk of the call -- a 2^31-symbol chunk of a 1-way stream keeps a lane busy for minutes, and the
+// waits for it are as long.
 constexpr unsigned long long kWaitTicks = 30ull * 100000000ull;
 constexpr uint32_t kProtocolErrorBits = ~7u; // EncParams::flags: everything but bad symbol / no space / LDS layout
 struct SpinWatch {
     unsigned long long t0 = 0;
+    unsigned long long limit;
     uint32_t polls = 0;
+    __device__ __forceinline__ explicit SpinWatch(unsigned long long limit_ticks) : limit(limit_ticks ? limit_ticks : kWaitTicks) {}
     // true when the wait should be abandoned: it has lasted kWaitTicks, or some other wait of this launch has given up
     // already (its flag is set: the launch has failed, and nobody should sit through the timeout a second time --
     // a failed look-back would otherwise cost every chunk behind it another half minute)
@@ -483,15 +488,15 @@ struct SpinWatch {
             t0 = t;
             return false;
         }
-        return t - t0 > kWaitTicks;
+        return t - t0 > limit;
     }
 };
 
-__device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t unit, uint32_t len, uint32_t *flags)
+__device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t unit, uint32_t len, uint32_t *flags, unsigned long long wait_ticks)
 {
     const uint32_t i = atomicAdd(&mb->tail, 1u) & 63u;
     volatile uint2 *e = &mb->entries[i];
-    SpinWatch watch;
+    SpinWatch watch(wait_ticks);
     while (e->x != 0u) { // (64 entries for at most 15 encoders: the copier would have to be 4 units per encoder behind)
         if (watch.expired(flags)) {
             atomicOr(flags, 8u);
@@ -505,14 +510,14 @@ __device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t unit, uint
 // Copier side (whole wave): the next entry in order, {ex = unit + 1, ey = bytes}; false when every one of the block's
 // `producers` coding waves has left its loop and nothing is left to take.
 __device__ __forceinline__ bool mailbox_pop(EncMailbox *mb, uint32_t lane, uint32_t producers, uint32_t &ex, uint32_t &ey,
-                                            uint32_t *flags)
+                                            uint32_t *flags, unsigned long long wait_ticks)
 {
     uint32_t h = 0;
     if (lane == 0)
         h = atomicAdd(&mb->claim, 1u);
     h = uniform(h);
     volatile uint2 *e = &mb->entries[h & 63u];
-    for (SpinWatch watch;;) {
+    for (SpinWatch watch(wait_ticks);;) {
         const unsigned long long ev = *reinterpret_cast<volatile unsigned long long *>(e);
         ex = uniform((uint32_t)ev);
         ey = uniform((uint32_t)(ev >> 32));

@@ -483,7 +483,7 @@ __device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chun
 {
     const unsigned long long alen = (len + 15u) & ~15u;
     unsigned long long base = 0;
-    SpinWatch watch;
+    SpinWatch watch(p.wait_ticks);
     for (uint64_t j = chunk;;) { // status[j-1], status[j-2], ... are still to be added
         unsigned long long st = kStPrefix; // virtual predecessor of chunk 0: an inclusive prefix of 0
         if (lane < j)
@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         if (wave >= waves_per_block) { // ---- copier wave
             for (;;) {
                 uint32_t ex = 0, ey = 0;
-                if (!mailbox_pop(mb, lane, waves_per_block, ex, ey, p.flags))
+                if (!mailbox_pop(mb, lane, waves_per_block, ex, ey, p.flags, p.wait_ticks))
                     break;
                 const uint64_t chunk = ex - 1u;
                 if (p.ring_slots) { // entry: length | slot of the ring << 26 | coding wave << 28
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             // is always in the hands of a running wave (the forward-progress argument above: the copier that drains this
             // wave's old chunk waits only for chunks smaller than ones its own block has claimed, and those are being coded)
             if (FUSED && p.ring_slots && coded >= p.ring_slots) {
-                SpinWatch watch;
+                SpinWatch watch(p.wait_ticks);
                 for (;;) {
                     uint32_t got_drained;
                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(got_drained) : "v"(drained_lds + 4u * wave) : "memory");
@@ -1029,7 +1029,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                                    __HIP_MEMORY_SCOPE_AGENT);
                 // (the copier will overwrite that word with the PREFIX: it must not learn of the chunk before the store is done)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a workgroup-scope fence emits no wait for global stores on this target)
-                mailbox_push(mb, (uint32_t)chunk, p.ring_slots ? (len | (ring_j << 26) | (wave << 28)) : len, p.flags);
+                mailbox_push(mb, (uint32_t)chunk, p.ring_slots ? (len | (ring_j << 26) | (wave << 28)) : len, p.flags, p.wait_ticks);
             }
         }
     }

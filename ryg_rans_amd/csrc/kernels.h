@@ -148,6 +148,8 @@ struct EncParams {
     // c's stream ends at the end of slot c exactly as the reference's encoder ends at the end of its buffer
     // (rans_byte.h:22-26, main.cpp:176-188), and the coding kernel writes offsets[c] = c * slot_bytes + (slot_bytes - len)
     // beside lengths[c]: every stream crosses HBM once, no look-back, no copier waves, no k_layout / k_compact.
+    unsigned long long wait_ticks; // fused placement: how long (100 MHz ticks) a wait of the protocol may last before the launch is
+                                   // declared failed (device_common.hpp SpinWatch); 0 = the default half minute
     uint32_t slot_layout;       // 1 = that; `offsets` is then set and `status` is NULL
     unsigned int *claims;       // wave encoders with dynamic chunk hand-out (fused placement, slot layout): kWorkPools claim
                                 // counters on a 64-byte line each, zero at launch
@@ -178,7 +180,9 @@ constexpr uint32_t kEncMailboxStride = 640; // a block's mailbox in global memor
 #endif
 constexpr uint32_t kEncRingSlots = RANS_ENC_RING_SLOTS;
 constexpr uint32_t kEncRingMaxWavesPerCu = 32;          // resident waves of a CU: upper bound of the coding waves
-constexpr uint64_t kEncRingMaxSlotBytes = 1ull << 26;   // mailbox entries of the ring protocol keep 26 bits of length
+constexpr uint64_t kEncRingMaxSlotBytes = (1ull << 26) - 64; // mailbox entries of the ring protocol keep 26 bits of length: a
+                                                             // stream that fills its slot must still be below 2^26 bytes
+static_assert(kEncRingSlots <= 4, "the ring protocol's mailbox entry keeps two bits of slot number");
 
 struct LayoutParams {
     const uint32_t *lengths;

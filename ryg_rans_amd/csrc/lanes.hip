@@ -1174,9 +1174,10 @@ struct LaneCoder { // a coding wave's view
 };
 
 // poll an LDS word until it has the value (whole wave; gives up after kWaitTicks and says so in flags)
-__device__ __forceinline__ bool lanes_wait_lds(volatile uint32_t *word, uint32_t value, uint32_t *flags, uint32_t flag_bit, uint32_t lane)
+__device__ __forceinline__ bool lanes_wait_lds(volatile uint32_t *word, uint32_t value, uint32_t *flags, uint32_t flag_bit, uint32_t lane,
+                                               unsigned long long wait_ticks)
 {
-    for (SpinWatch watch;;) {
+    for (SpinWatch watch(wait_ticks);;) {
         if (uniform(*word) == value)
             return true;
         if (watch.expired(flags)) {
@@ -1192,7 +1193,7 @@ __device__ __forceinline__ uint64_t lanes_round_begin(const EncParams &p, LaneRo
                                                       uint32_t coders, uint32_t lane)
 {
     const uint32_t r = cs.round;
-    if (!lanes_wait_lds(&ctl->unit_seq[r & 3u], r + 1u, p.flags, 128u, lane))
+    if (!lanes_wait_lds(&ctl->unit_seq[r & 3u], r + 1u, p.flags, 128u, lane, p.wait_ticks))
         return ~0ull;
     const uint64_t first = p.batch_begin + (uint64_t)uniform(*(volatile uint32_t *)&ctl->unit[r & 3u]) * coders;
     if (first >= p.batch_end)
@@ -1283,12 +1284,12 @@ __device__ __forceinline__ void lanes_round_end(const EncParams &p, LaneRounds *
 __device__ __forceinline__ void lanes_copier(const EncParams &p, LaneRounds *ctl, uint32_t k, uint32_t lane, uint32_t coders)
 {
     for (uint32_t r = 0;; ++r) {
-        if (!lanes_wait_lds(&ctl->unit_seq[r & 3u], r + 1u, p.flags, 128u, lane))
+        if (!lanes_wait_lds(&ctl->unit_seq[r & 3u], r + 1u, p.flags, 128u, lane, p.wait_ticks))
             return;
         const uint64_t first = p.batch_begin + (uint64_t)uniform(*(volatile uint32_t *)&ctl->unit[r & 3u]) * coders;
         if (first >= p.batch_end)
             return;
-        if (!lanes_wait_lds(&ctl->base_seq[r & 1u], r + 1u, p.flags, 64u, lane))
+        if (!lanes_wait_lds(&ctl->base_seq[r & 1u], r + 1u, p.flags, 64u, lane, p.wait_ticks))
             return;
         for (uint32_t w = k; w < coders && first + w < p.batch_end; w += kLaneCopyWaves) {
             const volatile uint32_t *b = reinterpret_cast<const volatile uint32_t *>(&ctl->bases[r & 1u][w]);
@@ -1321,7 +1322,7 @@ __device__ __forceinline__ void lanes_scanner(const EncParams &p, LaneRounds *ct
         const uint32_t un = claim(); // the coders find their next unit as soon as they are through with this one
         *(volatile uint32_t *)&ctl->unit[(r + 1u) & 3u] = un;
         *(volatile uint32_t *)&ctl->unit_seq[(r + 1u) & 3u] = r + 2u;
-        if (!lanes_wait_lds(&ctl->posted[r & 1u], coders, p.flags, 16u, lane))
+        if (!lanes_wait_lds(&ctl->posted[r & 1u], coders, p.flags, 16u, lane, p.wait_ticks))
             return;
         const uint32_t mine = *(volatile uint32_t *)&ctl->totals[r & 1u][slot];
         const uint32_t t = lane < coders ? mine : 0u;
@@ -1336,7 +1337,7 @@ __device__ __forceinline__ void lanes_scanner(const EncParams &p, LaneRounds *ct
         const uint64_t gu = p.unit_base + u;
         __hip_atomic_store(p.status + gu, kStAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (every lane)
         unsigned long long base = 0;
-        SpinWatch watch;
+        SpinWatch watch(p.wait_ticks);
         for (uint64_t j = gu;;) { // status[j-1], status[j-2], ... are still to be added
             unsigned long long st[kScanWords];
             uint64_t ready[kScanWords], pref[kScanWords];
@@ -1396,7 +1397,7 @@ __device__ __forceinline__ void lanes_scanner(const EncParams &p, LaneRounds *ct
         __hip_atomic_store(p.status + gu, kStPrefix | (base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (every lane)
         const unsigned long long place = base + incl - t; // of coder `lane`'s batch
         if (r >= 2u) { // the copiers are through with round r - 2, whose places these words still hold
-            if (!lanes_wait_lds(&ctl->copied[r & 1u], kLaneCopyWaves, p.flags, 16u, lane))
+            if (!lanes_wait_lds(&ctl->copied[r & 1u], kLaneCopyWaves, p.flags, 16u, lane, p.wait_ticks))
                 return;
             *(volatile uint32_t *)&ctl->copied[r & 1u] = 0u;
         }

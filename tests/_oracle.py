@@ -288,6 +288,12 @@ class HostSimd:
         return out
 
 
+class RefLoop2Times(C.Structure):
+    """ref_loop2_times (oracle/ref_driver.cpp)"""
+    _fields_ = [("enc_s", C.c_double), ("dec_s", C.c_double), ("enc_clocks", C.c_uint64), ("dec_clocks", C.c_uint64),
+                ("stream_bytes", C.c_uint64), ("ok", C.c_int32), ("pad", C.c_int32)]
+
+
 class Ref:
     """The unmodified reference behind a C ABI (oracle/ref_driver.cpp)."""
 
@@ -313,7 +319,28 @@ class Ref:
         lib.ref12_encode_alias.argtypes = [u32p, C.c_uint32, u16p, C.c_size_t, C.c_uint32, u8p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]
         lib.ref12_decode_alias.argtypes = [u32p, C.c_uint32, u8p, C.c_size_t, C.c_size_t, C.c_uint32, u16p]
+        if hasattr(lib, "ref_time_loop2_mt"):  # (a _ref built before round 4 lacks it)
+            lib.ref_time_loop2_mt.argtypes = [C.c_int, u32p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_int),
+                                              C.c_int, C.POINTER(RefLoop2Times)]
         self.lib = lib
+
+    def has_loop2(self):
+        return hasattr(self.lib, "ref_time_loop2_mt")
+
+    def time_loop2(self, which, freqs, scale_bits, data, n_per, threads=1, cpus=()):
+        """The reference's own 2-way loop of a format exactly as its main times it (main.cpp:226-280, main64.cpp:228-282,
+        main_alias.cpp:353-405; which = FMT_BYTE / FMT_R64 / FMT_ALIAS over bytes, 12 = the 4096-symbol alias model over
+        u16 symbols): `threads` shards of n_per symbols from the start of `data`, one (pinned) thread each, encode pass then
+        decode pass.  Returns one dict per thread: seconds and rdtsc clocks of each pass, stream bytes, ok (= decode ok!)."""
+        data = np.ascontiguousarray(data, dtype=np.uint16 if which == 12 else np.uint8)
+        assert data.size >= threads * n_per
+        f = np.ascontiguousarray(freqs, dtype=np.uint32)
+        times = (RefLoop2Times * threads)()
+        cpu_arr = (C.c_int * max(1, len(cpus)))(*cpus) if cpus else (C.c_int * 1)(0)
+        rc = self.lib.ref_time_loop2_mt(which, _ptr(f, u32p), scale_bits, data.ctypes.data, n_per, threads, cpu_arr, len(cpus), times)
+        assert rc == 0, "ref_time_loop2_mt failed (%d)" % rc
+        return [{"enc_s": t.enc_s, "dec_s": t.dec_s, "enc_clocks": t.enc_clocks, "dec_clocks": t.dec_clocks,
+                 "stream_bytes": t.stream_bytes, "ok": bool(t.ok)} for t in times]
 
     def build_model(self, data, target_total):
         data = np.ascontiguousarray(data, dtype=np.uint8)

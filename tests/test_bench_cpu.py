@@ -93,3 +93,27 @@ def test_threaded_oracle_container_equals_the_serial_one(oracle):
         c3[int(offs[17]) + 5] ^= 0x80
         c3[int(offs[40]) + 5] ^= 0x80
         assert oracle.compare_container(fmt, om, data, ways, chunk, c3, offs, lens, threads=3) == (len(lens), 17)
+
+
+def test_reference_loops_of_the_cpu_baseline_are_the_oracles_streams(oracle, ref):
+    """bench.py's per-configuration CPU baseline runs the reference's OWN 2-way loops (main.cpp:226-280, main64.cpp:228-282,
+    main_alias.cpp:353-405) and the 8-way word loop with its SSE4.1 decoder (main_simd.cpp:287-332) through
+    oracle/_ref: every shard must round-trip ("decode ok!") and its stream must have exactly the size the oracle's 2-way /
+    8-way stream of the same symbols has -- the timed loops are the format's loops, not look-alikes."""
+    from _oracle import FMT_ALIAS, FMT_BYTE, FMT_R64, FMT_WORD
+    if not ref.has_loop2():
+        import pytest
+        pytest.skip("oracle/_ref predates ref_time_loop2_mt")
+    data = oracle.gen_zipf(4 * 100001, K=256, s=1.0, seed=11)
+    for which, sb, ways in ((FMT_BYTE, 14, 2), (FMT_R64, 14, 2), (FMT_ALIAS, 16, 2), (FMT_WORD, 12, 8)):
+        f, _ = oracle.normalize(oracle.count_freqs(data, 256), 1 << sb)
+        om = oracle.model(f, sb, with_alias=(which == FMT_ALIAS))
+        res = ref.time_loop2(which, f, sb, data, 100001, threads=4)
+        for t, r in enumerate(res):
+            assert r["ok"] and r["enc_s"] > 0 and r["dec_s"] > 0 and r["enc_clocks"] > 0 and r["dec_clocks"] > 0
+            assert r["stream_bytes"] == oracle.encode(which, om, data[t * 100001:(t + 1) * 100001], ways).size, (which, t)
+    d16 = oracle.gen_zipf(2 * 50001, K=4096, s=1.0, seed=3)
+    f, _ = oracle.normalize(oracle.count_freqs(d16, 4096), 1 << 16)
+    om = oracle.model(f, 16, with_alias=True)
+    for t, r in enumerate(ref.time_loop2(12, f, 16, d16, 50001, threads=2)):
+        assert r["ok"] and r["stream_bytes"] == oracle.encode(FMT_ALIAS, om, d16[t * 50001:(t + 1) * 50001], 2).size

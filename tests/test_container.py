@@ -184,3 +184,28 @@ def test_gpu_adaptive_file_roundtrip(tmp_path, oracle):
         n_c = min(32768, data.size - c * 32768)
         got = oracle.decode(FMT_BYTE, oracle.model(f2[c].astype(np.uint32), 12), p2[o2[c]:o2[c] + l2[c]], n_c, 64)
         assert np.array_equal(got, data[c * 32768:c * 32768 + n_c]), c
+
+
+def test_container_slice_arithmetic():
+    """rans_amd_container_slice (host arrays): the byte hull of a chunk range, 16-byte aligned at its start, and offsets
+    rebased to it -- for compact, slot-layout and descending indexes; bad ranges are refused."""
+    import ryg_rans_amd as R
+    rng = np.random.default_rng(5)
+    lens = rng.integers(20, 5000, 40).astype(np.uint32)
+    compact = R.offsets_from_lengths(lens)[:-1]
+    slot = np.uint64(8192)
+    slots = (np.arange(40, dtype=np.uint64) + np.uint64(1)) * slot - lens
+    descending = compact[::-1].copy()
+    for offs, ls in ((compact, lens), (slots, lens), (descending, lens[::-1].copy())):
+        for lo, hi in ((0, 40), (0, 1), (7, 23), (39, 40), (12, 12)):
+            b, e, reb = R.container_slice(offs, ls, lo, hi)
+            if lo == hi:
+                assert b == e and reb.size == 1 and reb[0] == 0
+                continue
+            assert b % 16 == 0 and b == int(offs[lo:hi].min()) & ~15
+            assert e == int((offs[lo:hi] + ls[lo:hi]).max())
+            assert np.array_equal(reb[:-1], offs[lo:hi] - np.uint64(b)) and int(reb[-1]) == e - b
+    with pytest.raises(R.RansAmdError):
+        R.container_slice(compact, lens, 5, 41)
+    with pytest.raises(R.RansAmdError):
+        R.container_slice(compact, lens, 9, 3)

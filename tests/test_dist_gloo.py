@@ -98,6 +98,46 @@ def test_two_ranks_decode_real_shards_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started PLAINLY (no torchrun around it, no WORLD_SIZE in the environment -- the shape
+    of the driver's N = 1 command with another number) spawns its own two ranks, and the line is self-describing: it says
+    it launched itself, how many GPUs were asked for and how many the node shows, and carries the job-level roofline
+    fraction (algorithmic bytes of all ranks / slowest kernel / N x 8 TB/s) beside every rank's own."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+           "--all-on-device", "0", "--log2n", "26", "--prewarm-ms", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["bit_exact_roundtrip"] is True
+    assert d["launch"]["self_launched"] is True and d["launch"]["gpus_requested"] == 2 and d["launch"]["gpus_visible"] >= 1
+    pr, rl = d["per_rank"], d["roofline"]
+    assert len(pr["roofline_frac"]) == 2 and all(0.0 < f < 1.0 for f in pr["roofline_frac"])
+    alg = sum((1 << 26) + sb for sb in pr["stream_bytes"])
+    assert rl["frac_job"] == pytest.approx(alg / (max(pr["kernel_ms"]) * 1e-3) / 1e9 / (2 * 8000.0), rel=0.01)
+    assert rl["peak_job"] == 16000.0
+    # asked for more GPUs than the node has, without the dry-run aid: clamped, said so, still a valid line
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "2", "--warmup", "1", "--log2n", "24",
+           "--prewarm-ms", "0", "--no-configs", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    import torch
+    assert d["n_gpus"] == min(64, torch.cuda.device_count())
+    assert d["launch"] == {"self_launched": True, "gpus_requested": 64, "gpus_visible": torch.cuda.device_count(),
+                           "all_on_device": None}
+    assert d["roofline"]["frac_job"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_force_dist_runs_rccl_on_one_gpu():
     """bench.py --force-dist: torch.distributed over the nccl backend (RCCL) with a single rank -- init_process_group
     with device_id, both barriers and the on-device all_gather of the record execute on real RCCL on this box, so the

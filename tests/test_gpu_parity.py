@@ -280,7 +280,15 @@ def test_native_multi_gpu_example(gpu):
     assert out.returncode == 0 and "decode ok!" in out.stdout, (out.stdout, out.stderr)
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] >= 1 and line["bit_exact_roundtrip"] is True and line["records_gathered_by"] == "ncclAllGather"
-    assert line["value"] > 0
+    assert line["value"] > 0 and 0.0 < line["frac_job"] < 1.0 and "roofline frac" in out.stdout
+    # --split-one: ONE container split by chunk range over three ranks (they share this box's one GPU, a context each),
+    # every rank holding only the bytes rans_amd_container_slice assigns it; the pieces side by side are the input
+    out = subprocess.run([exe, "--split-one", "3", "24", "3"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "decode ok!" in out.stdout, (out.stdout, out.stderr)
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["ranks"] == 3 and line["mode"] == "one container split by chunk range" and line["bit_exact_roundtrip"] is True
+    rows = [ln.split() for ln in out.stdout.splitlines() if ln.strip() and ln.split()[0] in ("0", "1", "2")]
+    assert len(rows) == 3 and sum(float(r[1]) for r in rows) == float(1 << 24)  # the three ranges cover the input once
 
 
 def test_unaligned_buffers_and_streams(gpu, oracle):

@@ -84,7 +84,7 @@ def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways
     assert bench.oracle_check_chunks(art) == (n + chunk - 1) // chunk
     out = ctx.decode(gm, cont, total, offs, lens, n, ways, chunk)
     assert torch.equal(out, d_syms)
-    if name == "C3":
+    if name.startswith("C3"):  # (both chunk sizes: 16 Ki is the headline configuration of bench.py)
         assert ctx.last_decode_kernel() == "k_decode_word64"
     if name.startswith("C4"):
         assert ctx.last_decode_kernel() == "k_decode_dual<alias>"
@@ -102,7 +102,21 @@ def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways
         assert bench.oracle_check_chunks(art_r) == (n + chunk - 1) // chunk
         del cont_r, gm2
         ctx2.close()
-    # 4. a corrupted chunk is flagged (or at least does not decode to the input)
+    # 4. the slot layout (rans_amd_encode_slots: every chunk written once, where it was coded): every chunk == the
+    #    oracle's stream again, index == (c + 1) * slot - length, the slot container decodes as it is, and its compaction
+    #    is the container of step 1
+    s_cont, s_offs, s_lens, s_total = ctx.encode_slots(gm, d_syms, ways, chunk)
+    assert ctx.last_encode_placement() == 2 and torch.equal(s_lens, lens)
+    art_s = dict(art, cont=s_cont, offs=s_offs, lens=s_lens, total=s_total, slot=R.slot_bytes(fmt, n, ways, chunk))
+    assert bench.oracle_check_chunks(art_s) == (n + chunk - 1) // chunk
+    out = ctx.decode(gm, s_cont, s_total, s_offs, s_lens, n, ways, chunk)
+    assert torch.equal(out, d_syms)
+    del out
+    c_cont, c_offs, c_total = ctx.compact(s_cont, s_total, s_offs, s_lens, lens.numel())
+    assert c_total == total and torch.equal(c_offs, offs)
+    assert bench.oracle_check_chunks(dict(art, cont=c_cont, offs=c_offs)) == (n + chunk - 1) // chunk
+    del s_cont, c_cont
+    # 5. a corrupted chunk is flagged (or at least does not decode to the input)
     bad = cont.clone()
     bad[int(offs[0].item()) + int(lens[0].item()) // 2] ^= 0x10
     out2 = torch.empty_like(d_syms)

@@ -227,3 +227,42 @@ def test_compact_a_chunk_range_and_a_reordered_index(gpu, oracle):
     with pytest.raises(R.RansAmdError) as e:
         ctx.compact(d_cont, cont.size, d_offs, d_lens, nchunks, d_dst=tiny)
     assert e.value.status == R.E_SPACE and int(tiny.sum()) == 0
+
+
+@pytest.mark.parametrize("fmt,sb,n_ways,chunk", [(FMT_WORD, 12, 64, 4096), (FMT_R64, 14, 2, 512), (FMT_ALIAS, 16, 64, 4096)])
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_container_split_over_contexts(gpu, oracle, fmt, sb, n_ways, chunk, world):
+    """SURVEY 8(e)'s general rule on real data: ONE oracle-made container, shard g = chunks sharding.chunk_range(C, G, g);
+    every "rank" (its own context, its own model) holds ONLY the bytes rans_amd_container_slice assigns it, decodes its
+    chunk range through the plain ABI call, and the pieces laid side by side are the input.  Also the variant without a
+    slice: the whole container resident, d_offsets + lo / d_lengths + lo."""
+    R, ctx0, torch = gpu
+    from ryg_rans_amd.sharding import chunk_range, symbol_range
+    data = oracle.gen_zipf(300000 + 123, K=256, s=1.0, seed=8)
+    f, _ = oracle.normalize(oracle.count_freqs(data, 256), 1 << sb)
+    om = oracle.model(f, sb, with_alias=(fmt == FMT_ALIAS))
+    cont, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+    nchunks, n = len(lens), data.size
+    d_full = torch.from_numpy(np.concatenate([cont, np.zeros(16, np.uint8)])).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+    out_sliced = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    out_ranged = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    covered = 0
+    for g in range(world):
+        ctx = R.Context(0)  # one context per rank (here: all on the one GPU of the box)
+        gm = ctx.model(fmt, f, sb)
+        lo, hi = chunk_range(nchunks, world, g)
+        first, last = symbol_range(n, chunk, world, g)
+        assert first == lo * chunk and last == min(n, hi * chunk)
+        b, e, rebased = R.container_slice(offs, lens, lo, hi)
+        assert b % 16 == 0 and b <= int(offs[lo]) and e == int(offs[hi - 1]) + int(lens[hi - 1])
+        assert np.array_equal(rebased[:-1], offs[lo:hi] - np.uint64(b)) and int(rebased[-1]) == e - b
+        part = torch.from_numpy(np.concatenate([cont[b:e], np.zeros(16, np.uint8)])).cuda()  # ONLY this rank's bytes
+        d_reb = torch.from_numpy(rebased.astype(np.int64)).cuda()
+        ctx.decode(gm, part, e - b, d_reb, d_lens[lo:hi], last - first, n_ways, chunk, d_out=out_sliced[first:last])
+        ctx.decode(gm, d_full, cont.size, d_offs[lo:], d_lens[lo:], last - first, n_ways, chunk, d_out=out_ranged[first:last])
+        covered += last - first
+        ctx.close()
+    assert covered == n
+    assert np.array_equal(out_sliced.cpu().numpy(), data) and np.array_equal(out_ranged.cpu().numpy(), data)
