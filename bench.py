@@ -77,6 +77,11 @@ def parse_args():
                     help="measurement aid: index entry c points at chunk c mod K (stream reads come from cache); the "
                          "round trip check is skipped")
     ap.add_argument("--config-steps", type=int, default=20, help="back-to-back launches per `configs` entry")
+    ap.add_argument("--placement-candidates", type=int, default=8, metavar="K",
+                    help="setup (untimed): allocate K candidate output buffers (and 3 copies of the container), time the decode "
+                         "on every pair for a few launches and keep the fastest pair -- MI355X memory comes in two classes and "
+                         "a kernel that streams one buffer in and another out is 4-6 %% faster when the two lie in different "
+                         "ones (profiles/r04_allocation.md); 1 = take what the allocator returns first (rounds 1-3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="dry-run aid: every rank uses this GPU (needs --backend gloo)")
@@ -147,9 +152,21 @@ def timed_launches(torch, fn, steps, warmup):
     return sum(ms) / len(ms), min(ms)
 
 
-def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, steps, device, d_syms=None):
+def settle(torch, fn, ms=60.0):
+    """Run fn back to back for `ms` milliseconds: the clocks of an idle GPU need that long to settle, and a probe that compares
+    allocations must not compare a cold launch with a warm one."""
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < ms:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
+
+
+def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, steps, device, d_syms=None, probe=1):
     """One `configs` entry: decode and encode of a BASELINE configuration, `steps` back-to-back launches each,
-    round trip verified.  Returns (entry, artefacts for the CPU-side oracle check)."""
+    round trip verified.  Returns (entry, artefacts for the CPU-side oracle check).  probe > 1: every timed call first
+    chooses the buffer it WRITES among `probe` candidate allocations (ryg_rans_amd/placement.py; untimed)."""
+    from ryg_rans_amd.placement import choose_one
     n = 1 << log2n
     sym_bytes = 1 if K <= 256 else 2
     if d_syms is None:
@@ -159,12 +176,28 @@ def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, st
     model = ctx.model(fmt, freqs, sb)
     cont, offs, lens, total = ctx.encode(model, d_syms, ways, chunk)
     out = torch.empty_like(d_syms)
+    placement = {"candidates": probe}
+    if probe > 1:
+        outs = [out] + [torch.empty_like(d_syms) for _ in range(probe - 1)]
+        settle(torch, lambda: ctx.decode(model, cont, total, offs, lens, n, ways, chunk, d_out=out, sync=False))
+        pick, ms = choose_one(torch, lambda o: ctx.decode(model, cont, total, offs, lens, n, ways, chunk, d_out=o, sync=False), outs)
+        out = outs[pick]
+        placement["decode_probe_ms"] = [round(v, 4) for v in ms]
+        del outs
     dec_ms, dec_min = timed_launches(
         torch, lambda: ctx.decode(model, cont, total, offs, lens, n, ways, chunk, d_out=out, sync=False), steps, 2)
     bad = ctx.decode_errors()
     exact = bool(torch.equal(out, d_syms)) and bad == 0
     kernel = ctx.last_decode_kernel()
     cont2, offs2, lens2 = torch.empty_like(cont), torch.empty_like(offs), torch.empty_like(lens)
+    if probe > 1:
+        c2s = [cont2] + [torch.empty_like(cont) for _ in range(min(probe, 4) - 1)]
+        settle(torch, lambda: ctx.encode(model, d_syms, ways, chunk, d_out=cont2, sync=False, d_offsets=offs2, d_lengths=lens2))
+        pick, ms = choose_one(torch, lambda c: ctx.encode(model, d_syms, ways, chunk, d_out=c, sync=False, d_offsets=offs2,
+                                                          d_lengths=lens2), c2s)
+        cont2 = c2s[pick]
+        placement["encode_compact_probe_ms"] = [round(v, 4) for v in ms]
+        del c2s
     enc_ms, enc_min = timed_launches(
         torch, lambda: ctx.encode(model, d_syms, ways, chunk, d_out=cont2, sync=False, d_offsets=offs2, d_lengths=lens2),
         steps, 2)
@@ -178,6 +211,14 @@ def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, st
     # chunk starts are not 16-byte aligned and it is 2.6 x as large), and every chunk of it goes to the oracle check.
     s_cont, s_offs, s_lens, s_total = ctx.encode_slots(model, d_syms, ways, chunk)
     slot = R.slot_bytes(fmt, n, ways, chunk)
+    if probe > 1:
+        scs = [s_cont] + [torch.empty_like(s_cont) for _ in range(min(probe, 4) - 1)]
+        settle(torch, lambda: ctx.encode_slots(model, d_syms, ways, chunk, d_out=s_cont, sync=False, d_offsets=s_offs, d_lengths=s_lens))
+        pick, ms = choose_one(torch, lambda c: ctx.encode_slots(model, d_syms, ways, chunk, d_out=c, sync=False, d_offsets=s_offs,
+                                                                d_lengths=s_lens), scs)
+        s_cont = scs[pick]
+        placement["encode_slots_probe_ms"] = [round(v, 4) for v in ms]
+        del scs
     s_enc_ms, s_enc_min = timed_launches(
         torch, lambda: ctx.encode_slots(model, d_syms, ways, chunk, d_out=s_cont, sync=False, d_offsets=s_offs, d_lengths=s_lens),
         steps, 2)
@@ -211,6 +252,8 @@ def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, st
         "decode_slots": {"kernel": ctx.last_decode_kernel(), "ms_mean": round(s_dec_ms, 4), "ms_min": round(s_dec_min, 4),
                          "launches": steps, "frac": round(alg / s_dec_ms / 1e6 / HBM_PEAK_GBPS, 4)},
         "bit_exact_roundtrip": exact and same_container and slots_ok,
+        # the written buffer of every timed call was chosen among this many allocations (setup, untimed; see --placement-candidates)
+        "placement": placement,
     }
     art = {"fmt": fmt, "sb": sb, "K": K, "ways": ways, "chunk": chunk, "n": n, "freqs": freqs, "d_syms": d_syms,
            "cont": cont, "offs": offs, "lens": lens, "total": total, "entry": entry,
@@ -585,6 +628,30 @@ def main():
     model = ctx.model(fmt, freqs, sb)
     cont, offs, lens, total = ctx.encode(model, d_syms, args.ways, args.chunk)
     out = torch.empty(n + args.debug_out_offset, dtype=torch.uint8, device=device)[args.debug_out_offset:]
+    placement = {"candidates": 1}
+    if args.placement_candidates > 1 and not (args.debug_out_offset or args.debug_cont_offset or args.debug_same_chunk):
+        # Setup, untimed: where the buffers lie is worth 4-6 % on this part (two classes of device memory; container and
+        # output in DIFFERENT classes is the fast case, profiles/r04_allocation.md), and which class an allocation gets is
+        # the driver's choice.  Allocate candidates, let the clocks settle on the first pair, time every pair, keep the best.
+        from ryg_rans_amd.placement import choose_pair
+        conts = [cont] + [cont.clone() for _ in range(2)]
+        outs = [out] + [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(args.placement_candidates - 1)]
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            for _ in range(16):
+                ctx.decode(model, cont, total, offs, lens, n, args.ways, args.chunk, d_out=out, sync=False)
+            torch.cuda.synchronize()
+        ci, oi, matrix = choose_pair(torch, lambda c, o: ctx.decode(model, c, total, offs, lens, n, args.ways, args.chunk, d_out=o,
+                                                                    sync=False), conts, outs)
+        cont, out = conts[ci], outs[oi]
+        flat = [v for row in matrix for v in row]
+        placement = {"candidates": {"containers": len(conts), "outputs": len(outs)}, "chosen": [ci, oi],
+                     "probe_ms_chosen": round(matrix[ci][oi], 4), "probe_ms_min": round(min(flat), 4),
+                     "probe_ms_max": round(max(flat), 4), "probe_ms_first_pair": round(matrix[0][0], 4),
+                     "probe_ms": [[round(v, 4) for v in row] for row in matrix],
+                     "note": "setup, untimed: 6 launches x 2 sweeps per pair; the other candidates are freed before the timed region"}
+        del conts, outs
+        torch.cuda.empty_cache()
     if args.debug_cont_offset:
         moved = torch.empty(cont.numel() + args.debug_cont_offset, dtype=torch.uint8, device=device)[args.debug_cont_offset:]
         moved[:total] = cont[:total]
@@ -680,6 +747,7 @@ def main():
             "distributed": {"initialised": use_dist, "backend": args.backend if use_dist else None,
                             "records_gathered_on": ("device (RCCL)" if args.backend == "nccl" else "host") if use_dist else None},
             "prewarm_ms": args.prewarm_ms,
+            "placement": placement,
             "per_rank": {"kernel_ms": [round(r.kernel_ms, 4) for r in records],
                          "elapsed_ms_per_step": [round(r.elapsed_s / args.steps * 1e3, 4) for r in records],
                          "stream_bytes": [int(r.stream_bytes) for r in records],
@@ -755,28 +823,29 @@ def main():
             cfgs = []
             try:
                 ks = args.config_steps
+                cp = min(args.placement_candidates, 4)  # (the `configs` entries: up to four candidates per written buffer)
                 # the headline configuration's encoder
                 e, a = measure_config(torch, R, ctx, "C3 word 64-way 1 GiB (encoder of the headline config)", R.FMT_WORD, 12,
-                                      256, args.ways, args.chunk, args.log2n, 1, ks, device, d_syms=d_syms)
+                                      256, args.ways, args.chunk, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts[0]["entry"] = e  # (the headline's own artefacts: container checked below, CPU loop timed beside it)
                 arts[0]["slots"] = a["slots"]
                 e, a = measure_config(torch, R, ctx, "C2 rans64 2-way 256 MiB Zipf(256)", R.FMT_R64, 14, 256, 2, 512, 28, 1,
-                                      ks, device)
+                                      ks, device, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 e, a = measure_config(torch, R, ctx, "C4 alias 4096 symbols 64-way 512 Mi u16 symbols", R.FMT_ALIAS, 16,
-                                      4096, 64, args.chunk, 29, 1, ks, device)
+                                      4096, 64, args.chunk, 29, 1, ks, device, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256)", R.FMT_BYTE, 14, 256, 64, args.chunk,
-                                      30, 1, ks, device, d_syms=d_syms)
+                                      30, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 # "64-way and wider" (north_star): two and four states per lane over the headline's data
                 for wide in (128, 256):
                     e, a = measure_config(torch, R, ctx, "word %d-way 1 GiB Zipf(256) (%d states per lane)" % (wide, wide // 64),
-                                          R.FMT_WORD, 12, 256, wide, args.chunk, args.log2n, 1, ks, device, d_syms=d_syms)
+                                          R.FMT_WORD, 12, 256, wide, args.chunk, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
                     cfgs.append(e)
                     arts.append(a)
             except Exception as e:  # noqa: BLE001
