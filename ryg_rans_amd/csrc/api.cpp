@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "launchers.hpp"
 #include "model.h"
 
 using namespace rans_amd;
@@ -145,6 +146,7 @@ struct rans_amd_model {
     void *d_alias_recs8 = nullptr, *d_alias_remap16 = nullptr; // alias encoder's LDS tables, when they fit
     void *d_dual0 = nullptr, *d_dual1 = nullptr; // alias: the tables of the two-chunks-per-wave decoder (FMT_ALIAS2)
     void *d_packed = nullptr;                    // rans64: 4-byte slot records (HostModel::r64_packed), when the model has them
+    void *d_fused = nullptr;                     // byte format: 8-byte slot records (HostModel::byte_slots), scale_bits <= 13
     uint32_t table0_bytes = 0, table1_bytes = 0, dual0_bytes = 0, dual1_bytes = 0;
 };
 
@@ -490,6 +492,8 @@ int rans_amd_model_create(rans_amd_ctx *ctx, int format, const uint32_t *norm_fr
         }
         if (rc == RANS_AMD_OK && !h.r64_packed.empty())
             rc = upload(h.r64_packed.data(), h.r64_packed.size() * 4, &m->d_packed);
+        if (rc == RANS_AMD_OK && !h.byte_slots.empty())
+            rc = upload(h.byte_slots.data(), h.byte_slots.size() * sizeof(WordSlot), &m->d_fused);
         break;
     }
     case RANS_AMD_FMT_ALIAS:
@@ -549,7 +553,7 @@ int rans_amd_model_destroy(rans_amd_model *m)
     if (m->device >= 0) { // not m->ctx->device: a model may outlive its context
         DeviceGuard guard(m->device);
         for (void *p : {m->d_table0, m->d_table1, m->d_enc, m->d_word_enc, m->d_remap, m->d_alias_recs8, m->d_alias_remap16,
-                        m->d_dual0, m->d_dual1, m->d_packed})
+                        m->d_dual0, m->d_dual1, m->d_packed, m->d_fused})
             if (p)
                 (void)hipFree(p);
     }
@@ -1053,6 +1057,20 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
             dp.table0_bytes = model->dual0_bytes;
             dp.table1_bytes = model->dual1_bytes;
             dec_format = model->host.alias2_wide ? kKernelFormatAlias2W : kKernelFormatAlias2;
+        }
+        // Byte format, wave-per-chunk decoders: the fused slot records (one gather per symbol) where the model has them and
+        // the table leaves room for two blocks per CU (scale_bits <= 12: 32 KiB; at 13 bits one block per CU -- four waves
+        // per SIMD -- loses to eight with the two-gather tables; RANS_AMD_BYTE_FUSED13=1 in the measure build tries it).
+        // The lane-per-chunk kernels and the two-chunk kernel keep cum2sym + records.
+        static const bool fused13 = measure_knob("RANS_AMD_BYTE_FUSED13") != nullptr;
+        static const bool no_fused = measure_knob("RANS_AMD_NO_BYTE_FUSED") != nullptr;
+        if (dec_format == RANS_AMD_FMT_BYTE && model->d_fused && !no_fused && !lanes_applicable(nchunks, n_ways) &&
+            (model->host.scale_bits <= 12 || fused13)) {
+            dp.table0 = model->d_fused;
+            dp.table0_bytes = (uint32_t)(model->host.byte_slots.size() * sizeof(WordSlot));
+            dp.table1 = model->d_fused;
+            dp.table1_bytes = 0;
+            dec_format = kKernelFormatByteFused;
         }
         // (measure build, RANS_AMD_BYTE_DUAL=1: the byte format through the same kernel -- A/B runs)
         static const bool byte_dual = measure_knob("RANS_AMD_BYTE_DUAL") != nullptr;

@@ -784,7 +784,7 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     uint64_t cap = (uint64_t)num_cus * blocks_per_cu;
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
     if (name)
-        *name = FMT == FMT_WORD ? "k_decode<word>" : FMT == FMT_BYTE ? "k_decode<byte>"
+        *name = FMT == FMT_WORD ? "k_decode<word>" : FMT == FMT_BYTE ? "k_decode<byte>" : FMT == FMT_BYTEF ? "k_decode<byte, slot records>"
                 : FMT == FMT_R64 ? "k_decode<r64>" : FMT == FMT_R64S ? "k_decode<r64 search>"
                 : FMT == FMT_WORD16 ? "k_decode<word, u16 symbols>"
                 : FMT == FMT_BYTEA ? "k_decode<byte, per-chunk models>" : "k_decode<alias>";
@@ -809,6 +809,11 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
     static const bool no_asm = measure_knob("RANS_AMD_NO_ASM") != nullptr;   // compiler-scheduled renorm: -2 %
     static const bool lds_out = measure_knob("RANS_AMD_LDS_OUT") != nullptr;  // output via an LDS tile: -7 %
     static const bool byte_out = measure_knob("RANS_AMD_BYTE_OUT") != nullptr; // per-round byte stores: -5 %
+    if constexpr (FMT == FMT_BYTE || FMT == FMT_BYTEF) { // (measure build: per-round byte stores instead of the register transpose)
+        static const bool byte_fmt_out = measure_knob("RANS_AMD_BYTE_FMT_OUT") != nullptr;
+        if (fast && byte_fmt_out && p.n_ways == 64)
+            return launch_decode_t<FMT, 1, OUT_FAST8_BYTE>(p, num_cus, s, name);
+    }
     if constexpr (FMT == FMT_WORD) {
         if (fast && lds_out && p.n_ways == 64)
             return launch_decode_t<FMT_WORD, 1, OUT_FAST8_LDS>(p, num_cus, s, name);
@@ -866,6 +871,7 @@ hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipSt
     switch (format) {
     case FMT_WORD: return launch_decode_f<FMT_WORD>(p, num_cus, stream, name);
     case FMT_BYTE: return launch_decode_f<FMT_BYTE>(p, num_cus, stream, name);
+    case FMT_BYTEF: return launch_decode_f<FMT_BYTEF>(p, num_cus, stream, name);
     case FMT_R64: return launch_decode_f<FMT_R64>(p, num_cus, stream, name);
     case FMT_BYTEA: return launch_decode_f<FMT_BYTEA>(p, num_cus, stream, name);
     case FMT_WORD16: { // u16 symbols: paired-round stores for full waves, element stores otherwise

@@ -49,8 +49,13 @@ constexpr int FMT_BYTEA = 7;
 constexpr int FMT_ALIAS2 = 8;
 constexpr int FMT_ALIAS2W = 9;
 template <int FMT> constexpr bool kIsAlias2 = (FMT == FMT_ALIAS2 || FMT == FMT_ALIAS2W);
+// Internal kernel format of the DECODER: the byte format (RANS_AMD_FMT_BYTE to the caller) with the slot table of the word
+// format -- one 8-byte record {freq | sym << 24, slot - start} per cumulative slot at LDS address 8 * slot -- for models whose
+// table fits beside the stream windows (scale_bits <= 13).  D step: v_and, v_lshlrev, ds_read_b64, v_lshrrev, v_mad_u32_u24
+// (rans_byte.h:125-128 + :291-298 as rans_word_sse41.h:123-131 does it): one gather instead of two dependent ones.
+constexpr int FMT_BYTEF = 11;
 template <int FMT> constexpr bool kIsByteStream = (FMT == FMT_BYTE || FMT == FMT_ALIAS || FMT == FMT_ALIAS_LDS || FMT == FMT_BYTEA ||
-                                                   kIsAlias2<FMT>);
+                                                   kIsAlias2<FMT> || FMT == FMT_BYTEF);
 template <int FMT> constexpr bool kIsWord = (FMT == FMT_WORD || FMT == FMT_WORD16);
 
 // OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
@@ -93,6 +98,9 @@ template <> struct FmtTraits<FMT_R64> {
 template <> struct FmtTraits<FMT_R64S> : FmtTraits<FMT_R64> {};
 template <> struct FmtTraits<FMT_ALIAS_LDS> : FmtTraits<FMT_ALIAS> {};
 template <> struct FmtTraits<FMT_BYTEA> : FmtTraits<FMT_BYTE> {};
+template <> struct FmtTraits<FMT_BYTEF> : FmtTraits<FMT_BYTE> {
+    static constexpr int kSymByte = 3; // the slot record keeps the symbol in the top byte of its first word
+};
 template <> struct FmtTraits<FMT_ALIAS2> : FmtTraits<FMT_ALIAS> {};
 template <> struct FmtTraits<FMT_ALIAS2W> : FmtTraits<FMT_ALIAS> {};
 template <> struct FmtTraits<FMT_WORD16> : FmtTraits<FMT_WORD> {
@@ -210,6 +218,12 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         // freq <= 2^16 and x >> scale_bits < 2^23 (scale_bits >= 8): 24-bit multiply is exact
         x = (r.x & 0xffffffu) * ((x >> T.sbv) & 0xffffffu) + cf - r.y;
         return s;
+    } else if constexpr (FMT == FMT_BYTEF) {
+        // the fused slot record at LDS address 8 * slot (the table is the first thing in LDS): freq <= 2^13 and
+        // x >> scale_bits < 2^23 (scale_bits >= 8): the 24-bit multiply-add is exact, its mask drops the symbol byte
+        const u32x2 e = *reinterpret_cast<RANS_LDS const u32x2 *>((uintptr_t)((x & T.maskv) << 3));
+        x = (e.x & 0xffffffu) * ((x >> T.sbv) & 0xffffffu) + e.y;
+        return e.x;
     } else if constexpr (FMT == FMT_BYTEA) {
         // the same through the wave's own table pointers (per-chunk models)
         const uint32_t cf = x & T.maskv;

@@ -21,7 +21,7 @@ hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_
     if (format == kKernelFormatByteDual)
         return launch_decode_dual((int)RANS_AMD_FMT_BYTE, p, num_cus, stream, kernel_name);
     if (format != kKernelFormatR64Search && format != kKernelFormatWord16 && format != kKernelFormatByteAdaptive &&
-        lanes_applicable(p.nchunks, p.n_ways))
+        format != kKernelFormatByteFused && lanes_applicable(p.nchunks, p.n_ways))
         return launch_decode_lanes(format, p, num_cus, stream, kernel_name);
     return launch_decode_wave(format, p, num_cus, stream, kernel_name);
 }

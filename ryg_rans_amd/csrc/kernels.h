@@ -62,6 +62,9 @@ constexpr int kKernelFormatAlias2 = 8;
 constexpr int kKernelFormatAlias2W = 9;
 // The byte format (tables as for RANS_AMD_FMT_BYTE) through the two-chunks-per-wave decoder.
 constexpr int kKernelFormatByteDual = 10;
+// Kernel-side format number of the byte-format DECODER with one fused 8-byte record per slot (device_common.hpp FMT_BYTEF):
+// DecParams::table0 = {freq | sym << 24, slot - start}[1 << scale_bits], no table1.
+constexpr int kKernelFormatByteFused = 11;
 constexpr uint32_t kTraceWords = 5;      // per-wave record of DecParams::trace
 
 struct DecParams {

@@ -207,6 +207,20 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
         }
     }
 
+    byte_slots.clear();
+    if (fmt == RANS_AMD_FMT_BYTE && ns <= 256 && sb <= 13 && sb >= 8) {
+        bool fits = true; // (a frequency of M = 2^sb <= 8192 fits the record's 24 bits; kept as a guard)
+        for (uint32_t s = 0; s < ns; ++s)
+            fits = fits && freqs[s] < (1u << 24);
+        if (fits) {
+            byte_slots.resize(M);
+            for (uint32_t slot = 0; slot < M; ++slot) {
+                const uint32_t s = cum2sym[slot];
+                byte_slots[slot] = WordSlot{freqs[s] | (s << 24), slot - cum[s]};
+            }
+        }
+    }
+
     // per-symbol records
     sym_recs.resize(ns);
     enc_recs.resize(ns);

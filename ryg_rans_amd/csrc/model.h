@@ -117,6 +117,10 @@ struct HostModel {
     // rans64 with a cum2sym table, byte symbols, scale_bits <= 14 and no frequency above 4095: one 4-byte record per slot,
     // freq | (slot - start) << 12 | sym << 24 (k_decode_lanes_r64x2<packed>: one gather per symbol instead of two)
     std::vector<uint32_t> r64_packed;
+    // byte format, byte symbols, scale_bits <= 13: one 8-byte record per cumulative slot, {freq | sym << 24, slot - start} --
+    // rans_word_sse41.h:64-72's slot table for a caller-chosen scale_bits: the decoder's D step is ONE gather and one
+    // v_mad_u32_u24 where cum2sym + {freq, start} are two dependent gathers and a subtract (FMT_BYTEF; 8 << scale_bits bytes)
+    std::vector<WordSlot> byte_slots;
 
     // alias (main_alias.cpp:56-63)
     std::vector<uint32_t> divider, slot_adjust, slot_freqs, sym_id, alias_remap;
