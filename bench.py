@@ -842,6 +842,11 @@ def main():
                                       30, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
+                # the byte format at 12-bit probabilities: the decoder's fused slot records (one LDS gather per symbol, round 4)
+                e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256), scale_bits 12 (slot-record decoder)",
+                                      R.FMT_BYTE, 12, 256, 64, args.chunk, 30, 1, ks, device, d_syms=d_syms, probe=cp)
+                cfgs.append(e)
+                arts.append(a)
                 # "64-way and wider" (north_star): two and four states per lane over the headline's data
                 for wide in (128, 256):
                     e, a = measure_config(torch, R, ctx, "word %d-way 1 GiB Zipf(256) (%d states per lane)" % (wide, wide // 64),
@@ -858,7 +863,7 @@ def main():
                 checked = {}
                 t_or = time.perf_counter()
                 for a in arts:
-                    key = "%s/%d-way/%d" % (R.FORMAT_NAMES[a["fmt"]], a["ways"], a["chunk"])
+                    key = "%s-%d/%d-way/%d" % (R.FORMAT_NAMES[a["fmt"]], a["sb"], a["ways"], a["chunk"])
                     checked[key] = oracle_check_chunks(a, args.oracle_sample)
                     if a["entry"] is not None:
                         a["entry"]["oracle_chunks_checked"] = checked[key]
@@ -869,7 +874,7 @@ def main():
                             dict(a, cont=sl["cont"], offs=sl["offs"], lens=sl["lens"], total=sl["total"], slot=sl["slot"]),
                             args.oracle_sample)
                         del sl["cont"]
-                result["oracle_chunks_checked"] = checked["%s/%d-way/%d" % (args.format, args.ways, args.chunk)]
+                result["oracle_chunks_checked"] = checked["%s-%d/%d-way/%d" % (args.format, sb, args.ways, args.chunk)]
                 result["oracle_chunks_total"] = (n + args.chunk - 1) // args.chunk
                 result["oracle_chunks_checked_all"] = checked
                 # ... and the other direction: the headline decoder on a container the ORACLE made

@@ -1966,11 +1966,18 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
             const size_t table_lds3 = packed ? packed_lds : table_lds;
             uint32_t sw3 = (uint32_t)((160 * 1024 - table_lds3) / kR64WaveLds);
             sw3 = sw3 > 16 ? 16 : sw3;
+            // (measure build, RANS_AMD_R64_WAVES=n: fewer resident waves per CU than the LDS allows -- the occupancy scan of
+            //  profiles/r04_c2_bound.md)
+            static const char *cap_waves = measure_knob("RANS_AMD_R64_WAVES");
+            const bool capped = cap_waves && atoi(cap_waves) > 0 && (uint32_t)atoi(cap_waves) < sw3;
+            if (capped)
+                sw3 = (uint32_t)atoi(cap_waves);
             const uint64_t batches = (full + 63) / 64;
             const uint64_t per_cu = (batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
             const uint64_t rounds = (per_cu + sw3 - 1) / sw3;
             const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
-            sw3 = (uint32_t)(even ? even : 1);
+            if (!capped) // (a capped scan keeps the wave count it asked for: its last round may be ragged)
+                sw3 = (uint32_t)(even ? even : 1);
             auto kern3 = packed ? k_decode_lanes_r64x2<true> : k_decode_lanes_r64x2<false>;
             static std::atomic<uint64_t> lds_ok3[2] = {{0}, {0}};
             if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern3), 160 * 1024, lds_ok3[packed]); e != hipSuccess)

@@ -1123,3 +1123,43 @@ def test_staged_encoders_with_the_three_kernel_placement(gpu, oracle, fmt, sb):
             assert np.array_equal(out.cpu().numpy(), data)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("sb", [8, 10, 12])
+def test_byte_format_slot_record_decoder(gpu, oracle, sb):
+    """Byte format with scale_bits <= 12: the wave-per-chunk decoders read ONE fused 8-byte record per symbol
+    ({freq | sym << 24, slot - start}, rans_byte.h:125-128 + 291-298 in the form of rans_word_sse41.h:123-131) instead of
+    cum2sym + {freq, start}: containers made by the ORACLE decode to the input for every lane count, ragged chunks, skewed
+    and one-symbol models; at 13 bits and more, and for the lane-per-chunk interleaves, the two-gather tables stay."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(sb)
+    inputs = {"zipf": oracle.gen_zipf(250003, K=256, s=1.0, seed=2),
+              "two": (rng.integers(0, 2, 90001) * 255).astype(np.uint8),
+              "one": np.full(70000, 7, np.uint8)}
+    for name, data in inputs.items():
+        om, gm = _models(R, ctx, oracle, FMT_BYTE, sb, data)
+        for n_ways, chunk in ((64, 4096), (64, 5000), (128, 8192), (256, 16384), (33, 1000), (512, 32768)):
+            cont, offs, lens = oracle.encode_chunked(FMT_BYTE, om, data, n_ways, chunk, align=16)
+            d_cont = torch.from_numpy(np.concatenate([cont, np.zeros(64, np.uint8)])).cuda()
+            d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+            d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+            out = ctx.decode(gm, d_cont, cont.size, d_offs, d_lens, data.size, n_ways, chunk)
+            assert np.array_equal(out.cpu().numpy(), data), (name, n_ways, chunk)
+            assert ctx.last_decode_kernel() == "k_decode<byte, slot records>", ctx.last_decode_kernel()
+            # a flipped stream byte is caught by the same integrity check
+            bad = d_cont.clone()
+            bad[int(offs[1]) + int(lens[1]) // 2] ^= 0x55
+            out2 = torch.empty_like(out)
+            ctx.decode(gm, bad, cont.size, d_offs, d_lens, data.size, n_ways, chunk, d_out=out2, sync=False)
+            assert ctx.decode_errors() >= 1 or not np.array_equal(out2.cpu().numpy(), data)
+    data = inputs["zipf"]
+    om, gm = _models(R, ctx, oracle, FMT_BYTE, 13, data)
+    cont, offs, lens = oracle.encode_chunked(FMT_BYTE, om, data, 64, 4096, align=16)
+    out = ctx.decode(gm, torch.from_numpy(np.concatenate([cont, np.zeros(64, np.uint8)])).cuda(), cont.size,
+                     torch.from_numpy(offs.astype(np.int64)).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda(), data.size, 64, 4096)
+    assert np.array_equal(out.cpu().numpy(), data) and ctx.last_decode_kernel() == "k_decode<byte>"
+    om, gm = _models(R, ctx, oracle, FMT_BYTE, sb, data)
+    cont, offs, lens = oracle.encode_chunked(FMT_BYTE, om, data, 2, 512, align=16)
+    out = ctx.decode(gm, torch.from_numpy(np.concatenate([cont, np.zeros(64, np.uint8)])).cuda(), cont.size,
+                     torch.from_numpy(offs.astype(np.int64)).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda(), data.size, 2, 512)
+    assert np.array_equal(out.cpu().numpy(), data) and ctx.last_decode_kernel().startswith("k_decode_lanes")
