@@ -537,7 +537,14 @@ __device__ __forceinline__ rsrc_t chunk_rsrc(uint64_t cbase, uint64_t cbytes16, 
     return StreamWindow::stream_rsrc(cbase + (off - skip), skip + 64u * 4u, climit < room ? climit : (uint32_t)room);
 }
 
-__global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const DecParams p)
+// (experiment knob, profiles/r04_word64_launch_bounds.md: -DRANS_WORD64_WAVES=14 -DRANS_WORD64_MIN_WAVES=7 builds the kernel
+//  with 72 VGPRs -- no spills -- in blocks of 14 waves, two per CU: seven waves per SIMD instead of eight)
+#ifndef RANS_WORD64_WAVES
+#define RANS_WORD64_WAVES (kDecBlockThreads / 64)
+#define RANS_WORD64_MIN_WAVES 8
+#endif
+constexpr int kWord64Threads = 64 * RANS_WORD64_WAVES;
+__global__ void __launch_bounds__(kWord64Threads, RANS_WORD64_MIN_WAVES) k_decode_word64(const DecParams p)
 {
     using Tr = FmtTraits<FMT_WORD>;
     constexpr uint32_t N = 64;
@@ -750,7 +757,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, 8) k_decode_word64(const Dec
 hipError_t launch_decode_word64(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
     const uint32_t t0 = (p.table0_bytes + 15u) & ~15u;
-    const uint32_t waves = kDecBlockThreads / 64;
+    const uint32_t waves = kWord64Threads / 64;
     const size_t lds = (size_t)t0 + (size_t)waves * kRingStride;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_decode_word64), 160 * 1024, lds_ok); e != hipSuccess)
@@ -760,7 +767,7 @@ hipError_t launch_decode_word64(const DecParams &p, int num_cus, hipStream_t str
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
     if (name)
         *name = "k_decode_word64";
-    RANS_LAUNCH(k_decode_word64, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
+    RANS_LAUNCH(k_decode_word64, dim3(grid), dim3(kWord64Threads), lds, stream, p);
     return hipGetLastError();
 }
 
