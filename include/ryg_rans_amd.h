@@ -367,7 +367,8 @@ int rans_amd_container_pack(const rans_amd_container_info *info, const uint32_t 
                             const uint32_t *lengths, const void *payload, void *dst, uint64_t cap,
                             uint64_t *out_bytes);
 /* Validate and index a serialised container in place: *freqs, *lengths and *payload point INTO
- * src.  RANS_AMD_E_CORRUPT on a bad magic/version/checksum or inconsistent sizes. */
+ * src (which must be 4-byte aligned: RANS_AMD_E_ARG otherwise).  RANS_AMD_E_CORRUPT on a bad
+ * magic/version/checksum or inconsistent sizes; whatever is accepted lies inside [src, src + bytes). */
 int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container_info *info,
                              const uint32_t **freqs, const uint32_t **lengths, const void **payload);
 

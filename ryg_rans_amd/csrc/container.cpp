@@ -4,6 +4,7 @@
 // include/ryg_rans_amd.h for the layout.
 #include "../../include/ryg_rans_amd.h"
 
+#include <cstdint>
 #include <cstring>
 
 namespace {
@@ -166,7 +167,7 @@ int rans_amd_container_pack(const rans_amd_container_info *info, const uint32_t 
 int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container_info *info, const uint32_t **freqs,
                              const uint32_t **lengths, const void **payload)
 {
-    if (!src || !info)
+    if (!src || !info || (reinterpret_cast<uintptr_t>(src) & 3u) != 0) // (the tables are handed back as uint32_t pointers INTO src)
         return RANS_AMD_E_ARG;
     if (bytes < kHeaderBytes)
         return RANS_AMD_E_CORRUPT;
@@ -292,7 +293,7 @@ int rans_amd_container_pack_adaptive(const rans_amd_container_info *info, const 
 int rans_amd_container_parse_adaptive(const void *src, uint64_t bytes, rans_amd_container_info *info,
                                       const uint16_t **chunk_freqs, const uint32_t **lengths, const void **payload)
 {
-    if (!src || !info)
+    if (!src || !info || (reinterpret_cast<uintptr_t>(src) & 3u) != 0)
         return RANS_AMD_E_ARG;
     if (bytes < kHeaderBytes)
         return RANS_AMD_E_CORRUPT;
