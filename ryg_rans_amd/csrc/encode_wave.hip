@@ -241,130 +241,80 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 #ifndef RANS_ENC_STORE // (experiment knob: -DRANS_ENC_STORE='""' drops the stream stores of the word encoder)
 #define RANS_ENC_STORE "global_store_short %[t], %[x], %[base]\n\t"
 #endif
-// rec = WordEncRec {m', cmpl | bias << 12 | sh << 27} (model.h; eight bytes: one ds_read_b64).  SMALL: no frequency of the
-// model exceeds 2048, the renormalised state is below 2^31 and q = mulhi(x, m') >> sh is exact (Alverson,
-// rans_byte.h:201-243): 14 VALU.  Otherwise the round-up method of Granlund & Montgomery for 32-bit dividends,
-// t = mulhi(x, m'); q = (t + ((x - t) >> 1)) >> sh: 17 VALU.  (Round 2's 16-byte record needed 15 and no unpacking, and
-// lost twice as many LDS cycles to the bank conflicts of its gather: the LDS, not the VALU, bounds this kernel.)
+// rec = WordEncRec {m', cmpl << 20, cmpl | sh << 24, bias} (model.h; sixteen bytes: one ds_read_b128, nothing to take
+// apart).  SMALL: no frequency of the model exceeds 2048, the renormalised state is below 2^31 and q = mulhi(x, m') >> sh
+// is exact (Alverson, rans_byte.h:201-243): 10 VALU.  Otherwise the round-up method of Granlund & Montgomery for 32-bit
+// dividends, t = mulhi(x, m'); q = (t + ((x - t) >> 1)) >> sh: 13 VALU.  (Round 3 read an 8-byte record and spent four
+// instructions unpacking it -- 14 / 17 -- because the LDS pipe was the busiest unit then; with the stream staged in LDS
+// windows and, in the slot layout, no copier waves beside the coders, VALU issue is what bounds the loop.)
+//   v_or        bit 31 of cmpl_sh marks a symbol without a record; OR-accumulated, looked at once per chunk
+//   v_add_co    carry of x + (cmpl << 20)  <=>  x >= freq << 20 (rans_word_sse41.h:85): the lanes that emit
+//   v_mbcnt x2, v_lshl_add   rank among the emitting lanes -> place of the lane's word
+//   store + v_lshrrev under the emit mask
+//   v_mul_hi, v_lshrrev (count = byte 3 of cmpl_sh: SDWA), v_mad_u32_u24 (q < 2^20, cmpl in the low 24 bits), v_add bias
+#define RANS_ENC_WORD_HEAD                                       \
+    "v_or_b32_e32 %[worst], %[worst], %[cs]\n\t"                  \
+    "v_add_co_u32_e32 %[t], vcc, %[ad], %[x]\n\t"                 \
+    "s_bcnt1_i32_b64 %[cnt], vcc\n\t"                             \
+    "s_lshl_b32 %[cnt], %[cnt], 1\n\t"                            \
+    "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"                          \
+    "s_mov_b64 exec, vcc\n\t"                                     \
+    "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                      \
+    "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"                   \
+    "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
+#define RANS_ENC_WORD_TAIL_SMALL                                  \
+    "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"                        \
+    "s_mov_b64 exec, -1\n\t"                                      \
+    "v_mul_hi_u32 %[q], %[x], %[m]\n\t"                           \
+    "v_lshrrev_b32_sdwa %[q], %[cs], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
+    "v_mad_u32_u24 %[q], %[q], %[cs], %[x]\n\t"                   \
+    "v_add_u32_e32 %[x], %[q], %[bias]"
+#define RANS_ENC_WORD_TAIL_GM                                     \
+    "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"                        \
+    "s_mov_b64 exec, -1\n\t"                                      \
+    "v_mul_hi_u32 %[q], %[x], %[m]\n\t"                           \
+    "v_sub_u32_e32 %[t], %[x], %[q]\n\t"                          \
+    "v_lshrrev_b32_e32 %[t], 1, %[t]\n\t"                         \
+    "v_add_u32_e32 %[q], %[q], %[t]\n\t"                          \
+    "v_lshrrev_b32_sdwa %[q], %[cs], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
+    "v_mad_u32_u24 %[q], %[q], %[cs], %[x]\n\t"                   \
+    "v_add_u32_e32 %[x], %[q], %[bias]"
 template <bool SMALL>
-__device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x2 &rec, uint32_t &wp,
-                                              const uint8_t RANS_GLOBAL *slot, uint32_t &worst, uint32_t m12)
+__device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x4 &rec, uint32_t &wp,
+                                              const uint8_t RANS_GLOBAL *slot, uint32_t &worst)
 {
-    uint32_t t, q, c, cnt;
+    uint32_t t, q, cnt;
     if constexpr (SMALL) {
-        asm volatile("v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
-                     "v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
-                     "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
-                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                     "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
-                     "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
-                     "s_mov_b64 exec, vcc\n\t"
-                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                     "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
-                     RANS_ENC_STORE
-                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                     "s_mov_b64 exec, -1\n\t"
-                     "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
-                     "v_lshrrev_b32_e32 %[t], 27, %[w]\n\t"
-                     "v_and_b32_e32 %[c], %[m12], %[w]\n\t"
-                     "v_lshrrev_b32_e32 %[q], %[t], %[q]\n\t"
-                     "v_bfe_u32 %[t], %[w], 12, 13\n\t"
-                     "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
-                     "v_add_u32_e32 %[x], %[q], %[t]"
-                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12), [base] "s"(slot)
+        asm volatile(RANS_ENC_WORD_HEAD RANS_ENC_STORE RANS_ENC_WORD_TAIL_SMALL
+                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [cnt] "=&s"(cnt)
+                     : [m] "v"(rec.x), [ad] "v"(rec.y), [cs] "v"(rec.z), [bias] "v"(rec.w), [base] "s"(slot)
                      : "vcc", "scc", "memory");
     } else {
-        asm volatile("v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
-                     "v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
-                     "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
-                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                     "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
-                     "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
-                     "s_mov_b64 exec, vcc\n\t"
-                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                     "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
-                     RANS_ENC_STORE
-                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                     "s_mov_b64 exec, -1\n\t"
-                     "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
-                     "v_sub_u32_e32 %[t], %[x], %[q]\n\t"
-                     "v_lshrrev_b32_e32 %[t], 1, %[t]\n\t"
-                     "v_add_u32_e32 %[q], %[q], %[t]\n\t"
-                     "v_lshrrev_b32_e32 %[t], 27, %[w]\n\t"
-                     "v_and_b32_e32 %[c], %[m12], %[w]\n\t"
-                     "v_lshrrev_b32_e32 %[q], %[t], %[q]\n\t"
-                     "v_bfe_u32 %[t], %[w], 12, 13\n\t"
-                     "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
-                     "v_add_u32_e32 %[x], %[q], %[t]"
-                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12), [base] "s"(slot)
+        asm volatile(RANS_ENC_WORD_HEAD RANS_ENC_STORE RANS_ENC_WORD_TAIL_GM
+                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [cnt] "=&s"(cnt)
+                     : [m] "v"(rec.x), [ad] "v"(rec.y), [cs] "v"(rec.z), [bias] "v"(rec.w), [base] "s"(slot)
                      : "vcc", "scc", "memory");
     }
 }
 
 // The same with the emitted words staged in LDS: `wp` is an LDS address here, the write pointer into the wave's 2 KiB
 // window (one ds_write_b16 per round instead of one global_store_short: the per-round stores were 4.3e7 write requests
-// of 19 bytes on the 1 GiB encode and kept the address unit 87 % busy, profiles/r03_encoder_bound.md; the LDS pipe is 18 %
-// busy since the records are eight bytes).  stage_flush() in the kernel moves what sixteen rounds have produced to memory
-// in whole 16-byte pieces and sets the pointer back to the top of the window, so it never wraps.
+// of 19 bytes on the 1 GiB encode and kept the address unit 87 % busy, profiles/r03_encoder_bound.md).  stage_flush() in
+// the kernel moves what sixteen rounds have produced to memory in whole 16-byte pieces and sets the pointer back to the
+// top of the window, so it never wraps.
 template <bool SMALL>
-__device__ __forceinline__ void enc_word_full_staged(uint32_t &x, const u32x2 &rec, uint32_t &wp,
-                                              uint32_t &worst, uint32_t m12)
+__device__ __forceinline__ void enc_word_full_staged(uint32_t &x, const u32x4 &rec, uint32_t &wp, uint32_t &worst)
 {
-    uint32_t t, q, c, cnt;
+    uint32_t t, q, cnt;
     if constexpr (SMALL) {
-        asm volatile("v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
-                     "v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
-                     "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
-                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                     "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
-                     "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
-                     "s_mov_b64 exec, vcc\n\t"
-                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                     "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
-                     "ds_write_b16 %[t], %[x]\n\t"
-                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                     "s_mov_b64 exec, -1\n\t"
-                     "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
-                     "v_lshrrev_b32_e32 %[t], 27, %[w]\n\t"
-                     "v_and_b32_e32 %[c], %[m12], %[w]\n\t"
-                     "v_lshrrev_b32_e32 %[q], %[t], %[q]\n\t"
-                     "v_bfe_u32 %[t], %[w], 12, 13\n\t"
-                     "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
-                     "v_add_u32_e32 %[x], %[q], %[t]"
-                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12)
+        asm volatile(RANS_ENC_WORD_HEAD "ds_write_b16 %[t], %[x]\n\t" RANS_ENC_WORD_TAIL_SMALL
+                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [cnt] "=&s"(cnt)
+                     : [m] "v"(rec.x), [ad] "v"(rec.y), [cs] "v"(rec.z), [bias] "v"(rec.w)
                      : "vcc", "scc", "memory");
     } else {
-        asm volatile("v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
-                     "v_lshlrev_b32_e32 %[t], 20, %[w]\n\t"
-                     "v_add_co_u32_e32 %[t], vcc, %[t], %[x]\n\t"
-                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                     "s_lshl_b32 %[cnt], %[cnt], 1\n\t"
-                     "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"
-                     "s_mov_b64 exec, vcc\n\t"
-                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                     "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
-                     "ds_write_b16 %[t], %[x]\n\t"
-                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                     "s_mov_b64 exec, -1\n\t"
-                     "v_mul_hi_u32 %[q], %[x], %[m]\n\t"
-                     "v_sub_u32_e32 %[t], %[x], %[q]\n\t"
-                     "v_lshrrev_b32_e32 %[t], 1, %[t]\n\t"
-                     "v_add_u32_e32 %[q], %[q], %[t]\n\t"
-                     "v_lshrrev_b32_e32 %[t], 27, %[w]\n\t"
-                     "v_and_b32_e32 %[c], %[m12], %[w]\n\t"
-                     "v_lshrrev_b32_e32 %[q], %[t], %[q]\n\t"
-                     "v_bfe_u32 %[t], %[w], 12, 13\n\t"
-                     "v_mad_u32_u24 %[q], %[q], %[c], %[x]\n\t"
-                     "v_add_u32_e32 %[x], %[q], %[t]"
-                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [c] "=&v"(c), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [w] "v"(rec.y), [m12] "v"(m12)
+        asm volatile(RANS_ENC_WORD_HEAD "ds_write_b16 %[t], %[x]\n\t" RANS_ENC_WORD_TAIL_GM
+                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [cnt] "=&s"(cnt)
+                     : [m] "v"(rec.x), [ad] "v"(rec.y), [cs] "v"(rec.z), [bias] "v"(rec.w)
                      : "vcc", "scc", "memory");
     }
 }
@@ -387,7 +337,7 @@ __device__ __forceinline__ void enc_byte_full(uint32_t &x, const u32x4 &rec, uin
     uint32_t t, r, q, c1, c2;
     asm volatile("v_cmp_ge_u32_e32 vcc, %[x], %[xm]\n\t"
                  "v_lshrrev_b32_e32 %[t], 8, %[x]\n\t"
-                 "v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                 "v_or_b32_e32 %[worst], %[worst], %[w]\n\t"
                  "v_cmp_ge_u32_e64 s[34:35], %[t], %[xm]\n\t"
                  "s_bcnt1_i32_b64 %[c1], vcc\n\t"
                  "s_bcnt1_i32_b64 %[c2], s[34:35]\n\t"
@@ -424,7 +374,7 @@ __device__ __forceinline__ void enc_byte_full_staged(uint32_t &x, const u32x4 &r
     uint32_t t, r, q, c1, c2;
     asm volatile("v_cmp_ge_u32_e32 vcc, %[x], %[xm]\n\t"
                  "v_lshrrev_b32_e32 %[t], 8, %[x]\n\t"
-                 "v_max_u32_e32 %[worst], %[worst], %[w]\n\t"
+                 "v_or_b32_e32 %[worst], %[worst], %[w]\n\t"
                  "v_cmp_ge_u32_e64 s[34:35], %[t], %[xm]\n\t"
                  "s_bcnt1_i32_b64 %[c1], vcc\n\t"
                  "s_bcnt1_i32_b64 %[c2], s[34:35]\n\t"
@@ -578,9 +528,9 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
     constexpr uint32_t kWordRecBytes = (FMT == FMT_WORD || FMT == FMT_BYTE) ? 256u * 16u : 0u; // (word: 2 KiB of it in use)
     if constexpr (FMT == FMT_WORD) {
         if (p.word_enc_recs) { // (absent for alphabets beyond 256 symbols: they never take the full-wave path)
-            const uint4 *g = reinterpret_cast<const uint4 *>(p.word_enc_recs); // 256 records of 8 bytes
+            const uint4 *g = reinterpret_cast<const uint4 *>(p.word_enc_recs); // 256 records of 16 bytes
             uint4 *l = reinterpret_cast<uint4 *>(smem);
-            for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x)
+            for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x)
                 l[i] = g[i];
         }
     }
@@ -811,14 +761,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             }
         } else if (fast_rounds) {
             uint32_t rec_mask = 0xff0u, swap_sel = 0x0c0c0001u; // (v_perm selector: the low two bytes swapped, zeros above)
-            uint32_t k3v = 3u, m12v = 0xfffu; // (word format: 8-byte records)
+            uint32_t k3v = 4u; // (word format: 16-byte records; the name is round 3's, when they had eight)
             asm volatile("" : "+v"(k3v)); // (SDWA takes no literal; a VGPR operand is also the faster VALU form)
-            asm volatile("" : "+v"(m12v));
             if (kMeasureBuild && (p.debug & 4u)) // measurement only: every lane reads record 0 (word format: or, symbols with bit 0
                 rec_mask = 0u, k3v = 31u;        // set, an address beyond the LDS, which reads zeros) -- what the bank conflicts of
                                                  // the record gather cost; the output is wrong by construction
             (void)k3v;
-            (void)m12v;
             asm volatile("" : "+v"(rec_mask)); // keep the mask in a VGPR (a literal operand costs a slower VALU form)
             asm volatile("" : "+v"(swap_sel));
             // byte format: the hand-written sub-step needs its records at LDS address 0 and the one model of the launch
@@ -920,20 +868,20 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                             asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(at) : "v"(k3v), "v"(t[k]));
                         else
                             asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(at) : "v"(k3v), "v"(t[k]));
-                        return *reinterpret_cast<const __attribute__((address_space(3))) u32x2 *>((uintptr_t)at); // table at LDS address 0
+                        return *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>((uintptr_t)at); // table at LDS address 0
                     };
-                    u32x2 rec = rec_at(0);
+                    u32x4 rec = rec_at(0);
                     wp = uniform(wp); // (asm results count as divergent: say what they are, or the "s" operands below get VGPRs)
                     lp = uniform(lp);
 #pragma unroll
                     for (int step = 0; step < 4 * K; ++step) {
-                        const u32x2 now = rec;
+                        const u32x4 now = rec;
                         if (step + 1 < 4 * K)
                             rec = rec_at(step + 1);
                         if constexpr (kStage)
-                            enc_word_full_staged<kSmall>(x[K - 1 - step % K], now, lp, worst, m12v);
+                            enc_word_full_staged<kSmall>(x[K - 1 - step % K], now, lp, worst);
                         else
-                            enc_word_full<kSmall>(x[K - 1 - step % K], now, wp, slot, worst, m12v);
+                            enc_word_full<kSmall>(x[K - 1 - step % K], now, wp, slot, worst);
                     }
                     wp = uniform(wp);
                     lp = uniform(lp);
@@ -990,7 +938,10 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 fast_loop(std::false_type{});
         }
 
-        if (worst > (FMT == FMT_WORD ? 0x7fffffffu : 0x0fffffffu)) // (a symbol without a record: all ones in the word v_max tracks)
+        // (a symbol without a record: word format -- bit 31 of the OR over the records' cmpl_sh words; byte format -- its
+        //  second word is all ones where a real one keeps cmpl | rshift << 24 below 2^28: the OR of them shows it too, and
+        //  v_or issues in the fast VALU class where v_max does not)
+        if (worst > (FMT == FMT_WORD ? 0x7fffffffu : 0x0fffffffu))
             bad = true;
         // flush: lane N-1 first, i.e. lane 0's state ends up first in memory
         // (main.cpp:244-245, main_simd.cpp:298-299)

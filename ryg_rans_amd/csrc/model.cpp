@@ -294,23 +294,25 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
             word_small = false;
 #endif
         if (ns <= 256)
-            word_enc_recs.assign(256, WordEncRec{0u, 0xffffffffu});
-        auto pack = [](uint32_t cmpl, uint32_t bias, uint32_t sh) { return cmpl | (bias << 12) | (sh << 27); };
+            word_enc_recs.assign(256, WordEncRec{0u, 0u, 0x80000000u, 0u});
+        auto rec16 = [](uint32_t mprime, uint32_t cmpl, uint32_t bias, uint32_t sh) {
+            return WordEncRec{mprime, cmpl << 20, cmpl | (sh << 24), bias};
+        };
         for (uint32_t s = 0; s < ns && ns <= 256; ++s) {
             const uint32_t f = freqs[s];
             if (f == 0)
                 continue;
             if (f == 1) { // q = x - 1 either way: mulhi(x, 2^32 - 1) = x - 1, no shift; bias = start + M - 1 (13 bits)
-                word_enc_recs[s] = WordEncRec{0xffffffffu, pack(M - 1, cum[s] + M - 1, 0)};
+                word_enc_recs[s] = rec16(0xffffffffu, M - 1, cum[s] + M - 1, 0);
                 continue;
             }
             const uint32_t l = ceil_log2(f);
             if (word_small) { // x < 2^31 after renormalisation: Alverson (rans_byte.h:201-243), q = mulhi(x, rcp) >> (l - 1)
                 const uint32_t rcp = (uint32_t)((((uint64_t)1 << (l + 31)) + f - 1) / f);
-                word_enc_recs[s] = WordEncRec{rcp, pack(M - f, cum[s], l - 1)};
+                word_enc_recs[s] = rec16(rcp, M - f, cum[s], l - 1);
             } else {
                 const uint64_t mprime = (((uint64_t)1 << 32) * (((uint64_t)1 << l) - f)) / f + 1;
-                word_enc_recs[s] = WordEncRec{(uint32_t)mprime, pack(M - f, cum[s], l - 1)};
+                word_enc_recs[s] = rec16((uint32_t)mprime, M - f, cum[s], l - 1);
             }
         }
     }

@@ -93,11 +93,23 @@ struct EncRec {
 //            round-up method above
 //   packed   cmpl (bits 0..11) | bias (bits 12..24) | sh (bits 27..31); packed << 20 is cmpl << 20 = 2^32 - (freq << 20),
 //            the addend whose carry out of x is the renormalisation test (rans_word_sse41.h:85).  No record: 0xffffffff.
+// Round 4: sixteen bytes again, one ds_read_b128, every field where the instruction that uses it wants it.  With the
+// slot layout (rans_amd_encode_slots) nothing but the coding loop is left in the kernel and its VALU issue is the bound
+// (LDS pipe 30 % busy): the four instructions that took the 8-byte record apart -- a slow-class v_lshlrev and v_bfe among
+// them -- are worth more than the LDS cycles of the wider gather (9.7 against 4.9 per wave instruction).
+//   mprime   as above
+//   addend   cmpl << 20: the carry of x + addend is the renormalisation test (rans_word_sse41.h:85)
+//   cmpl_sh  cmpl (bits 0..11; v_mad_u32_u24 reads the low 24 bits as they are) | sh << 24 (the shift takes its count from
+//            byte 3: SDWA).  No record: 0x80000000 -- bit 31 is what the kernel OR-accumulates to find such a symbol --
+//            with addend 0 (never emits), mprime 0 and bias 0 (the state stays put)
+//   bias     start (freq >= 2) or start + 4095 (freq == 1)
 struct WordEncRec {
     uint32_t mprime;
-    uint32_t packed;
+    uint32_t addend;
+    uint32_t cmpl_sh;
+    uint32_t bias;
 };
-static_assert(sizeof(WordEncRec) == 8, "one ds_read_b64");
+static_assert(sizeof(WordEncRec) == 16, "one ds_read_b128");
 
 int count_freqs_host(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *freqs);
 int normalize_freqs(uint32_t *freqs, uint32_t *cum, uint32_t nsyms, uint32_t target_total);
