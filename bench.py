@@ -806,7 +806,7 @@ def main():
         # (tools/profile.sh -> tools/summarize_profile.py -> profiles/<tag>_traffic.json); PMC passes cannot
         # share a process with the timed run, so a committed measurement is quoted only when it was taken on
         # this workload AND on the kernel sources of this checkout (its `kernel_source_tag`), else null.
-        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r03_traffic.json"))
+        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r04_traffic.json"))
         default_workload = (args.format == "word" and args.ways == 64 and args.chunk == 16384 and args.log2n == 30)
         if os.path.exists(tj) and default_workload:
             try:

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs --prewarm-ms 0 ${BENCH_ARGS:-}"
+BENCH="python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs --prewarm-ms 0 --placement-candidates 1 ${BENCH_ARGS:-}"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES SQ_INST_CYCLES_SALU" \

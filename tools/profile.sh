@@ -16,7 +16,7 @@ cat "$OUT/${TAG}_bench.json"
 # kernel durations of the same command (the `configs` entries included: every dominant kernel shows up)
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/${TAG}_stats" -o stats -- $BENCH --no-cpu-baseline > "$OUT/${TAG}_stats.log" 2>&1
 # counter passes: no clock pre-warm (hundreds of launches under the counter collector), 5 steps, headline only
-PMC="$BENCH --no-cpu-baseline --no-configs --prewarm-ms 0 --steps 5"
+PMC="$BENCH --no-cpu-baseline --no-configs --prewarm-ms 0 --steps 5 --placement-candidates 1"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$OUT/${TAG}_pmc_fetch" -o pmc -- $PMC > "$OUT/${TAG}_pmc_fetch.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$OUT/${TAG}_pmc_write" -o pmc -- $PMC > "$OUT/${TAG}_pmc_write.log" 2>&1
 find "$OUT" -name "*.csv" | head -30
