@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             }
         } else if (fast_rounds) {
             uint32_t rec_mask = 0xff0u, swap_sel = 0x0c0c0001u; // (v_perm selector: the low two bytes swapped, zeros above)
-            uint32_t k3v = 4u; // (word format: 16-byte records; the name is round 3's, when they had eight)
+            uint32_t k3v = 4u; // (word and byte format: 16-byte records; the name is round 3's, when the word format had eight)
             asm volatile("" : "+v"(k3v)); // (SDWA takes no literal; a VGPR operand is also the faster VALU form)
             if (kMeasureBuild && (p.debug & 4u)) // measurement only: every lane reads record 0 (word format: or, symbols with bit 0
                 rec_mask = 0u, k3v = 31u;        // set, an address beyond the LDS, which reads zeros) -- what the bank conflicts of
@@ -889,7 +889,15 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                     if constexpr (FMT == FMT_BYTE) { // (the same walk over the 4 K symbols as the word format's)
                         auto rec_at = [&](int step) {
                             const int J = 3 - step / K, k = K - 1 - step % K;
-                            const uint32_t at = (J == 0 ? (t[k] << 4) : (t[k] >> (8 * J - 4))) & rec_mask;
+                            uint32_t at; // byte J of t[k] times the sixteen bytes of a record: one SDWA shift (round 4; shift + mask before)
+                            if (J == 3)
+                                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(at) : "v"(k3v), "v"(t[k]));
+                            else if (J == 2)
+                                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(at) : "v"(k3v), "v"(t[k]));
+                            else if (J == 1)
+                                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(at) : "v"(k3v), "v"(t[k]));
+                            else
+                                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(at) : "v"(k3v), "v"(t[k]));
                             return *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>((uintptr_t)at); // table at LDS address 0
                         };
                         u32x4 rec = rec_at(0);
