@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--shifts", default="0,256,4096,65536,1048576,2097152,33554432,34603008,1073741824")
     ap.add_argument("--torch-pairs", type=int, default=6)
     ap.add_argument("--hip-pairs", type=int, default=4)
+    ap.add_argument("--ext-flags", default="", help="comma-separated hipExtMallocWithFlags flags to try, e.g. 0x4,0x1,0x3")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = R.Context(0)
@@ -79,6 +80,19 @@ def main():
         assert h.hipMalloc(C.byref(pc), nb + 4096) == 0 and h.hipMalloc(C.byref(po), n + 4096) == 0
         assert h.hipMemcpy(pc, C.c_void_p(cont.data_ptr()), nb, 3) == 0  # hipMemcpyDeviceToDevice
         places.append(("hip%d" % i, pc.value, po.value))
+    if a.ext_flags:
+        # hipExtMallocWithFlags: 0x4 contiguous, 0x1 fine-grained, 0x3 uncached (hip_runtime_api.h:879-891): does a flag
+        # choose the memory class?  (one pair per flag, and mixed pairs with plain hipMalloc)
+        h.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+        for fl in [int(v, 0) for v in a.ext_flags.split(",")]:
+            pc, po = C.c_void_p(), C.c_void_p()
+            if h.hipExtMallocWithFlags(C.byref(pc), nb + 4096, fl) != 0 or h.hipExtMallocWithFlags(C.byref(po), n + 4096, fl) != 0:
+                print("  hipExtMallocWithFlags(%#x) refused" % fl, flush=True)
+                continue
+            assert h.hipMemcpy(pc, C.c_void_p(cont.data_ptr()), nb, 3) == 0
+            places.append(("ext%#x" % fl, pc.value, po.value))
+            places.append(("ext%#x-out" % fl, places[0][1], po.value))   # torch0's container, this output
+            places.append(("ext%#x-cont" % fl, pc.value, places[0][2]))  # this container, torch0's output
     print("placements:", flush=True)
     for name, c, o in places:
         print("  %-16s cont %#x  out %#x  (out - cont) mod 2 MiB = %d KiB, mod 1 GiB = %d MiB" % (
