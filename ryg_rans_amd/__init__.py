@@ -359,14 +359,15 @@ class Context:
                                           C.byref(total) if sync else None, _torch_stream()), "encode_slots")
         return d_out, d_offsets, d_lengths, (total.value if sync else None)
 
-    def compact(self, d_src, src_bytes, d_src_offsets, d_lengths, n_chunks, d_dst=None, sync=True):
+    def compact(self, d_src, src_bytes, d_src_offsets, d_lengths, n_chunks, d_dst=None, sync=True, d_dst_offsets=None):
         """rans_amd_container_compact: -> (d_dst, d_dst_offsets, total_bytes)."""
         import torch
         dev = d_src.device
         if d_dst is None:
             cap = int(((d_lengths[:n_chunks].to(torch.int64) + 15) & ~15).sum().item()) + 16 if n_chunks else 16
             d_dst = torch.empty(cap, dtype=torch.uint8, device=dev)
-        d_dst_offsets = torch.zeros(n_chunks + 1, dtype=torch.int64, device=dev)
+        if d_dst_offsets is None:
+            d_dst_offsets = torch.zeros(n_chunks + 1, dtype=torch.int64, device=dev)
         total = C.c_uint64(0)
         _check(_lib.rans_amd_container_compact(self._h, d_src.data_ptr(), src_bytes, d_src_offsets.data_ptr(),
                                                d_lengths.data_ptr(), n_chunks, d_dst.data_ptr(), d_dst.numel(),

@@ -100,7 +100,8 @@ struct DeviceBuffer {
 struct rans_amd_ctx {
     int device = 0;
     int num_cus = 0;
-    // device words: [0] decode error counter (u64), [8] encode flags (u32), [12] histogram flags (u32)
+    // device words: [0] decode error counter (u64), [8] encode flags (u32), [12] histogram flags (u32), [16] flags of
+    // rans_amd_container_compact (u32: a compaction behind an asynchronous encode must not wipe that encode's verdict)
     uint8_t *d_words = nullptr;
     DeviceBuffer scratch;   // encode slots
     DeviceBuffer lengths;   // encode lengths when the caller passes none
@@ -132,6 +133,7 @@ struct rans_amd_ctx {
     unsigned long long *d_err() { return reinterpret_cast<unsigned long long *>(d_words); }
     uint32_t *d_enc_flags() { return reinterpret_cast<uint32_t *>(d_words + 8); }
     uint32_t *d_hist_flags() { return reinterpret_cast<uint32_t *>(d_words + 12); }
+    uint32_t *d_compact_flags() { return reinterpret_cast<uint32_t *>(d_words + 16); }
 };
 
 struct rans_amd_model {
@@ -155,8 +157,11 @@ namespace {
 // the encoders' device flags (EncParams::flags) as a status
 int encode_flags_status(uint32_t flags)
 {
-    if (flags & 1u)
-        return fail(RANS_AMD_E_MODEL, "encode: input holds a symbol with frequency 0");
+    if (flags & 1u) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "encode: input holds a symbol with frequency 0 (flags 0x%x)", flags);
+        return fail(RANS_AMD_E_MODEL, msg);
+    }
     if (flags & 2u)
         return fail(RANS_AMD_E_SPACE, "encode: container does not fit out_cap");
     if (flags & 4u) // (a kernel that addresses its LDS tables by raw offsets found them elsewhere: never code on that)
@@ -168,6 +173,35 @@ int encode_flags_status(uint32_t flags)
     }
     return RANS_AMD_OK;
 }
+
+// Words a launch expects to find zero, cleared by one k_zero launch per three regions (kernels.h ZeroParams says why
+// this is a kernel and not hipMemsetAsync).
+struct ZeroList {
+    ZeroParams p{};
+    int count = 0;
+    hipStream_t stream;
+    explicit ZeroList(hipStream_t s) : stream(s) {}
+    hipError_t add(void *ptr, uint64_t bytes)
+    {
+        if (bytes == 0)
+            return hipSuccess;
+        if (count == 3) {
+            const hipError_t e = flush();
+            if (e != hipSuccess)
+                return e;
+        }
+        p.ptr[count] = ptr;
+        p.bytes[count++] = bytes;
+        return hipSuccess;
+    }
+    hipError_t flush()
+    {
+        const hipError_t e = count ? launch_zero(p, stream) : hipSuccess;
+        p = ZeroParams{};
+        count = 0;
+        return e;
+    }
+};
 
 // counter slot of a launch that is being captured (kernels.h kCaptureSlots: that many captured launches of one context
 // may run at the same time)
@@ -410,8 +444,12 @@ int rans_amd_count_freqs(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, int 
     int rc = ctx->hist.reserve((size_t)nsyms * 4);
     if (rc)
         return rc;
-    HIP_TRY(hipMemsetAsync(ctx->hist.ptr, 0, (size_t)nsyms * 4, s));
-    HIP_TRY(hipMemsetAsync(ctx->d_hist_flags(), 0, 4, s));
+    {
+        ZeroList zero(s);
+        HIP_TRY(zero.add(ctx->hist.ptr, (uint64_t)nsyms * 4));
+        HIP_TRY(zero.add(ctx->d_hist_flags(), 4));
+        HIP_TRY(zero.flush());
+    }
     if (n)
         HIP_TRY(launch_histogram(d_syms, n, sym_bytes, nsyms, static_cast<uint32_t *>(ctx->hist.ptr),
                                  ctx->d_hist_flags(), ctx->num_cus, s));
@@ -679,7 +717,8 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
     if (slots && (nchunks > (~0ull) / slot || out_cap < nchunks * slot)) // (known up front: nothing is launched)
         return fail(RANS_AMD_E_SPACE, "encode_slots: out_cap is below rans_amd_encode_slots_bound()");
     int rc = RANS_AMD_OK;
-    HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
+    ZeroList zero(s); // (everything the kernels below expect to find zero: one launch)
+    HIP_TRY(zero.add(ctx->d_enc_flags(), 4));
 
     // The wave-per-chunk encoders place and copy their chunks themselves (EncParams::status; encode_wave.hip
     // place_and_copy): no k_layout / k_compact.  The lane-per-chunk encoders (N = 1, 2, 4, 8 with many chunks) and the
@@ -707,6 +746,14 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
     // chunk -- a lane codes a symbol in well under a microsecond, and min(n_ways, 64) lanes share a chunk (a 2^31-symbol
     // chunk of a 1-way stream: the waits for it may last as long as it does).
     ep.wait_ticks = 30ull * 100000000ull + ((uint64_t)chunk_syms / (n_ways < 64u ? n_ways : 64u)) * 100ull;
+    {   // (measure build only: a base of milliseconds instead of half a minute, and the per-chunk share switched off -- what
+        //  tests/test_gpu_slots.py uses to show that the share is what lets one huge low-way chunk through)
+        static const char *base_ms = measure_knob("RANS_AMD_WATCHDOG_BASE_MS");
+        static const bool no_scale = measure_knob("RANS_AMD_WATCHDOG_NO_SCALE") != nullptr;
+        if (base_ms)
+            ep.wait_ticks = (uint64_t)atoi(base_ms) * 100000ull +
+                            (no_scale ? 0ull : ((uint64_t)chunk_syms / (n_ways < 64u ? n_ways : 64u)) * 100ull);
+    }
     const bool lanes = encode_uses_lanes(enc_format, nchunks, n_ways);
     // context option RANS_AMD_OPT_LANE_FUSED_PLACEMENT: the lane encoders place their chunks themselves as well -- bit-exact,
     // tested, and on config 2 no faster than k_layout + k_compact_small behind them (lanes.hip says why), hence opt-in
@@ -728,11 +775,11 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
             rc = ctx->enc_status.reserve(claim_bytes);
             if (rc)
                 return rc;
-            HIP_TRY(hipMemsetAsync(ctx->enc_status.ptr, 0, claim_bytes, s));
+            HIP_TRY(zero.add(ctx->enc_status.ptr, claim_bytes));
             ep.claims = static_cast<unsigned int *>(ctx->enc_status.ptr);
         }
         if (nchunks == 0)
-            HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, s));
+            HIP_TRY(zero.add(d_offsets, 8));
     } else {
         rc = ctx->scratch.reserve((size_t)((ring ? ring_waves * kEncRingSlots : nchunks) * slot + 64) + ctx->scratch_shift);
         if (rc)
@@ -747,19 +794,20 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
         rc = ctx->enc_status.reserve(status_bytes + ctx->status_shift);
         if (rc)
             return rc;
-        HIP_TRY(hipMemsetAsync(static_cast<uint8_t *>(ctx->enc_status.ptr) + ctx->status_shift, 0, status_bytes, s));
+        HIP_TRY(zero.add(static_cast<uint8_t *>(ctx->enc_status.ptr) + ctx->status_shift, status_bytes));
         if (fits == 2) { // the tables fill the LDS: one mailbox per block in global memory
             const size_t mb_bytes = (size_t)ctx->num_cus * kEncMailboxStride;
             rc = ctx->enc_mailboxes.reserve(mb_bytes);
             if (rc)
                 return rc;
-            HIP_TRY(hipMemsetAsync(ctx->enc_mailboxes.ptr, 0, mb_bytes, s));
+            HIP_TRY(zero.add(ctx->enc_mailboxes.ptr, mb_bytes));
             ep.mailbox_global = static_cast<uint8_t *>(ctx->enc_mailboxes.ptr);
         }
     }
 
     if (ctx->timing && !t_capturing)
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
+    HIP_TRY(zero.flush());
     if (nchunks) {
         ep.syms = static_cast<const uint8_t *>(d_syms);
         ep.n = n;
@@ -881,13 +929,17 @@ int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t sr
     const CaptureScope capture(s);
     if (capture.active && h_total_bytes)
         return fail(RANS_AMD_E_ARG, "container_compact: h_total_bytes must be NULL while the stream is capturing");
-    HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
+    {
+        ZeroList zero(s);
+        HIP_TRY(zero.add(ctx->d_compact_flags(), 4));
+        HIP_TRY(zero.flush());
+    }
     LayoutParams lp;
     lp.lengths = d_lengths;
     lp.offsets = d_dst_offsets;
     lp.nchunks = n_chunks;
     lp.out_cap = dst_cap;
-    lp.flags = ctx->d_enc_flags();
+    lp.flags = ctx->d_compact_flags();
     lp.block_sums = nullptr;
     if (layout_blocks(n_chunks) > 1) {
         int rc = ctx->layout_sums.reserve((size_t)layout_blocks(n_chunks) * 8);
@@ -906,13 +958,13 @@ int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t sr
         cp.offsets = d_dst_offsets;
         cp.out = static_cast<uint8_t *>(d_dst);
         cp.nchunks = n_chunks;
-        cp.flags = ctx->d_enc_flags();
+        cp.flags = ctx->d_compact_flags();
         HIP_TRY(launch_compact(cp, ctx->num_cus, s));
     }
     if (h_total_bytes) {
         uint32_t flags = 0;
         uint64_t total = 0;
-        HIP_TRY(hipMemcpyAsync(&flags, ctx->d_enc_flags(), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&flags, ctx->d_compact_flags(), 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(&total, d_dst_offsets + n_chunks, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         *h_total_bytes = total;
@@ -928,10 +980,12 @@ int rans_amd_encode_status(rans_amd_ctx *ctx, void *stream)
     DeviceGuard guard(ctx->device);
     std::lock_guard<std::mutex> lock(ctx->mu);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    uint32_t flags = 0;
+    uint32_t flags = 0, cflags = 0;
     HIP_TRY(hipMemcpyAsync(&flags, ctx->d_enc_flags(), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&cflags, ctx->d_compact_flags(), 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    return encode_flags_status(flags);
+    const int rc = encode_flags_status(flags);
+    return rc != RANS_AMD_OK ? rc : encode_flags_status(cflags & 2u); // (a compaction whose destination was too small)
 }
 
 /* ---- decode ------------------------------------------------------------- */
@@ -1008,10 +1062,14 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
             static const bool no_span = measure_knob("RANS_AMD_NO_SPAN") != nullptr; // A/B: cost of the span record
             if (capture.active) {
                 // A launch that becomes a graph node runs again and again with these very arguments: its counters are one
-                // of kCaptureSlots slots of their own, zeroed by a memset node in front of the kernel (so every replay
+                // of kCaptureSlots slots of their own, zeroed by a k_zero node in front of the kernel (so every replay
                 // starts from zero, and the ring of the eager launches never sees a slot a replay has used).
                 dp.work_counter = capture_counters(ctx);
-                HIP_TRY(hipMemsetAsync(dp.work_counter, 0, (size_t)per_slot * 4, s));
+                {
+                    ZeroList zero(s);
+                    HIP_TRY(zero.add(dp.work_counter, (uint64_t)per_slot * 4));
+                    HIP_TRY(zero.flush());
+                }
                 if (!no_span)
                     dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
             } else {
@@ -1185,7 +1243,11 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
     int rc = ctx->scratch.reserve((size_t)(nchunks * slot + 64));
     if (rc)
         return rc;
-    HIP_TRY(hipMemsetAsync(ctx->d_enc_flags(), 0, 4, s));
+    {
+        ZeroList zero(s);
+        HIP_TRY(zero.add(ctx->d_enc_flags(), 4));
+        HIP_TRY(zero.flush());
+    }
     if (nchunks) {
         // 1 + 2. count_freqs and normalize_freqs per chunk ON THE DEVICE (main.cpp:59-129, one wave per chunk; the
         // arithmetic of model.cpp normalize_freqs): the rows go straight into d_chunk_freqs -- no copy to the host, no
@@ -1296,7 +1358,11 @@ int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_
         dp.chunk_freqs = d_chunk_freqs;
         if (nchunks < 0xffffffffull && capture.active) { // (as in rans_amd_decode)
             dp.work_counter = capture_counters(ctx);
-            HIP_TRY(hipMemsetAsync(dp.work_counter, 0, (size_t)kWorkSlotWords * 4, s));
+            {
+                ZeroList zero(s);
+                HIP_TRY(zero.add(dp.work_counter, (uint64_t)kWorkSlotWords * 4));
+                HIP_TRY(zero.flush());
+            }
             dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
         } else if (nchunks < 0xffffffffull) {
             unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);

@@ -375,6 +375,44 @@ hipError_t launch_layout(const LayoutParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
+// kernels.h ZeroParams: every region's unaligned head and tail by words, the body in 16-byte stores
+__global__ __launch_bounds__(256) void k_zero(const ZeroParams p)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        uint8_t *b = static_cast<uint8_t *>(p.ptr[r]);
+        const uint64_t n = p.bytes[r];
+        if (n == 0)
+            continue;
+        uint64_t head = (16u - (reinterpret_cast<uintptr_t>(b) & 15u)) & 15u;
+        head = head < n ? head : n;
+        const uint64_t body = (n - head) & ~uint64_t(15);
+        for (uint64_t i = tid * 4; i < head; i += nth * 4)
+            *reinterpret_cast<uint32_t *>(b + i) = 0u;
+        for (uint64_t i = tid * 16; i < body; i += nth * 16)
+            *reinterpret_cast<uint4 *>(b + head + i) = make_uint4(0u, 0u, 0u, 0u);
+        for (uint64_t i = head + body + tid * 4; i < n; i += nth * 4)
+            *reinterpret_cast<uint32_t *>(b + i) = 0u;
+    }
+}
+
+hipError_t launch_zero(const ZeroParams &p, hipStream_t stream)
+{
+    uint64_t most = 0;
+    for (int r = 0; r < 3; ++r) {
+        if (p.bytes[r] && ((reinterpret_cast<uintptr_t>(p.ptr[r]) | p.bytes[r]) & 3u))
+            return hipErrorInvalidValue;
+        most = p.bytes[r] > most ? p.bytes[r] : most;
+    }
+    if (most == 0)
+        return hipSuccess;
+    const uint64_t want = (most + 256u * 16u - 1) / (256u * 16u);
+    RANS_LAUNCH(k_zero, dim3((uint32_t)(want < 2048 ? want : 2048)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t stream)
 {
     const uint64_t cap = (uint64_t)num_cus * 8;

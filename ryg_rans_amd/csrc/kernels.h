@@ -211,6 +211,16 @@ struct CompactParams {
     const uint32_t *flags; // skip everything when bit1 is set
 };
 
+// Workspace words that a launch expects to find zero (status flags, chunk claims, placement status words, mailboxes): up
+// to three regions cleared by ONE kernel in front of the consumer.  Not hipMemsetAsync: as a node of a captured graph a
+// small memset was seen replayed with another fill value from the second replay on (flags read back as 0x81818181,
+// profiles/r04_graph_memset.md) -- a kernel's arguments are captured by value.
+struct ZeroParams {
+    void *ptr[3];      // 4-byte aligned
+    uint64_t bytes[3]; // multiples of 4; 0 = unused
+};
+hipError_t launch_zero(const ZeroParams &p, hipStream_t stream);
+
 // All launchers return hipSuccess or the launch error; they never synchronise.
 hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **kernel_name);
 hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **kernel_names);

@@ -266,3 +266,79 @@ def test_one_container_split_over_contexts(gpu, oracle, fmt, sb, n_ways, chunk, 
         ctx.close()
     assert covered == n
     assert np.array_equal(out_sliced.cpu().numpy(), data) and np.array_equal(out_ranged.cpu().numpy(), data)
+
+
+def test_slot_encoder_and_compaction_inside_a_hip_graph(gpu, oracle):
+    """rans_amd_encode_slots, rans_amd_container_compact and rans_amd_decode captured into one hipGraph (the rules of
+    rans_amd_encode apply: one eager call first, no host result pointer): every replay leaves the oracle's chunks in
+    their slots, the oracle's compact container behind the compaction, and the symbols in the output."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf((1 << 19) + 333, K=256, s=1.0, seed=21)
+    n = data.size
+    d = torch.from_numpy(data).cuda()
+    for fmt, sb, ways, chunk in ((FMT_WORD, 12, 64, 4096), (FMT_R64, 14, 2, 512), (FMT_BYTE, 12, 128, 8192)):
+        om, gm = _models(ctx, oracle, fmt, sb, data)
+        want, w_offs, w_lens = oracle.encode_chunked(fmt, om, data, ways, chunk, align=16)
+        nchunks = len(w_lens)
+        s_cont, s_offs, s_lens, s_total = ctx.encode_slots(gm, d, ways, chunk)                 # eager once: workspaces exist
+        c_cont, c_offs, c_total = ctx.compact(s_cont, s_total, s_offs, s_lens, nchunks)
+        out = ctx.decode(gm, s_cont, s_total, s_offs, s_lens, n, ways, chunk)
+        assert c_total == want.size and torch.equal(out, d)
+        s2, so2, sl2 = torch.zeros_like(s_cont), torch.zeros_like(s_offs), torch.zeros_like(s_lens)
+        c2, co2, out2 = torch.zeros_like(c_cont), torch.zeros_like(c_offs), torch.zeros_like(out)
+        stream = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            ctx.encode_slots(gm, d, ways, chunk, d_out=s2, sync=False, d_offsets=so2, d_lengths=sl2)
+            ctx.compact(s2, s_total, so2, sl2, nchunks, d_dst=c2, sync=False, d_dst_offsets=co2)
+            ctx.decode(gm, s2, s_total, so2, sl2, n, ways, chunk, d_out=out2, sync=False)
+        assert not bool(out2.any())
+        for rep in range(2):
+            s2.zero_(); so2.zero_(); sl2.zero_(); c2.zero_(); out2.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            ctx.encode_status()
+            assert ctx.decode_errors() == 0 and torch.equal(out2, d), (fmt, rep)
+            assert torch.equal(sl2, s_lens) and torch.equal(so2, s_offs)
+            assert np.array_equal(co2.cpu().numpy().astype(np.uint64), w_offs)
+            got = c2.cpu().numpy()
+            for c in range(nchunks):
+                a = int(w_offs[c])
+                assert np.array_equal(got[a:a + int(w_lens[c])], want[a:a + int(w_lens[c])]), (fmt, rep, c)
+        del g
+
+
+def test_placement_watchdog_scales_with_the_chunk():
+    """every wait of the fused placement gives up after a wall-clock limit; one huge chunk of a low-way stream
+    keeps its coding wave busy for seconds, and the copier that waits for it must not call that a protocol failure.  The
+    limit is half a minute PLUS a microsecond per symbol and lane of the call's largest chunk.  Shown with the measure
+    build (its knobs shrink the base to 20 ms): a 1-way chunk of 4 Mi symbols (~0.5 s of coding) passes with the per-chunk
+    share and fails with 'placement protocol timed out' without it -- the share, not the base, lets it through."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "ryg_rans_amd", "lib", "libryg_rans_amd_measure.so")
+    if not os.path.exists(lib):
+        pytest.skip("measure build not present (make -C ryg_rans_amd/csrc measure)")
+    script = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import ryg_rans_amd as R
+ctx = R.Context(0)
+f = np.zeros(256, np.uint32); f[:4] = [1024, 1024, 1024, 1024]
+m = ctx.model(R.FMT_WORD, f, 12)
+d = torch.randint(0, 4, (1 << 22,), dtype=torch.uint8, device="cuda")
+try:
+    cont, offs, lens, total = ctx.encode(m, d, 1, 1 << 22)          # ONE chunk, one lane: the fused wave encoder
+    out = ctx.decode(m, cont, total, offs, lens, d.numel(), 1, 1 << 22)
+    print("RESULT ok" if torch.equal(out, d) and ctx.last_encode_kernel()[1] else "RESULT mismatch")
+except R.RansAmdError as e:
+    print("RESULT status %%d %%s" %% (e.status, e))
+""" % (root,)
+    env = dict(os.environ, RANS_AMD_LIB=lib, RANS_AMD_WATCHDOG_BASE_MS="20")
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+    assert "RESULT ok" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+    env["RANS_AMD_WATCHDOG_NO_SCALE"] = "1"
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+    assert "RESULT status 6" in out.stdout and "timed out" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
