@@ -819,6 +819,7 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
         ep.enc_recs = model->d_enc;
         ep.word_enc_recs = model->d_word_enc;
         ep.word_small = model->host.word_small ? 1u : 0u;
+        ep.dense256 = model->host.dense256 ? 1u : 0u;
         ep.alias_remap = static_cast<const uint32_t *>(model->d_remap);
         ep.alias_recs8 = model->d_alias_recs8;
         ep.alias_remap16 = static_cast<const uint16_t *>(model->d_alias_remap16);

@@ -226,7 +226,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 
 // Hand-written encoder sub-step of the word format for a FULL wave (64 active lanes, symbols
 // already turned into LDS addresses of their WordEncRec): rans_word_sse41.h:81-93 for 64 lanes.
-//   v_add_co    carry of x + (cmpl << 20)  <=>  x >= freq << 20: the lanes that emit a word
+//   v_cmpx_gt   x > (freq << 20) - 1  <=>  x >= freq << 20: the lanes that emit a word, in vcc and exec
 //   s_bcnt1 ..  words emitted -> the wave's write offset moves down (these SALU ops are also the
 //               wait states a VALU write of vcc needs before v_mbcnt may read it)
 //   v_mbcnt x2  rank among the emitting lanes = word index (ascending lane = ascending address)
@@ -241,27 +241,38 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 #ifndef RANS_ENC_STORE // (experiment knob: -DRANS_ENC_STORE='""' drops the stream stores of the word encoder)
 #define RANS_ENC_STORE "global_store_short %[t], %[x], %[base]\n\t"
 #endif
-// rec = WordEncRec {m', cmpl << 20, cmpl | sh << 24, bias} (model.h; sixteen bytes: one ds_read_b128, nothing to take
+// rec = WordEncRec {m', (freq << 20) - 1, cmpl | sh << 24, bias} (model.h; sixteen bytes: one ds_read_b128, nothing to take
 // apart).  SMALL: no frequency of the model exceeds 2048, the renormalised state is below 2^31 and q = mulhi(x, m') >> sh
 // is exact (Alverson, rans_byte.h:201-243): 10 VALU.  Otherwise the round-up method of Granlund & Montgomery for 32-bit
 // dividends, t = mulhi(x, m'); q = (t + ((x - t) >> 1)) >> sh: 13 VALU.  (Round 3 read an 8-byte record and spent four
 // instructions unpacking it -- 14 / 17 -- because the LDS pipe was the busiest unit then; with the stream staged in LDS
-// windows and, in the slot layout, no copier waves beside the coders, VALU issue is what bounds the loop.)
+// windows and, in the slot layout, no copier waves beside the coders, instruction issue is what bounds the loop -- and a
+// scalar instruction takes an issue slot of the SIMD like a vector one: 3 SALU per sub-step in the staged form, 5 before.)
 //   v_or        bit 31 of cmpl_sh marks a symbol without a record; OR-accumulated, looked at once per chunk
-//   v_add_co    carry of x + (cmpl << 20)  <=>  x >= freq << 20 (rans_word_sse41.h:85): the lanes that emit
-//   v_mbcnt x2, v_lshl_add   rank among the emitting lanes -> place of the lane's word
+//   v_cmpx_gt   x > (freq << 20) - 1 (rans_word_sse41.h:85): the lanes that emit, in vcc AND exec
+//   s_bcnt1, s_sub   the wave's write pointer moves down (also the wait state between the VALU write of vcc and the
+//               v_mbcnt that reads vcc_lo as a scalar operand)
+//   v_mbcnt x2, one VOP3 add-shift   rank among the emitting lanes -> place of the lane's word
 //   store + v_lshrrev under the emit mask
 //   v_mul_hi, v_lshrrev (count = byte 3 of cmpl_sh: SDWA), v_mad_u32_u24 (q < 2^20, cmpl in the low 24 bits), v_add bias
+// HEAD: `wp` counts bytes (the sub-step that stores to memory itself); HEAD_W: `wp` counts 16-bit WORDS (the staged
+// sub-step: an LDS address / 2), which saves the s_lshl of the count.
+#define RANS_ENC_WORD_TRACK "v_or_b32_e32 %[worst], %[worst], %[cs]\n\t"
 #define RANS_ENC_WORD_HEAD                                       \
-    "v_or_b32_e32 %[worst], %[worst], %[cs]\n\t"                  \
-    "v_add_co_u32_e32 %[t], vcc, %[ad], %[x]\n\t"                 \
+    "v_cmpx_gt_u32_e32 vcc, %[x], %[thr]\n\t"                     \
     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"                             \
     "s_lshl_b32 %[cnt], %[cnt], 1\n\t"                            \
     "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"                          \
-    "s_mov_b64 exec, vcc\n\t"                                     \
     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                      \
     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"                   \
     "v_lshl_add_u32 %[t], %[t], 1, %[wp]\n\t"
+#define RANS_ENC_WORD_HEAD_W                                     \
+    "v_cmpx_gt_u32_e32 vcc, %[x], %[thr]\n\t"                     \
+    "s_bcnt1_i32_b64 %[cnt], vcc\n\t"                             \
+    "s_sub_u32 %[wp], %[wp], %[cnt]\n\t"                          \
+    "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                      \
+    "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"                   \
+    "v_add_lshl_u32 %[t], %[t], %[wp], 1\n\t"
 #define RANS_ENC_WORD_TAIL_SMALL                                  \
     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"                        \
     "s_mov_b64 exec, -1\n\t"                                      \
@@ -279,44 +290,48 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
     "v_lshrrev_b32_sdwa %[q], %[cs], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
     "v_mad_u32_u24 %[q], %[q], %[cs], %[x]\n\t"                   \
     "v_add_u32_e32 %[x], %[q], %[bias]"
-template <bool SMALL>
+// TRACK: OR-accumulate the records' cmpl_sh words (models with symbols that have no record; EncParams::dense256 = none)
+#define RANS_ENC_WORD_ASM(TRACKSTR, HEAD, STORE, TAIL, ...)                                                              \
+    asm volatile(TRACKSTR HEAD STORE TAIL                                                                                  \
+                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [cnt] "=&s"(cnt)           \
+                 : [m] "v"(rec.x), [thr] "v"(rec.y), [cs] "v"(rec.z), [bias] "v"(rec.w) __VA_ARGS__                        \
+                 : "vcc", "scc", "memory")
+template <bool SMALL, bool TRACK>
 __device__ __forceinline__ void enc_word_full(uint32_t &x, const u32x4 &rec, uint32_t &wp,
                                               const uint8_t RANS_GLOBAL *slot, uint32_t &worst)
 {
     uint32_t t, q, cnt;
-    if constexpr (SMALL) {
-        asm volatile(RANS_ENC_WORD_HEAD RANS_ENC_STORE RANS_ENC_WORD_TAIL_SMALL
-                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [ad] "v"(rec.y), [cs] "v"(rec.z), [bias] "v"(rec.w), [base] "s"(slot)
-                     : "vcc", "scc", "memory");
-    } else {
-        asm volatile(RANS_ENC_WORD_HEAD RANS_ENC_STORE RANS_ENC_WORD_TAIL_GM
-                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [ad] "v"(rec.y), [cs] "v"(rec.z), [bias] "v"(rec.w), [base] "s"(slot)
-                     : "vcc", "scc", "memory");
-    }
+#define RANS_COMMA_BASE , [base] "s"(slot)
+    if constexpr (SMALL && TRACK)
+        RANS_ENC_WORD_ASM(RANS_ENC_WORD_TRACK, RANS_ENC_WORD_HEAD, RANS_ENC_STORE, RANS_ENC_WORD_TAIL_SMALL, RANS_COMMA_BASE);
+    else if constexpr (SMALL)
+        RANS_ENC_WORD_ASM("", RANS_ENC_WORD_HEAD, RANS_ENC_STORE, RANS_ENC_WORD_TAIL_SMALL, RANS_COMMA_BASE);
+    else if constexpr (TRACK)
+        RANS_ENC_WORD_ASM(RANS_ENC_WORD_TRACK, RANS_ENC_WORD_HEAD, RANS_ENC_STORE, RANS_ENC_WORD_TAIL_GM, RANS_COMMA_BASE);
+    else
+        RANS_ENC_WORD_ASM("", RANS_ENC_WORD_HEAD, RANS_ENC_STORE, RANS_ENC_WORD_TAIL_GM, RANS_COMMA_BASE);
+#undef RANS_COMMA_BASE
 }
 
-// The same with the emitted words staged in LDS: `wp` is an LDS address here, the write pointer into the wave's 2 KiB
+// The same with the emitted words staged in LDS: `wp` is an LDS address / 2 here, the write pointer into the wave's 2 KiB
 // window (one ds_write_b16 per round instead of one global_store_short: the per-round stores were 4.3e7 write requests
 // of 19 bytes on the 1 GiB encode and kept the address unit 87 % busy, profiles/r03_encoder_bound.md).  stage_flush() in
 // the kernel moves what sixteen rounds have produced to memory in whole 16-byte pieces and sets the pointer back to the
 // top of the window, so it never wraps.
-template <bool SMALL>
+template <bool SMALL, bool TRACK>
 __device__ __forceinline__ void enc_word_full_staged(uint32_t &x, const u32x4 &rec, uint32_t &wp, uint32_t &worst)
 {
     uint32_t t, q, cnt;
-    if constexpr (SMALL) {
-        asm volatile(RANS_ENC_WORD_HEAD "ds_write_b16 %[t], %[x]\n\t" RANS_ENC_WORD_TAIL_SMALL
-                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [ad] "v"(rec.y), [cs] "v"(rec.z), [bias] "v"(rec.w)
-                     : "vcc", "scc", "memory");
-    } else {
-        asm volatile(RANS_ENC_WORD_HEAD "ds_write_b16 %[t], %[x]\n\t" RANS_ENC_WORD_TAIL_GM
-                     : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [q] "=&v"(q), [cnt] "=&s"(cnt)
-                     : [m] "v"(rec.x), [ad] "v"(rec.y), [cs] "v"(rec.z), [bias] "v"(rec.w)
-                     : "vcc", "scc", "memory");
-    }
+#define RANS_DS_STORE "ds_write_b16 %[t], %[x]\n\t"
+    if constexpr (SMALL && TRACK)
+        RANS_ENC_WORD_ASM(RANS_ENC_WORD_TRACK, RANS_ENC_WORD_HEAD_W, RANS_DS_STORE, RANS_ENC_WORD_TAIL_SMALL, );
+    else if constexpr (SMALL)
+        RANS_ENC_WORD_ASM("", RANS_ENC_WORD_HEAD_W, RANS_DS_STORE, RANS_ENC_WORD_TAIL_SMALL, );
+    else if constexpr (TRACK)
+        RANS_ENC_WORD_ASM(RANS_ENC_WORD_TRACK, RANS_ENC_WORD_HEAD_W, RANS_DS_STORE, RANS_ENC_WORD_TAIL_GM, );
+    else
+        RANS_ENC_WORD_ASM("", RANS_ENC_WORD_HEAD_W, RANS_DS_STORE, RANS_ENC_WORD_TAIL_GM, );
+#undef RANS_DS_STORE
 }
 
 // The same for the byte format (rans_byte.h:62-74 renormalisation, :83-90 / :258-280 update) -- the compiler's version
@@ -367,41 +382,54 @@ __device__ __forceinline__ void enc_byte_full(uint32_t &x, const u32x4 &rec, uin
 }
 
 // The same with the emitted bytes staged in LDS (`wp` is the LDS write pointer of the wave's window, as in
-// enc_word_full_staged): the two-byte lanes write their bytes with ds_write_b8 + ds_write_b8_d16_hi from one register that
-// holds byte 1 of x in its byte 0 and byte 0 of x in its byte 2 (`split_sel`), the one-byte lanes with one ds_write_b8.
-__device__ __forceinline__ void enc_byte_full_staged(uint32_t &x, const u32x4 &rec, uint32_t &wp, uint32_t &worst, uint32_t split_sel)
+// enc_word_full_staged), and with the lanes in REVERSE order: lane l codes stream 63 - l (the kernel mirrors the states
+// before and after its fast loop and loads the symbols mirrored).  The stream grows downwards and a higher stream's bytes
+// lie at the higher addresses (rans_byte.h:62-74 run for lane N-1 first): with the lanes mirrored, the bytes ABOVE a
+// lane's are those of the lanes BELOW it -- the exclusive prefix v_mbcnt delivers -- so a lane's low byte goes to
+// wp - 1 - Q and, if it emits two, the next one to wp - 2 - Q (Q = bytes of the lanes below), whatever the lane's own
+// count: one address register, two ds_write_b8 (the second under the two-byte mask, from the x >> 8 the second compare
+// needed anyway).  In ascending-lane order the low byte's place depends on the lane's own count: round 4's first version
+// spent a v_perm, a third ds_write and an s_andn2 on that.
+//   v_cmp (e64) s[34:35] = (x >> 8) >= x_max: two bytes leave;  v_cmpx vcc = exec = x >= x_max: at least one
+//   v_mbcnt x4 from 2, v_sub from wp   r = wp - 2 - Q
+//   15 VALU + 6 SALU + 2 LDS writes (16 + 7 + 3 before)
+#define RANS_ENC_BYTE_STAGED_A "v_lshrrev_b32_e32 %[t], 8, %[x]\n\t"
+#define RANS_ENC_BYTE_STAGED_B                                                                                            \
+    "v_cmp_ge_u32_e64 s[34:35], %[t], %[xm]\n\t"                                                                          \
+    "v_cmpx_ge_u32_e32 vcc, %[x], %[xm]\n\t"                                                                              \
+    "s_bcnt1_i32_b64 %[c1], vcc\n\t"                                                                                      \
+    "s_bcnt1_i32_b64 %[c2], s[34:35]\n\t"                                                                                 \
+    "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 2\n\t"                                                                              \
+    "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"                                                                           \
+    "v_mbcnt_lo_u32_b32 %[r], s34, %[r]\n\t"                                                                              \
+    "v_mbcnt_hi_u32_b32 %[r], s35, %[r]\n\t"                                                                              \
+    "v_sub_u32_e32 %[r], %[wp], %[r]\n\t"                                                                                 \
+    "s_sub_u32 %[wp], %[wp], %[c1]\n\t"                                                                                   \
+    "s_sub_u32 %[wp], %[wp], %[c2]\n\t"                                                                                   \
+    "ds_write_b8 %[r], %[x] offset:1\n\t"                                                                                 \
+    "v_mov_b32_e32 %[x], %[t]\n\t"                                                                                        \
+    "s_mov_b64 exec, s[34:35]\n\t"                                                                                        \
+    "ds_write_b8 %[r], %[t]\n\t"                                                                                          \
+    "v_lshrrev_b32_e32 %[x], 8, %[x]\n\t"                                                                                 \
+    "s_mov_b64 exec, -1\n\t"                                                                                              \
+    "v_mul_hi_u32 %[q], %[x], %[rcp]\n\t"                                                                                 \
+    "v_lshrrev_b32_sdwa %[q], %[w], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"          \
+    "v_mad_u32_u24 %[q], %[q], %[w], %[x]\n\t"                                                                            \
+    "v_add_u32_e32 %[x], %[q], %[bias]"
+#define RANS_ENC_BYTE_STAGED_ASM(TRACKSTR)                                                                                \
+    asm volatile(RANS_ENC_BYTE_STAGED_A TRACKSTR RANS_ENC_BYTE_STAGED_B                                                   \
+                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [r] "=&v"(r), [q] "=&v"(q),             \
+                   [c1] "=&s"(c1), [c2] "=&s"(c2)                                                                         \
+                 : [rcp] "v"(rec.x), [w] "v"(rec.y), [bias] "v"(rec.z), [xm] "v"(rec.w)                                   \
+                 : "vcc", "scc", "memory", "s34", "s35")
+template <bool TRACK> // (TRACK: the model has symbols without a record -- OR-accumulate the records' second words)
+__device__ __forceinline__ void enc_byte_full_staged(uint32_t &x, const u32x4 &rec, uint32_t &wp, uint32_t &worst)
 {
     uint32_t t, r, q, c1, c2;
-    asm volatile("v_cmp_ge_u32_e32 vcc, %[x], %[xm]\n\t"
-                 "v_lshrrev_b32_e32 %[t], 8, %[x]\n\t"
-                 "v_or_b32_e32 %[worst], %[worst], %[w]\n\t"
-                 "v_cmp_ge_u32_e64 s[34:35], %[t], %[xm]\n\t"
-                 "s_bcnt1_i32_b64 %[c1], vcc\n\t"
-                 "s_bcnt1_i32_b64 %[c2], s[34:35]\n\t"
-                 "s_add_u32 %[c1], %[c1], %[c2]\n\t"
-                 "s_sub_u32 %[wp], %[wp], %[c1]\n\t"
-                 "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 0\n\t"
-                 "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"
-                 "v_mbcnt_lo_u32_b32 %[r], s34, %[r]\n\t"
-                 "v_mbcnt_hi_u32_b32 %[r], s35, %[r]\n\t"
-                 "v_add_u32_e32 %[r], %[wp], %[r]\n\t"
-                 "v_perm_b32 %[t], %[x], %[x], %[sel]\n\t"
-                 "s_mov_b64 exec, s[34:35]\n\t"
-                 "ds_write_b8 %[r], %[t]\n\t"
-                 "ds_write_b8_d16_hi %[r], %[t] offset:1\n\t"
-                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                 "s_andn2_b64 exec, vcc, s[34:35]\n\t"
-                 "ds_write_b8 %[r], %[x]\n\t"
-                 "v_lshrrev_b32_e32 %[x], 8, %[x]\n\t"
-                 "s_mov_b64 exec, -1\n\t"
-                 "v_mul_hi_u32 %[q], %[x], %[rcp]\n\t"
-                 "v_lshrrev_b32_sdwa %[q], %[w], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-                 "v_mad_u32_u24 %[q], %[q], %[w], %[x]\n\t"
-                 "v_add_u32_e32 %[x], %[q], %[bias]"
-                 : [x] "+v"(x), [wp] "+s"(wp), [worst] "+v"(worst), [t] "=&v"(t), [r] "=&v"(r), [q] "=&v"(q),
-                   [c1] "=&s"(c1), [c2] "=&s"(c2)
-                 : [rcp] "v"(rec.x), [w] "v"(rec.y), [bias] "v"(rec.z), [xm] "v"(rec.w), [sel] "v"(split_sel)
-                 : "vcc", "scc", "memory", "s34", "s35");
+    if constexpr (TRACK)
+        RANS_ENC_BYTE_STAGED_ASM("v_or_b32_e32 %[worst], %[worst], %[w]\n\t");
+    else
+        RANS_ENC_BYTE_STAGED_ASM("");
 }
 
 constexpr int kEncAliasLdsThreads = 1024; // FMT_ALIAS_LDS: 16 waves share the (up to 160 KiB) tables of a CU
@@ -721,6 +749,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         }
 
         uint32_t worst = 0; // word fast path: max of cmpl_sh, > 0x0fffffff iff a symbol has no record
+        bool mirrored = false; // byte format, staged: lane l holds stream 63 - l during the fast loop (enc_byte_full_staged)
         if (fast_rounds && fast_in16) {
             if constexpr ((kIsAlias<FMT> || FMT == FMT_WORD) && K <= 2) {
                 // lane l of a pair loads the dword {row 2j + (l & 1), columns l & ~1 and (l & ~1) + 1}
@@ -827,6 +856,18 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 wp -= top - lp;
             };
             (void)stage_flush;
+            // byte format, staged: the lanes in reverse order.  Lane q of a quad still loads row q of its quad's four columns
+            // -- the quad of lanes 4g .. 4g+3 takes columns 60-4g .. 63-4g -- and the transpose hands lane q column 3 - q:
+            // its first v_perm reads both dwords byte-reversed (selector indices i -> 3 - i, 4 + i -> 7 - i).
+            uint32_t in_off = in_lane_off, tsel1 = sel1;
+            if constexpr (kStageB) {
+                if (stage_b) {
+                    mirrored = true;
+                    x[0] = (state_t)__builtin_amdgcn_ds_bpermute((int)((63u - lane) * 4u), (int)x[0]);
+                    in_off = (lane & 3u) * N + (60u - (lane & ~3u));
+                    tsel1 = (lane & 1u) ? 0x00040206u : 0x05010703u;
+                }
+            }
             uint32_t cur[4][K], nxt[4][K];
             auto load_super = [&](uint32_t (&dstq)[4][K], uint32_t sg) {
 #pragma unroll
@@ -834,11 +875,13 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
 #pragma unroll
                     for (int k = 0; k < K; ++k)
                         dstq[j][k] = *reinterpret_cast<const uint32_t RANS_GLOBAL *>(
-                            src + (uint64_t)(sg * 16u + j * 4u) * N + in_lane_off + k * 64u);
+                            src + (uint64_t)(sg * 16u + j * 4u) * N + in_off + k * 64u);
             };
             // (the loop once per reciprocal method of the word format: a branch inside it costs register copies at every join)
-            auto fast_loop = [&](auto small_tag) {
+            auto fast_loop = [&](auto small_tag, auto track_tag) {
             constexpr bool kSmall = decltype(small_tag)::value; // word: the reciprocal method; byte: staged or not
+            constexpr bool kTrack = decltype(track_tag)::value; // the model has byte values without a record (EncParams::dense256 = 0)
+            (void)kTrack;
             constexpr bool kStage = kStageW || ((kStageB || kStageA) && kSmall);
             uint32_t sg = fast_rounds >> 4;
             load_super(cur, sg - 1);
@@ -846,13 +889,14 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 if (sg > 0)
                     load_super(nxt, sg - 1);
                 uint32_t win_top = win_base + kTopPiece + (uniform(wp) & 15u);
-                uint32_t lp = win_top; // (staged path: the coding loop moves this LDS pointer, stage_flush() sets wp)
+                uint32_t lp = kStageW ? win_top >> 1 : win_top; // (staged path: the coding loop moves this LDS pointer -- the word
+                                                                // format's counts 16-bit words -- and stage_flush() sets wp)
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     uint32_t t[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k)
-                        t[k] = quad_transpose(cur[j][k], sel1, sel2);
+                        t[k] = quad_transpose(cur[j][k], tsel1, sel2);
                 if constexpr (FMT == FMT_WORD) {
                     // symbol byte J -> LDS address of its record, (sym << 4) + table offset; the record
                     // of the next sub-step is read before the current one is worked on (the asm block is
@@ -879,9 +923,9 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                         if (step + 1 < 4 * K)
                             rec = rec_at(step + 1);
                         if constexpr (kStage)
-                            enc_word_full_staged<kSmall>(x[K - 1 - step % K], now, lp, worst);
+                            enc_word_full_staged<kSmall, kTrack>(x[K - 1 - step % K], now, lp, worst);
                         else
-                            enc_word_full<kSmall>(x[K - 1 - step % K], now, wp, slot, worst);
+                            enc_word_full<kSmall, kTrack>(x[K - 1 - step % K], now, wp, slot, worst);
                     }
                     wp = uniform(wp);
                     lp = uniform(lp);
@@ -908,7 +952,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                             if (step + 1 < 4 * K)
                                 rec = rec_at(step + 1);
                             if constexpr (kStageB && kSmall)
-                                enc_byte_full_staged(x[K - 1 - step % K], now, lp, worst, split_sel);
+                                enc_byte_full_staged<kTrack>(x[K - 1 - step % K], now, lp, worst);
                             else
                                 enc_byte_full(x[K - 1 - step % K], now, wp, slot, worst, swap_sel);
                         }
@@ -932,7 +976,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 }
                 }
                 if constexpr (kStage)
-                    stage_flush(win_top, uniform(lp));
+                    stage_flush(win_top, kStageW ? uniform(lp) << 1 : uniform(lp));
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -940,10 +984,25 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                         cur[j][k] = nxt[j][k];
             }
             };
-            if ((FMT == FMT_WORD && p.word_small) || (FMT == FMT_BYTE && stage_b) || (FMT == FMT_ALIAS_LDS && stage_a))
-                fast_loop(std::true_type{});
-            else
-                fast_loop(std::false_type{});
+            // (the variants without the search for record-less symbols: the word format and the staged byte format over a
+            //  model in which every byte value has a frequency -- one VALU instruction of 10 resp. 15 less)
+            const bool small = (FMT == FMT_WORD && p.word_small) || (FMT == FMT_BYTE && stage_b) || (FMT == FMT_ALIAS_LDS && stage_a);
+            const bool untracked = p.dense256 && (FMT == FMT_WORD || (FMT == FMT_BYTE && stage_b));
+            if constexpr (FMT == FMT_WORD || (FMT == FMT_BYTE && K == 1)) {
+                if (small && untracked)
+                    fast_loop(std::true_type{}, std::false_type{});
+                else if (small)
+                    fast_loop(std::true_type{}, std::true_type{});
+                else if (untracked)
+                    fast_loop(std::false_type{}, std::false_type{});
+                else
+                    fast_loop(std::false_type{}, std::true_type{});
+            } else {
+                if (small)
+                    fast_loop(std::true_type{}, std::true_type{});
+                else
+                    fast_loop(std::false_type{}, std::true_type{});
+            }
         }
 
         // (a symbol without a record: word format -- bit 31 of the OR over the records' cmpl_sh words; byte format -- its
@@ -951,6 +1010,10 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         //  v_or issues in the fast VALU class where v_max does not)
         if (worst > (FMT == FMT_WORD ? 0x7fffffffu : 0x0fffffffu))
             bad = true;
+        if constexpr (FMT == FMT_BYTE && K == 1) {
+            if (mirrored) // back to lane l = stream l
+                x[0] = (state_t)__builtin_amdgcn_ds_bpermute((int)((63u - lane) * 4u), (int)x[0]);
+        }
         // flush: lane N-1 first, i.e. lane 0's state ends up first in memory
         // (main.cpp:244-245, main_simd.cpp:298-299)
         wp -= N * Tr::kStateBytes;

@@ -111,6 +111,7 @@ struct EncParams {
     uint32_t *lengths;    // out: stream bytes per chunk
     const void *enc_recs; // EncRec[nsyms]
     const void *word_enc_recs; // WordEncRec[256] (FMT_WORD only, else NULL)
+    uint32_t dense256;         // every byte value is a symbol of the model: the full-wave sub-steps skip the search for symbols without a record
     uint32_t word_small;       // FMT_WORD: the records hold Alverson reciprocals (no frequency above 2048, model.h)
     const uint32_t *alias_remap;
     const uint16_t *chunk_freqs;    // byte format with one model per chunk: u16[256] per chunk (else NULL); the waves

@@ -276,6 +276,10 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
         enc_recs[s] = EncRec{f, cum[s], rcp, cum[s]};
     }
 
+    dense256 = ns == 256;
+    for (uint32_t s = 0; s < ns && dense256; ++s)
+        dense256 = freqs[s] != 0;
+
     if (fmt == RANS_AMD_FMT_WORD) {
         // rans_word_sse41.h:64-72, packed for the device
         word_slots.resize(M);
@@ -294,9 +298,9 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
             word_small = false;
 #endif
         if (ns <= 256)
-            word_enc_recs.assign(256, WordEncRec{0u, 0u, 0x80000000u, 0u});
-        auto rec16 = [](uint32_t mprime, uint32_t cmpl, uint32_t bias, uint32_t sh) {
-            return WordEncRec{mprime, cmpl << 20, cmpl | (sh << 24), bias};
+            word_enc_recs.assign(256, WordEncRec{0u, 0xffffffffu, 0x80000000u, 0u});
+        auto rec16 = [M](uint32_t mprime, uint32_t cmpl, uint32_t bias, uint32_t sh) { // (freq = M - cmpl; thresh = (freq << 20) - 1)
+            return WordEncRec{mprime, (uint32_t)(((uint64_t)(M - cmpl) << 20) - 1u), cmpl | (sh << 24), bias};
         };
         for (uint32_t s = 0; s < ns && ns <= 256; ++s) {
             const uint32_t f = freqs[s];

@@ -98,14 +98,17 @@ struct EncRec {
 // (LDS pipe 30 % busy): the four instructions that took the 8-byte record apart -- a slow-class v_lshlrev and v_bfe among
 // them -- are worth more than the LDS cycles of the wider gather (9.7 against 4.9 per wave instruction).
 //   mprime   as above
-//   addend   cmpl << 20: the carry of x + addend is the renormalisation test (rans_word_sse41.h:85)
+//   thresh   (freq << 20) - 1: x > thresh is the renormalisation test (rans_word_sse41.h:85) as ONE v_cmpx, which leaves
+//            the emitting lanes in exec and vcc at once (the carry of x + (cmpl << 20), until late in round 4, needed an
+//            s_mov to exec behind it -- a scalar instruction costs the SIMD an issue slot like a vector one); "- 1" because
+//            freq == 4096 (a one-symbol model) makes freq << 20 = 2^32: 0xffffffff never emits, as it should
 //   cmpl_sh  cmpl (bits 0..11; v_mad_u32_u24 reads the low 24 bits as they are) | sh << 24 (the shift takes its count from
 //            byte 3: SDWA).  No record: 0x80000000 -- bit 31 is what the kernel OR-accumulates to find such a symbol --
-//            with addend 0 (never emits), mprime 0 and bias 0 (the state stays put)
+//            with thresh 0xffffffff (never emits), mprime 0 and bias 0 (the state stays put)
 //   bias     start (freq >= 2) or start + 4095 (freq == 1)
 struct WordEncRec {
     uint32_t mprime;
-    uint32_t addend;
+    uint32_t thresh;
     uint32_t cmpl_sh;
     uint32_t bias;
 };
@@ -143,6 +146,7 @@ struct HostModel {
     std::vector<AliasHalf> alias_halves; // [2*nsyms]        FMT_ALIAS
     std::vector<EncRec> enc_recs;       // [nsyms]          all formats
     std::vector<WordEncRec> word_enc_recs; // [256]         FMT_WORD
+    bool dense256 = false;                 // 256 byte symbols, every one with a frequency: an encoder need not look for symbols without a record
     bool word_small = false;               // FMT_WORD: no frequency above 2048 -> Alverson reciprocals in word_enc_recs
     // FMT_ALIAS, when 2 M + 8 max(nsyms, 256) bytes fit in LDS: the encoder's tables in their LDS form --
     // {freq | start << 16, floor(2^32 / freq)} per symbol (zero records up to 256) and alias_remap as u16
