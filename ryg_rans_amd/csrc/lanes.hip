@@ -1584,15 +1584,14 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
 // image of k_decode_lanes_r64x2.  The staged kernel above spends 38 VALU instructions per symbol (compiler-scheduled
 // 64-bit arithmetic full of register-pair moves, a branch around every renormalisation, a wait after every record read);
 // here one 16-symbol group is ONE asm statement:
-//  * record {rcp lo, rcp hi, bias | rcp_shift << 26, cmpl} (16 bytes, one ds_read_b128 per symbol; the LDS pipe could
+//  * record {rcp lo, rcp hi, bias << 6 | rcp_shift, cmpl} (16 bytes, one ds_read_b128 per symbol; the LDS pipe could
 //    not feed two), the records of the next pair of symbols are read while the current pair is worked on;
 //  * renormalisation test (rans64.h:83: x >= ((L >> scale_bits) << 32) * freq) on the high dword alone: the low dword of
 //    that bound is 0, and x.hi >= (M - cmpl) << k  <=>  x.hi + (cmpl << k) >= 2^31 (k = 31 - scale_bits): one
 //    v_lshl_add + v_cmpx; the lanes that emit run under the exec mask (dword into the ring, x >>= 32 as two moves);
-//  * q = mulhi64(x, rcp) >> rcp_shift (rans64.h:91, exact): v_mul_hi + 3 x v_mad_u64_u32 whose 64-bit addends are
-//    {value, 0} pairs -- a permanently zero register next to the one that takes the value; x += bias + q * cmpl
-//    (rans64.h:92, Rans64EncSymbolInit's identity) as v_lshl_add_u64 + v_mad_u64_u32 + v_mad_u32_u24;
-//    12.5 slow + 10 fast VALU forms per symbol (DESIGN 4.1 "issue cost model");
+//  * q = mulhi64(x, rcp) >> rcp_shift (rans64.h:91, exact): v_mul_hi + 3 x v_mad_u64_u32, the middle sum's carry through
+//    vcc (E64_BACK below); x += bias + q * cmpl (rans64.h:92, Rans64EncSymbolInit's identity) as v_lshl_add_u64 +
+//    v_mad_u64_u32 + v_mad_u32_u24; 18.5 VALU per symbol (22.5 until late in round 4);
 //  * output ring per lane: 32 dwords, dword d of lane l at ring + 256 d + 4 l (every ds_write_b32 conflict-free), the ring
 //    8 KiB aligned so that the write position wraps with one v_bfi; a lane's bytes written are never counted per symbol,
 //    the flush derives them from the ring position (at most 64 bytes per group);
@@ -1609,11 +1608,14 @@ constexpr uint32_t kR64EncTable = 8192;  // 256 records of 16 bytes at LDS addre
 // temporaries v64..v79 with the permanently zero v65, v69, v77 (the two states are worked on one after the other)
 #define E64_ZERO                                                                                                        \
     "v_mov_b32 v65, 0\n\tv_mov_b32 v69, 0\n\tv_mov_b32 v77, 0\n\t"
-// address of the record of byte J of symbol dword S: (sym << 4)
-#define E64_ADDR3(D, S) "v_lshrrev_b32 " D ", 20, " S "\n\tv_and_b32 " D ", %[mff0], " D "\n\t"
-#define E64_ADDR2(D, S) "v_lshrrev_b32 " D ", 12, " S "\n\tv_and_b32 " D ", %[mff0], " D "\n\t"
-#define E64_ADDR1(D, S) "v_lshrrev_b32 " D ", 4, " S "\n\tv_and_b32 " D ", %[mff0], " D "\n\t"
-#define E64_ADDR0(D, S) "v_lshlrev_b32 " D ", 4, " S "\n\tv_and_b32 " D ", %[mff0], " D "\n\t"
+// address of the record of byte J of symbol dword S: sym << 4 -- one SDWA shift of the selected byte (the count in a VGPR:
+// SDWA takes no literal)
+#define E64_SDWA(D, S, SEL)                                                                                             \
+    "v_lshlrev_b32_sdwa " D ", %[k4], " S " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL "\n\t"
+#define E64_ADDR3(D, S) E64_SDWA(D, S, "BYTE_3")
+#define E64_ADDR2(D, S) E64_SDWA(D, S, "BYTE_2")
+#define E64_ADDR1(D, S) E64_SDWA(D, S, "BYTE_1")
+#define E64_ADDR0(D, S) E64_SDWA(D, S, "BYTE_0")
 // renormalisation of state {XL, XH} with record dword C = cmpl (T: temporary)
 #define E64_FRONT(XL, XH, C, T)                                                                                         \
     "v_lshl_add_u32 " T ", " C ", %[kv], " XH "\n\t"                                                                    \
@@ -1624,39 +1626,45 @@ constexpr uint32_t kR64EncTable = 8192;  // 256 records of 16 bytes at LDS addre
     "v_mov_b32 " XL ", " XH "\n\t"                                                                                      \
     "v_mov_b32 " XH ", 0\n\t"                                                                                           \
     "s_mov_b64 exec, -1\n\t"
-// x = x + bias + (mulhi64(x, rcp) >> rcp_shift) * cmpl; X = "v[a:b]" of {XL, XH}; record R0..R3; TA / TZ / BP: pairs
-// whose high register is zero (TAL, TZL, BPL their low registers), P1 / P2 / RR pairs with named halves
-#define E64_BACK(X, XL, XH, R0, R1, R2, R3, TA, TAL, P1, P1L, P1H, TZ, TZL, P2, P2H, RR, RRL, RRH, RS, BP, BPL)          \
+// x = x + bias + (mulhi64(x, rcp) >> rcp_shift) * cmpl; X = "v[a:b]" of {XL, XH}; record R0..R3 = {rcp lo, rcp hi,
+// bias << 6 | rcp_shift, cmpl}; TA / BP: pairs whose high register is permanently zero (TAL, BPL their low registers),
+// TZ = {TZL, TZH}: the high dword of the middle sum and its carry.  mulhi64 as
+//   t  = hi(xl * r0)
+//   P1 = xh * r0 + t                 (< 2^63 + 2^32: xh < 2^31)
+//   P2 = xl * r1 + P1                (may pass 2^64: the carry comes out of v_mad_u64_u32 in vcc)
+//   RR = xh * r1 + {hi(P2), carry}
+// -- the second product takes the WHOLE first one as its addend instead of a {low dword, 0} pair (round 4; three moves and
+// a 64-bit add less); the shift takes its count from the low six bits of the record's third dword as they are
+// (v_lshrrev_b64 looks at no others).  11 VALU (14 before).  Two instructions stand between the v_mad_u64_u32 that
+// writes vcc and the v_addc that reads it (gfx940: a VALU write of an SGPR needs two wait states before a VALU reads it).
+#define E64_BACK(X, XL, XH, R0, R1, R2, R3, TA, TAL, P1, TZ, TZL, TZH, P2, P2H, RR, RRL, RRH, BP, BPL, ZERO)             \
     "v_mul_hi_u32 " TAL ", " XL ", " R0 "\n\t"                                                                          \
     "v_mad_u64_u32 " P1 ", vcc, " XH ", " R0 ", " TA "\n\t"                                                             \
-    "v_lshrrev_b32 " RS ", 26, " R2 "\n\t"                                                                              \
-    "v_and_b32 " BPL ", %[mbias], " R2 "\n\t"                                                                           \
-    "v_mov_b32 " TAL ", " P1L "\n\t"                                                                                    \
-    "v_mad_u64_u32 " P2 ", vcc, " XL ", " R1 ", " TA "\n\t"                                                             \
-    "v_mov_b32 " TZL ", " P1H "\n\t"                                                                                    \
+    "v_mad_u64_u32 " P2 ", vcc, " XL ", " R1 ", " P1 "\n\t"                                                             \
+    "v_lshrrev_b32 " BPL ", 6, " R2 "\n\t"                                                                              \
+    "v_mov_b32 " TZL ", " P2H "\n\t"                                                                                    \
+    "v_addc_co_u32 " TZH ", vcc, 0, " ZERO ", vcc\n\t"                                                                  \
     "v_mad_u64_u32 " RR ", vcc, " XH ", " R1 ", " TZ "\n\t"                                                             \
-    "v_mov_b32 " TAL ", " P2H "\n\t"                                                                                    \
-    "v_lshl_add_u64 " RR ", " RR ", 0, " TA "\n\t"                                                                      \
-    "v_lshrrev_b64 " RR ", " RS ", " RR "\n\t"                                                                          \
+    "v_lshrrev_b64 " RR ", " R2 ", " RR "\n\t"                                                                          \
     "v_lshl_add_u64 " X ", " X ", 0, " BP "\n\t"                                                                        \
     "v_mad_u64_u32 " X ", vcc, " RRL ", " R3 ", " X "\n\t"                                                              \
     "v_mad_u32_u24 " XH ", " RRH ", " R3 ", " XH "\n\t"
 #define E64_BACK_A(R0, R1, R2, R3)                                                                                      \
-    E64_BACK("v[40:41]", "v40", "v41", R0, R1, R2, R3, "v[64:65]", "v64", "v[66:67]", "v66", "v67", "v[68:69]", "v68",   \
-             "v[70:71]", "v71", "v[72:73]", "v72", "v73", "v75", "v[76:77]", "v76")
+    E64_BACK("v[40:41]", "v40", "v41", R0, R1, R2, R3, "v[64:65]", "v64", "v[66:67]", "v[68:69]", "v68", "v69",          \
+             "v[70:71]", "v71", "v[72:73]", "v72", "v73", "v[76:77]", "v76", "v65")
 #define E64_BACK_B(R0, R1, R2, R3)                                                                                      \
-    E64_BACK("v[42:43]", "v42", "v43", R0, R1, R2, R3, "v[64:65]", "v64", "v[66:67]", "v66", "v67", "v[68:69]", "v68",   \
-             "v[70:71]", "v71", "v[72:73]", "v72", "v73", "v75", "v[76:77]", "v76")
+    E64_BACK("v[42:43]", "v42", "v43", R0, R1, R2, R3, "v[64:65]", "v64", "v[66:67]", "v[68:69]", "v68", "v69",          \
+             "v[70:71]", "v71", "v[72:73]", "v72", "v73", "v[76:77]", "v76", "v65")
 // one pair of symbols (the odd one = state 1 first: it is the later symbol) with its records in set 0 (v48..v55: state 1
 // in v[48:51], state 0 in v[52:55]) or set 1 (v56..v63); PRE = address + read instructions of the NEXT pair, WAIT = lgkmcnt
 #define E64_PAIR0(PRE, WAIT)                                                                                            \
     PRE "s_waitcnt lgkmcnt(" WAIT ")\n\t"                                                                               \
-    "v_max3_u32 %[worst], %[worst], v51, v55\n\t"                                                                       \
+    E64_TRACK0                                                                                                          \
     E64_FRONT("v42", "v43", "v51", "v74") E64_FRONT("v40", "v41", "v55", "v74")                                         \
     E64_BACK_B("v48", "v49", "v50", "v51") E64_BACK_A("v52", "v53", "v54", "v55")
 #define E64_PAIR1(PRE, WAIT)                                                                                            \
     PRE "s_waitcnt lgkmcnt(" WAIT ")\n\t"                                                                               \
-    "v_max3_u32 %[worst], %[worst], v59, v63\n\t"                                                                       \
+    E64_TRACK1                                                                                                          \
     E64_FRONT("v42", "v43", "v59", "v74") E64_FRONT("v40", "v41", "v63", "v74")                                         \
     E64_BACK_B("v56", "v57", "v58", "v59") E64_BACK_A("v60", "v61", "v62", "v63")
 // reads of a pair into set 0 / set 1: bytes (JB, JA) of symbol dword S
@@ -1669,37 +1677,55 @@ constexpr uint32_t kR64EncTable = 8192;  // 256 records of 16 bytes at LDS addre
         "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
 
 // 16 symbols (dwords s3 = the last four .. s0 = the first four of the group), last symbol first
+#define E64_GROUP_ASM                                                                                                   \
+    asm volatile(E64_ZERO                                                                                               \
+                 E64_READ0(E64_ADDR3, E64_ADDR2, "%[s3]")                                                               \
+                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s3]"), "2")                                               \
+                 E64_PAIR1(E64_READ0(E64_ADDR3, E64_ADDR2, "%[s2]"), "2")                                               \
+                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s2]"), "2")                                               \
+                 E64_PAIR1(E64_READ0(E64_ADDR3, E64_ADDR2, "%[s1]"), "2")                                               \
+                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s1]"), "2")                                               \
+                 E64_PAIR1(E64_READ0(E64_ADDR3, E64_ADDR2, "%[s0]"), "2")                                               \
+                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s0]"), "2")                                               \
+                 E64_PAIR1("", "0")                                                                                     \
+                 : "+{v[40:41]}"(xA), "+{v[42:43]}"(xB), [wk] "+v"(wk), [worst] "+v"(worst)                             \
+                 : [s3] "v"(s3), [s2] "v"(s2), [s1] "v"(s1), [s0] "v"(s0), [k4] "v"(k4), [m256] "v"(m256),              \
+                   [m1fff] "v"(m1fff), [ring] "v"(ring), [kv] "v"(kv)                                                   \
+                 : E64_CLOBBERS)
+// TRACK: the model has byte values without a record (their cmpl = M is the largest value any record holds: v_max3 over
+// the pairs' cmpl words finds it); EncParams::dense256 models run without
+template <bool TRACK>
 __device__ __forceinline__ void r64x2_encode_group(uint64_t &xA, uint64_t &xB, uint32_t &wk, uint32_t &worst, uint32_t s3,
-                                                   uint32_t s2, uint32_t s1, uint32_t s0, uint32_t mff0, uint32_t m256,
-                                                   uint32_t m1fff, uint32_t ring, uint32_t kv, uint32_t mbias)
+                                                   uint32_t s2, uint32_t s1, uint32_t s0, uint32_t k4, uint32_t m256,
+                                                   uint32_t m1fff, uint32_t ring, uint32_t kv)
 {
-    asm volatile(E64_ZERO
-                 E64_READ0(E64_ADDR3, E64_ADDR2, "%[s3]")
-                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s3]"), "2")
-                 E64_PAIR1(E64_READ0(E64_ADDR3, E64_ADDR2, "%[s2]"), "2")
-                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s2]"), "2")
-                 E64_PAIR1(E64_READ0(E64_ADDR3, E64_ADDR2, "%[s1]"), "2")
-                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s1]"), "2")
-                 E64_PAIR1(E64_READ0(E64_ADDR3, E64_ADDR2, "%[s0]"), "2")
-                 E64_PAIR0(E64_READ1(E64_ADDR1, E64_ADDR0, "%[s0]"), "2")
-                 E64_PAIR1("", "0")
-                 : "+{v[40:41]}"(xA), "+{v[42:43]}"(xB), [wk] "+v"(wk), [worst] "+v"(worst)
-                 : [s3] "v"(s3), [s2] "v"(s2), [s1] "v"(s1), [s0] "v"(s0), [mff0] "v"(mff0), [m256] "v"(m256),
-                   [m1fff] "v"(m1fff), [ring] "v"(ring), [kv] "v"(kv), [mbias] "v"(mbias)
-                 : E64_CLOBBERS);
+    if constexpr (TRACK) {
+#define E64_TRACK0 "v_max3_u32 %[worst], %[worst], v51, v55\n\t"
+#define E64_TRACK1 "v_max3_u32 %[worst], %[worst], v59, v63\n\t"
+        E64_GROUP_ASM;
+#undef E64_TRACK0
+#undef E64_TRACK1
+    } else {
+#define E64_TRACK0 ""
+#define E64_TRACK1 ""
+        E64_GROUP_ASM;
+#undef E64_TRACK0
+#undef E64_TRACK1
+    }
 }
 
+template <bool TRACK>
 __global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    {   // EncRec {freq | rcp_shift << 24, bias, rcp lo, rcp hi} (model.h) -> {rcp lo, rcp hi, bias | rcp_shift << 26, cmpl};
+    {   // EncRec {freq | rcp_shift << 24, bias, rcp lo, rcp hi} (model.h) -> {rcp lo, rcp hi, bias << 6 | rcp_shift, cmpl};
         // a symbol without a frequency: cmpl = M (the largest value any record holds: v_max3 finds it), rcp = 0
         const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
         uint4 *l = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) {
             uint4 r = i < p.nsyms ? g[i] : uint4{0u, 0u, 0u, 0u};
             const uint32_t freq = r.x & 0xffffffu;
-            l[i] = freq ? uint4{r.z, r.w, r.y | ((r.x >> 24) << 26), (1u << p.scale_bits) - freq}
+            l[i] = freq ? uint4{r.z, r.w, (r.y << 6) | (r.x >> 24), (1u << p.scale_bits) - freq}
                         : uint4{0u, 0u, 0u, 1u << p.scale_bits};
         }
         if (p.status) // (a block may be as small as one coding wave + the scanner: 128 threads for 132 words)
@@ -1726,14 +1752,12 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
     }
     const uint32_t ringbase = kR64EncTable + wave * kR64EncRing; // LDS byte offset, 8 KiB aligned
     const uint32_t *ringp = reinterpret_cast<const uint32_t *>(smem + ringbase);
-    uint32_t mff0 = 0xff0u, m256 = 0xffffff00u, m1fff = 0x1fffu, ringv = ringbase, kv = 31u - p.scale_bits,
-             mbias = 0x03ffffffu;
-    asm volatile("v_mov_b32 %0, %0" : "+v"(mff0)); // VGPR copies: a VALU op with a literal or an SGPR operand issues slower
+    uint32_t k4 = 4u, m256 = 0xffffff00u, m1fff = 0x1fffu, ringv = ringbase, kv = 31u - p.scale_bits;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(k4)); // VGPR copies: a VALU op with a literal or an SGPR operand issues slower
     asm volatile("v_mov_b32 %0, %0" : "+v"(m256));
     asm volatile("v_mov_b32 %0, %0" : "+v"(m1fff));
     asm volatile("v_mov_b32 %0, %0" : "+v"(ringv));
     asm volatile("v_mov_b32 %0, %0" : "+v"(kv));
-    asm volatile("v_mov_b32 %0, %0" : "+v"(mbias));
     const uint32_t m = lane & 3u, q4 = lane & ~3u;
     const uint32_t slot_lines = (uint32_t)(p.slot_bytes / kLaneLine);
     const uint32_t nblocks = p.chunk_syms >> 6;
@@ -1800,8 +1824,8 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
                 load_block(nxt, b - 1u);
 #pragma unroll
             for (int g = 3; g >= 0; --g) {
-                r64x2_encode_group(xA, xB, wk, worst, cur[g][3], cur[g][2], cur[g][1], cur[g][0], mff0, m256, m1fff, ringv, kv,
-                                   mbias);
+                r64x2_encode_group<TRACK>(xA, xB, wk, worst, cur[g][3], cur[g][2], cur[g][1], cur[g][0], k4, m256, m1fff, ringv,
+                                          kv);
                 flush(pending() >= 64u);
             }
             if (b > 0) {
@@ -2095,8 +2119,10 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p_i
                 const uint64_t rounds = (per_cu + sw3 - 1) / sw3;
                 const uint64_t even = (per_cu + rounds - 1) / rounds;
                 sw3 = (uint32_t)(even ? even : 1);
-                static std::atomic<uint64_t> lds_ok3{0};
-                if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_encode_lanes_r64x2), 160 * 1024, lds_ok3);
+                // (a model in which every byte value has a frequency: the variant without the search for record-less symbols)
+                auto kern3 = p.dense256 ? k_encode_lanes_r64x2<false> : k_encode_lanes_r64x2<true>;
+                static std::atomic<uint64_t> lds_ok3[2] = {{0}, {0}};
+                if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern3), 160 * 1024, lds_ok3[p.dense256 ? 0 : 1]);
                     e != hipSuccess)
                     return e;
                 EncParams q = p;
@@ -2112,7 +2138,7 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p_i
                 const uint32_t grid3 = (uint32_t)(want3 < (uint64_t)num_cus ? want3 : (uint64_t)num_cus);
                 if (name)
                     *name = "k_encode_lanes_r64x2";
-                RANS_LAUNCH(k_encode_lanes_r64x2, dim3(grid3), dim3(64 * waves3), lds3, stream, q);
+                RANS_LAUNCH(kern3, dim3(grid3), dim3(64 * waves3), lds3, stream, q);
                 if (hipError_t e = hipGetLastError(); e != hipSuccess)
                     return e;
                 if (full_batches == batches)
