@@ -4,6 +4,6 @@ timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_slots.py -x
 for r in 1 2 3; do
   for v in prev new; do
     if [ $v = prev ]; then export RANS_AMD_LIB=$GRAFT_REPO_ROOT/build/libexp_prev.so; else unset RANS_AMD_LIB; fi
-    python tools/time_slots.py --configs c2 --rounds 2 --launches 20 2>&1 | grep -E "enc slots|enc compact|ok" | sed "s/^/$v /" | tee -a gpurun_out/r4l/ab.log
+    python tools/time_slots.py --configs c2 --rounds 2 --launches 20 2>&1 | grep -E "enc slots|dec|ok" | sed "s/^/$v /" | tee -a gpurun_out/r4l/ab.log
   done
 done
