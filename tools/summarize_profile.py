@@ -96,6 +96,55 @@ def main():
     if os.path.exists(sq):
         lines += ["## SQ counters, decode kernel (avg per launch)", "", "```"] + open(sq).read().splitlines() + ["```", ""]
 
+    # the encoders in both layouts and the other configs' decoders (tools/r04_profile.sh: tools/time_slots.py under the same
+    # two passes).  Algorithmic bytes: symbols read + stream bytes written of the fixed BASELINE shapes (bench.py's
+    # generator and seeds, 16 Ki-symbol chunks; config 2: 512-symbol chunks) -- the streams' sizes do not change with
+    # the kernels.
+    enc = {}
+    for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = os.path.join(src, "%senc_pmc_%s" % (tag, which), "pmc_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        vals = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and "rans_amd" in r["Kernel_Name"]:
+                vals[short_name(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in vals.items():
+            enc.setdefault(k, {})[counter] = sum(v) / len(v)
+    shapes = [  # kernel prefix, what, algorithmic bytes, FETCH_SIZE multiplier
+        ("k_encode<1, 1, 1>", "word 64-way, compact (fused placement)", 1.922e9, 2),
+        ("k_encode<1, 1, 2>", "word 64-way, SLOT layout", 1.922e9, 2),
+        ("k_encode<0, 1, 1>", "byte 64-way, compact", 1.924e9, 2),
+        ("k_encode<0, 1, 2>", "byte 64-way, SLOT layout", 1.924e9, 2),
+        ("k_encode<5, 1, 1>", "config 4 (alias, 4096 symbols), compact", 1.669e9, 2),
+        ("k_encode<5, 1, 2>", "config 4, SLOT layout", 1.669e9, 2),
+        ("k_encode_lanes_r64x2", "config 2 coding kernel (both layouts; 64-byte requests: FETCH_SIZE x 1)", 4.866e8, 1),
+        ("k_compact_small", "config 2, compact only: the copy", 4.364e8, 2),
+        ("k_decode_word64", "word 64-way decode", 1.922e9, 2),
+        ("k_decode<0, 1, 1>", "byte 64-way decode", 1.924e9, 2),
+        ("k_decode_dual<8, true>", "config 4 decode", 1.669e9, 2),
+        ("k_decode_lanes_r64x2<true>", "config 2 decode (64-byte requests: x 1)", 4.866e8, 1),
+    ]
+    if enc:
+        lines += ["## HBM traffic of the encoders in both layouts and of the decoders (`tools/time_slots.py` under separate "
+                  "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)", "",
+                  "FETCH_SIZE x 1024 x 2 for the kernels that read with 16 bytes per lane (calibrated on `k_histogram_u8`: 1.074e9 B "
+                  "for its 1 GiB), x 1 for the lane kernels' 64-byte quad requests (MI355X_MICROARCH \"HBM\": the counter tallies "
+                  "128-byte requests at 64 bytes); WRITE_SIZE x 1024.", "",
+                  "| kernel | what | read B | write B | total | algorithmic B | ratio |", "|---|---|---|---|---|---|---|"]
+        out["encoders"] = {}
+        for prefix, what, alg, mult in shapes:
+            hit = [k for k in enc if k.startswith(prefix)]
+            if not hit:
+                continue
+            v = enc[hit[0]]
+            rd = v.get("FETCH_SIZE", 0) * 1024 * mult
+            wr = v.get("WRITE_SIZE", 0) * 1024
+            lines.append("| `%s` | %s | %.4g | %.4g | %.4g | %.4g | **%.3f** |" % (hit[0], what, rd, wr, rd + wr, alg, (rd + wr) / alg))
+            out["encoders"][hit[0]] = {"read": rd, "write": wr, "algorithmic": alg, "ratio": (rd + wr) / alg}
+        lines += ["", "The slot layout takes every wave encoder from 1.75-1.94 x its algorithmic bytes to 1.00-1.02 x (VERDICT r03 next "
+                  "#1: <= 1.3 x): the stream is written once.", ""]
+
     # which kernel sources the measurement belongs to: bench.py quotes it as roofline.traffic only on a match
     sys.path.insert(0, ROOT)
     try:
