@@ -82,6 +82,9 @@ def parse_args():
                          "on every pair for a few launches and keep the fastest pair -- MI355X memory comes in two classes and "
                          "a kernel that streams one buffer in and another out is 4-6 %% faster when the two lie in different "
                          "ones (profiles/r04_allocation.md); 1 = take what the allocator returns first (rounds 1-3)")
+    ap.add_argument("--placement-spread", type=float, default=1.02, metavar="R",
+                    help="setup (untimed): when the slowest probed pair is within this factor of the fastest, every candidate "
+                         "lies in one class of memory -- keep them and allocate another round of candidates (twice at most)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="dry-run aid: every rank uses this GPU (needs --backend gloo)")
@@ -641,11 +644,20 @@ def main():
             for _ in range(16):
                 ctx.decode(model, cont, total, offs, lens, n, args.ways, args.chunk, d_out=out, sync=False)
             torch.cuda.synchronize()
-        ci, oi, matrix = choose_pair(torch, lambda c, o: ctx.decode(model, c, total, offs, lens, n, args.ways, args.chunk, d_out=o,
-                                                                    sync=False), conts, outs)
+        # (a process whose first candidates ALL lie in one class -- every pair within 2 % -- keeps them alive and allocates
+        #  more, twice at most: the other class is a window of a few GiB somewhere in allocation order)
+        extended = 0
+        while True:
+            ci, oi, matrix = choose_pair(torch, lambda c, o: ctx.decode(model, c, total, offs, lens, n, args.ways, args.chunk, d_out=o,
+                                                                        sync=False), conts, outs)
+            flat = [v for row in matrix for v in row]
+            if max(flat) >= args.placement_spread * min(flat) or extended == 2:
+                break
+            extended += 1
+            conts += [cont.clone() for _ in range(2)]
+            outs += [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(args.placement_candidates)]
         cont, out = conts[ci], outs[oi]
-        flat = [v for row in matrix for v in row]
-        placement = {"candidates": {"containers": len(conts), "outputs": len(outs)}, "chosen": [ci, oi],
+        placement = {"candidates": {"containers": len(conts), "outputs": len(outs), "extended": extended}, "chosen": [ci, oi],
                      "probe_ms_chosen": round(matrix[ci][oi], 4), "probe_ms_min": round(min(flat), 4),
                      "probe_ms_max": round(max(flat), 4), "probe_ms_first_pair": round(matrix[0][0], 4),
                      "probe_ms": [[round(v, 4) for v in row] for row in matrix],

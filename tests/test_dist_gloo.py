@@ -138,6 +138,37 @@ def test_bench_gpus_n_launches_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_placement_probe_allocates_more_when_all_candidates_look_alike():
+    """The headline's placement probe (setup, untimed; profiles/r04_allocation.md): when every probed pair lies within
+    --placement-spread of the fastest -- all candidates in one class of memory -- the candidates stay alive and another round
+    is allocated, twice at most.  Forced here with a spread no measurement reaches: 2 + 2 + 2 outputs, 3 + 2 + 2 containers,
+    the line says so, and the round trip of the chosen pair is bit-exact."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--log2n", "24", "--prewarm-ms", "0",
+           "--no-configs", "--no-cpu-baseline", "--placement-candidates", "2", "--placement-spread", "100"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    p = d["placement"]
+    assert p["candidates"] == {"containers": 7, "outputs": 6, "extended": 2}
+    assert len(p["probe_ms"]) == 7 and all(len(row) == 6 for row in p["probe_ms"])
+    assert 0 <= p["chosen"][0] < 7 and 0 <= p["chosen"][1] < 6
+    assert p["probe_ms_chosen"] == p["probe_ms_min"] and d["bit_exact_roundtrip"] is True
+    # the default spread on a small run: whatever the probe saw, the line carries the counts
+    cmd[-1] = "1.02"
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["placement"]["candidates"]["extended"] in (0, 1, 2) and d["bit_exact_roundtrip"] is True
+
+
+@pytest.mark.gpu
 def test_bench_force_dist_runs_rccl_on_one_gpu():
     """bench.py --force-dist: torch.distributed over the nccl backend (RCCL) with a single rank -- init_process_group
     with device_id, both barriers and the on-device all_gather of the record execute on real RCCL on this box, so the
