@@ -1099,6 +1099,49 @@ def test_byte_encoder_staging_extremes(gpu, oracle):
                 assert np.array_equal(out.cpu().numpy(), data), (sb, name, n_ways, chunk)
 
 
+def test_byte_encoder_sparse_model_and_stray_symbols(gpu, oracle):
+    """The mirrored byte sub-step comes in two variants: models in which every byte value has a frequency skip the search
+    for symbols without a record (the dense models of the test above), all others OR-accumulate a marker of the records they
+    touch.  Here the other kind -- 100 of 256 symbols, frequencies of every size class -- in both layouts against the
+    oracle, and a stray symbol deep inside the full-wave part of a chunk: RANS_AMD_E_MODEL from either entry point."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(29)
+    n = 1 << 17
+    for sb in (12, 14):
+        M = 1 << sb
+        f = np.zeros(256, np.uint32)
+        live = np.sort(rng.choice(256, 100, replace=False))
+        w = rng.integers(1, 50, 100).astype(np.float64) ** 2
+        q = np.maximum(1, np.floor(w / w.sum() * (M - 100)).astype(np.int64))
+        q[0] += M - q.sum()
+        f[live] = q
+        assert f.sum() == M and (f[live] > 0).all()
+        data = rng.choice(live, n, p=f[live] / float(M)).astype(np.uint8)
+        om, gm = oracle.model(f, sb), ctx.model(FMT_BYTE, f, sb)
+        d = torch.from_numpy(data).cuda()
+        for chunk in (8192, 5000):
+            want, offs, lens = oracle.encode_chunked(FMT_BYTE, om, data, 64, chunk, align=16)
+            cont, d_offs, d_lens, total = ctx.encode(gm, d, 64, chunk)
+            s_cont, s_offs, s_lens, s_total = ctx.encode_slots(gm, d, 64, chunk)
+            assert total == want.size and np.array_equal(d_lens.cpu().numpy().astype(np.int64), lens.astype(np.int64))
+            assert np.array_equal(s_lens.cpu().numpy().astype(np.int64), lens.astype(np.int64))
+            got, sgot, so = cont[:total].cpu().numpy(), s_cont.cpu().numpy(), s_offs.cpu().numpy()
+            for c in range(len(lens)):
+                o, ln, a = int(offs[c]), int(lens[c]), int(so[c])
+                assert np.array_equal(got[o:o + ln], want[o:o + ln]), (sb, chunk, c)
+                assert np.array_equal(sgot[a:a + ln], want[o:o + ln]), (sb, chunk, c)
+            out = ctx.decode(gm, s_cont, s_total, s_offs, s_lens, n, 64, chunk)
+            assert np.array_equal(out.cpu().numpy(), data), (sb, chunk)
+        stray = [v for v in range(256) if f[v] == 0]
+        for bad_sym in (stray[0], stray[-1]):
+            bad = data.copy()
+            bad[3 * 8192 + 4321] = bad_sym
+            for call in (ctx.encode, ctx.encode_slots):
+                with pytest.raises(R.RansAmdError) as e:
+                    call(gm, torch.from_numpy(bad).cuda(), 64, 8192)
+                assert e.value.status == R.E_MODEL, (sb, bad_sym)
+
+
 @pytest.mark.parametrize("fmt,sb", [(FMT_WORD, 12), (FMT_BYTE, 14), (FMT_BYTE, 16)])
 def test_staged_encoders_with_the_three_kernel_placement(gpu, oracle, fmt, sb):
     """RANS_AMD_OPT_FUSED_PLACEMENT = 0 (k_encode + k_layout + k_compact): the coding kernel is the same template with
