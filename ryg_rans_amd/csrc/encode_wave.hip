@@ -231,9 +231,9 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 //               wait states a VALU write of vcc needs before v_mbcnt may read it)
 //   v_mbcnt x2  rank among the emitting lanes = word index (ascending lane = ascending address)
 //   global_store_short + v_lshrrev under the emit mask, then exec back to all ones
-//   x / freq    round-up reciprocal (model.h, WordEncRec): one v_mul_hi_u32 and four cheap ops,
-//               exact, so no compare/select; x' = x + bias + q * cmpl in one v_mad_u32_u24 + add
-// 15 VALU, no v_cndmask, no branch.  `wp` is the byte offset of the lowest word written so far.
+//   x / freq    reciprocal from the record (model.h, WordEncRec; Alverson or round-up, see below): exact, so no
+//               compare/select; x' = x + bias + q * cmpl in one v_mad_u32_u24 + add
+// 10 VALU (13 with the round-up reciprocal), no v_cndmask, no branch.  `wp` is the byte offset of the lowest word written.
 // (One state per lane -- every 64-way launch -- runs enc_word_full_staged below instead: the words go to LDS first.)
 #ifndef RANS_ENC_STAGE // (experiment knob: -DRANS_ENC_STAGE=0 = the word encoder stores every round's words itself)
 #define RANS_ENC_STAGE 1
