@@ -55,11 +55,15 @@ def main():
         s_cont, s_offs, s_lens, s_total = ctx.encode_slots(m, d, ways, chunk)
         ok = bool(torch.equal(c_lens, s_lens))
         out = torch.empty_like(d)
-        ctx.decode(m, c_cont, c_total, c_offs, c_lens, n, ways, chunk, d_out=out)
-        ok = ok and bool(torch.equal(out, d))
-        out.zero_()
-        ctx.decode(m, s_cont, s_total, s_offs, s_lens, n, ways, chunk, d_out=out)
-        ok = ok and bool(torch.equal(out, d))
+        try:  # (a library variant that is wrong by construction -- a dropped store, timing only -- still gets its encode times)
+            ctx.decode(m, c_cont, c_total, c_offs, c_lens, n, ways, chunk, d_out=out)
+            ok = ok and bool(torch.equal(out, d))
+            out.zero_()
+            ctx.decode(m, s_cont, s_total, s_offs, s_lens, n, ways, chunk, d_out=out)
+            ok = ok and bool(torch.equal(out, d))
+        except R.RansAmdError as e:
+            print("%-8s decode of the encoder's output failed: %s" % (name, e), flush=True)
+            ok = False
         alg = n * d.element_size() + c_total
         k_dec = ctx.last_decode_kernel()
         for r in range(a.rounds):
