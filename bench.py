@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: 64-way interleaved rANS decode (word format) of
-synthetic order-0 byte streams, one 1 GiB shard per GPU (BASELINE.json configs[2] / [4]), 16 Ki-symbol chunks.
+synthetic order-0 byte streams, one 1 GiB shard per GPU (BASELINE.json configs[2] / [4]), 32 Ki-symbol chunks
+(the `configs` entries: 16 Ki, --config-chunk).
 
   python bench.py                                  # 1 GPU
   python bench.py --gpus N --steps K --warmup W    # N GPUs of this node: spawns its own N ranks (torch.distributed.run)
@@ -51,10 +52,13 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=30, help="symbols per GPU = 2^log2n (default 1 GiB)")
     ap.add_argument("--ways", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=16384,
-                    help="symbols per independent chunk stream (16 Ki since round 3: the tail of a launch -- waves that finish "
-                         "between 0.8 and 1.0 of its duration -- is shorter with smaller chunks; measured -1.2 to -1.7 %% kernel time "
-                         "against 32 Ki on three boxes for 0.8 %% more stream bytes, DESIGN 4.1)")
+    ap.add_argument("--chunk", type=int, default=32768,
+                    help="symbols per independent chunk stream of the HEADLINE workload (32 Ki as in rounds 1-2 and BASELINE; "
+                         "round 3 quoted 16 Ki, which the placement lottery of its boxes favoured: with the placement probe in "
+                         "front, five fresh processes per size on two boxes put 32 Ki 1.9 %% ahead -- 0.379-0.383 against "
+                         "0.386-0.390 ms -- for 0.8 %% fewer stream bytes; profiles/r04_chunk_sweep.log, DESIGN 5)")
+    ap.add_argument("--config-chunk", type=int, default=16384,
+                    help="symbols per chunk of the `configs` entries (16 Ki: config 4's and the byte format's optimum)")
     ap.add_argument("--format", default="word", choices=["word", "byte", "r64", "alias"])
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (reference timing + oracle checks)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
@@ -819,7 +823,7 @@ def main():
         # share a process with the timed run, so a committed measurement is quoted only when it was taken on
         # this workload AND on the kernel sources of this checkout (its `kernel_source_tag`), else null.
         tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r04_traffic.json"))
-        default_workload = (args.format == "word" and args.ways == 64 and args.chunk == 16384 and args.log2n == 30)
+        default_workload = (args.format == "word" and args.ways == 64 and args.chunk == 32768 and args.log2n == 30)
         if os.path.exists(tj) and default_workload:
             try:
                 t = json.load(open(tj))
@@ -836,33 +840,38 @@ def main():
             try:
                 ks = args.config_steps
                 cp = min(args.placement_candidates, 4)  # (the `configs` entries: up to four candidates per written buffer)
-                # the headline configuration's encoder
-                e, a = measure_config(torch, R, ctx, "C3 word 64-way 1 GiB (encoder of the headline config)", R.FMT_WORD, 12,
-                                      256, args.ways, args.chunk, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
+                cc = args.config_chunk
+                # the headline configuration's encoder (and its decoder once more) at the `configs` chunk size
+                e, a = measure_config(torch, R, ctx, "C3 word 64-way 1 GiB, %d-symbol chunks (the headline's format: encoder, "
+                                      "and decoder at this chunk size)" % cc, R.FMT_WORD, 12,
+                                      256, args.ways, cc, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
-                arts[0]["entry"] = e  # (the headline's own artefacts: container checked below, CPU loop timed beside it)
-                arts[0]["slots"] = a["slots"]
+                if cc == args.chunk:  # (the headline's own artefacts: container checked below, CPU loop timed beside it)
+                    arts[0]["entry"] = e
+                    arts[0]["slots"] = a["slots"]
+                else:
+                    arts.append(a)
                 e, a = measure_config(torch, R, ctx, "C2 rans64 2-way 256 MiB Zipf(256)", R.FMT_R64, 14, 256, 2, 512, 28, 1,
                                       ks, device, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 e, a = measure_config(torch, R, ctx, "C4 alias 4096 symbols 64-way 512 Mi u16 symbols", R.FMT_ALIAS, 16,
-                                      4096, 64, args.chunk, 29, 1, ks, device, probe=cp)
+                                      4096, 64, cc, 29, 1, ks, device, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
-                e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256)", R.FMT_BYTE, 14, 256, 64, args.chunk,
+                e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256)", R.FMT_BYTE, 14, 256, 64, cc,
                                       30, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 # the byte format at 12-bit probabilities: the decoder's fused slot records (one LDS gather per symbol, round 4)
                 e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256), scale_bits 12 (slot-record decoder)",
-                                      R.FMT_BYTE, 12, 256, 64, args.chunk, 30, 1, ks, device, d_syms=d_syms, probe=cp)
+                                      R.FMT_BYTE, 12, 256, 64, cc, 30, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 # "64-way and wider" (north_star): two and four states per lane over the headline's data
                 for wide in (128, 256):
                     e, a = measure_config(torch, R, ctx, "word %d-way 1 GiB Zipf(256) (%d states per lane)" % (wide, wide // 64),
-                                          R.FMT_WORD, 12, 256, wide, args.chunk, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
+                                          R.FMT_WORD, 12, 256, wide, cc, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
                     cfgs.append(e)
                     arts.append(a)
             except Exception as e:  # noqa: BLE001
