@@ -84,7 +84,7 @@ def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways
     assert bench.oracle_check_chunks(art) == (n + chunk - 1) // chunk
     out = ctx.decode(gm, cont, total, offs, lens, n, ways, chunk)
     assert torch.equal(out, d_syms)
-    if name.startswith("C3"):  # (both chunk sizes: 16 Ki is the headline configuration of bench.py)
+    if name.startswith("C3"):  # (both chunk sizes: 32 Ki is bench.py's headline, 16 Ki its `configs` entries)
         assert ctx.last_decode_kernel() == "k_decode_word64"
     if name.startswith("C4"):
         assert ctx.last_decode_kernel() == "k_decode_dual<alias>"
