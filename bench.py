@@ -172,7 +172,8 @@ def settle(torch, fn, ms=60.0):
 def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, steps, device, d_syms=None, probe=1):
     """One `configs` entry: decode and encode of a BASELINE configuration, `steps` back-to-back launches each,
     round trip verified.  Returns (entry, artefacts for the CPU-side oracle check).  probe > 1: every timed call first
-    chooses the buffer it WRITES among `probe` candidate allocations (ryg_rans_amd/placement.py; untimed)."""
+    chooses the buffer it WRITES among `probe` candidate allocations -- the decode the (container, output) pair among two
+    copies of the container and `probe` outputs (ryg_rans_amd/placement.py; untimed)."""
     from ryg_rans_amd.placement import choose_one
     n = 1 << log2n
     sym_bytes = 1 if K <= 256 else 2
@@ -184,18 +185,26 @@ def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, st
     cont, offs, lens, total = ctx.encode(model, d_syms, ways, chunk)
     out = torch.empty_like(d_syms)
     placement = {"candidates": probe}
+    cont_dec = cont
     if probe > 1:
+        # the decode reads one buffer and writes another: the PAIR decides (two memory classes, profiles/r04_allocation.md),
+        # so a second copy of the container is a candidate as well
+        from ryg_rans_amd.placement import choose_pair
+        conts = [cont, cont.clone()]
         outs = [out] + [torch.empty_like(d_syms) for _ in range(probe - 1)]
         settle(torch, lambda: ctx.decode(model, cont, total, offs, lens, n, ways, chunk, d_out=out, sync=False))
-        pick, ms = choose_one(torch, lambda o: ctx.decode(model, cont, total, offs, lens, n, ways, chunk, d_out=o, sync=False), outs)
-        out = outs[pick]
-        placement["decode_probe_ms"] = [round(v, 4) for v in ms]
-        del outs
+        ci, oi, matrix = choose_pair(torch, lambda c, o: ctx.decode(model, c, total, offs, lens, n, ways, chunk, d_out=o, sync=False),
+                                     conts, outs)
+        cont_dec, out = conts[ci], outs[oi]
+        placement["decode_probe_ms"] = [[round(v, 4) for v in row] for row in matrix]
+        placement["decode_chosen"] = [ci, oi]
+        del conts, outs
     dec_ms, dec_min = timed_launches(
-        torch, lambda: ctx.decode(model, cont, total, offs, lens, n, ways, chunk, d_out=out, sync=False), steps, 2)
+        torch, lambda: ctx.decode(model, cont_dec, total, offs, lens, n, ways, chunk, d_out=out, sync=False), steps, 2)
     bad = ctx.decode_errors()
     exact = bool(torch.equal(out, d_syms)) and bad == 0
     kernel = ctx.last_decode_kernel()
+    del cont_dec
     cont2, offs2, lens2 = torch.empty_like(cont), torch.empty_like(offs), torch.empty_like(lens)
     if probe > 1:
         c2s = [cont2] + [torch.empty_like(cont) for _ in range(min(probe, 4) - 1)]
