@@ -207,7 +207,7 @@ def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, st
     del cont_dec
     cont2, offs2, lens2 = torch.empty_like(cont), torch.empty_like(offs), torch.empty_like(lens)
     if probe > 1:
-        c2s = [cont2] + [torch.empty_like(cont) for _ in range(min(probe, 4) - 1)]
+        c2s = [cont2] + [torch.empty_like(cont) for _ in range(2 * probe - 1)]  # (the compact encoders are the most placement-sensitive calls: 10-12 %)
         settle(torch, lambda: ctx.encode(model, d_syms, ways, chunk, d_out=cont2, sync=False, d_offsets=offs2, d_lengths=lens2))
         pick, ms = choose_one(torch, lambda c: ctx.encode(model, d_syms, ways, chunk, d_out=c, sync=False, d_offsets=offs2,
                                                           d_lengths=lens2), c2s)
