@@ -1,7 +1,9 @@
 """Randomised GPU-vs-oracle parity sweep (run on the GPU box): random format, scale_bits, alphabet
 skew, n, N, chunk size, buffer misalignment and kernel-family options of the context; every case checks
   * GPU encode == oracle encode (lengths, offsets, every chunk's bytes),
-  * GPU decode of the ORACLE container == input, GPU decode of its own container == input.
+  * GPU decode of the ORACLE container == input, GPU decode of its own container == input,
+  * the slot layout (rans_amd_encode_slots): every chunk == the oracle's stream at the end of its slot, decode from it,
+    rans_amd_container_compact of it == the compact container, a random chunk range of it decoded on its own.
     python tools/stress.py [--cases 300] [--seed 1]
 """
 import argparse
@@ -111,9 +113,46 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
             if ok:
                 out2 = ctx.decode(gm, cont, total, d_offs, d_lens, n, n_ways, chunk)
                 ok_dec = ok_dec and np.array_equal(out2.cpu().numpy().view(dt), data)
-            if not (ok and ok_dec):
+            # round 4: the slot layout (every chunk == the oracle's stream, at the end of its slot), the decoders on it,
+            # its compaction == the compact container, and a chunk RANGE of it decoded on its own
+            ok_slots = True
+            if ok:
+                nchunks = len(lens)
+                s_cont, s_offs, s_lens, s_total = ctx.encode_slots(gm, d_syms, n_ways, chunk)
+                slot = R.slot_bytes(fmt, n, n_ways, chunk)
+                so = s_offs.cpu().numpy().astype(np.int64)
+                ok_slots = s_total == nchunks * slot and np.array_equal(s_lens.cpu().numpy().astype(np.uint32), lens) and \
+                    np.array_equal(so[:nchunks], (np.arange(nchunks, dtype=np.int64) + 1) * slot - lens.astype(np.int64))
+                if ok_slots:
+                    sg = s_cont.cpu().numpy()
+                    for c in range(nchunks):
+                        a, o, ln = int(so[c]), int(offs[c]), int(lens[c])
+                        if not np.array_equal(sg[a:a + ln], want[o:o + ln]):
+                            ok_slots = False
+                            desc["bad_slot_chunk"] = c
+                            break
+                if ok_slots:
+                    out3 = ctx.decode(gm, s_cont, s_total, s_offs, s_lens, n, n_ways, chunk)
+                    ok_slots = np.array_equal(out3.cpu().numpy().view(dt), data)
+                if ok_slots:
+                    c_cont, c_offs, c_total = ctx.compact(s_cont, s_total, s_offs, s_lens, nchunks)
+                    ok_slots = c_total == want.size and np.array_equal(c_offs.cpu().numpy().astype(np.uint64), offs)
+                    cg = c_cont[:c_total].cpu().numpy()
+                    for c in range(nchunks):
+                        o, ln = int(offs[c]), int(lens[c])
+                        if ok_slots and not np.array_equal(cg[o:o + ln], want[o:o + ln]):
+                            ok_slots = False
+                            desc["bad_compacted_chunk"] = c
+                if ok_slots and nchunks >= 3:  # chunks [lo, hi) of the slot container through rans_amd_decode's pointer arithmetic
+                    lo = int(rng.integers(0, nchunks - 1))
+                    hi = int(rng.integers(lo + 1, nchunks + 1))
+                    n_range = min(n, hi * chunk) - lo * chunk
+                    part = ctx.decode(gm, s_cont, s_total, s_offs[lo:], s_lens[lo:], n_range, n_ways, chunk)
+                    ok_slots = np.array_equal(part.cpu().numpy().view(dt), data[lo * chunk:lo * chunk + n_range])
+                    desc["range"] = (lo, hi)
+            if not (ok and ok_dec and ok_slots):
                 fails += 1
-                print("FAIL", desc, "encode_ok", ok, "decode_ok", ok_dec, flush=True)
+                print("FAIL", desc, "encode_ok", ok, "decode_ok", ok_dec, "slots_ok", ok_slots, flush=True)
         except Exception as e:  # noqa: BLE001
             fails += 1
             print("EXC", desc, repr(e), flush=True)
