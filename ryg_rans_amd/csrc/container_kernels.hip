@@ -237,26 +237,42 @@ __global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
 // Histogram (count_freqs, main.cpp:59-66).  1 byte of HBM traffic per symbol, so the LDS
 // atomic rate is what has to keep up: a skewed source (Zipf: the top symbol is 16 % of
 // the input) sends ~10 lanes of every wave to the same counter, and same-bank atomics
-// serialise.  u8 path: every wave owns kHistCopies private copies of the 256 counters, a
-// lane uses copy (lane & 7), and the copies start 8 banks apart, so the lanes that hit
-// one symbol spread over eight banks; counters of symbols >= nsyms are simply counted and
+// serialise.  u8 path: kHistCopies copies of the 256 counters, a lane uses copy
+// (lane & (kHistCopies - 1)), and the copies start a few banks apart, so the lanes that hit
+// one symbol spread over as many banks; counters of symbols >= nsyms are simply counted and
 // flagged at the end (no per-symbol range check).  u16 path (alphabets up to 4096): one
 // table per block.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kHistCopies = 8;
-constexpr uint32_t kHistCopyStride = 256 + 8; // dwords: copy c starts in bank 8 * c
+// Round 4: the copies belong to the BLOCK, not to each of its waves (atomics from different waves never meet inside one
+// LDS instruction, so private copies per wave bought nothing and cost LDS): 32 copies 2 banks apart, a lane uses copy
+// (lane & 31), 33 KiB per block, twice as many blocks -- 1 GiB of Zipf(256) bytes 0.358 -> 0.281 ms per call, uniform bytes
+// 0.303 -> 0.283, one repeated byte 0.495 -> 0.228 (tools/r4w_call.sh; the knobs are for such A/B builds).
+#ifndef RANS_HIST_COPIES
+#define RANS_HIST_COPIES 32
+#endif
+#ifndef RANS_HIST_PAD
+#define RANS_HIST_PAD 2
+#endif
+#ifndef RANS_HIST_SHARED // 1: the copies belong to the block (all its waves), 0: to each wave (rounds 1-3 with 8 copies, pad 8)
+#define RANS_HIST_SHARED 1
+#endif
+#ifndef RANS_HIST_BLOCKS // blocks per CU in the grid
+#define RANS_HIST_BLOCKS 8
+#endif
+constexpr uint32_t kHistCopies = RANS_HIST_COPIES;
+constexpr uint32_t kHistCopyStride = 256 + RANS_HIST_PAD; // dwords: copy c starts in bank RANS_HIST_PAD * c
 
 __global__ void __launch_bounds__(256) k_histogram_u8(const void *syms, uint64_t n, uint32_t nsyms, uint32_t *hist,
                                                       uint32_t *flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *all = reinterpret_cast<uint32_t *>(smem);
-    const uint32_t waves = blockDim.x >> 6;
+    const uint32_t waves = RANS_HIST_SHARED ? 1u : blockDim.x >> 6;
     const uint32_t total = waves * kHistCopies * kHistCopyStride;
     for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
         all[i] = 0;
     __syncthreads();
-    uint32_t *h = all + ((threadIdx.x >> 6) * kHistCopies + (threadIdx.x & (kHistCopies - 1))) * kHistCopyStride;
+    uint32_t *h = all + ((RANS_HIST_SHARED ? 0u : (threadIdx.x >> 6) * kHistCopies) + (threadIdx.x & (kHistCopies - 1))) * kHistCopyStride;
 
     const uint8_t *p = static_cast<const uint8_t *>(syms);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -310,14 +326,18 @@ __global__ void __launch_bounds__(256) k_histogram_u8(const void *syms, uint64_t
         atomicOr(flags, 1u);
 }
 
+// (`copies` tables per block, 8 banks apart, a lane uses table (lane & (copies - 1)): as for the byte symbols above, the lanes
+//  that meet on a frequent symbol spread over several counters -- 4 copies of a 4096-symbol table are 64 KiB)
 __global__ void __launch_bounds__(256) k_histogram_u16(const void *syms, uint64_t n, uint32_t nsyms, uint32_t *hist,
-                                                       uint32_t *flags)
+                                                       uint32_t *flags, uint32_t copies)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
-    for (uint32_t i = threadIdx.x; i < nsyms; i += blockDim.x)
-        h[i] = 0;
+    uint32_t *all = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t cstride = nsyms + 8u;
+    for (uint32_t i = threadIdx.x; i < copies * cstride; i += blockDim.x)
+        all[i] = 0;
     __syncthreads();
+    uint32_t *h = all + (threadIdx.x & (copies - 1u)) * cstride;
     bool bad = false;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,9 +367,13 @@ __global__ void __launch_bounds__(256) k_histogram_u16(const void *syms, uint64_
     for (uint64_t j = nhead + nvec * 8 + tid; j < n; j += stride)
         count1(p[j]);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nsyms; i += blockDim.x)
-        if (h[i])
-            atomicAdd(&hist[i], h[i]);
+    for (uint32_t i = threadIdx.x; i < nsyms; i += blockDim.x) {
+        uint32_t sum = 0;
+        for (uint32_t c = 0; c < copies; ++c)
+            sum += all[c * cstride + i];
+        if (sum)
+            atomicAdd(&hist[i], sum);
+    }
     if (bad)
         atomicOr(flags, 1u);
 }
@@ -552,13 +576,19 @@ hipError_t launch_chunk_models(const void *syms, uint64_t n, uint32_t chunk_syms
 hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
                             uint32_t *d_flags, int num_cus, hipStream_t stream)
 {
-    const uint32_t grid = (uint32_t)num_cus * 4;
+    const uint32_t grid = (uint32_t)num_cus * (sym_bytes == 1 ? RANS_HIST_BLOCKS : 4);
     if (sym_bytes == 1) {
-        const size_t lds = (size_t)(256 / 64) * kHistCopies * kHistCopyStride * 4;
+        const size_t lds = (size_t)(RANS_HIST_SHARED ? 1 : 256 / 64) * kHistCopies * kHistCopyStride * 4;
         RANS_LAUNCH(k_histogram_u8, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
     } else {
-        const size_t lds = (size_t)nsyms * 4;
-        RANS_LAUNCH(k_histogram_u16, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
+        uint32_t copies = 8; // a power of two, as many as fit 33 KiB (four blocks per CU stay resident; one copy above 4096 symbols)
+        while (copies > 1 && (size_t)copies * (nsyms + 8) * 4 > 33 * 1024)
+            copies >>= 1;
+        const size_t lds = (size_t)copies * (nsyms + 8) * 4;
+        static std::atomic<uint64_t> lds_ok{0};
+        if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_histogram_u16), 160 * 1024, lds_ok); e != hipSuccess)
+            return e;
+        RANS_LAUNCH(k_histogram_u16, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags, copies);
     }
     return hipGetLastError();
 }
