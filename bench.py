@@ -14,19 +14,19 @@ the GPU (SURVEY 8(d) generator: splitmix64 + inverse CDF, seed = rank+1 -- the s
 bytes tests/_oracle.py's gen_zipf makes on the CPU), build the order-0 model (GPU
 histogram + exact normalize_freqs), encode with the GPU encoder (setup, untimed), then
 W warm-up and K timed decodes.  Shards are independent: no collective on the data
-path; RCCL only carries the barriers and the 40-byte per-rank result record (weak scaling).
+path; RCCL only carries the barriers and the 48-byte per-rank result record (weak scaling).
 
-Rank 0 prints ONE JSON line.  `value` = decoded (uncompressed) GB/s of the whole job.
-`roofline` = algorithmic bytes (compressed stream read + symbols written) of one decode
-launch / its average duration measured with HIP events on the launch stream, vs the
-8 TB/s HBM peak.  `clocks` = shader clock and per-wave clocks per 64-symbol round measured
-by the kernel itself in one extra instrumented launch.  `configs` (N=1 only) = the other
-BASELINE configurations and the encoders, each timed over back-to-back launches in this same
-run: decode, encode into the slot layout (rans_amd_encode_slots: every stream written once) and
-into the compact layout, each with the reference's own CPU loop of that format timed on this
-box beside it.  `cpu_baseline` (N=1 only) = the reference's own fastest decoder (SSE4.1 8-way,
-oracle/_ref) on this box's host cores over a bounded sample of the same data; the same CPU
-leg re-encodes EVERY chunk of every container with the oracle and compares the bytes.
+Rank 0 prints ONE SHORT JSON line (<= 3.5 KB, the last line of stdout: judged_line()) and writes the full record --
+probe matrices, per-thread CPU sweeps, per-config timings -- to bench_details.json (--details).  `value` = decoded
+(uncompressed) GB/s of the whole job.  `roofline` = algorithmic bytes (compressed stream read + symbols written) of one
+decode launch / its average duration measured with HIP events on the launch stream, vs the 8 TB/s HBM peak.  `clocks` =
+shader clock and per-wave clocks per 64-symbol round measured by the kernel itself in one extra instrumented launch.
+`configs` (N=1 only) = one row per other BASELINE configuration: decode, encode (compact layout, rans_amd_encode), the
+write-once encoders, the reference's own CPU loop of that format on this box, and whether EVERY chunk equalled the oracle's.
+`cpu_baseline` (rank 0, every N) = the reference's own fastest decoder (SSE4.1 8-way, oracle/_ref) on this box's host cores
+over a bounded sample of the same data (`port_value`: this repo's AVX-512 host decoder, extra).  At N=1 the CPU leg
+re-encodes EVERY chunk of every container with the oracle and compares the bytes; at N>1 every rank does that for a
+256-chunk sample of its own shard and the counts are summed over the gathered records.
 """
 import argparse
 import hashlib
@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0  # measured float4 streaming copy (same guide)
 MAX_CLOCK_HZ = 2.4e9
+MAX_LINE_BYTES = 3500   # the judged stdout line (tests/test_bench_cpu.py pins it; the driver keeps ~8 KB of stdout)
 WAVES_PER_SIMD = 8      # resident waves per SIMD of the wave-per-chunk decoder (2 blocks x 16 waves per CU)
 
 
@@ -89,6 +90,9 @@ def parse_args():
     ap.add_argument("--placement-spread", type=float, default=1.02, metavar="R",
                     help="setup (untimed): when the slowest probed pair is within this factor of the fastest, every candidate "
                          "lies in one class of memory -- keep them and allocate another round of candidates (twice at most)")
+    ap.add_argument("--details", default=None, metavar="PATH",
+                    help="where rank 0 writes the full record (every probe matrix, per-thread CPU sweep, per-config timing); "
+                         "default bench_details.json beside this script.  stdout carries only the short judged line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="dry-run aid: every rank uses this GPU (needs --backend gloo)")
@@ -169,7 +173,7 @@ def settle(torch, fn, ms=60.0):
         torch.cuda.synchronize()
 
 
-def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, steps, device, d_syms=None, probe=1):
+def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, seed, steps, device, d_syms=None, probe=1):
     """One `configs` entry: decode and encode of a BASELINE configuration, `steps` back-to-back launches each,
     round trip verified.  Returns (entry, artefacts for the CPU-side oracle check).  probe > 1: every timed call first
     chooses the buffer it WRITES among `probe` candidate allocations -- the decode the (container, output) pair among two
@@ -247,24 +251,22 @@ def measure_config(torch, R, ctx, name, fmt, sb, K, ways, chunk, log2n, seed, st
     slots_ok = slots_ok and ctx.decode_errors() == 0 and bool(torch.equal(out, d_syms))
     alg = n * sym_bytes + total
     entry = {
-        "name": name, "format": R.FORMAT_NAMES[fmt], "scale_bits": sb, "alphabet": K, "n_ways": ways, "chunk_syms": chunk,
+        "short": short, "name": name, "format": R.FORMAT_NAMES[fmt], "scale_bits": sb, "alphabet": K, "n_ways": ways, "chunk_syms": chunk,
         "symbols": n, "decoded_bytes": n * sym_bytes, "stream_bytes": total,
         "algorithmic_bytes_per_launch": alg,
         "decode": {"kernel": kernel, "ms_mean": round(dec_ms, 4), "ms_min": round(dec_min, 4), "launches": steps,
                    "decoded_GBps": round(n * sym_bytes / dec_ms / 1e6, 1),
                    "achieved_GBps": round(alg / dec_ms / 1e6, 1), "frac": round(alg / dec_ms / 1e6 / HBM_PEAK_GBPS, 4)},
-        # `encode`: the slot layout -- one write per stream, as the reference writes its buffers; `encode_compact`: the
-        # compact container of rans_amd_encode (chunk c at the sum of the aligned lengths before it: the coder's stream goes
-        # through scratch and is moved once more)
-        "encode": {"layout": "slots (rans_amd_encode_slots: chunk c = the last lengths[c] bytes of slot c, written once)",
-                   "kernels": s_kernel + " (nothing to place: no scratch, no copier waves, no layout / compaction kernel)",
-                   "ms_mean": round(s_enc_ms, 4), "ms_min": round(s_enc_min, 4), "launches": steps,
-                   "input_GBps": round(n * sym_bytes / s_enc_ms / 1e6, 1), "achieved_GBps": round(alg / s_enc_ms / 1e6, 1),
-                   "frac": round(alg / s_enc_ms / 1e6 / HBM_PEAK_GBPS, 4),
-                   "slot_bytes": slot, "container_bytes": s_total},
-        "encode_compact": {"layout": "compact (rans_amd_encode)", "kernels": enc_kernels, "ms_mean": round(enc_ms, 4),
-                           "ms_min": round(enc_min, 4), "launches": steps, "input_GBps": round(n * sym_bytes / enc_ms / 1e6, 1),
-                           "achieved_GBps": round(alg / enc_ms / 1e6, 1), "frac": round(alg / enc_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+        # `encode`: the compact container of rans_amd_encode (chunk c at the sum of the aligned lengths before it) -- the key
+        # rounds 1-3 reported under this name; `encode_slots`: the slot layout of rans_amd_encode_slots (one write per
+        # stream, as the reference writes its buffers, main.cpp:176-188; a larger container)
+        "encode": {"layout": "compact (rans_amd_encode)", "kernels": enc_kernels, "ms_mean": round(enc_ms, 4),
+                   "ms_min": round(enc_min, 4), "launches": steps, "input_GBps": round(n * sym_bytes / enc_ms / 1e6, 1),
+                   "achieved_GBps": round(alg / enc_ms / 1e6, 1), "frac": round(alg / enc_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+        "encode_slots": {"layout": "slots (rans_amd_encode_slots: chunk c = the last lengths[c] bytes of slot c, written once)",
+                         "kernels": s_kernel, "ms_mean": round(s_enc_ms, 4), "ms_min": round(s_enc_min, 4), "launches": steps,
+                         "input_GBps": round(n * sym_bytes / s_enc_ms / 1e6, 1), "achieved_GBps": round(alg / s_enc_ms / 1e6, 1),
+                         "frac": round(alg / s_enc_ms / 1e6 / HBM_PEAK_GBPS, 4), "slot_bytes": slot, "container_bytes": s_total},
         "decode_slots": {"kernel": ctx.last_decode_kernel(), "ms_mean": round(s_dec_ms, 4), "ms_min": round(s_dec_min, 4),
                          "launches": steps, "frac": round(alg / s_dec_ms / 1e6 / HBM_PEAK_GBPS, 4)},
         "bit_exact_roundtrip": exact and same_container and slots_ok,
@@ -468,12 +470,18 @@ def cpu_baseline(d_syms, freqs, n):
         report.append(entry)
         if best is None or sweep[bt] > best[0]:
             best = (sweep[bt], bt, entry)
-    res = {"value": best[0], "unit": "GB/s", "cores": best[1], "kind": best[2]["kind"], "decoder": best[2]["decoder"],
+    # `value` is the REFERENCE's number (its fastest thread count); a faster decoder of this repo's own (the AVX-512 port)
+    # is listed beside it as port_value -- a stronger baseline is extra, not the baseline
+    head = report[0] if ref is not None else best[2]
+    res = {"value": head["best_GBps"], "unit": "GB/s", "cores": head["best_threads"], "kind": head["kind"],
+           "decoder": head["decoder"],
            "sample": "%d x %d MiB shards from the start of rank 0's data, each its own N-way word stream, one PINNED "
                      "pthread per shard (physical cores first, then SMT siblings), thread counts %s swept for every "
-                     "decoder, fastest (decoder, threads) reported" % (max_threads, shard >> 20, cands),
+                     "decoder" % (max_threads, shard >> 20, cands),
            "decoders": report, "host_cpus": cores, "usable_cpus": usable, "physical_cores": physical,
            "cpu_quota_cores": quota}
+    for r in report[1:] if ref is not None else []:
+        res["port_value"], res["port_cores"], res["port_decoder"] = r["best_GBps"], r["best_threads"], r["decoder"]
     if ref is not None:
         r0 = report[0]
         res["reference_value"] = r0["best_GBps"]
@@ -548,6 +556,85 @@ def config_cpu_baseline(art):
                   % ((max_threads * n_per * sym_bytes) >> 20, max_threads, max_threads, quota, usable),
     }
     return res
+
+
+def judged_line(full, details_path=None):
+    """The ONE line rank 0 prints (last line of stdout, <= MAX_LINE_BYTES): the contract's fields, `roofline`,
+    `cpu_baseline` (value = the REFERENCE's decoder on this box), `clocks`, the placement probe's summary (no matrix), and
+    one row per `configs` entry.  Everything else lives in the details file.  Pure function of the full record, so that
+    tests/test_bench_cpu.py can pin its size on a canned record."""
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    c = full.get("config", {})
+    line["config"] = {k: c.get(k) for k in ("workload", "format", "n_ways", "chunk_syms", "scale_bits", "symbols_per_gpu",
+                                            "compressed_bytes_per_symbol")}
+    line["bit_exact_roundtrip"] = full.get("bit_exact_roundtrip")
+    line["headline"] = full.get("headline")
+    if full.get("knobs"):
+        line["knobs"] = sorted(full["knobs"])
+    rl = full.get("roofline", {})
+    line["roofline"] = {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg",
+                                               "algorithmic_bytes_per_launch", "frac_job", "wave_span_ms_avg")}
+    pl = full.get("placement", {})
+    if "probe_ms_chosen" in pl:  # the un-probed figure beside the chosen one: what two plain hipMallocs would have got
+        n_sym = c.get("symbols_per_gpu") or 0
+        line["placement"] = {"chosen_ms": pl["probe_ms_chosen"], "first_pair_ms": pl["probe_ms_first_pair"],
+                             "min_ms": pl["probe_ms_min"], "max_ms": pl["probe_ms_max"],
+                             "pairs": pl["candidates"]["containers"] * pl["candidates"]["outputs"]}
+        if (full.get("n_gpus") or 1) == 1 and pl["probe_ms_first_pair"] > 0:
+            line["value_first_pair"] = round(n_sym / pl["probe_ms_first_pair"] / 1e6, 2)
+            line["frac_first_pair"] = round(rl.get("algorithmic_bytes_per_launch", 0) / pl["probe_ms_first_pair"] / 1e6
+                                            / HBM_PEAK_GBPS, 4)
+    ck = full.get("clocks", {})
+    if "error" not in ck:
+        line["clocks"] = {k: ck.get(k) for k in ("sclk_hz_measured", "per_wave_clocks_per_round_of_64",
+                                                 "clocks_per_symbol_per_simd", "gpu_aggregate_clocks_per_symbol")}
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = {"value": None if cb.get("value") is None else round(cb["value"], 3), "unit": cb.get("unit"),
+                                "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": (cb.get("sample") or "")[:120]}
+        for k in ("single_thread_value", "single_thread_clocks_per_symbol", "port_value", "port_cores"):
+            if cb.get(k) is not None:
+                line["cpu_baseline"][k] = round(cb[k], 3)
+    for k in ("oracle_chunks_checked", "oracle_chunks_total", "decodes_oracle_container", "error", "oracle_check_error"):
+        if k in full:
+            line[k] = full[k]
+    rows = []
+    for e in full.get("configs", []):
+        if "error" in e:
+            rows.append({"error": e["error"][:120]})
+            continue
+        cpu = e.get("cpu_baseline") or {}
+        total = e.get("oracle_chunks_total")
+        row = {"name": e["short"], "decode_ms": e["decode"]["ms_mean"], "decode_frac": e["decode"]["frac"],
+               "encode_ms": e["encode"]["ms_mean"], "encode_frac": e["encode"]["frac"]}
+        for key, tag in (("encode_slots", "enc_slots"), ("encode_tight", "enc_tight"), ("decode_slots", "dec_slots"),
+                         ("decode_tight", "dec_tight")):
+            if key in e:
+                row[tag + "_ms"] = e[key]["ms_mean"]
+        if cpu.get("value") is not None:
+            row["cpu_ref_GBps"] = cpu["value"]
+            row["cpu_ref_cores"] = cpu.get("cores")
+        row["oracle_ok"] = bool(e.get("bit_exact_roundtrip")) and total is not None and \
+            e.get("oracle_chunks_checked") == total and e.get("oracle_chunks_checked_slots", total) == total
+        rows.append(row)
+    if rows:
+        line["configs"] = rows
+    if full.get("per_rank") and (full.get("n_gpus") or 1) > 1:
+        line["per_rank_kernel_ms"] = full["per_rank"]["kernel_ms"]
+    line["details"] = details_path
+    # the size is a guarantee, not a hope: shed the optional per-config keys, then whole rows, until the line fits
+    for drop in ("cpu_ref_cores", "dec_tight_ms", "dec_slots_ms", "enc_tight_ms", "enc_slots_ms", "cpu_ref_GBps", None):
+        if len(json.dumps(line, separators=(",", ":"))) <= MAX_LINE_BYTES:
+            break
+        if drop is None:
+            while line.get("configs") and len(json.dumps(line, separators=(",", ":"))) > MAX_LINE_BYTES - 40:
+                line["configs"].pop()
+                line["configs_truncated"] = True
+        else:
+            for row in line.get("configs", []):
+                row.pop(drop, None)
+    return line
 
 
 def kernel_source_tag():
@@ -731,11 +818,25 @@ def main():
     exact = bool(torch.equal(out, d_syms))  # (always the real comparison: a --measure run with an output-dropping knob says false)
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
 
+    # N > 1: EVERY rank pins its own shard against the oracle before the records are gathered -- a 256-chunk sample (first,
+    # last, the offset-scan block edges, random ones) re-encoded on the host and compared byte for byte; the count travels
+    # in the record and rank 0 sums it.  (N = 1 checks every chunk of every container further down.)
+    sampled, sample_ok = 0, True
+    if world > 1 and not args.no_cpu_baseline:
+        try:
+            sampled = oracle_check_chunks({"fmt": fmt, "sb": sb, "K": 256, "ways": args.ways, "chunk": args.chunk, "n": n,
+                                           "freqs": freqs, "d_syms": d_syms, "cont": cont, "offs": offs, "lens": lens,
+                                           "total": total}, args.oracle_sample or 256)
+        except AssertionError as e:
+            print("rank %d: %s" % (rank, e), file=sys.stderr)
+            sample_ok = False
+
     from ryg_rans_amd.sharding import ShardRecord, aggregate, gather_records
-    rec = ShardRecord(elapsed, float(n), float(total), kernel_ms, 1.0 if (exact and bad == 0) else 0.0)
-    # the only payload RCCL carries: 40 bytes per rank
+    rec = ShardRecord(elapsed, float(n), float(total), kernel_ms, 1.0 if (exact and bad == 0 and sample_ok) else 0.0, float(sampled))
+    # the only payload RCCL carries: 48 bytes per rank
     records = gather_records(rec, device=device if args.backend == "nccl" else "cpu", force=args.force_dist)
 
+    exit_code = 0
     if rank == 0:
         agg = aggregate(records, args.steps)
         all_ok = agg["all_ok"]
@@ -851,7 +952,7 @@ def main():
                 cp = min(args.placement_candidates, 4)  # (the `configs` entries: up to four candidates per written buffer)
                 cc = args.config_chunk
                 # the headline configuration's encoder (and its decoder once more) at the `configs` chunk size
-                e, a = measure_config(torch, R, ctx, "C3 word 64-way 1 GiB, %d-symbol chunks (the headline's format: encoder, "
+                e, a = measure_config(torch, R, ctx, "C3-word64", "C3 word 64-way 1 GiB, %d-symbol chunks (the headline's format: encoder, "
                                       "and decoder at this chunk size)" % cc, R.FMT_WORD, 12,
                                       256, args.ways, cc, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
@@ -860,26 +961,26 @@ def main():
                     arts[0]["slots"] = a["slots"]
                 else:
                     arts.append(a)
-                e, a = measure_config(torch, R, ctx, "C2 rans64 2-way 256 MiB Zipf(256)", R.FMT_R64, 14, 256, 2, 512, 28, 1,
+                e, a = measure_config(torch, R, ctx, "C2-r64x2", "C2 rans64 2-way 256 MiB Zipf(256)", R.FMT_R64, 14, 256, 2, 512, 28, 1,
                                       ks, device, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
-                e, a = measure_config(torch, R, ctx, "C4 alias 4096 symbols 64-way 512 Mi u16 symbols", R.FMT_ALIAS, 16,
+                e, a = measure_config(torch, R, ctx, "C4-alias4096", "C4 alias 4096 symbols 64-way 512 Mi u16 symbols", R.FMT_ALIAS, 16,
                                       4096, 64, cc, 29, 1, ks, device, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
-                e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256)", R.FMT_BYTE, 14, 256, 64, cc,
+                e, a = measure_config(torch, R, ctx, "byte14", "byte format 64-way 1 GiB Zipf(256)", R.FMT_BYTE, 14, 256, 64, cc,
                                       30, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 # the byte format at 12-bit probabilities: the decoder's fused slot records (one LDS gather per symbol, round 4)
-                e, a = measure_config(torch, R, ctx, "byte format 64-way 1 GiB Zipf(256), scale_bits 12 (slot-record decoder)",
+                e, a = measure_config(torch, R, ctx, "byte12", "byte format 64-way 1 GiB Zipf(256), scale_bits 12 (slot-record decoder)",
                                       R.FMT_BYTE, 12, 256, 64, cc, 30, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 # "64-way and wider" (north_star): two and four states per lane over the headline's data
                 for wide in (128, 256):
-                    e, a = measure_config(torch, R, ctx, "word %d-way 1 GiB Zipf(256) (%d states per lane)" % (wide, wide // 64),
+                    e, a = measure_config(torch, R, ctx, "word%d" % wide, "word %d-way 1 GiB Zipf(256) (%d states per lane)" % (wide, wide // 64),
                                           R.FMT_WORD, 12, 256, wide, cc, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
                     cfgs.append(e)
                     arts.append(a)
@@ -888,6 +989,15 @@ def main():
             result["configs"] = cfgs
             if any(not c.get("bit_exact_roundtrip", False) for c in cfgs):
                 all_ok = False
+        if world > 1 and not args.no_cpu_baseline:
+            result["oracle_chunks_checked"] = int(sum(r.oracle_chunks for r in records))
+            result["oracle_chunks_total"] = len(records) * ((n + args.chunk - 1) // args.chunk)
+            result["oracle_chunks_checked_per_rank"] = [int(r.oracle_chunks) for r in records]
+            try:  # (the other ranks wait in the barrier below: their host threads sleep, the reference gets the cores)
+                result["cpu_baseline"] = cpu_baseline(d_syms, freqs, n)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "reference",
+                                          "sample": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 checked = {}
@@ -933,11 +1043,26 @@ def main():
         result["bit_exact_roundtrip"] = all_ok  # (after the configs and the oracle leg have had their say)
         if not all_ok:
             result["error"] = "round trip mismatch, corrupt chunk reported, or a chunk differs from the oracle"
-        print(json.dumps(result), flush=True)
+        # The full record goes to a FILE; stdout gets ONE short line (the reference prints ~70 characters per run,
+        # main_simd.cpp:267) -- the driver keeps only the last few KB of stdout, and round 4's 20 KB line was cut in two.
+        details = args.details or os.path.join(ROOT, "bench_details.json")
+        try:
+            with open(details, "w") as fh:
+                json.dump(result, fh, indent=1)
+                fh.write("\n")
+        except OSError as e:
+            print("bench.py: could not write %s: %s" % (details, e), file=sys.stderr)
+            details = None
+        line = judged_line(result, os.path.relpath(details, ROOT) if details else None)
+        text = json.dumps(line, separators=(",", ":"))
+        assert len(text) <= MAX_LINE_BYTES, "judged line is %d bytes" % len(text)
+        print(text, flush=True)
         if not all_ok and not args.measure:
-            sys.exit(1)
+            exit_code = 1
     if use_dist:
+        barrier()
         dist.destroy_process_group()
+    sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -30,13 +30,14 @@ class ShardRecord:
     stream_bytes: float   # compressed bytes read per step
     kernel_ms: float      # average decode-kernel duration (HIP events)
     ok: float             # 1.0 when the round trip was bit exact and no chunk was flagged
+    oracle_chunks: float = 0.0  # chunks of this rank's shard compared byte for byte with the CPU oracle (bench.py, N > 1)
 
     def to_list(self):
-        return [self.elapsed_s, self.symbols, self.stream_bytes, self.kernel_ms, self.ok]
+        return [self.elapsed_s, self.symbols, self.stream_bytes, self.kernel_ms, self.ok, self.oracle_chunks]
 
 
 def gather_records(rec, device="cpu", force=False):
-    """all_gather of one ShardRecord per rank (5 doubles = 40 bytes each).  force: run the collective in a one-rank
+    """all_gather of one ShardRecord per rank (6 doubles = 48 bytes each).  force: run the collective in a one-rank
     group as well (bench.py --force-dist: the RCCL call path of the N-GPU run on one GPU)."""
     import torch
     import torch.distributed as dist

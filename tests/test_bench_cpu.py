@@ -117,3 +117,53 @@ def test_reference_loops_of_the_cpu_baseline_are_the_oracles_streams(oracle, ref
     om = oracle.model(f, 16, with_alias=True)
     for t, r in enumerate(ref.time_loop2(12, f, 16, d16, 50001, threads=2)):
         assert r["ok"] and r["stream_bytes"] == oracle.encode(FMT_ALIAS, om, d16[t * 50001:(t + 1) * 50001], 2).size
+
+
+def test_judged_line_is_short_and_complete():
+    """bench.py's LAST stdout line is what the driver parses, and the driver keeps only the last few KB of stdout: round 4's
+    20.6 KB line came back `parsed: null`.  judged_line() is a pure function of the full record; here it runs on a canned
+    full record (round 4's, renamed to this round's keys) and on a worst case (12 configs with every optional key, 8 ranks,
+    an error string), and must stay under 4096 bytes with every field the contract and the judge ask for."""
+    import copy
+
+    import bench
+    full = json.load(open(os.path.join(HERE, "golden", "bench_record_r04.json")))
+    line = bench.judged_line(full, "bench_details.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= bench.MAX_LINE_BYTES < 4096, len(text)
+    assert "\n" not in text and json.loads(text) == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "clocks", "configs", "details"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    assert line["config"]["workload"] == full["config"]["workload"] and "model" not in line["config"]
+    rl = line["roofline"]
+    assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and rl["unit"] == "GB/s" and rl["traffic"] == full["roofline"]["traffic"]
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["value"] == round(full["cpu_baseline"]["value"], 3) and cb["cores"] >= 1 and cb["sample"]
+    assert cb["port_value"] > cb["value"]                       # the AVX-512 port is extra, never `value`
+    # the un-probed placement beside the chosen one, and no matrix
+    assert line["placement"]["first_pair_ms"] >= line["placement"]["chosen_ms"] and "probe_ms" not in line["placement"]
+    assert line["value_first_pair"] == round((1 << 30) / line["placement"]["first_pair_ms"] / 1e6, 2)
+    assert line["value_first_pair"] <= line["value"] * 1.02
+    rows = line["configs"]
+    assert [r["name"] for r in rows] == ["C3-word64", "C2-r64x2", "C4-alias4096", "byte14", "byte12", "word128", "word256"]
+    for r, e in zip(rows, full["configs"]):
+        assert r["decode_ms"] == e["decode"]["ms_mean"] and r["encode_ms"] == e["encode"]["ms_mean"]
+        assert r["enc_slots_ms"] == e["encode_slots"]["ms_mean"] and r["oracle_ok"] is True
+        assert r["cpu_ref_GBps"] == e["cpu_baseline"]["value"]
+    # a config whose oracle check did not cover every chunk is not "ok"
+    broken = copy.deepcopy(full)
+    broken["configs"][1]["oracle_chunks_checked"] -= 1
+    assert bench.judged_line(broken)["configs"][1]["oracle_ok"] is False
+    # worst case
+    worst = copy.deepcopy(full)
+    for e in worst["configs"]:
+        e["encode_tight"] = e["decode_tight"] = e["decode_slots"]
+    worst["configs"] = (worst["configs"] * 2)[:12]
+    worst["n_gpus"] = 8
+    worst["per_rank"] = {"kernel_ms": [0.38123] * 8}
+    worst["error"] = "round trip mismatch, corrupt chunk reported, or a chunk differs from the oracle"
+    worst["knobs"] = {"RANS_AMD_LIB": "x" * 100}
+    assert len(json.dumps(bench.judged_line(worst, "bench_details.json"), separators=(",", ":"))) < 4096

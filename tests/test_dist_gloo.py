@@ -32,6 +32,29 @@ def _free_port():
     return port
 
 
+def _run_bench(argv, env, timeout=600, launcher=None):
+    """Run bench.py, return (judged line parsed from ONLY the last 4 KB of stdout, full record from --details, CompletedProcess).
+    The driver keeps a few KB of stdout: whatever the test needs from the line must survive that cut."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        details = os.path.join(tmp, "details.json")
+        cmd = (launcher or [sys.executable]) + [os.path.join(root, "bench.py")] + argv + ["--details", details]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+        if out.returncode != 0:
+            return None, None, out
+        tail = out.stdout[-4096:]
+        last = tail.rstrip("\n").splitlines()[-1]
+        assert last.startswith("{") and len(last) < 4096, out.stdout[-500:]
+        assert len([ln for ln in out.stdout.splitlines() if ln.startswith("{")]) == 1, "exactly one JSON line on stdout"
+        line = json.loads(last)
+        full = json.load(open(details))
+    return line, full, out
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -70,71 +93,91 @@ def test_two_rank_gather_and_aggregate():
 @pytest.mark.gpu
 def test_two_ranks_decode_real_shards_on_one_gpu():
     """The multi-GPU path end to end on the one GPU this box has: `torch.distributed.run` starts two ranks of
-    bench.py (gloo for the 40-byte record gather, both ranks on device 0), each generates, encodes and decodes ITS
+    bench.py (gloo for the 48-byte record gather, both ranks on device 0), each generates, encodes and decodes ITS
     OWN shard (seed = rank + 1) bit-exactly, and the printed line proves what it claims: `n_gpus` is the number of
     records the all-gather delivered, not an environment variable; every rank's kernel time, stream size and
     verdict is listed."""
-    import json
-    import subprocess
     import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--backend", "gloo", "--all-on-device", "0", "--log2n", "26", "--prewarm-ms", "0"]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(_free_port())]
+    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--all-on-device", "0", "--log2n", "26",
+            "--prewarm-ms", "0"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    line, d, out = _run_bench(argv, env, launcher=launcher)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["bit_exact_roundtrip"] is True and d["scaling"] == "weak"
+    assert line["n_gpus"] == 2 and line["bit_exact_roundtrip"] is True and line["scaling"] == "weak"
     pr = d["per_rank"]
-    assert len(pr["kernel_ms"]) == 2 and all(v > 0 for v in pr["kernel_ms"])
+    assert len(pr["kernel_ms"]) == 2 and all(v > 0 for v in pr["kernel_ms"]) and line["per_rank_kernel_ms"] == pr["kernel_ms"]
     assert len(pr["stream_bytes"]) == 2 and pr["stream_bytes"][0] != pr["stream_bytes"][1]  # different shards
     # whole-job value = symbols of both ranks / the slower rank's time
     slow = max(pr["elapsed_ms_per_step"])
-    assert d["value"] == pytest.approx(2 * (1 << 26) / (slow * 1e-3) / 1e9, rel=0.02)
-    assert "cpu_baseline" not in d and "configs" not in d  # rank-0-at-N=1 legs stay out of multi-rank lines
+    assert line["value"] == pytest.approx(2 * (1 << 26) / (slow * 1e-3) / 1e9, rel=0.02)
+    # north_star: the N-GPU number stands "next to the reference CPU path timed on the same box's host cores" -- rank 0
+    # attaches it at every N -- and every rank pinned a sample of ITS shard against the oracle (count summed over the records)
+    assert "configs" not in line
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port")
+    assert d["oracle_chunks_checked_per_rank"][0] >= 256 and d["oracle_chunks_checked_per_rank"][1] >= 256
+    assert line["oracle_chunks_checked"] == sum(d["oracle_chunks_checked_per_rank"])
+    assert line["oracle_chunks_total"] == 2 * ((1 << 26) // 32768)
 
 
 @pytest.mark.gpu
 def test_bench_gpus_n_launches_its_own_ranks():
     """`python bench.py --gpus 2` started PLAINLY (no torchrun around it, no WORLD_SIZE in the environment -- the shape
-    of the driver's N = 1 command with another number) spawns its own two ranks, and the line is self-describing: it says
+    of the driver's N = 1 command with another number) spawns its own two ranks, and the record is self-describing: it says
     it launched itself, how many GPUs were asked for and how many the node shows, and carries the job-level roofline
     fraction (algorithmic bytes of all ranks / slowest kernel / N x 8 TB/s) beside every rank's own."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
-           "--all-on-device", "0", "--log2n", "26", "--prewarm-ms", "0"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    line, d, out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--all-on-device", "0",
+                               "--log2n", "26", "--prewarm-ms", "0", "--no-cpu-baseline"], env)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["bit_exact_roundtrip"] is True
+    assert line["n_gpus"] == 2 and line["bit_exact_roundtrip"] is True
     assert d["launch"]["self_launched"] is True and d["launch"]["gpus_requested"] == 2 and d["launch"]["gpus_visible"] >= 1
     pr, rl = d["per_rank"], d["roofline"]
     assert len(pr["roofline_frac"]) == 2 and all(0.0 < f < 1.0 for f in pr["roofline_frac"])
     alg = sum((1 << 26) + sb for sb in pr["stream_bytes"])
     assert rl["frac_job"] == pytest.approx(alg / (max(pr["kernel_ms"]) * 1e-3) / 1e9 / (2 * 8000.0), rel=0.01)
-    assert rl["peak_job"] == 16000.0
+    assert rl["peak_job"] == 16000.0 and line["roofline"]["frac_job"] == rl["frac_job"]
+    assert "cpu_baseline" not in line and "oracle_chunks_checked" not in line  # (--no-cpu-baseline: no CPU leg at all)
     # asked for more GPUs than the node has, without the dry-run aid: clamped, said so, still a valid line
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "2", "--warmup", "1", "--log2n", "24",
-           "--prewarm-ms", "0", "--no-configs", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    line, d, out = _run_bench(["--gpus", "64", "--steps", "2", "--warmup", "1", "--log2n", "24", "--prewarm-ms", "0",
+                               "--no-configs", "--no-cpu-baseline"], env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    import torch
-    assert d["n_gpus"] == min(64, torch.cuda.device_count())
+    assert line["n_gpus"] == min(64, torch.cuda.device_count())
     assert d["launch"] == {"self_launched": True, "gpus_requested": 64, "gpus_visible": torch.cuda.device_count(),
                            "all_on_device": None}
-    assert d["roofline"]["frac_job"] > 0
+    assert line["roofline"]["frac_job"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_default_command_line_survives_the_drivers_stdout_window():
+    """The driver's command at a small size, everything on (configs, CPU leg, placement probe): the judged line is the LAST
+    line of stdout, parses from the last 4 KB alone, and carries value / ms_per_step / roofline / cpu_baseline (reference) /
+    one row per config with its oracle verdict -- round 4's line was 20.6 KB and came back unparsed."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    line, d, out = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--log2n", "24", "--config-steps", "3"], env,
+                              timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["bit_exact_roundtrip"] is True and line["headline"] is True
+    rl = line["roofline"]
+    assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and 0 < rl["frac"] < 1 and rl["kernel"] == "k_decode_word64"
+    assert rl["frac"] == pytest.approx(rl["algorithmic_bytes_per_launch"] / (rl["kernel_ms_avg"] * 1e-3) / 8e12, rel=2e-3)
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] in ("reference", "port") and cb["cores"] >= 1
+    rows = line["configs"]
+    assert [r["name"] for r in rows] == ["C3-word64", "C2-r64x2", "C4-alias4096", "byte14", "byte12", "word128", "word256"]
+    assert all(r["oracle_ok"] is True and r["decode_ms"] > 0 and r["encode_ms"] > 0 for r in rows)
+    assert line["oracle_chunks_checked"] == line["oracle_chunks_total"] and line["decodes_oracle_container"] is True
+    assert line["placement"]["first_pair_ms"] > 0 and line["value_first_pair"] > 0
+    # and the file has what the line dropped
+    assert len(d["placement"]["probe_ms"]) >= 3 and len(d["configs"]) == len(rows) and "decoders" in d["cpu_baseline"]
 
 
 @pytest.mark.gpu
@@ -142,30 +185,26 @@ def test_bench_placement_probe_allocates_more_when_all_candidates_look_alike():
     """The headline's placement probe (setup, untimed; profiles/r04_allocation.md): when every probed pair lies within
     --placement-spread of the fastest -- all candidates in one class of memory -- the candidates stay alive and another round
     is allocated, twice at most.  Forced here with a spread no measurement reaches: 2 + 2 + 2 outputs, 3 + 2 + 2 containers,
-    the line says so, and the round trip of the chosen pair is bit-exact."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    the record says so, and the round trip of the chosen pair is bit-exact."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--log2n", "24", "--prewarm-ms", "0",
-           "--no-configs", "--no-cpu-baseline", "--placement-candidates", "2", "--placement-spread", "100"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    argv = ["--steps", "2", "--warmup", "1", "--log2n", "24", "--prewarm-ms", "0", "--no-configs", "--no-cpu-baseline",
+            "--placement-candidates", "2", "--placement-spread", "100"]
+    line, d, out = _run_bench(argv, env)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     p = d["placement"]
     assert p["candidates"] == {"containers": 7, "outputs": 6, "extended": 2}
     assert len(p["probe_ms"]) == 7 and all(len(row) == 6 for row in p["probe_ms"])
     assert 0 <= p["chosen"][0] < 7 and 0 <= p["chosen"][1] < 6
-    assert p["probe_ms_chosen"] == p["probe_ms_min"] and d["bit_exact_roundtrip"] is True
-    # the default spread on a small run: whatever the probe saw, the line carries the counts
-    cmd[-1] = "1.02"
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p["probe_ms_chosen"] == p["probe_ms_min"] and line["bit_exact_roundtrip"] is True
+    assert line["placement"] == {"chosen_ms": p["probe_ms_chosen"], "first_pair_ms": p["probe_ms_first_pair"],
+                                 "min_ms": p["probe_ms_min"], "max_ms": p["probe_ms_max"], "pairs": 42}
+    # the default spread on a small run: whatever the probe saw, the record carries the counts
+    argv[-1] = "1.02"
+    line, d, out = _run_bench(argv, env)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    assert d["placement"]["candidates"]["extended"] in (0, 1, 2) and d["bit_exact_roundtrip"] is True
+    assert d["placement"]["candidates"]["extended"] in (0, 1, 2) and line["bit_exact_roundtrip"] is True
 
 
 @pytest.mark.gpu
@@ -173,19 +212,13 @@ def test_bench_force_dist_runs_rccl_on_one_gpu():
     """bench.py --force-dist: torch.distributed over the nccl backend (RCCL) with a single rank -- init_process_group
     with device_id, both barriers and the on-device all_gather of the record execute on real RCCL on this box, so the
     N-GPU call path is not dead code until an 8-GPU node shows up."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1", "--log2n", "26",
-           "--prewarm-ms", "0", "--no-configs", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    line, d, out = _run_bench(["--force-dist", "--steps", "3", "--warmup", "1", "--log2n", "26", "--prewarm-ms", "0",
+                               "--no-configs", "--no-cpu-baseline"], env)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    assert d["n_gpus"] == 1 and d["bit_exact_roundtrip"] is True and d["headline"] is True and d["knobs"] == {}
+    assert line["n_gpus"] == 1 and line["bit_exact_roundtrip"] is True and line["headline"] is True and d["knobs"] == {}
     assert d["distributed"] == {"initialised": True, "backend": "nccl", "records_gathered_on": "device (RCCL)"}
 
 
