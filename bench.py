@@ -173,6 +173,12 @@ def settle(torch, fn, ms=60.0):
         torch.cuda.synchronize()
 
 
+def trace(*a):
+    """BENCH_TRACE=1: progress on stderr (which stage a failing run had reached)."""
+    if os.environ.get("BENCH_TRACE"):
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
 def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, seed, steps, device, d_syms=None, probe=1):
     """One `configs` entry: decode and encode of a BASELINE configuration, `steps` back-to-back launches each,
     round trip verified.  Returns (entry, artefacts for the CPU-side oracle check).  probe > 1: every timed call first
@@ -181,6 +187,7 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
     from ryg_rans_amd.placement import choose_one
     n = 1 << log2n
     sym_bytes = 1 if K <= 256 else 2
+    trace("config", short, "n", n)
     if d_syms is None:
         d_syms = gen_zipf(torch, n, K, 1.0, seed, device)
     counts = ctx.count_freqs_device(d_syms, K)
@@ -203,12 +210,14 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
         placement["decode_probe_ms"] = [[round(v, 4) for v in row] for row in matrix]
         placement["decode_chosen"] = [ci, oi]
         del conts, outs
+    trace(" decode")
     dec_ms, dec_min = timed_launches(
         torch, lambda: ctx.decode(model, cont_dec, total, offs, lens, n, ways, chunk, d_out=out, sync=False), steps, 2)
     bad = ctx.decode_errors()
     exact = bool(torch.equal(out, d_syms)) and bad == 0
     kernel = ctx.last_decode_kernel()
     del cont_dec
+    trace(" encode (compact)")
     cont2, offs2, lens2 = torch.empty_like(cont), torch.empty_like(offs), torch.empty_like(lens)
     if probe > 1:
         c2s = [cont2] + [torch.empty_like(cont) for _ in range(2 * probe - 1)]  # (the compact encoders are the most placement-sensitive calls: 10-12 %)
@@ -229,6 +238,7 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
     # slot layout (rans_amd_encode_slots): every chunk written once, where it was coded -- what the reference does with
     # each of its buffers (main.cpp:176-188).  Encoder timed, the slot container decoded as it is (timed as well: its
     # chunk starts are not 16-byte aligned and it is 2.6 x as large), and every chunk of it goes to the oracle check.
+    trace(" encode_slots")
     s_cont, s_offs, s_lens, s_total = ctx.encode_slots(model, d_syms, ways, chunk)
     slot = R.slot_bytes(fmt, n, ways, chunk)
     if probe > 1:
@@ -245,10 +255,39 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
     ctx.encode_status()
     s_kernel = ctx.last_encode_kernel()[0]
     slots_ok = ctx.last_encode_placement() == 2 and bool(torch.equal(s_lens, lens))
+    trace(" decode_slots")
     out.zero_()
     s_dec_ms, s_dec_min = timed_launches(
         torch, lambda: ctx.decode(model, s_cont, s_total, s_offs, s_lens, n, ways, chunk, d_out=out, sync=False), steps, 2)
     slots_ok = slots_ok and ctx.decode_errors() == 0 and bool(torch.equal(out, d_syms))
+    # sized slots (rans_amd_encode_slots_sized): one write per stream AND a container about the compact one's size -- slots
+    # of rans_amd_tight_slot_bytes() (the model's expected chunk stream + 2 % + states + 4 sigma), chunks that do not fit
+    # coded again behind them.  Encoder timed, the container decoded as it is (timed), every chunk goes to the oracle check.
+    trace(" encode_sized")
+    t_cont, t_offs, t_lens, t_total, t_slot = ctx.encode_sized(model, d_syms, ways, chunk)
+    if probe > 1:
+        tcs = [t_cont] + [torch.empty_like(t_cont) for _ in range(min(probe, 4) - 1)]
+        settle(torch, lambda: ctx.encode_sized(model, d_syms, ways, chunk, slot=t_slot, d_out=t_cont, sync=False, d_offsets=t_offs,
+                                               d_lengths=t_lens))
+        pick, ms = choose_one(torch, lambda c: ctx.encode_sized(model, d_syms, ways, chunk, slot=t_slot, d_out=c, sync=False,
+                                                                d_offsets=t_offs, d_lengths=t_lens), tcs)
+        t_cont = tcs[pick]
+        placement["encode_tight_probe_ms"] = [round(v, 4) for v in ms]
+        del tcs
+    t_enc_ms, t_enc_min = timed_launches(
+        torch, lambda: ctx.encode_sized(model, d_syms, ways, chunk, slot=t_slot, d_out=t_cont, sync=False, d_offsets=t_offs,
+                                        d_lengths=t_lens), steps, 2)
+    ctx.encode_status()
+    t_kernel = ctx.last_encode_kernel()[0]
+    t_total = int(t_offs[-1].item())
+    nchunks = (n + chunk - 1) // chunk
+    t_over = (t_total - nchunks * t_slot) // slot if t_slot < slot else 0
+    tight_ok = bool(torch.equal(t_lens, lens))
+    trace(" decode_tight")
+    out.zero_()
+    t_dec_ms, t_dec_min = timed_launches(
+        torch, lambda: ctx.decode(model, t_cont, t_total, t_offs, t_lens, n, ways, chunk, d_out=out, sync=False), steps, 2)
+    tight_ok = tight_ok and ctx.decode_errors() == 0 and bool(torch.equal(out, d_syms))
     alg = n * sym_bytes + total
     entry = {
         "short": short, "name": name, "format": R.FORMAT_NAMES[fmt], "scale_bits": sb, "alphabet": K, "n_ways": ways, "chunk_syms": chunk,
@@ -269,13 +308,24 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
                          "frac": round(alg / s_enc_ms / 1e6 / HBM_PEAK_GBPS, 4), "slot_bytes": slot, "container_bytes": s_total},
         "decode_slots": {"kernel": ctx.last_decode_kernel(), "ms_mean": round(s_dec_ms, 4), "ms_min": round(s_dec_min, 4),
                          "launches": steps, "frac": round(alg / s_dec_ms / 1e6 / HBM_PEAK_GBPS, 4)},
-        "bit_exact_roundtrip": exact and same_container and slots_ok,
+        "encode_tight": {"layout": "sized slots (rans_amd_encode_slots_sized, slot = rans_amd_tight_slot_bytes(); a chunk that "
+                                   "does not fit is coded again into a worst-case slot behind the sized ones)",
+                         "kernels": t_kernel + " + the redo launch", "ms_mean": round(t_enc_ms, 4), "ms_min": round(t_enc_min, 4),
+                         "launches": steps, "input_GBps": round(n * sym_bytes / t_enc_ms / 1e6, 1),
+                         "achieved_GBps": round(alg / t_enc_ms / 1e6, 1), "frac": round(alg / t_enc_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                         "slot_bytes": t_slot, "container_bytes": t_total, "overflowed_chunks": int(t_over),
+                         "container_over_input": round(t_total / (n * sym_bytes), 4),
+                         "container_over_compact": round(t_total / total, 4)},
+        "decode_tight": {"kernel": ctx.last_decode_kernel(), "ms_mean": round(t_dec_ms, 4), "ms_min": round(t_dec_min, 4),
+                         "launches": steps, "frac": round(alg / t_dec_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+        "bit_exact_roundtrip": exact and same_container and slots_ok and tight_ok,
         # the written buffer of every timed call was chosen among this many allocations (setup, untimed; see --placement-candidates)
         "placement": placement,
     }
     art = {"fmt": fmt, "sb": sb, "K": K, "ways": ways, "chunk": chunk, "n": n, "freqs": freqs, "d_syms": d_syms,
            "cont": cont, "offs": offs, "lens": lens, "total": total, "entry": entry,
-           "slots": {"cont": s_cont, "offs": s_offs, "lens": s_lens, "total": s_total, "slot": slot}}
+           "slots": {"cont": s_cont, "offs": s_offs, "lens": s_lens, "total": s_total, "slot": slot},
+           "tight": {"cont": t_cont, "offs": t_offs, "lens": t_lens, "total": t_total, "slot": t_slot, "worst": slot}}
     return entry, art
 
 
@@ -296,7 +346,19 @@ def oracle_check_chunks(art, sample=0):
     lens = lens32.astype(np.uint64)
     offs = art["offs"].cpu().numpy().astype(np.uint64)
     nchunks = (n + chunk - 1) // chunk
-    if art.get("slot"):  # slot layout (rans_amd_encode_slots): chunk c is the last lens[c] bytes of slot c
+    if art.get("worst"):  # sized slots: a chunk ends at its slot's end, or at the end of a worst-case slot of the overflow region
+        slot, worst = np.uint64(art["slot"]), np.uint64(art["worst"])
+        ends = offs[:nchunks] + lens[:nchunks]
+        region = np.uint64(nchunks) * slot
+        inside = offs[:nchunks] < region
+        assert np.array_equal(ends[inside], (np.nonzero(inside)[0].astype(np.uint64) + np.uint64(1)) * slot), \
+            "a chunk of a sized slot does not end at its slot's end"
+        k = ends[~inside] - region
+        assert np.all(k % worst == 0) and sorted((k // worst).tolist()) == list(range(1, int((~inside).sum()) + 1)), \
+            "overflowed chunks do not fill the overflow slots one each"
+        assert int(offs[nchunks]) == int(region) + int((~inside).sum()) * int(worst)
+        assert np.all(lens[:nchunks][inside] <= slot)
+    elif art.get("slot"):  # slot layout (rans_amd_encode_slots): chunk c is the last lens[c] bytes of slot c
         slot = np.uint64(art["slot"])
         want_offs = np.zeros(nchunks + 1, dtype=np.uint64)
         want_offs[:nchunks] = (np.arange(nchunks, dtype=np.uint64) + np.uint64(1)) * slot - lens[:nchunks]
@@ -612,11 +674,14 @@ def judged_line(full, details_path=None):
                          ("decode_tight", "dec_tight")):
             if key in e:
                 row[tag + "_ms"] = e[key]["ms_mean"]
+        if "encode_tight" in e:
+            row["tight_over_input"] = e["encode_tight"]["container_over_input"]
         if cpu.get("value") is not None:
             row["cpu_ref_GBps"] = cpu["value"]
             row["cpu_ref_cores"] = cpu.get("cores")
         row["oracle_ok"] = bool(e.get("bit_exact_roundtrip")) and total is not None and \
-            e.get("oracle_chunks_checked") == total and e.get("oracle_chunks_checked_slots", total) == total
+            e.get("oracle_chunks_checked") == total and e.get("oracle_chunks_checked_slots", total) == total and \
+            e.get("oracle_chunks_checked_tight", total) == total
         rows.append(row)
     if rows:
         line["configs"] = rows
@@ -624,7 +689,7 @@ def judged_line(full, details_path=None):
         line["per_rank_kernel_ms"] = full["per_rank"]["kernel_ms"]
     line["details"] = details_path
     # the size is a guarantee, not a hope: shed the optional per-config keys, then whole rows, until the line fits
-    for drop in ("cpu_ref_cores", "dec_tight_ms", "dec_slots_ms", "enc_tight_ms", "enc_slots_ms", "cpu_ref_GBps", None):
+    for drop in ("cpu_ref_cores", "dec_slots_ms", "enc_slots_ms", "tight_over_input", "dec_tight_ms", "enc_tight_ms", "cpu_ref_GBps", None):
         if len(json.dumps(line, separators=(",", ":"))) <= MAX_LINE_BYTES:
             break
         if drop is None:
@@ -724,6 +789,7 @@ def main():
     n = 1 << args.log2n
 
     # ---- setup (untimed): data, model, GPU encode ------------------------------
+    trace("setup")
     ctx = R.Context(gpu_index)
     d_syms = gen_zipf(torch, n, 256, 1.0, rank + 1, device)
     counts = ctx.count_freqs_device(d_syms, 256)
@@ -775,6 +841,8 @@ def main():
         lens = lens[idx].contiguous()
     torch.cuda.synchronize()
 
+    trace("placement done", placement.get("chosen"))
+
     def step():
         ctx.decode(model, cont, total, offs, lens, n, args.ways, args.chunk, d_out=out, sync=False)
 
@@ -814,6 +882,7 @@ def main():
         spans = []
 
     # ---- verification (after the timed region) -------------------------------------
+    trace("timed region done")
     bad = ctx.decode_errors()
     exact = bool(torch.equal(out, d_syms))  # (always the real comparison: a --measure run with an output-dropping knob says false)
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
@@ -959,6 +1028,7 @@ def main():
                 if cc == args.chunk:  # (the headline's own artefacts: container checked below, CPU loop timed beside it)
                     arts[0]["entry"] = e
                     arts[0]["slots"] = a["slots"]
+                    arts[0]["tight"] = a["tight"]
                 else:
                     arts.append(a)
                 e, a = measure_config(torch, R, ctx, "C2-r64x2", "C2 rans64 2-way 256 MiB Zipf(256)", R.FMT_R64, 14, 256, 2, 512, 28, 1,
@@ -970,12 +1040,12 @@ def main():
                 cfgs.append(e)
                 arts.append(a)
                 e, a = measure_config(torch, R, ctx, "byte14", "byte format 64-way 1 GiB Zipf(256)", R.FMT_BYTE, 14, 256, 64, cc,
-                                      30, 1, ks, device, d_syms=d_syms, probe=cp)
+                                      args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 # the byte format at 12-bit probabilities: the decoder's fused slot records (one LDS gather per symbol, round 4)
                 e, a = measure_config(torch, R, ctx, "byte12", "byte format 64-way 1 GiB Zipf(256), scale_bits 12 (slot-record decoder)",
-                                      R.FMT_BYTE, 12, 256, 64, cc, 30, 1, ks, device, d_syms=d_syms, probe=cp)
+                                      R.FMT_BYTE, 12, 256, 64, cc, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
                 # "64-way and wider" (north_star): two and four states per lane over the headline's data
@@ -1000,6 +1070,7 @@ def main():
                                           "sample": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:
             try:
+                trace("oracle checks")
                 checked = {}
                 t_or = time.perf_counter()
                 for a in arts:
@@ -1014,6 +1085,12 @@ def main():
                             dict(a, cont=sl["cont"], offs=sl["offs"], lens=sl["lens"], total=sl["total"], slot=sl["slot"]),
                             args.oracle_sample)
                         del sl["cont"]
+                    if a.get("tight"):  # ... and of the sized-slot container
+                        tg = a["tight"]
+                        a["entry"]["oracle_chunks_checked_tight"] = oracle_check_chunks(
+                            dict(a, cont=tg["cont"], offs=tg["offs"], lens=tg["lens"], total=tg["total"], slot=tg["slot"],
+                                 worst=tg["worst"]), args.oracle_sample)
+                        del tg["cont"]
                 result["oracle_chunks_checked"] = checked["%s-%d/%d-way/%d" % (args.format, sb, args.ways, args.chunk)]
                 result["oracle_chunks_total"] = (n + args.chunk - 1) // args.chunk
                 result["oracle_chunks_checked_all"] = checked

@@ -54,12 +54,15 @@
 extern "C" {
 #endif
 
-/* 0.4.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
+/* 0.5.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
  * inside a hipGraph capture (0.3.0); rans_amd_encode_slots + rans_amd_slot_bytes / rans_amd_encode_slots_bound,
  * rans_amd_container_compact, rans_amd_container_slice, chunk offsets on any multiple of the format's unit in every decoder
- * (0.4.0).  A caller built
- * against an older header keeps working. */
-#define RANS_AMD_VERSION 400
+ * (0.4.0); rans_amd_encode_slots_sized + rans_amd_tight_slot_bytes / rans_amd_encode_sized_bound (0.5.0).  A caller built
+ * against an older header keeps working, with two behaviour changes it can observe: since 0.4.0
+ * rans_amd_container_parse[_adaptive] want a 4-byte aligned `src` (RANS_AMD_E_ARG otherwise; an mmap at an odd offset must
+ * be copied first), and since 0.5.0 rans_amd_container_compact checks its SOURCE index against src_bytes
+ * (RANS_AMD_E_CORRUPT for an entry outside the source, which earlier versions read). */
+#define RANS_AMD_VERSION 500
 
 typedef enum rans_amd_status {
     RANS_AMD_OK = 0,
@@ -256,12 +259,42 @@ int rans_amd_encode_slots(rans_amd_ctx *ctx, const rans_amd_model *model, const 
                           uint32_t n_ways, uint32_t chunk_syms, void *d_out, uint64_t out_cap,
                           uint64_t *d_offsets, uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream);
 
+/* Slots of the CALLER's size -- one trip through HBM and a container about as large as the compact one.
+ *
+ * The reference does not hand its encoder the worst case either: main_simd.cpp:145 allocates in_size + in_size/8 + 128
+ * bytes for a stream it expects to be smaller than the input, main.cpp:150 a fixed 32 MB.  Here:
+ *
+ *     slot c  =  d_out[c * slot_bytes, (c + 1) * slot_bytes)        slot_bytes: a multiple of 64, the caller's choice
+ *     a chunk whose stream fits:   the last d_lengths[c] bytes of slot c, exactly as in rans_amd_encode_slots
+ *     a chunk whose stream does NOT fit:  coded again (a second, normally empty launch) into the OVERFLOW region behind
+ *         the slots, d_out[n_chunks * slot_bytes + k * W, + W) for the k-th such chunk (W = rans_amd_slot_bytes(): the
+ *         worst case, nothing overflows there), d_offsets[c] pointing into it
+ *     d_offsets[n_chunks] = n_chunks * slot_bytes + overflowed chunks * W   (the container's size)
+ *
+ * Every chunk's bytes are the oracle's stream for that chunk, wherever they lie; the decoders take the index as it is.
+ * rans_amd_tight_slot_bytes() sizes a slot from the MODEL: chunk_syms times the model's expected code length (its entropy
+ * under itself) plus 2 %, the N flushed states, four standard deviations of a chunk's code length and a line of slack --
+ * input that follows the model overflows about one chunk in 30 000; input that does not (a model built from other data, an
+ * incompressible stretch) overflows more often and still encodes correctly, each overflowed chunk at twice its cost.
+ * out_cap must hold the slots (RANS_AMD_E_SPACE up front otherwise); whatever it has beyond them is overflow region, and a
+ * call whose overflowed chunks do not fit there reports RANS_AMD_E_SPACE (with h_total_bytes, or later through
+ * rans_amd_encode_status) -- rans_amd_encode_sized_bound(.., overflow_chunks) is the capacity for that many.  slot_bytes at
+ * or above rans_amd_slot_bytes() is rans_amd_encode_slots. */
+uint64_t rans_amd_tight_slot_bytes(const rans_amd_model *model, uint32_t n_ways, uint32_t chunk_syms);
+uint64_t rans_amd_encode_sized_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms, uint64_t slot_bytes,
+                                     uint64_t overflow_chunks);
+int rans_amd_encode_slots_sized(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,
+                                uint32_t n_ways, uint32_t chunk_syms, uint64_t slot_bytes, void *d_out, uint64_t out_cap,
+                                uint64_t *d_offsets, uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream);
+
 /* Copy the n_chunks streams [d_src + d_src_offsets[c], + d_lengths[c]) -- any layout the decoders accept: a slot
  * container, a chunk range of another container, chunks in any order -- into the compact layout at d_dst:
  * d_dst_offsets[c] = sum_{i<c} align16(d_lengths[i]), d_dst_offsets[n_chunks] = end of the last stream (n_chunks + 1
  * entries).  d_src (src_bytes long) and d_dst (dst_cap) must not overlap.  Asynchronous on `stream` unless h_total_bytes is
  * given (then: synchronises, stores d_dst_offsets[n_chunks], reports RANS_AMD_E_SPACE when dst_cap was too small --
- * nothing is copied in that case; rans_amd_encode_status reports the same later for an asynchronous call). */
+ * nothing is copied in that case; rans_amd_encode_status reports the same later for an asynchronous call).  The source
+ * index is data: an entry that does not lie inside [0, src_bytes) is neither read nor written and the call reports
+ * RANS_AMD_E_CORRUPT (the other chunks are copied). */
 int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t src_bytes, const uint64_t *d_src_offsets,
                                const uint32_t *d_lengths, uint64_t n_chunks, void *d_dst, uint64_t dst_cap,
                                uint64_t *d_dst_offsets, uint64_t *h_total_bytes, void *stream);

@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "rans_amd_encode", "rans_amd_encode_status", "rans_amd_decode", "rans_amd_decode_errors",
     "rans_amd_encode_slots", "rans_amd_slot_bytes", "rans_amd_encode_slots_bound", "rans_amd_container_compact",
     "rans_amd_container_slice",
+    "rans_amd_encode_slots_sized", "rans_amd_tight_slot_bytes", "rans_amd_encode_sized_bound",
     "rans_amd_encode_host", "rans_amd_decode_host",
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_encode_kernel", "rans_amd_last_wave_clocks",
     "rans_amd_launch_spans",
@@ -113,6 +114,9 @@ def _load():
         "rans_amd_encode": (i32, [vp, vp, vp, u64, u32, u32, vp, u64, vp, vp, u64p, vp]),
         "rans_amd_encode_slots": (i32, [vp, vp, vp, u64, u32, u32, vp, u64, vp, vp, u64p, vp]),
         "rans_amd_slot_bytes": (u64, [i32, u64, u32, u32]),
+        "rans_amd_encode_slots_sized": (i32, [vp, vp, vp, u64, u32, u32, u64, vp, u64, vp, vp, u64p, vp]),
+        "rans_amd_tight_slot_bytes": (u64, [vp, u32, u32]),
+        "rans_amd_encode_sized_bound": (u64, [i32, u64, u32, u32, u64, u64]),
         "rans_amd_encode_slots_bound": (u64, [i32, u64, u32, u32]),
         "rans_amd_container_compact": (i32, [vp, vp, u64, vp, vp, u64, vp, u64, vp, u64p, vp]),
         "rans_amd_container_slice": (i32, [u64p, u32p, u64, u64, u64, u64p, u64p, u64p]),
@@ -209,6 +213,10 @@ def slot_bytes(fmt, n, n_ways, chunk_syms):
 
 def encode_slots_bound(fmt, n, n_ways, chunk_syms):
     return int(_lib.rans_amd_encode_slots_bound(fmt, n, n_ways, chunk_syms))
+
+
+def encode_sized_bound(fmt, n, n_ways, chunk_syms, slot, overflow_chunks):
+    return int(_lib.rans_amd_encode_sized_bound(fmt, n, n_ways, chunk_syms, slot, overflow_chunks))
 
 
 def ways_supported(fmt, n_ways):
@@ -358,6 +366,37 @@ class Context:
                                           d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
                                           C.byref(total) if sync else None, _torch_stream()), "encode_slots")
         return d_out, d_offsets, d_lengths, (total.value if sync else None)
+
+    def tight_slot_bytes(self, model, n_ways, chunk_syms):
+        """rans_amd_tight_slot_bytes: the slot rans_amd_encode_slots_sized is meant to run with -- the model's expected
+        chunk stream + 2 % + the flushed states + four standard deviations + a line."""
+        return int(_lib.rans_amd_tight_slot_bytes(model._h, n_ways, chunk_syms))
+
+    def encode_sized(self, model, d_syms, n_ways, chunk_syms, slot=None, overflow_chunks=None, d_out=None, sync=True,
+                     d_offsets=None, d_lengths=None):
+        """rans_amd_encode_slots_sized: slots of `slot` bytes (default tight_slot_bytes()), chunks that do not fit coded
+        again into worst-case slots behind them (room for `overflow_chunks` of those; default 1/64 of the chunks + 4).
+        Returns (d_container, d_offsets, d_lengths, total_bytes, slot)."""
+        import torch
+        n = d_syms.numel()
+        nchunks = num_chunks(n, chunk_syms)
+        if slot is None:
+            slot = self.tight_slot_bytes(model, n_ways, chunk_syms)
+        if overflow_chunks is None:
+            overflow_chunks = nchunks // 64 + 4
+        dev = d_syms.device
+        if d_out is None:
+            d_out = torch.empty(encode_sized_bound(model.fmt, n, n_ways, chunk_syms, slot, overflow_chunks), dtype=torch.uint8,
+                                device=dev)
+        if d_offsets is None:
+            d_offsets = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
+        if d_lengths is None:
+            d_lengths = torch.zeros(max(nchunks, 1), dtype=torch.int32, device=dev)
+        total = C.c_uint64(0)
+        _check(_lib.rans_amd_encode_slots_sized(self._h, model._h, d_syms.data_ptr(), n, n_ways, chunk_syms, slot,
+                                                d_out.data_ptr(), d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
+                                                C.byref(total) if sync else None, _torch_stream()), "encode_slots_sized")
+        return d_out, d_offsets, d_lengths, (total.value if sync else None), slot
 
     def compact(self, d_src, src_bytes, d_src_offsets, d_lengths, n_chunks, d_dst=None, sync=True, d_dst_offsets=None):
         """rans_amd_container_compact: -> (d_dst, d_dst_offsets, total_bytes)."""

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <mutex>
 #include <new>
 #include <string>
@@ -166,6 +167,8 @@ int encode_flags_status(uint32_t flags)
         return fail(RANS_AMD_E_SPACE, "encode: container does not fit out_cap");
     if (flags & 4u) // (a kernel that addresses its LDS tables by raw offsets found them elsewhere: never code on that)
         return fail(RANS_AMD_E_HIP, "encode: internal error (dynamic LDS does not start at offset 0)");
+    if (flags & 512u) // rans_amd_container_compact: an index entry (offset, length) does not lie inside the source buffer
+        return fail(RANS_AMD_E_CORRUPT, "container_compact: a chunk of the source index lies outside [0, src_bytes)");
     if (flags & ~7u) { // a wait of the fused placement gave up (device_common.hpp SpinWatch; 256: a coder waiting for its scratch slot)
         char msg[160];
         snprintf(msg, sizeof msg, "encode: internal error (placement protocol timed out, flags 0x%x)", flags);
@@ -690,9 +693,11 @@ int rans_amd_build_model_o0(rans_amd_ctx *ctx, int format, const void *syms, uin
 
 // rans_amd_encode (slots == false: the compact layout) and rans_amd_encode_slots (slots == true: every chunk stays in the
 // slot it was coded into)
+// sized_slot != 0: rans_amd_encode_slots_sized (slots == true; the slot is the caller's, overflowed chunks are coded again
+// into worst-case slots behind the sized ones)
 static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n, uint32_t n_ways,
                        uint32_t chunk_syms, void *d_out, uint64_t out_cap, uint64_t *d_offsets, uint32_t *d_lengths,
-                       uint64_t *h_total_bytes, void *stream, const bool slots)
+                       uint64_t *h_total_bytes, void *stream, const bool slots, const uint64_t sized_slot = 0)
 {
     if (!ctx || !model || !d_out || !d_offsets || !d_lengths || (n && !d_syms) || chunk_syms == 0)
         return fail(RANS_AMD_E_ARG, "encode: NULL argument or chunk_syms == 0");
@@ -711,14 +716,19 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
     if (capture.active && h_total_bytes)
         return fail(RANS_AMD_E_ARG, "encode: h_total_bytes must be NULL while the stream is capturing (d_offsets[n_chunks] holds the total)");
 
-    const uint64_t slot = encode_slot_bytes(format, n, n_ways, chunk_syms);
-    if (slot > 0xfffffff0ull) // chunk stream lengths and in-slot cursors are 32-bit
+    const uint64_t worst_slot = encode_slot_bytes(format, n, n_ways, chunk_syms);
+    if (worst_slot > 0xfffffff0ull) // chunk stream lengths and in-slot cursors are 32-bit
         return fail(RANS_AMD_E_UNSUPPORTED, "encode: chunk_syms too large (a chunk's stream must stay below 4 GiB)");
+    // sized slots: the caller's slot, as long as it is smaller than the worst case (else: plain rans_amd_encode_slots)
+    const bool sized = slots && sized_slot != 0 && sized_slot < worst_slot && nchunks > 0 && nchunks < (1ull << 32);
+    const uint64_t slot = sized ? sized_slot : worst_slot;
     if (slots && (nchunks > (~0ull) / slot || out_cap < nchunks * slot)) // (known up front: nothing is launched)
-        return fail(RANS_AMD_E_SPACE, "encode_slots: out_cap is below rans_amd_encode_slots_bound()");
+        return fail(RANS_AMD_E_SPACE, sized ? "encode_slots_sized: out_cap does not hold n_chunks * slot_bytes"
+                                            : "encode_slots: out_cap is below rans_amd_encode_slots_bound()");
     int rc = RANS_AMD_OK;
     ZeroList zero(s); // (everything the kernels below expect to find zero: one launch)
-    HIP_TRY(zero.add(ctx->d_enc_flags(), 4));
+    HIP_TRY(zero.add(ctx->d_enc_flags(), 12)); // encode flags, histogram flags (unused by an encode), and the compaction's verdict:
+                                              // rans_amd_encode_status after THIS call must not report an older compaction
 
     // The wave-per-chunk encoders place and copy their chunks themselves (EncParams::status; encode_wave.hip
     // place_and_copy): no k_layout / k_compact.  The lane-per-chunk encoders (N = 1, 2, 4, 8 with many chunks) and the
@@ -733,6 +743,7 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
                                                                                                   : format;
     EncParams ep{};
     ep.syms = static_cast<const uint8_t *>(d_syms);
+    ep.n = n;
     ep.nchunks = nchunks;
     ep.chunk_syms = chunk_syms;
     ep.n_ways = n_ways;
@@ -766,17 +777,35 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
     // measured 2-4 % slower, hence opt-in.
     const uint64_t ring_waves = (uint64_t)ctx->num_cus * kEncRingMaxWavesPerCu;
     const bool ring = fused && !lanes && fits == 1 && ctx->scratch_ring && slot <= kEncRingMaxSlotBytes && nchunks > ring_waves * kEncRingSlots;
+    bool use_lanes = lanes;
     if (slots) { // the caller's container is where the chunks are coded: no scratch at all
         ep.scratch = static_cast<uint8_t *>(d_out);
         ep.slot_layout = 1u;
         ep.offsets = d_offsets;
-        if (!lanes && nchunks > 0 && nchunks < (1ull << 32)) { // wave encoders hand their chunks out dynamically
-            const size_t claim_bytes = (size_t)kWorkPools * kWorkPoolStride * 4;
-            rc = ctx->enc_status.reserve(claim_bytes);
+        // (sized slots: of the lane encoders only the staged ones -- whole-line flushes that stop at their slot's first line --
+        //  can tell that a chunk does not fit; a shape they would not take goes to the wave encoders)
+        if (sized && lanes && !encode_lanes_sized_ok(enc_format, ep, ctx->num_cus)) {
+            use_lanes = false;
+            ep.no_lanes = 1u;
+        }
+        if (!use_lanes && nchunks > 0 && nchunks < (1ull << 32)) { // wave encoders hand their chunks out dynamically
+            // claim counters; sized slots: + the overflow count and the redo launch's claim counter (a line each) + the list
+            const size_t claim_bytes = (size_t)(kWorkPools + 2) * kWorkPoolStride * 4;
+            rc = ctx->enc_status.reserve(claim_bytes + (sized ? (size_t)nchunks * 4 : 0));
             if (rc)
                 return rc;
             HIP_TRY(zero.add(ctx->enc_status.ptr, claim_bytes));
             ep.claims = static_cast<unsigned int *>(ctx->enc_status.ptr);
+        } else if (sized) { // lane encoders: only the overflow words
+            const size_t claim_bytes = (size_t)(kWorkPools + 2) * kWorkPoolStride * 4;
+            rc = ctx->enc_status.reserve(claim_bytes + (size_t)nchunks * 4);
+            if (rc)
+                return rc;
+            HIP_TRY(zero.add(ctx->enc_status.ptr, claim_bytes));
+        }
+        if (sized) {
+            ep.ovf_ctl = static_cast<unsigned int *>(ctx->enc_status.ptr) + kWorkPools * kWorkPoolStride;
+            ep.ovf_list = static_cast<uint32_t *>(ctx->enc_status.ptr) + (kWorkPools + 2) * kWorkPoolStride;
         }
         if (nchunks == 0)
             HIP_TRY(zero.add(d_offsets, 8));
@@ -841,6 +870,19 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
         HIP_TRY(launch_encode(enc_format, ep, ctx->num_cus, s, &ctx->last_enc_kernel));
         ctx->last_enc_fused = fused;
         ctx->last_enc_slots = slots;
+        if (sized) {
+            // the second launch: the chunks the first one abandoned, coded by the wave encoder into worst-case slots behind
+            // the sized ones (normally none: the launch reads one word and ends)
+            EncParams redo = ep;
+            redo.redo = 1u;
+            redo.no_lanes = 1u;
+            redo.slot_bytes = worst_slot;
+            redo.ovf_base = nchunks * slot;
+            const uint64_t room = (out_cap - nchunks * slot) / worst_slot;
+            redo.ovf_cap = (uint32_t)(room < nchunks ? room : nchunks);
+            redo.claims = static_cast<unsigned int *>(ctx->enc_status.ptr); // (unused by the redo claims; MODE 3 wants it set)
+            HIP_TRY(launch_encode(enc_format, redo, ctx->num_cus, s, nullptr));
+        }
     }
     if (!fused && !slots) {
         LayoutParams lp;
@@ -903,6 +945,57 @@ int rans_amd_encode_slots(rans_amd_ctx *ctx, const rans_amd_model *model, const 
     return encode_impl(ctx, model, d_syms, n, n_ways, chunk_syms, d_out, out_cap, d_offsets, d_lengths, h_total_bytes, stream, true);
 }
 
+int rans_amd_encode_slots_sized(rans_amd_ctx *ctx, const rans_amd_model *model, const void *d_syms, uint64_t n,
+                                uint32_t n_ways, uint32_t chunk_syms, uint64_t slot_bytes, void *d_out, uint64_t out_cap,
+                                uint64_t *d_offsets, uint32_t *d_lengths, uint64_t *h_total_bytes, void *stream)
+{
+    if (slot_bytes == 0 || (slot_bytes & 63u) != 0)
+        return fail(RANS_AMD_E_ARG, "encode_slots_sized: slot_bytes must be a positive multiple of 64");
+    return encode_impl(ctx, model, d_syms, n, n_ways, chunk_syms, d_out, out_cap, d_offsets, d_lengths, h_total_bytes, stream, true,
+                       slot_bytes);
+}
+
+uint64_t rans_amd_tight_slot_bytes(const rans_amd_model *model, uint32_t n_ways, uint32_t chunk_syms)
+{
+    if (!model || chunk_syms == 0 || n_ways == 0)
+        return 0;
+    // expected code length of a symbol drawn from the model, and its variance, in bits: the model coded by itself
+    const HostModel &h = model->host;
+    const double M = (double)(1ull << h.scale_bits);
+    double mean = 0.0, sq = 0.0;
+    for (uint32_t f : h.freqs)
+        if (f) {
+            const double pr = (double)f / M, bits = -std::log2(pr);
+            mean += pr * bits;
+            sq += pr * bits * bits;
+        }
+    const double var = sq > mean * mean ? sq - mean * mean : 0.0;
+    const double state_bytes = h.format == RANS_AMD_FMT_R64 ? 8.0 : 4.0;
+    // The coders that stage their stream in LDS (word / byte / LDS-alias format, byte symbols, 64 lanes) check the slot
+    // exactly; the others before every group of rounds, by what the group can emit at most -- their slot gets that margin
+    const bool staged = h.sym_bytes == 1 && n_ways == 64 && h.nsyms <= 256 && h.scale_bits <= 16 &&
+                        (h.format == RANS_AMD_FMT_WORD || h.format == RANS_AMD_FMT_BYTE || h.format == RANS_AMD_FMT_ALIAS);
+    const double lanes = n_ways >= 64 ? (double)((n_ways + 63u) & ~63u) : 0.0; // (narrow interleaves: lane encoders, whole lines)
+    const double margin = staged ? 0.0 : (h.sym_bytes == 2 ? 2.0 : 4.0) * lanes * (h.format == RANS_AMD_FMT_R64 ? 4.0 : 2.0);
+    const double bytes = 1.02 * mean * (double)chunk_syms / 8.0 + state_bytes * (double)n_ways +
+                         4.0 * std::sqrt(var * (double)chunk_syms) / 8.0 + 16.0 + margin;
+    const uint64_t worst = encode_slot_bytes(h.format, chunk_syms, n_ways, chunk_syms);
+    const uint64_t tight = ((uint64_t)bytes + 63u) & ~uint64_t(63);
+    return tight < worst ? tight : worst;
+}
+
+uint64_t rans_amd_encode_sized_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms, uint64_t slot_bytes,
+                                     uint64_t overflow_chunks)
+{
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    if (nchunks == 0 || chunk_syms == 0)
+        return 16;
+    const uint64_t worst = encode_slot_bytes(format, n, n_ways, chunk_syms);
+    if (slot_bytes == 0 || slot_bytes >= worst)
+        return nchunks * worst;
+    return nchunks * slot_bytes + (overflow_chunks < nchunks ? overflow_chunks : nchunks) * worst;
+}
+
 uint64_t rans_amd_slot_bytes(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
 {
     return chunk_syms ? encode_slot_bytes(format, n, n_ways, chunk_syms) : 0;
@@ -954,6 +1047,7 @@ int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t sr
         cp.scratch = static_cast<const uint8_t *>(d_src);
         cp.src_offsets = d_src_offsets;
         cp.src_limit = (reinterpret_cast<uint64_t>(d_src) + src_bytes + 15u) & ~uint64_t(15);
+        cp.src_bytes = src_bytes;
         cp.slot_bytes = n_chunks >= 4096 ? 4096 : 1u << 20; // (many chunks: most likely small ones -- 16 lanes per chunk)
         cp.lengths = d_lengths;
         cp.offsets = d_dst_offsets;
@@ -986,7 +1080,9 @@ int rans_amd_encode_status(rans_amd_ctx *ctx, void *stream)
     HIP_TRY(hipMemcpyAsync(&cflags, ctx->d_compact_flags(), 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const int rc = encode_flags_status(flags);
-    return rc != RANS_AMD_OK ? rc : encode_flags_status(cflags & 2u); // (a compaction whose destination was too small)
+    // (a compaction whose destination was too small or whose source index was corrupt -- the verdict of the LAST compaction
+    //  only as long as no encode followed it: every encode call clears the word)
+    return rc != RANS_AMD_OK ? rc : encode_flags_status(cflags & (2u | 512u));
 }
 
 /* ---- decode ------------------------------------------------------------- */
@@ -1246,7 +1342,7 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         return rc;
     {
         ZeroList zero(s);
-        HIP_TRY(zero.add(ctx->d_enc_flags(), 4));
+        HIP_TRY(zero.add(ctx->d_enc_flags(), 12)); // (with the verdict of an older compaction, as encode_impl does)
         HIP_TRY(zero.flush());
     }
     if (nchunks) {

@@ -125,14 +125,19 @@ __global__ void __launch_bounds__(256) k_compact(const CompactParams p)
     for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave; chunk_v < p.nchunks; chunk_v += total_waves) {
         const uint64_t chunk = uniform64(chunk_v);
         const uint32_t len = uniform(p.lengths[chunk]);
-        const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) +
-                            (p.src_offsets ? uniform64(p.src_offsets[chunk]) : (chunk + 1) * p.slot_bytes - len);
+        const uint64_t from = p.src_offsets ? uniform64(p.src_offsets[chunk]) : (chunk + 1) * p.slot_bytes - len;
+        if (p.src_offsets && (from > p.src_bytes || len > p.src_bytes - from)) { // (wave-uniform) the index points outside the source
+            if (lane == 0)
+                atomicOr(p.flags, 512u);
+            continue;
+        }
+        const uint64_t sa = reinterpret_cast<uint64_t>(p.scratch) + from;
         gvec_cptr src = reinterpret_cast<gvec_cptr>(sa & ~uint64_t(15));
         u32x4 RANS_GLOBAL *dst = reinterpret_cast<u32x4 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + p.offsets[chunk]);
         const uint32_t dsh = uniform((uint32_t)(sa & 15u) >> 2), bsh = uniform((uint32_t)(sa & 3u));
         const uint32_t n16 = (len + 15u) >> 4;
         for (uint32_t i = lane; i < n16; i += 64u) {
-            const u32x4 a = __builtin_nontemporal_load(src + i);
+            const u32x4 a = __builtin_nontemporal_load(src + i); // (below src_limit: the chunk lies inside the source, checked above)
             u32x4 b = {0u, 0u, 0u, 0u}; // (the granule behind the source's last one is not there to be read)
             if (reinterpret_cast<uint64_t>(src + i + 1) < p.src_limit)
                 b = __builtin_nontemporal_load(src + i + 1);
@@ -185,6 +190,10 @@ __global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
             len = p.lengths[mine];
             off = p.offsets[mine];
             from = p.src_offsets ? p.src_offsets[mine] : (mine + 1u) * p.slot_bytes - len;
+            if (p.src_offsets && (from > p.src_bytes || len > p.src_bytes - from)) { // the index points outside the source:
+                atomicOr(p.flags, 512u);                                             // nothing of this chunk is read or written
+                len = 0;
+            }
         }
         // four chunks per group at a time, two pieces of each in flight (512 bytes of a chunk per pass): a wave's trip is
         // a chain of memory round trips, and with a load -> store pair per piece (the compiler may not move a load above

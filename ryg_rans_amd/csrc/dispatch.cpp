@@ -63,7 +63,7 @@ hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_
     // (the lane encoders know the public formats: a narrow alias interleave gathers alias_remap from L2)
     if (format == kKernelFormatByteAdaptive) // one model per chunk: the wave encoder builds them, whatever the interleave
         return launch_encode_wave((int)RANS_AMD_FMT_BYTE, p, num_cus, stream, name);
-    if (lanes_applicable(p.nchunks, p.n_ways) && format != kKernelFormatR64Search && format != kKernelFormatWord16)
+    if (!p.no_lanes && lanes_applicable(p.nchunks, p.n_ways) && format != kKernelFormatR64Search && format != kKernelFormatWord16)
         return launch_encode_lanes(format == kKernelFormatAliasLds ? (int)RANS_AMD_FMT_ALIAS : format, p, num_cus, stream, name);
     // (word format over u16 symbols: the wave encoder's general path, whatever the interleave)
     return launch_encode_wave(format == kKernelFormatWord16 ? (int)RANS_AMD_FMT_WORD : format, p, num_cus, stream, name);

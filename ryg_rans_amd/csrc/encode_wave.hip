@@ -539,6 +539,10 @@ constexpr int enc_fused_waves_per_simd(int K) { return K == 1 ? 8 : (K <= 4 ? 4 
 // MODE 1: fused placement -- dynamic chunk claims, the last wave(s) of a block copy the finished streams to their place.
 // MODE 2: slot layout -- dynamic chunk claims, every wave codes, a chunk stays in its slot (EncParams::slot_layout):
 //         what the reference does with each of its buffers (main.cpp:176-188), every stream byte written exactly once.
+// MODE 3: MODE 2 with slots of the CALLER's size (EncParams::ovf_ctl): before anything is stored the coder makes sure it
+//         still lies inside the slot -- exactly where the stream is staged in LDS (the flush knows what it is about to
+//         write), by the round's worst case elsewhere -- and a chunk that does not fit is abandoned and listed for the
+//         second launch (EncParams::redo), which codes the listed chunks into worst-case slots behind the sized ones.
 template <int FMT, int K, int MODE>
 __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (MODE != 0 ? kEncFusedThreads : kEncBlockThreads),
                                   (MODE != 0 && FMT != FMT_ALIAS_LDS) ? enc_fused_waves_per_simd(K) : 1)
@@ -548,7 +552,23 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
     using state_t = typename Tr::state_t;
     constexpr bool FUSED = MODE == 1;
     constexpr bool DYNAMIC = MODE != 0; // chunks are claimed from EncParams::claims
+    constexpr bool SIZED = MODE == 3;   // slots of the caller's size: overflow checks, abandoned chunks, the redo launch
+    constexpr uint32_t kMaxEmit = kIsR64<FMT> ? 4u : 2u; // bytes one symbol can push out of one state (scale_bits <= 16 for the byte formats)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t redo_todo = 0; // redo launch: listed chunks this launch codes
+    if constexpr (SIZED) {
+        if (p.redo) { // (the first launch is complete: stream order)
+            const uint32_t listed = __hip_atomic_load(p.ovf_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            redo_todo = uniform(listed < p.ovf_cap ? listed : p.ovf_cap);
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                p.offsets[p.nchunks] = p.ovf_base + (uint64_t)redo_todo * p.slot_bytes; // the container's end
+                if (listed > p.ovf_cap)
+                    atomicOr(p.flags, 2u); // the overflow region is too small: RANS_AMD_E_SPACE
+            }
+            if (redo_todo == 0u) // the usual case: nothing overflowed, the launch ends before it has loaded a table
+                return;
+        }
+    }
 
     // word format: the 256 WordEncRec of the full-wave path come first (LDS address = sym << 4),
     // the per-symbol EncRec table of the general path behind them
@@ -659,6 +679,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
     const uint32_t in_lane_off = (lane & 3u) * N + (lane & ~3u);
 
     uint32_t coded = 0; // chunks this wave has coded (scratch ring: chunk number `coded` goes into slot coded % R)
+    uint32_t redo_slot = 0; // redo launch: the overflow slot of the chunk in hand
     for (uint64_t chunk_v = (uint64_t)blockIdx.x * waves_per_block + wave;; chunk_v += total_waves) {
         if constexpr (DYNAMIC) {
             // scratch ring: the slot about to be reused must have been drained -- BEFORE the claim, so that a claimed chunk
@@ -684,9 +705,18 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             const uint32_t npools = gridDim.x < kWorkPools ? gridDim.x : kWorkPools;
             const uint32_t pool = blockIdx.x % npools;
             uint32_t got = 0;
-            if (lane == 0)
-                got = atomicAdd(p.claims + kWorkPoolStride * pool, 1u);
-            chunk_v = (uint64_t)uniform(got) * npools + pool;
+            if (SIZED && p.redo) { // the i-th listed chunk goes into the i-th overflow slot
+                if (lane == 0)
+                    got = atomicAdd(p.ovf_ctl + kWorkPoolStride, 1u);
+                redo_slot = uniform(got);
+                if (redo_slot >= redo_todo)
+                    break;
+                chunk_v = p.ovf_list[redo_slot];
+            } else {
+                if (lane == 0)
+                    got = atomicAdd(p.claims + kWorkPoolStride * pool, 1u);
+                chunk_v = (uint64_t)uniform(got) * npools + pool;
+            }
         }
         if (chunk_v >= p.nchunks)
             break;
@@ -696,8 +726,11 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + first * p.sym_bytes;
         const uint32_t ring_j = (FUSED && p.ring_slots) ? coded % p.ring_slots : 0u;
         const uint64_t slot_no = (FUSED && p.ring_slots) ? ((uint64_t)blockIdx.x * waves_per_block + wave) * p.ring_slots + ring_j : chunk;
-        uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + uniform64(slot_no) * p.slot_bytes;
+        // (sized slots, redo launch: the overflow region behind the sized slots, one worst-case slot per listed chunk)
+        const uint64_t slot_at = (SIZED && p.redo) ? p.ovf_base + (uint64_t)redo_slot * p.slot_bytes : uniform64(slot_no) * p.slot_bytes;
+        uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + slot_at;
         uint32_t wp = (uint32_t)p.slot_bytes;
+        bool ovf = false; // SIZED, wave-uniform: the chunk's stream does not fit its slot
         ++coded;
 
         if (adaptive) // this chunk's model -> this wave's records (RansEncSymbolInit per chunk, main.cpp:159-162)
@@ -731,6 +764,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             const uint32_t cnt = (rr < rounds) ? N : tail;
             if (cnt == 0)
                 continue;
+            if constexpr (SIZED) {
+                if (wp < N * kMaxEmit) { // (what a round can emit at most)
+                    ovf = true;
+                    break;
+                }
+            }
             const uint8_t RANS_GLOBAL *rsrc = src + (uint64_t)rr * N * p.sym_bytes;
             uint32_t sym[K];
 #pragma unroll
@@ -767,10 +806,18 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 uint32_t sg = fast_rounds >> 4;
                 load_super16(cur, sg - 1);
                 while (sg-- > 0) {
+                    if (SIZED && ovf)
+                        break;
                     if (sg > 0)
                         load_super16(nxt, sg - 1);
 #pragma unroll
                     for (int j = 7; j >= 0; --j) {
+                        if constexpr (SIZED) {
+                            if (wp < 2u * 64u * K * kMaxEmit) { // (two rounds of K x 64 states)
+                                ovf = true;
+                                break;
+                            }
+                        }
                         uint32_t t[K]; // this lane's symbol of row 2j (low half) and of row 2j + 1 (high half)
 #pragma unroll
                         for (int k = 0; k < K; ++k)
@@ -839,6 +886,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             // offset is whatever the window held: it is written again, correctly, by the next flush, and at the end by the
             // state flush (same wave, same address: in order).  The lowest piece then becomes the window's top piece.
             auto stage_flush = [&](uint32_t top, uint32_t lp) {
+                if constexpr (SIZED) {
+                    if (top - lp > wp) { // the bytes in the window do not fit below the write offset: nothing more is stored
+                        ovf = true;
+                        return;
+                    }
+                }
                 const uint32_t hi = (top + 15u) & ~15u, lo = lp & ~15u;
                 const uint32_t to_slot = wp - top; // (wraps; congruent to 0 modulo 16)
                 const int32_t a = (int32_t)hi - 16 * (int32_t)(lane + 1u);
@@ -886,6 +939,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             uint32_t sg = fast_rounds >> 4;
             load_super(cur, sg - 1);
             while (sg-- > 0) {
+                if (SIZED && ovf)
+                    break;
                 if (sg > 0)
                     load_super(nxt, sg - 1);
                 uint32_t win_top = win_base + kTopPiece + (uniform(wp) & 15u);
@@ -893,6 +948,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                                                                 // format's counts 16-bit words -- and stage_flush() sets wp)
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
+                    if constexpr (SIZED && !kStage) { // (the staged forms are checked, exactly, where they flush)
+                        if (wp < 4u * 64u * K * kMaxEmit) { // four rounds of K x 64 states
+                            ovf = true;
+                            break;
+                        }
+                    }
                     uint32_t t[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k)
@@ -1014,6 +1075,13 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             if (mirrored) // back to lane l = stream l
                 x[0] = (state_t)__builtin_amdgcn_ds_bpermute((int)((63u - lane) * 4u), (int)x[0]);
         }
+        if constexpr (SIZED) {
+            if (ovf || wp < N * Tr::kStateBytes) { // abandoned: the redo launch codes this chunk into a worst-case slot
+                if (lane == 0)
+                    p.ovf_list[atomicAdd(p.ovf_ctl, 1u)] = (uint32_t)chunk;
+                continue;
+            }
+        }
         // flush: lane N-1 first, i.e. lane 0's state ends up first in memory
         // (main.cpp:244-245, main_simd.cpp:298-299)
         wp -= N * Tr::kStateBytes;
@@ -1040,8 +1108,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         if (lane == 0)
             p.lengths[chunk] = len;
         if (p.slot_layout && lane == 0) { // the slot is the chunk's place: the stream is [slot end - len, slot end)
-            p.offsets[chunk] = chunk * p.slot_bytes + wp;
-            if (chunk + 1 == p.nchunks)
+            p.offsets[chunk] = slot_at + wp;
+            if (chunk + 1 == p.nchunks && !(SIZED && p.redo)) // (sized slots: the redo launch has the last word on the end)
                 p.offsets[p.nchunks] = p.nchunks * p.slot_bytes;
         }
         if constexpr (FUSED) {
@@ -1069,6 +1137,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
 {
     const bool fused = p.status != nullptr;
     const bool slots = !fused && p.slot_layout && p.claims; // MODE 2: dynamic claims, no copiers
+    const bool sized = slots && p.ovf_ctl;                  // MODE 3: ... slots of the caller's size
     const bool dynamic = fused || slots;
     const uint32_t threads = FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (dynamic ? kEncFusedThreads : kEncBlockThreads);
     const uint32_t waves = threads / 64;
@@ -1107,9 +1176,19 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
         per_cu = per_cu > fit ? (fit ? fit : 1) : per_cu;
     }
     uint64_t cap = (uint64_t)num_cus * (FMT == FMT_ALIAS_LDS || dynamic ? per_cu : 8);
+    if (sized && p.redo) // (a handful of chunks at most, usually none: one block per CU finds that out quickly)
+        cap = (uint64_t)num_cus;
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
     if (fused) {
         auto kern = k_encode<FMT, K, 1>;
+        static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
+        if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), (int)lds_cap, lds_ok); e != hipSuccess)
+            return e;
+        RANS_LAUNCH(kern, dim3(grid), dim3(threads), lds, stream, q);
+        return hipGetLastError();
+    }
+    if (sized) {
+        auto kern = k_encode<FMT, K, 3>;
         static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
         if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), (int)lds_cap, lds_ok); e != hipSuccess)
             return e;

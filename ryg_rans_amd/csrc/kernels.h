@@ -157,6 +157,18 @@ struct EncParams {
     uint32_t slot_layout;       // 1 = that; `offsets` is then set and `status` is NULL
     unsigned int *claims;       // wave encoders with dynamic chunk hand-out (fused placement, slot layout): kWorkPools claim
                                 // counters on a 64-byte line each, zero at launch
+    // Sized slots (rans_amd_encode_slots_sized): slot_bytes is whatever the caller chose -- normally a little above the
+    // chunk's expected stream, the way the reference sizes its one buffer from the input (main_simd.cpp:145:
+    // n + n/8 + 128), not from the worst case.  A chunk whose stream does not fit is ABANDONED by its coder: nothing of it
+    // counts, its number is appended to ovf_list (ovf_ctl[0] = how many).  A second launch (redo = 1, wave kernel,
+    // slot_bytes = the worst-case slot) codes exactly those chunks again, chunk ovf_list[i] into the i-th slot of the
+    // overflow region that starts at byte ovf_base of `scratch`, and writes the final offsets[nchunks].
+    unsigned int *ovf_ctl;      // NULL: slots cannot overflow.  [0] overflowed chunks, [kWorkPoolStride] the redo launch's claim counter
+    uint32_t *ovf_list;         // nchunks entries
+    uint32_t ovf_cap;           // redo: slots the overflow region holds (more overflowed chunks than that: flags bit 1, E_SPACE)
+    uint32_t redo;              // 1 = the second launch
+    uint64_t ovf_base;          // redo: byte offset of the overflow region (= nchunks * the first launch's slot_bytes)
+    uint32_t no_lanes;          // the request goes to the wave encoders whatever its interleave (sized slots the lane encoders cannot take)
 };
 #ifndef RANS_FUSED_THREADS
 #define RANS_FUSED_THREADS 512
@@ -204,12 +216,16 @@ struct CompactParams {
     // or beyond address src_limit (16-byte aligned end of the source buffer) is read
     const uint64_t *src_offsets;
     uint64_t src_limit; // ~0 = no limit (the encoders' scratch carries slack)
+    // rans_amd_container_compact: the caller's index is DATA (it may have been parsed from a file) -- a chunk whose
+    // (src_offsets[c], lengths[c]) does not lie inside [0, src_bytes) is skipped and bit 9 (512) of *flags is set
+    // (RANS_AMD_E_CORRUPT), so nothing outside the source buffer is ever read.  Ignored when src_offsets is NULL.
+    uint64_t src_bytes;
     uint64_t slot_bytes;
     const uint32_t *lengths;
     const uint64_t *offsets;
     uint8_t *out;
     uint64_t nchunks;
-    const uint32_t *flags; // skip everything when bit1 is set
+    uint32_t *flags; // skip everything when bit1 is set; bit 9: an index entry outside the source (see src_bytes)
 };
 
 // Workspace words that a launch expects to find zero (status flags, chunk claims, placement status words, mailboxes): up

@@ -1049,8 +1049,14 @@ constexpr uint32_t kEncRowStride = 80; // 64 symbol bytes, rows 16-byte aligned,
 constexpr uint32_t kEncWaveLds = 64 * kEncRowStride + 64 * kLaneRingStride + 64 * 4;
 
 // slot layout (EncParams::slot_layout): the chunk stays in its slot, its stream is [slot end - len, slot end)
-__device__ __forceinline__ void lanes_publish_slot(const EncParams &p, uint64_t chunk, uint32_t len)
+// (sized slots, EncParams::ovf_ctl: a lane whose chunk did not fit its slot -- ovf -- lists it for the redo launch instead;
+//  whatever it stored lies inside its own slot and counts for nothing)
+__device__ __forceinline__ void lanes_publish_slot(const EncParams &p, uint64_t chunk, uint32_t len, bool ovf = false)
 {
+    if (ovf) {
+        p.ovf_list[atomicAdd(p.ovf_ctl, 1u)] = (uint32_t)chunk;
+        return;
+    }
     if (p.slot_layout) {
         p.offsets[chunk] = (chunk + 1u) * p.slot_bytes - len;
         if (chunk + 1 == p.nchunks)
@@ -1568,7 +1574,8 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_staged(const EncParams p)
                 }
             }
             p.lengths[chunk] = (uint32_t)p.slot_bytes - O.w;
-            lanes_publish_slot(p, chunk, (uint32_t)p.slot_bytes - O.w);
+            // (sized slots: a write offset that went below 0 has wrapped -- the flushes stopped at line 0, the ring took the rest)
+            lanes_publish_slot(p, chunk, (uint32_t)p.slot_bytes - O.w, O.w > (uint32_t)p.slot_bytes);
         }
         flush(true);
         flush(true);
@@ -1795,7 +1802,12 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
         auto pending = [&]() { return (((flushed & 1u) << 6) - ((wk >> 6) & 124u)) & 127u; };
         // the whole wave takes part: lanes say which line they have filled (or, at the end, hold anything of), the quad
         // writes the line of its lane t with instruction t
+        bool ovf = false; // sized slots: this lane's chunk needs a line below its slot
         auto flush = [&](bool need) {
+            if (need && flushed == 0u) {
+                ovf = true;
+                need = false;
+            }
             const int32_t line = need ? (int32_t)(flushed - 1u) : -1;
             if (need)
                 flushed -= 1u;
@@ -1848,10 +1860,10 @@ __global__ void __launch_bounds__(1024) k_encode_lanes_r64x2(const EncParams p)
         }
         const uint32_t in_ring = pending(); // <= 63 + 16
         const uint32_t len = (uint32_t)p.slot_bytes - (flushed * kLaneLine - in_ring);
-        p.lengths[chunk0 + lane] = len;
-        lanes_publish_slot(p, chunk0 + lane, len);
         flush(in_ring > 0u); // the line(s) that hold anything; what lies below the stream start in the lowest one is never read
         flush(in_ring > 64u);
+        p.lengths[chunk0 + lane] = len;
+        lanes_publish_slot(p, chunk0 + lane, len, ovf);
         if (fused)
             lanes_round_end(p, ctl, cs, wave, lane, batch, len);
     }
@@ -2222,6 +2234,16 @@ hipError_t launch_decode_lanes(int format, const DecParams &p, int num_cus, hipS
 }
 
 bool encode_lanes_fused(const EncParams &p, int num_cus) { return encode_lanes_staged_waves(p, num_cus) >= 1; }
+
+// Sized slots: would launch_encode_lanes_t take one of its STAGED kernels (the 2-way rans64 one included) for this
+// request?  Those flush whole lines and stop at their slot's first one; the per-lane kernel stores unit by unit and cannot
+// tell that a chunk does not fit.  (The same predicate as the launcher's, r64x2 shape and all.)
+bool encode_lanes_sized_ok(int format, const EncParams &p, int num_cus)
+{
+    const bool r64x2_shape = format == FMT_R64 && p.n_ways == 2 && !p.status && (p.chunk_syms & 63u) == 0 && p.scale_bits >= 7 &&
+                             p.scale_bits <= 16 && p.nsyms <= 256 && (p.n / p.chunk_syms) / 64 >= (uint64_t)num_cus;
+    return encode_lanes_staged_waves(p, num_cus, r64x2_shape ? 1 : 6) >= 1;
+}
 
 hipError_t launch_encode_lanes(int format, const EncParams &p, int num_cus, hipStream_t stream, const char **name)
 {

@@ -51,5 +51,7 @@ hipError_t launch_encode_lanes(int format, const EncParams &p, int num_cus, hipS
 // true when launch_encode_lanes would take the staged kernel for this request -- the one that can place its chunks
 // itself (EncParams::status); everything but status / offsets / out / out_cap must be filled in
 bool encode_lanes_fused(const EncParams &p, int num_cus);
+// true when launch_encode_lanes would take a staged kernel for this SIZED-slot request (EncParams::ovf_ctl): lanes.hip
+bool encode_lanes_sized_ok(int format, const EncParams &p, int num_cus);
 
 } // namespace rans_amd

@@ -160,7 +160,8 @@ def test_judged_line_is_short_and_complete():
     # worst case
     worst = copy.deepcopy(full)
     for e in worst["configs"]:
-        e["encode_tight"] = e["decode_tight"] = e["decode_slots"]
+        e["encode_tight"] = dict(e["encode_slots"], container_over_input=0.8512)
+        e["decode_tight"] = e["decode_slots"]
     worst["configs"] = (worst["configs"] * 2)[:12]
     worst["n_gpus"] = 8
     worst["per_rank"] = {"kernel_ms": [0.38123] * 8}

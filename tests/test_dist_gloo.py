@@ -44,7 +44,8 @@ def _run_bench(argv, env, timeout=600, launcher=None):
         details = os.path.join(tmp, "details.json")
         cmd = (launcher or [sys.executable]) + [os.path.join(root, "bench.py")] + argv + ["--details", details]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
-        if out.returncode != 0:
+        if out.returncode != 0:  # (the caller asserts on the return code: hand it what the run said)
+            out.stderr = (out.stderr or "")[-1500:] + "\n--- stdout tail ---\n" + (out.stdout or "")[-2500:]
             return None, None, out
         tail = out.stdout[-4096:]
         last = tail.rstrip("\n").splitlines()[-1]

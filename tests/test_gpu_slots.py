@@ -227,6 +227,47 @@ def test_compact_a_chunk_range_and_a_reordered_index(gpu, oracle):
     with pytest.raises(R.RansAmdError) as e:
         ctx.compact(d_cont, cont.size, d_offs, d_lens, nchunks, d_dst=tiny)
     assert e.value.status == R.E_SPACE and int(tiny.sum()) == 0
+    # ... and that verdict does not outlive the compaction: an encode that follows starts with a clean word
+    g_cont, g_offs, g_lens, g_total = ctx.encode(gm, torch.from_numpy(data).cuda(), n_ways, chunk)
+    ctx.encode_status()
+    assert g_total == cont.size
+
+
+@pytest.mark.parametrize("n_ways,chunk", [(64, 4096), (2, 512)])  # k_compact (a wave per chunk) and k_compact_small (16 lanes)
+def test_compact_rejects_an_index_that_leaves_the_source(gpu, oracle, n_ways, chunk):
+    """The source index of rans_amd_container_compact is data (it may come from a file): an (offset, length) pair outside
+    [0, src_bytes) is reported as RANS_AMD_E_CORRUPT, that chunk is neither read nor written, the others are copied."""
+    R, ctx, torch = gpu
+    fmt, sb = (FMT_WORD, 12) if n_ways == 64 else (FMT_R64, 14)
+    data = oracle.gen_zipf(150000 if n_ways == 64 else 4200 * 512, K=256, s=1.0, seed=12)  # (>= 4096 chunks: k_compact_small)
+    om, gm = _models(ctx, oracle, fmt, sb, data)
+    cont, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+    nchunks = len(lens)
+    d_cont = torch.from_numpy(cont.copy()).cuda()  # exactly src_bytes long: nothing behind it belongs to the caller
+    d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+    want_offs = R.offsets_from_lengths(lens)
+    for victim, off, ln in ((3, int(cont.size) - 8, None), (nchunks - 1, 1 << 40, None), (0, int(cont.size) + 1, None),
+                            (7, None, int(cont.size))):
+        o2, l2 = offs.astype(np.int64).copy(), lens.astype(np.int32).copy()
+        if off is not None:
+            o2[victim] = off
+        if ln is not None:
+            l2[victim] = ln
+        w2 = R.offsets_from_lengths(l2.astype(np.uint32))
+        dst = torch.full((int(w2[-1]) + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        with pytest.raises(R.RansAmdError) as e:
+            ctx.compact(d_cont, cont.size, torch.from_numpy(o2).cuda(), torch.from_numpy(l2).cuda(), nchunks, d_dst=dst)
+        assert e.value.status == R.E_CORRUPT, (victim, off, ln)
+        got = dst.cpu().numpy()
+        for c in range(nchunks):
+            a, b = int(w2[c]), int(w2[c]) + int(l2[c])
+            if c == victim:
+                assert np.all(got[a:b] == 0xEE), "the rejected chunk was written"
+            else:
+                assert np.array_equal(got[a:b], cont[int(offs[c]):int(offs[c]) + int(lens[c])]), c
+    # a healthy index right behind: the verdict is per call
+    d_dst, d_doffs, total = ctx.compact(d_cont, cont.size, torch.from_numpy(offs.astype(np.int64)).cuda(), d_lens, nchunks)
+    assert total == int(want_offs[-1])
 
 
 @pytest.mark.parametrize("fmt,sb,n_ways,chunk", [(FMT_WORD, 12, 64, 4096), (FMT_R64, 14, 2, 512), (FMT_ALIAS, 16, 64, 4096)])
