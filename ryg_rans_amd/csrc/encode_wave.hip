@@ -102,10 +102,12 @@ __device__ __forceinline__ void enc_renorm_byte_full_staged(uint32_t &x, uint32_
 // PADDED: the record table holds 256 entries (zero records behind nsyms) and `sym` is a byte, so it
 // indexes the table as it is -- no range select (a v_cndmask costs ~22 issue cycles on gfx950).
 // FULL: all 64 lanes hold a symbol (the byte-stream formats then renormalise with enc_renorm_byte_full).
+// dead: 0, or ~0 (wave-uniform) when nothing may leave the states any more -- a coder of sized slots (k_encode MODE 3) whose
+// chunk no longer fits keeps running through its loop, storing nothing, and abandons the chunk at the end.
 template <int FMT, bool PADDED = false, bool FULL = false, bool STAGED = false> // (STAGED: FULL, and wp is an LDS pointer)
 __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename FmtTraits<FMT>::state_t &x,
                                             uint32_t sym, bool active, uint8_t RANS_GLOBAL *slot, uint32_t &wp,
-                                            bool &bad)
+                                            bool &bad, uint32_t dead = 0u)
 {
     if constexpr (FMT == FMT_ALIAS_LDS && FULL) {
         // Full waves of the alias coder with its tables in LDS (main_alias.cpp:241-250), without a single select (a
@@ -128,7 +130,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         if constexpr (STAGED)
             enc_renorm_byte_full_staged(y, x_max, wp, T.split_sel);
         else
-            enc_renorm_byte_full(y, x_max, wp, slot, T.swap_sel);
+            enc_renorm_byte_full(y, x_max | dead, wp, slot, T.swap_sel);
         const uint32_t q0 = __umulhi(y, rcp);
         const uint32_t d = y - __umul24(q0, freq) - freq;          // rem0 - freq: negative iff the estimate was exact
         const uint32_t m = (uint32_t)((int32_t)d >> 31);
@@ -151,6 +153,8 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         bad = true;
         active = false;
     }
+    if constexpr (!FULL || FMT == FMT_WORD || kIsR64<FMT>) // (the byte-stream formats' FULL form takes `dead` in its threshold)
+        active = active && dead == 0u;
 
     if constexpr (FMT == FMT_WORD) {
         // rans_word_sse41.h:81-93
@@ -186,7 +190,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
             if constexpr (STAGED)
                 enc_renorm_byte_full_staged(y, active ? x_max : 0xffffffffu, wp, T.split_sel);
             else
-                enc_renorm_byte_full(y, active ? x_max : 0xffffffffu, wp, slot, T.swap_sel);
+                enc_renorm_byte_full(y, (active ? x_max : 0xffffffffu) | dead, wp, slot, T.swap_sel);
         } else {
         const bool e1 = active && x >= x_max;
         const bool e2 = e1 && (x >> 8) >= x_max;
@@ -731,6 +735,11 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + slot_at;
         uint32_t wp = (uint32_t)p.slot_bytes;
         bool ovf = false; // SIZED, wave-uniform: the chunk's stream does not fit its slot
+        // SIZED, the coders that store every round's units themselves: 0, or ~0 from the round on before which the slot no
+        // longer had room for what a round can emit at most -- OR-ed into the renormalisation thresholds, so that nothing
+        // leaves the states any more (no branch out of the unrolled loops: a `break` there cost the 4096-symbol alias coder
+        // a third of its speed)
+        uint32_t dead = 0u;
         ++coded;
 
         if (adaptive) // this chunk's model -> this wave's records (RansEncSymbolInit per chunk, main.cpp:159-162)
@@ -806,27 +815,24 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 uint32_t sg = fast_rounds >> 4;
                 load_super16(cur, sg - 1);
                 while (sg-- > 0) {
-                    if (SIZED && ovf)
+                    if (SIZED && dead)
                         break;
                     if (sg > 0)
                         load_super16(nxt, sg - 1);
 #pragma unroll
                     for (int j = 7; j >= 0; --j) {
-                        if constexpr (SIZED) {
-                            if (wp < 2u * 64u * K * kMaxEmit) { // (two rounds of K x 64 states)
-                                ovf = true;
-                                break;
-                            }
-                        }
                         uint32_t t[K]; // this lane's symbol of row 2j (low half) and of row 2j + 1 (high half)
 #pragma unroll
                         for (int k = 0; k < K; ++k)
                             t[k] = __builtin_amdgcn_perm(quad_perm<1, 0, 3, 2>(cur[j][k]), cur[j][k], sel16);
 #pragma unroll
-                        for (int h = 1; h >= 0; --h)
+                        for (int h = 1; h >= 0; --h) {
+                            if constexpr (SIZED)
+                                dead = uniform(wp) < 64u * K * kMaxEmit ? ~0u : dead; // (a round of K x 64 states)
 #pragma unroll
                             for (int k = K - 1; k >= 0; --k)
-                                enc_substep<FMT, false, true>(T, x[k], (t[k] >> (16 * h)) & 0xffffu, true, slot, wp, bad);
+                                enc_substep<FMT, false, true>(T, x[k], (t[k] >> (16 * h)) & 0xffffu, true, slot, wp, bad, dead);
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
@@ -939,7 +945,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             uint32_t sg = fast_rounds >> 4;
             load_super(cur, sg - 1);
             while (sg-- > 0) {
-                if (SIZED && ovf)
+                if (SIZED && (ovf || dead))
                     break;
                 if (sg > 0)
                     load_super(nxt, sg - 1);
@@ -948,12 +954,6 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                                                                 // format's counts 16-bit words -- and stage_flush() sets wp)
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
-                    if constexpr (SIZED && !kStage) { // (the staged forms are checked, exactly, where they flush)
-                        if (wp < 4u * 64u * K * kMaxEmit) { // four rounds of K x 64 states
-                            ovf = true;
-                            break;
-                        }
-                    }
                     uint32_t t[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k)
@@ -980,13 +980,19 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                     lp = uniform(lp);
 #pragma unroll
                     for (int step = 0; step < 4 * K; ++step) {
-                        const u32x4 now = rec;
+                        u32x4 now = rec;
                         if (step + 1 < 4 * K)
                             rec = rec_at(step + 1);
-                        if constexpr (kStage)
+                        if constexpr (kStage) {
                             enc_word_full_staged<kSmall, kTrack>(x[K - 1 - step % K], now, lp, worst);
-                        else
+                        } else {
+                            if constexpr (SIZED) { // (the staged form is checked, exactly, where it flushes)
+                                if (step % K == 0)
+                                    dead = uniform(wp) < 64u * K * kMaxEmit ? ~0u : dead; // (a round of K x 64 states)
+                                now.y |= dead; // x > threshold never holds: no word leaves
+                            }
                             enc_word_full<kSmall, kTrack>(x[K - 1 - step % K], now, wp, slot, worst);
+                        }
                     }
                     wp = uniform(wp);
                     lp = uniform(lp);
@@ -1009,24 +1015,33 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                         lp = uniform(lp);
 #pragma unroll
                         for (int step = 0; step < 4 * K; ++step) {
-                            const u32x4 now = rec;
+                            u32x4 now = rec;
                             if (step + 1 < 4 * K)
                                 rec = rec_at(step + 1);
-                            if constexpr (kStageB && kSmall)
+                            if constexpr (kStageB && kSmall) {
                                 enc_byte_full_staged<kTrack>(x[K - 1 - step % K], now, lp, worst);
-                            else
+                            } else {
+                                if constexpr (SIZED) {
+                                    if (step % K == 0)
+                                        dead = uniform(wp) < 64u * K * kMaxEmit ? ~0u : dead;
+                                    now.w |= dead; // x >= x_max never holds: no byte leaves
+                                }
                                 enc_byte_full(x[K - 1 - step % K], now, wp, slot, worst, swap_sel);
+                            }
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int J = 3; J >= 0; --J)
+                    for (int J = 3; J >= 0; --J) {
+                        if constexpr (SIZED && !(kStageA && kSmall))
+                            dead = uniform(wp) < 64u * K * kMaxEmit ? ~0u : dead; // (a round of K x 64 states)
 #pragma unroll
                         for (int k = K - 1; k >= 0; --k)
                             if constexpr (kStageA && kSmall)
                                 enc_substep<FMT, true, true, true>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, lp, bad);
                             else
-                                enc_substep<FMT, true, kIsAlias<FMT>>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad);
+                                enc_substep<FMT, true, kIsAlias<FMT>>(T, x[k], (t[k] >> (8 * J)) & 0xffu, true, slot, wp, bad, dead);
+                    }
                 }
                 if constexpr ((kStageB || kStageA) && kStage) { // (16-bit models: half a super-group fills the window)
                     if (j == 2 && flush8) {
@@ -1076,7 +1091,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 x[0] = (state_t)__builtin_amdgcn_ds_bpermute((int)((63u - lane) * 4u), (int)x[0]);
         }
         if constexpr (SIZED) {
-            if (ovf || wp < N * Tr::kStateBytes) { // abandoned: the redo launch codes this chunk into a worst-case slot
+            if (ovf || dead || wp < N * Tr::kStateBytes) { // abandoned: the redo launch codes this chunk into a worst-case slot
                 if (lane == 0)
                     p.ovf_list[atomicAdd(p.ovf_ctl, 1u)] = (uint32_t)chunk;
                 continue;

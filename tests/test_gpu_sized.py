@@ -140,7 +140,13 @@ def test_forced_overflow_inside_a_skewed_model(gpu, oracle, fmt, sb, n_ways, chu
     data[40 * chunk:41 * chunk] = rng.integers(0, 256, chunk).astype(np.uint8)
     om, gm = _models(ctx, oracle, fmt, sb, data)
     over, slot, total = _check_sized(R, ctx, torch, oracle, fmt, om, gm, data, n_ways, chunk)
-    assert set(range(8, 12)) | {40} <= set(over.tolist()), over
+    _, _, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+    must = {c for c in range(len(lens)) if int(lens[c]) > slot}  # (what cannot fit MUST have moved; the check is conservative beyond)
+    assert must <= set(over.tolist()), (must, over)
+    if n_ways <= 64:  # (wide interleaves of short chunks: states and the round's margin dominate the slot, random bytes may fit)
+        assert set(range(8, 12)) | {40} <= must, (must, slot)
+    if over.size == 0:
+        return
     # ... and with room for exactly that many: still fine; for one fewer: RANS_AMD_E_SPACE
     d_syms = _dev(torch, data)
     ctx.encode_sized(gm, d_syms, n_ways, chunk, slot=slot, overflow_chunks=over.size)

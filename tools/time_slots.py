@@ -53,13 +53,17 @@ def main():
         m = ctx.model(fmt, f, sb)
         c_cont, c_offs, c_lens, c_total = ctx.encode(m, d, ways, chunk)
         s_cont, s_offs, s_lens, s_total = ctx.encode_slots(m, d, ways, chunk)
-        ok = bool(torch.equal(c_lens, s_lens))
+        t_cont, t_offs, t_lens, t_total, t_slot = ctx.encode_sized(m, d, ways, chunk)  # sized slots (rans_amd_encode_slots_sized)
+        ok = bool(torch.equal(c_lens, s_lens)) and bool(torch.equal(c_lens, t_lens))
         out = torch.empty_like(d)
         try:  # (a library variant that is wrong by construction -- a dropped store, timing only -- still gets its encode times)
             ctx.decode(m, c_cont, c_total, c_offs, c_lens, n, ways, chunk, d_out=out)
             ok = ok and bool(torch.equal(out, d))
             out.zero_()
             ctx.decode(m, s_cont, s_total, s_offs, s_lens, n, ways, chunk, d_out=out)
+            ok = ok and bool(torch.equal(out, d))
+            out.zero_()
+            ctx.decode(m, t_cont, t_total, t_offs, t_lens, n, ways, chunk, d_out=out)
             ok = ok and bool(torch.equal(out, d))
         except R.RansAmdError as e:
             print("%-8s decode of the encoder's output failed: %s" % (name, e), flush=True)
@@ -72,16 +76,19 @@ def main():
             k_c = ctx.last_encode_kernel()[0]
             res["enc slots  "] = timed(lambda: ctx.encode_slots(m, d, ways, chunk, d_out=s_cont, sync=False, d_offsets=s_offs, d_lengths=s_lens), a.launches)
             k_s = ctx.last_encode_kernel()[0]
+            res["enc tight  "] = timed(lambda: ctx.encode_sized(m, d, ways, chunk, slot=t_slot, d_out=t_cont, sync=False, d_offsets=t_offs, d_lengths=t_lens), a.launches)
             res["dec compact"] = timed(lambda: ctx.decode(m, c_cont, c_total, c_offs, c_lens, n, ways, chunk, d_out=out, sync=False), a.launches)
             res["dec slots  "] = timed(lambda: ctx.decode(m, s_cont, s_total, s_offs, s_lens, n, ways, chunk, d_out=out, sync=False), a.launches)
+            res["dec tight  "] = timed(lambda: ctx.decode(m, t_cont, t_total, t_offs, t_lens, n, ways, chunk, d_out=out, sync=False), a.launches)
             bad = ctx.decode_errors()
             for k, (mean, mn) in res.items():
                 print("%-8s chunk %-6d round %d  %s  mean %.4f ms  min %.4f ms  frac %.4f   %s" % (
                     name, chunk, r, k, mean, mn, alg / mean / 1e6 / 8000.0,
                     (k_c if k == "enc compact" else k_s if k.startswith("enc") else k_dec)), flush=True)
-        print("%-8s %s  stream %.4f B/sym  slot container %.2f x input  bad chunks %d" % (
-            name, "ok" if ok and bad == 0 else "MISMATCH", c_total / n, s_total / (n * d.element_size()), bad), flush=True)
-        del d, c_cont, s_cont, out
+        print("%-8s %s  stream %.4f B/sym  slot container %.2f x input  sized-slot container %.3f x input (slot %d)  bad chunks %d" % (
+            name, "ok" if ok and bad == 0 else "MISMATCH", c_total / n, s_total / (n * d.element_size()),
+            t_total / (n * d.element_size()), t_slot, bad), flush=True)
+        del d, c_cont, s_cont, t_cont, out
         torch.cuda.empty_cache()
 
 
