@@ -1177,6 +1177,12 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
             lds = at + (size_t)enc_waves * kEncStageBytes;
         }
     }
+    {   // measure build, RANS_AMD_ENC_LDS_MIN=bytes: ask for at least that much LDS per block -- fewer resident blocks per CU,
+        // the occupancy scan of profiles/r05_encoder_occupancy.md (what an encoder that kept whole chunks in LDS would run at)
+        static const char *lds_min = measure_knob("RANS_AMD_ENC_LDS_MIN");
+        if (lds_min && (size_t)atoi(lds_min) > lds && FMT != FMT_ALIAS_LDS)
+            lds = (size_t)atoi(lds_min);
+    }
     const size_t lds_cap = FMT == FMT_ALIAS_LDS ? 160 * 1024 : 128 * 1024;
     if (lds > lds_cap || (FMT == FMT_WORD && !p.word_enc_recs && p.sym_bytes == 1) ||
         (FMT == FMT_ALIAS_LDS && (!p.alias_recs8 || !p.alias_remap16)))
