@@ -802,7 +802,6 @@ def main():
         # Setup, untimed: where the buffers lie is worth 4-6 % on this part (two classes of device memory; container and
         # output in DIFFERENT classes is the fast case, profiles/r04_allocation.md), and which class an allocation gets is
         # the driver's choice.  Allocate candidates, let the clocks settle on the first pair, time every pair, keep the best.
-        from ryg_rans_amd.placement import choose_pair
         conts = [cont] + [cont.clone() for _ in range(2)]
         outs = [out] + [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(args.placement_candidates - 1)]
         t_pre = time.perf_counter()
@@ -814,8 +813,8 @@ def main():
         #  more, twice at most: the other class is a window of a few GiB somewhere in allocation order)
         extended = 0
         while True:
-            ci, oi, matrix = choose_pair(torch, lambda c, o: ctx.decode(model, c, total, offs, lens, n, args.ways, args.chunk, d_out=o,
-                                                                        sync=False), conts, outs)
+            # (the C ABI's own probe -- rans_amd_probe_placement, what a C++ caller uses: examples/multi_gpu.cpp)
+            ci, oi, matrix = ctx.probe_placement(model, conts, total, offs, lens, n, args.ways, args.chunk, outs, launches=6, sweeps=2)
             flat = [v for row in matrix for v in row]
             if max(flat) >= args.placement_spread * min(flat) or extended == 2:
                 break

@@ -77,6 +77,7 @@ struct Rank {
     int steps = 10;
     ncclComm_t comm = nullptr;
     std::vector<ShardRecord> gathered; // filled on every rank by the all-gather
+    float first_pair_ms = 0.f, chosen_ms = 0.f; // rans_amd_probe_placement: what two plain allocations got / what the chosen pair gets
     int rc = 0;
     char msg[256] = "";
 };
@@ -107,6 +108,7 @@ void run_rank(Rank &r)
     rans_amd_ctx *ctx = nullptr;
     rans_amd_model *model = nullptr;
     uint8_t *d_in = nullptr, *d_out = nullptr, *d_cont = nullptr;
+    uint8_t *d_cont2 = nullptr, *d_out2 = nullptr, *d_out3 = nullptr; // placement candidates (the ones not kept are freed at the end)
     uint64_t *d_off = nullptr;
     uint32_t *d_len = nullptr;
     double *d_rec = nullptr, *d_all = nullptr;
@@ -149,6 +151,23 @@ void run_rank(Rank &r)
         R_CHECK(rans_amd_build_model_o0(ctx, RANS_AMD_FMT_WORD, d_in, n, 1, 256, scale_bits, freqs, &model, stream));
         uint64_t total = 0, bad = 0;
         R_CHECK(rans_amd_encode(ctx, model, d_in, n, n_ways, chunk, d_cont, cap, d_off, d_len, &total, stream));
+        {   // Setup: where the two buffers of a streaming decode lie is worth 4-6 % on this part and hipMalloc cannot be
+            // steered (include/ryg_rans_amd.h, rans_amd_probe_placement) -- a second copy of the container and two more
+            // outputs, the library times the six pairs, the fastest pair is the one the timed loop uses.
+            R_HIP(hipMalloc((void **)&d_cont2, cap + 256));
+            R_HIP(hipMalloc((void **)&d_out2, n + 256));
+            R_HIP(hipMalloc((void **)&d_out3, n + 256));
+            R_HIP(hipMemcpyAsync(d_cont2, d_cont, total, hipMemcpyDeviceToDevice, stream));
+            const void *conts[2] = {d_cont, d_cont2};
+            void *outs[3] = {d_out, d_out2, d_out3};
+            uint32_t bc = 0, bo = 0;
+            float ms[6];
+            R_CHECK(rans_amd_probe_placement(ctx, model, conts, 2, total, d_off, d_len, n, n_ways, chunk, outs, 3, 0, 0, &bc, &bo, ms, stream));
+            r.first_pair_ms = ms[0];
+            r.chosen_ms = ms[bc * 3 + bo];
+            std::swap(d_cont, bc ? d_cont2 : d_cont); // (the kept pair in d_cont / d_out; everything is freed at the end)
+            std::swap(d_out, bo == 1 ? d_out2 : (bo == 2 ? d_out3 : d_out));
+        }
         // warm-up, then `steps` timed decodes of the whole shard (device resident in, device resident out)
         for (int i = 0; i < 3; ++i)
             R_CHECK(rans_amd_decode(ctx, model, d_cont, total, d_off, d_len, n, n_ways, chunk, d_out, nullptr, stream));
@@ -235,7 +254,8 @@ done:
         rans_amd_model_destroy(model);
     if (ctx)
         rans_amd_ctx_destroy(ctx);
-    for (void *p : {(void *)d_in, (void *)d_out, (void *)d_cont, (void *)d_off, (void *)d_len, (void *)d_rec, (void *)d_all})
+    for (void *p : {(void *)d_in, (void *)d_out, (void *)d_cont, (void *)d_off, (void *)d_len, (void *)d_rec, (void *)d_all,
+                    (void *)d_cont2, (void *)d_out2, (void *)d_out3})
         if (p)
             (void)hipFree(p);
     if (ev0)
@@ -370,6 +390,10 @@ int main(int argc, char **argv)
     }
     if (split_one) // the pieces side by side are the input
         all_ok = all_ok && memcmp(shared.decoded.data(), shared.syms.data(), shared.n) == 0;
+    else
+        for (const Rank &r : ranks) // rans_amd_probe_placement: two plain allocations against the fastest of 2 x 3 candidates
+            printf("rank %d placement: first pair %.4f ms, chosen pair %.4f ms (%+.1f %%)\n", r.rank, r.first_pair_ms, r.chosen_ms,
+                   r.first_pair_ms > 0 ? (r.chosen_ms / r.first_pair_ms - 1.0) * 100.0 : 0.0);
     const int gpus_used = std::min(world, visible);
     // frac_job: algorithmic bytes of all ranks over the slowest rank's kernel, against the peak of the GPUs in use
     // (bench.py roofline.frac_job); ranks that share a GPU run one after the other on it, so the figure is low by design there

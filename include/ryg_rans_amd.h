@@ -57,7 +57,7 @@ extern "C" {
 /* 0.5.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
  * inside a hipGraph capture (0.3.0); rans_amd_encode_slots + rans_amd_slot_bytes / rans_amd_encode_slots_bound,
  * rans_amd_container_compact, rans_amd_container_slice, chunk offsets on any multiple of the format's unit in every decoder
- * (0.4.0); rans_amd_encode_slots_sized + rans_amd_tight_slot_bytes / rans_amd_encode_sized_bound (0.5.0).  A caller built
+ * (0.4.0); rans_amd_encode_slots_sized + rans_amd_tight_slot_bytes / rans_amd_encode_sized_bound, rans_amd_probe_placement (0.5.0).  A caller built
  * against an older header keeps working, with two behaviour changes it can observe: since 0.4.0
  * rans_amd_container_parse[_adaptive] want a 4-byte aligned `src` (RANS_AMD_E_ARG otherwise; an mmap at an odd offset must
  * be copied first), and since 0.5.0 rans_amd_container_compact checks its SOURCE index against src_bytes
@@ -333,6 +333,27 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
  * relative to *byte_begin -- copy that byte range to the device, pass it with the rebased offsets and d_lengths + lo. */
 int rans_amd_container_slice(const uint64_t *offsets, const uint32_t *lengths, uint64_t n_chunks, uint64_t lo, uint64_t hi,
                              uint64_t *byte_begin, uint64_t *byte_end, uint64_t *rebased_offsets);
+
+/* Placement probe (setup time, not the data path).  On MI355X the same decode over the same bytes runs 4-6 % faster when
+ * its container and its output lie in DIFFERENT classes of device memory than when they share one (profiles/r04_allocation.md:
+ * a container x output matrix of allocations shows an XOR pattern; what moves is the memory-side read latency).  Which class
+ * a hipMalloc lands in is the driver's choice and no allocation flag steers it -- the library cannot pick for the caller.
+ * What a caller that keeps its buffers for a while CAN do is allocate a few candidates and ask which pair is fastest:
+ *
+ *   d_containers[0 .. n_containers)   device buffers holding THE SAME container_bytes bytes (copies of one container)
+ *   d_outs[0 .. n_outs)               candidate output buffers (n symbols each)
+ *
+ * Every pair is decoded `launches` times (after two warm-up launches), `sweeps` times over, interleaved so that a drift of
+ * the clocks favours nobody; times come from HIP events on `stream`.  *best_container / *best_out name the fastest pair;
+ * ms_matrix (NULL, or n_containers * n_outs floats, row = container) receives the mean milliseconds of every pair, so the
+ * caller sees what the choice was worth (ms_matrix[0] is the pair two plain allocations would have got).  Synchronous;
+ * every decode is checked (RANS_AMD_E_CORRUPT if one fails).  launches = 0 -> 6, sweeps = 0 -> 2.  The caller frees the
+ * candidates it does not keep. */
+int rans_amd_probe_placement(rans_amd_ctx *ctx, const rans_amd_model *model, const void *const *d_containers,
+                             uint32_t n_containers, uint64_t container_bytes, const uint64_t *d_offsets,
+                             const uint32_t *d_lengths, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
+                             void *const *d_outs, uint32_t n_outs, uint32_t launches, uint32_t sweeps,
+                             uint32_t *best_container, uint32_t *best_out, float *ms_matrix, void *stream);
 
 /* Synchronise `stream` and return (and reset) the failed-chunk count accumulated
  * by asynchronous rans_amd_decode calls on this context. */

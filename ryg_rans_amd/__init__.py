@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "rans_amd_encode", "rans_amd_encode_status", "rans_amd_decode", "rans_amd_decode_errors",
     "rans_amd_encode_slots", "rans_amd_slot_bytes", "rans_amd_encode_slots_bound", "rans_amd_container_compact",
     "rans_amd_container_slice",
-    "rans_amd_encode_slots_sized", "rans_amd_tight_slot_bytes", "rans_amd_encode_sized_bound",
+    "rans_amd_encode_slots_sized", "rans_amd_tight_slot_bytes", "rans_amd_encode_sized_bound", "rans_amd_probe_placement",
     "rans_amd_encode_host", "rans_amd_decode_host",
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_encode_kernel", "rans_amd_last_wave_clocks",
     "rans_amd_launch_spans",
@@ -122,6 +122,8 @@ def _load():
         "rans_amd_container_slice": (i32, [u64p, u32p, u64, u64, u64, u64p, u64p, u64p]),
         "rans_amd_decode": (i32, [vp, vp, vp, u64, vp, vp, u64, u32, u32, vp, u64p, vp]),
         "rans_amd_decode_errors": (i32, [vp, u64p, vp]),
+        "rans_amd_probe_placement": (i32, [vp, vp, C.POINTER(vp), u32, u64, vp, vp, u64, u32, u32, C.POINTER(vp), u32, u32, u32,
+                                         u32p, u32p, C.POINTER(C.c_float), vp]),
         "rans_amd_encode_host": (i32, [vp, vp, vp, u64, u32, vp, u64, u64p]),
         "rans_amd_decode_host": (i32, [vp, vp, vp, u64, u64, u32, vp]),
         "rans_amd_set_timing": (i32, [vp, i32]),
@@ -425,6 +427,19 @@ class Context:
                                     d_lengths.data_ptr(), n, n_ways, chunk_syms, d_out.data_ptr(),
                                     C.byref(bad) if sync else None, _torch_stream()), "decode")
         return d_out
+
+    def probe_placement(self, model, d_containers, container_bytes, d_offsets, d_lengths, n, n_ways, chunk_syms, d_outs,
+                        launches=6, sweeps=2):
+        """rans_amd_probe_placement: -> (best container index, best output index, matrix[container][output] of mean ms)."""
+        conts = (C.c_void_p * len(d_containers))(*[t.data_ptr() for t in d_containers])
+        outs = (C.c_void_p * len(d_outs))(*[t.data_ptr() for t in d_outs])
+        bi, bj = C.c_uint32(0), C.c_uint32(0)
+        ms = (C.c_float * (len(d_containers) * len(d_outs)))()
+        _check(_lib.rans_amd_probe_placement(self._h, model._h, conts, len(d_containers), container_bytes, d_offsets.data_ptr(),
+                                             d_lengths.data_ptr(), n, n_ways, chunk_syms, outs, len(d_outs), launches, sweeps,
+                                             C.byref(bi), C.byref(bj), ms, _torch_stream()), "probe_placement")
+        k = len(d_outs)
+        return bi.value, bj.value, [[ms[i * k + j] for j in range(k)] for i in range(len(d_containers))]
 
     # -- one model per chunk (byte format, 256 symbols, scale_bits 8..12)
     def encode_adaptive(self, d_syms, n_ways, chunk_syms, scale_bits, sync=True):

@@ -1290,6 +1290,75 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
     return RANS_AMD_OK;
 }
 
+int rans_amd_probe_placement(rans_amd_ctx *ctx, const rans_amd_model *model, const void *const *d_containers,
+                             uint32_t n_containers, uint64_t container_bytes, const uint64_t *d_offsets,
+                             const uint32_t *d_lengths, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
+                             void *const *d_outs, uint32_t n_outs, uint32_t launches, uint32_t sweeps,
+                             uint32_t *best_container, uint32_t *best_out, float *ms_matrix, void *stream)
+{
+    if (!ctx || !model || !d_containers || !d_outs || n_containers == 0 || n_outs == 0 || !best_container || !best_out ||
+        (uint64_t)n_containers * n_outs > 4096)
+        return fail(RANS_AMD_E_ARG, "probe_placement: NULL argument, no candidates, or more than 4096 pairs");
+    launches = launches ? launches : 6;
+    sweeps = sweeps ? sweeps : 2;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    {
+        DeviceGuard guard(ctx->device);
+        HIP_TRY(hipEventCreate(&ev0));
+        if (hipError_t e = hipEventCreate(&ev1); e != hipSuccess) {
+            (void)hipEventDestroy(ev0);
+            HIP_TRY(e);
+        }
+    }
+    std::vector<double> acc((size_t)n_containers * n_outs, 0.0);
+    int rc = RANS_AMD_OK;
+    // (rans_amd_decode takes the context's lock itself: this loop holds none)
+    for (uint32_t sw = 0; sw < sweeps && rc == RANS_AMD_OK; ++sw)
+        for (uint32_t i = 0; i < n_containers && rc == RANS_AMD_OK; ++i)
+            for (uint32_t j = 0; j < n_outs && rc == RANS_AMD_OK; ++j) {
+                for (uint32_t k = 0; k < launches + 2 && rc == RANS_AMD_OK; ++k) {
+                    if (k == 2) {
+                        DeviceGuard guard(ctx->device);
+                        if (hipEventRecord(ev0, s) != hipSuccess)
+                            rc = fail(RANS_AMD_E_HIP, "probe_placement: hipEventRecord failed");
+                    }
+                    if (rc == RANS_AMD_OK)
+                        rc = rans_amd_decode(ctx, model, d_containers[i], container_bytes, d_offsets, d_lengths, n, n_ways, chunk_syms,
+                                             d_outs[j], nullptr, stream);
+                }
+                if (rc != RANS_AMD_OK)
+                    break;
+                DeviceGuard guard(ctx->device);
+                float ms = 0.f;
+                if (hipEventRecord(ev1, s) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess ||
+                    hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess)
+                    rc = fail(RANS_AMD_E_HIP, "probe_placement: timing a pair failed");
+                acc[(size_t)i * n_outs + j] += (double)ms / launches;
+            }
+    {
+        DeviceGuard guard(ctx->device);
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+    }
+    if (rc != RANS_AMD_OK)
+        return rc;
+    uint64_t bad = 0;
+    rc = rans_amd_decode_errors(ctx, &bad, stream);
+    if (rc != RANS_AMD_OK)
+        return rc;
+    size_t best = 0;
+    for (size_t k = 0; k < acc.size(); ++k) {
+        if (ms_matrix)
+            ms_matrix[k] = (float)(acc[k] / sweeps);
+        if (acc[k] < acc[best])
+            best = k;
+    }
+    *best_container = (uint32_t)(best / n_outs);
+    *best_out = (uint32_t)(best % n_outs);
+    return RANS_AMD_OK;
+}
+
 int rans_amd_decode_errors(rans_amd_ctx *ctx, uint64_t *h_bad_chunks, void *stream)
 {
     if (!ctx || !h_bad_chunks)

@@ -281,6 +281,10 @@ def test_native_multi_gpu_example(gpu):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] >= 1 and line["bit_exact_roundtrip"] is True and line["records_gathered_by"] == "ncclAllGather"
     assert line["value"] > 0 and 0.0 < line["frac_job"] < 1.0 and "roofline frac" in out.stdout
+    # the caller chose its buffers through the ABI's placement probe (rans_amd_probe_placement): first pair vs chosen pair
+    import re
+    m = re.search(r"rank 0 placement: first pair ([0-9.]+) ms, chosen pair ([0-9.]+) ms", out.stdout)
+    assert m and 0 < float(m.group(2)) <= float(m.group(1)), out.stdout
     # --split-one: ONE container split by chunk range over three ranks (they share this box's one GPU, a context each),
     # every rank holding only the bytes rans_amd_container_slice assigns it; the pieces side by side are the input
     out = subprocess.run([exe, "--split-one", "3", "24", "3"], capture_output=True, text=True, timeout=600, env=env)
@@ -289,6 +293,29 @@ def test_native_multi_gpu_example(gpu):
     assert line["ranks"] == 3 and line["mode"] == "one container split by chunk range" and line["bit_exact_roundtrip"] is True
     rows = [ln.split() for ln in out.stdout.splitlines() if ln.strip() and ln.split()[0] in ("0", "1", "2")]
     assert len(rows) == 3 and sum(float(r[1]) for r in rows) == float(1 << 24)  # the three ranges cover the input once
+
+
+def test_placement_probe_through_the_abi(gpu, oracle):
+    """rans_amd_probe_placement: every (container copy, output) pair is decoded and timed, the fastest pair is named, the
+    matrix is what was measured, every output holds the symbols; a corrupt copy among the candidates is reported."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(1 << 22, K=256, s=1.0, seed=31)
+    om, gm = _models(R, ctx, oracle, FMT_WORD, 12, data)
+    d = torch.from_numpy(data).cuda()
+    cont, offs, lens, total = ctx.encode(gm, d, 64, 16384)
+    conts = [cont, cont.clone()]
+    outs = [torch.zeros_like(d) for _ in range(3)]
+    bi, bj, ms = ctx.probe_placement(gm, conts, total, offs, lens, d.numel(), 64, 16384, outs, launches=3, sweeps=2)
+    assert 0 <= bi < 2 and 0 <= bj < 3 and len(ms) == 2 and all(len(r) == 3 for r in ms)
+    assert all(v > 0 for r in ms for v in r) and ms[bi][bj] == min(v for r in ms for v in r)
+    assert all(torch.equal(o, d) for o in outs)
+    conts[1][int(offs[5]) + 40] ^= 0x5A
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.probe_placement(gm, conts, total, offs, lens, d.numel(), 64, 16384, outs, launches=1, sweeps=1)
+    assert e.value.status == R.E_CORRUPT
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.probe_placement(gm, [], total, offs, lens, d.numel(), 64, 16384, outs)
+    assert e.value.status == R.E_ARG
 
 
 def test_unaligned_buffers_and_streams(gpu, oracle):
