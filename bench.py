@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--config-chunk", type=int, default=16384,
                     help="symbols per chunk of the `configs` entries (16 Ki: config 4's and the byte format's optimum)")
     ap.add_argument("--format", default="word", choices=["word", "byte", "r64", "alias"])
+    ap.add_argument("--scale-bits", type=int, default=0, help="probability bits of the model (default: the format's -- word 12, "
+                                                               "byte / r64 14, alias 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (reference timing + oracle checks)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
@@ -785,12 +787,22 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     fmt = {"word": R.FMT_WORD, "byte": R.FMT_BYTE, "r64": R.FMT_R64, "alias": R.FMT_ALIAS}[args.format]
-    sb = {"word": 12, "byte": 14, "r64": 14, "alias": 16}[args.format]
+    sb = args.scale_bits or {"word": 12, "byte": 14, "r64": 14, "alias": 16}[args.format]
     n = 1 << args.log2n
 
     # ---- setup (untimed): data, model, GPU encode ------------------------------
     trace("setup")
     ctx = R.Context(gpu_index)
+    # every decode call of this process is counted (one launch of the decode kernel each; the ABI's placement probe reports
+    # its own): the record then says WHICH dispatches of the headline kernel were the timed ones, so that a kernel trace
+    # of this command (tools/r05_profile.sh) can be cut to exactly them
+    launches = {"decode": 0}
+    _decode = ctx.decode
+
+    def counted_decode(*a, **k):
+        launches["decode"] += 1
+        return _decode(*a, **k)
+    ctx.decode = counted_decode
     d_syms = gen_zipf(torch, n, 256, 1.0, rank + 1, device)
     counts = ctx.count_freqs_device(d_syms, 256)
     freqs, _ = R.normalize_freqs(counts, 1 << sb)
@@ -815,6 +827,7 @@ def main():
         while True:
             # (the C ABI's own probe -- rans_amd_probe_placement, what a C++ caller uses: examples/multi_gpu.cpp)
             ci, oi, matrix = ctx.probe_placement(model, conts, total, offs, lens, n, args.ways, args.chunk, outs, launches=6, sweeps=2)
+            launches["decode"] += len(conts) * len(outs) * 2 * (6 + 2)  # (pairs x sweeps x (launches + 2 warm-up launches))
             flat = [v for row in matrix for v in row]
             if max(flat) >= args.placement_spread * min(flat) or extended == 2:
                 break
@@ -865,6 +878,7 @@ def main():
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     barrier()
     torch.cuda.synchronize()
+    timed_first = launches["decode"]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev0[k].record()  # HIP events on the launch stream (torch's current stream)
@@ -905,6 +919,7 @@ def main():
     records = gather_records(rec, device=device if args.backend == "nccl" else "cpu", force=args.force_dist)
 
     exit_code = 0
+    text = ""
     if rank == 0:
         agg = aggregate(records, args.steps)
         all_ok = agg["all_ok"]
@@ -913,7 +928,7 @@ def main():
         k_s = kernel_ms * 1e-3
         achieved = (n + total) / k_s / 1e9
         result = {
-            "metric": "decode GB/s (uncompressed), 64-way interleaved rANS (word format)",
+            "metric": "decode GB/s (uncompressed), %d-way interleaved rANS (%s format)" % (args.ways, args.format),
             "value": round(value, 2),
             "unit": "GB/s",
             "n_gpus": agg["n_ranks"],  # counted from the records the all-gather delivered, not from the environment
@@ -956,6 +971,8 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "kernel": ctx.last_decode_kernel(), "kernel_ms_avg": round(kernel_ms, 4),
+                # the timed launches are dispatches [first, first + steps) of this kernel in this process, counted from 0
+                "timed_dispatches": [timed_first, timed_first + args.steps],
                 "algorithmic_bytes_per_launch": n + total,
                 # the job: algorithmic bytes of ALL ranks over the slowest rank's kernel time, against N GPUs' peak (at N = 1
                 # this is `frac`); achieved / peak / frac above are rank 0's kernel on rank 0's GPU
@@ -1000,7 +1017,7 @@ def main():
         # (tools/profile.sh -> tools/summarize_profile.py -> profiles/<tag>_traffic.json); PMC passes cannot
         # share a process with the timed run, so a committed measurement is quoted only when it was taken on
         # this workload AND on the kernel sources of this checkout (its `kernel_source_tag`), else null.
-        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r04_traffic.json"))
+        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r05_traffic.json"))
         default_workload = (args.format == "word" and args.ways == 64 and args.chunk == 32768 and args.log2n == 30)
         if os.path.exists(tj) and default_workload:
             try:
@@ -1132,12 +1149,21 @@ def main():
         line = judged_line(result, os.path.relpath(details, ROOT) if details else None)
         text = json.dumps(line, separators=(",", ":"))
         assert len(text) <= MAX_LINE_BYTES, "judged line is %d bytes" % len(text)
-        print(text, flush=True)
         if not all_ok and not args.measure:
             exit_code = 1
     if use_dist:
         barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # The line is the LAST thing this process writes to stdout: RCCL prints a version banner through C stdio, which
+        # sits in libc's buffer until somebody flushes it -- at exit, i.e. BEHIND a line printed earlier (seen on the GPU
+        # box: the judged line followed by "RCCL version : ...").  Flush C stdio first, then print.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(text, flush=True)
     sys.exit(exit_code)
 
 

@@ -57,7 +57,8 @@ extern "C" {
 /* 0.5.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
  * inside a hipGraph capture (0.3.0); rans_amd_encode_slots + rans_amd_slot_bytes / rans_amd_encode_slots_bound,
  * rans_amd_container_compact, rans_amd_container_slice, chunk offsets on any multiple of the format's unit in every decoder
- * (0.4.0); rans_amd_encode_slots_sized + rans_amd_tight_slot_bytes / rans_amd_encode_sized_bound, rans_amd_probe_placement (0.5.0).  A caller built
+ * (0.4.0); rans_amd_encode_slots_sized + rans_amd_tight_slot_bytes / rans_amd_encode_sized_bound, rans_amd_probe_placement,
+ * rans_amd_encode_adaptive_fmt / rans_amd_decode_adaptive_fmt (0.5.0).  A caller built
  * against an older header keeps working, with two behaviour changes it can observe: since 0.4.0
  * rans_amd_container_parse[_adaptive] want a 4-byte aligned `src` (RANS_AMD_E_ARG otherwise; an mmap at an odd offset must
  * be copied first), and since 0.5.0 rans_amd_container_compact checks its SOURCE index against src_bytes
@@ -307,8 +308,8 @@ int rans_amd_encode_status(rans_amd_ctx *ctx, void *stream);
 
 /* Decode a container.  d_out receives n symbols.  Chunk c is the d_lengths[c] bytes at d_container + d_offsets[c];
  * offsets may be any multiple of the format's renormalisation unit (byte / alias: 1, word: 2, rans64: 4) and need not
- * ascend -- compact containers (rans_amd_encode), slot containers (rans_amd_encode_slots) and hand-made indexes over
- * reference streams all decode.  Every chunk is checked the way
+ * ascend nor lie near each other -- compact containers (rans_amd_encode), slot containers (rans_amd_encode_slots[_sized],
+ * overflow region included) and hand-made indexes over reference streams all decode.  Every chunk is checked the way
  * the reference's streams allow (all final states == L, cursor == end of the
  * chunk's stream, no read past it); failures are counted on the device.  If
  * h_bad_chunks != NULL the call synchronises `stream`, stores the number of
@@ -364,8 +365,9 @@ int rans_amd_decode_errors(rans_amd_ctx *ctx, uint64_t *h_bad_chunks, void *stre
  * The reference builds ONE order-0 model per input (main.cpp:139-162: count_freqs, normalize_freqs,
  * RansEncSymbolInit / RansDecSymbolInit, cum2sym).  Here every CHUNK is such an input: its own histogram, its own
  * normalised frequencies (exactly normalize_freqs of that chunk), its own tables -- built by the wavefront that
- * codes the chunk, in its LDS, from the chunk's 256 frequencies.  Byte format (rans_byte.h), 256 symbols,
- * scale_bits 8..12; n_ways 1..512.  Chunk c's stream is the reference-format stream of a model built for chunk c
+ * codes the chunk, in its LDS, from the chunk's 256 frequencies.  Byte format (rans_byte.h; scale_bits 8..12) or -- the
+ * _fmt entry points -- word format (rans_word_sse41.h; its own 12 bits: the model main_simd.cpp:138-143 builds, per chunk),
+ * 256 symbols; n_ways 1..512.  Chunk c's stream is the reference-format stream of a model built for chunk c
  * alone; the container layout and index are those of rans_amd_encode.  d_chunk_freqs (device, u16[256] per chunk,
  * rans_amd_chunk_freqs_bytes) travels with the container: rans_amd_encode_adaptive fills it, rans_amd_decode_adaptive
  * reads it (a chunk whose frequencies do not sum to 1 << scale_bits is counted as corrupt, never decoded). */
@@ -378,6 +380,15 @@ int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_
                              const uint64_t *d_offsets, const uint32_t *d_lengths, const uint16_t *d_chunk_freqs,
                              uint64_t n, uint32_t n_ways, uint32_t chunk_syms, uint32_t scale_bits, void *d_out,
                              uint64_t *h_bad_chunks, void *stream);
+/* The same with the stream format as an argument: RANS_AMD_FMT_BYTE (= the two above) or RANS_AMD_FMT_WORD (scale_bits must be
+ * 12); RANS_AMD_E_UNSUPPORTED for any other format. */
+int rans_amd_encode_adaptive_fmt(rans_amd_ctx *ctx, int format, const void *d_syms, uint64_t n, uint32_t n_ways,
+                                 uint32_t chunk_syms, uint32_t scale_bits, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
+                                 uint32_t *d_lengths, uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream);
+int rans_amd_decode_adaptive_fmt(rans_amd_ctx *ctx, int format, const void *d_container, uint64_t container_bytes,
+                                 const uint64_t *d_offsets, const uint32_t *d_lengths, const uint16_t *d_chunk_freqs,
+                                 uint64_t n, uint32_t n_ways, uint32_t chunk_syms, uint32_t scale_bits, void *d_out,
+                                 uint64_t *h_bad_chunks, void *stream);
 
 /* ---- host-buffer convenience: one raw reference-format stream -------------- */
 
@@ -429,7 +440,8 @@ int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container
                              const uint32_t **freqs, const uint32_t **lengths, const void **payload);
 
 /* Version 2 of the same wrapper, for rans_amd_encode_adaptive containers: the single frequency table is replaced by
- * u16 chunk_freqs[n_chunks][256] (info->format == RANS_AMD_FMT_BYTE, nsyms 256, sym_bytes 1, scale_bits 8..12):
+ * u16 chunk_freqs[n_chunks][256] (info->format RANS_AMD_FMT_BYTE with scale_bits 8..12 or RANS_AMD_FMT_WORD with 12 -- the
+ * header carries it --, nsyms 256, sym_bytes 1):
  *   [ 80-byte header (version 2) | u16 chunk_freqs[n_chunks][256] | u32 lengths[n_chunks] | pad to 16 | payload ] */
 uint64_t rans_amd_container_bytes_adaptive(const rans_amd_container_info *info);
 int rans_amd_container_pack_adaptive(const rans_amd_container_info *info, const uint16_t *chunk_freqs,

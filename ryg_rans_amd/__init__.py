@@ -45,6 +45,7 @@ ABI_SYMBOLS = [
     "rans_amd_set_timing", "rans_amd_last_kernel_ms", "rans_amd_last_decode_kernel", "rans_amd_last_encode_kernel", "rans_amd_last_wave_clocks",
     "rans_amd_launch_spans",
     "rans_amd_chunk_freqs_bytes", "rans_amd_encode_adaptive", "rans_amd_decode_adaptive",
+    "rans_amd_encode_adaptive_fmt", "rans_amd_decode_adaptive_fmt",
     "rans_amd_container_bytes_adaptive", "rans_amd_container_pack_adaptive", "rans_amd_container_parse_adaptive",
     "rans_amd_offsets_from_lengths", "rans_amd_container_bytes", "rans_amd_container_pack",
     "rans_amd_container_parse", "rans_amd_encode_workspace_bytes", "rans_amd_build_model_o0",
@@ -135,6 +136,8 @@ def _load():
         "rans_amd_chunk_freqs_bytes": (u64, [u64, u32]),
         "rans_amd_encode_adaptive": (i32, [vp, vp, u64, u32, u32, u32, vp, u64, vp, vp, vp, u64p, vp]),
         "rans_amd_decode_adaptive": (i32, [vp, vp, u64, vp, vp, vp, u64, u32, u32, u32, vp, u64p, vp]),
+        "rans_amd_encode_adaptive_fmt": (i32, [vp, i32, vp, u64, u32, u32, u32, vp, u64, vp, vp, vp, u64p, vp]),
+        "rans_amd_decode_adaptive_fmt": (i32, [vp, i32, vp, u64, vp, vp, vp, u64, u32, u32, u32, vp, u64p, vp]),
         "rans_amd_encode_workspace_bytes": (u64, [i32, u64, u32, u32]),
         "rans_amd_build_model_o0": (i32, [vp, i32, vp, u64, i32, u32, u32, u32p, C.POINTER(vp), vp]),
         "rans_amd_offsets_from_lengths": (i32, [u32p, u64, u64p]),
@@ -442,12 +445,12 @@ class Context:
         return bi.value, bj.value, [[ms[i * k + j] for j in range(k)] for i in range(len(d_containers))]
 
     # -- one model per chunk (byte format, 256 symbols, scale_bits 8..12)
-    def encode_adaptive(self, d_syms, n_ways, chunk_syms, scale_bits, sync=True):
-        """Returns (d_container, d_offsets, d_lengths, d_chunk_freqs, total_bytes)."""
+    def encode_adaptive(self, d_syms, n_ways, chunk_syms, scale_bits, sync=True, fmt=FMT_BYTE):
+        """Returns (d_container, d_offsets, d_lengths, d_chunk_freqs, total_bytes).  fmt: FMT_BYTE or FMT_WORD (scale_bits 12)."""
         import torch
         n = d_syms.numel()
         nchunks = num_chunks(n, chunk_syms)
-        cap = encode_bound(FMT_BYTE, n, n_ways, chunk_syms) + 16
+        cap = encode_bound(fmt, n, n_ways, chunk_syms) + 16
         dev = d_syms.device
         d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
         d_offsets = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
@@ -455,22 +458,32 @@ class Context:
         d_freqs = torch.zeros(max(nchunks, 1) * 256, dtype=torch.int16, device=dev)
         assert int(_lib.rans_amd_chunk_freqs_bytes(n, chunk_syms)) == nchunks * 512
         total = C.c_uint64(0)
-        _check(_lib.rans_amd_encode_adaptive(self._h, d_syms.data_ptr(), n, n_ways, chunk_syms, scale_bits,
-                                             d_out.data_ptr(), d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
-                                             d_freqs.data_ptr(), C.byref(total) if sync else None, _torch_stream()),
-               "encode_adaptive")
+        if fmt == FMT_BYTE:  # (the entry point older callers bind)
+            rc = _lib.rans_amd_encode_adaptive(self._h, d_syms.data_ptr(), n, n_ways, chunk_syms, scale_bits, d_out.data_ptr(),
+                                               d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(), d_freqs.data_ptr(),
+                                               C.byref(total) if sync else None, _torch_stream())
+        else:
+            rc = _lib.rans_amd_encode_adaptive_fmt(self._h, fmt, d_syms.data_ptr(), n, n_ways, chunk_syms, scale_bits,
+                                                   d_out.data_ptr(), d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
+                                                   d_freqs.data_ptr(), C.byref(total) if sync else None, _torch_stream())
+        _check(rc, "encode_adaptive")
         return d_out, d_offsets, d_lengths, d_freqs, (total.value if sync else None)
 
     def decode_adaptive(self, d_container, container_bytes, d_offsets, d_lengths, d_freqs, n, n_ways, chunk_syms,
-                        scale_bits, d_out=None, sync=True):
+                        scale_bits, d_out=None, sync=True, fmt=FMT_BYTE):
         import torch
         if d_out is None:
             d_out = torch.empty(n, dtype=torch.uint8, device=d_container.device)
         bad = C.c_uint64(0)
-        _check(_lib.rans_amd_decode_adaptive(self._h, d_container.data_ptr(), container_bytes, d_offsets.data_ptr(),
-                                             d_lengths.data_ptr(), d_freqs.data_ptr(), n, n_ways, chunk_syms, scale_bits,
-                                             d_out.data_ptr(), C.byref(bad) if sync else None, _torch_stream()),
-               "decode_adaptive")
+        if fmt == FMT_BYTE:
+            rc = _lib.rans_amd_decode_adaptive(self._h, d_container.data_ptr(), container_bytes, d_offsets.data_ptr(),
+                                               d_lengths.data_ptr(), d_freqs.data_ptr(), n, n_ways, chunk_syms, scale_bits,
+                                               d_out.data_ptr(), C.byref(bad) if sync else None, _torch_stream())
+        else:
+            rc = _lib.rans_amd_decode_adaptive_fmt(self._h, fmt, d_container.data_ptr(), container_bytes, d_offsets.data_ptr(),
+                                                   d_lengths.data_ptr(), d_freqs.data_ptr(), n, n_ways, chunk_syms, scale_bits,
+                                                   d_out.data_ptr(), C.byref(bad) if sync else None, _torch_stream())
+        _check(rc, "decode_adaptive")
         return d_out
 
     def encode_status(self):

@@ -1382,14 +1382,31 @@ uint64_t rans_amd_chunk_freqs_bytes(uint64_t n, uint32_t chunk_syms)
     return rans_amd_num_chunks(n, chunk_syms) * 256u * sizeof(uint16_t);
 }
 
-int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
-                             uint32_t scale_bits, void *d_out, uint64_t out_cap, uint64_t *d_offsets, uint32_t *d_lengths,
-                             uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream)
+} // extern "C"
+
+// format: RANS_AMD_FMT_BYTE (scale_bits 8..12) or RANS_AMD_FMT_WORD (scale_bits 12, the format's own)
+static int adaptive_format_check(int format, uint32_t scale_bits, const char *who)
+{
+    char msg[160];
+    if (format != RANS_AMD_FMT_BYTE && format != RANS_AMD_FMT_WORD) {
+        snprintf(msg, sizeof msg, "%s: per-chunk models exist for the byte and the word format", who);
+        return fail(RANS_AMD_E_UNSUPPORTED, msg);
+    }
+    if (format == RANS_AMD_FMT_WORD ? scale_bits != 12 : (scale_bits < 8 || scale_bits > 12)) {
+        snprintf(msg, sizeof msg, "%s: scale_bits must be 8..12 (a chunk's tables live in one wave's LDS), 12 for the word format", who);
+        return fail(RANS_AMD_E_UNSUPPORTED, msg);
+    }
+    return RANS_AMD_OK;
+}
+
+static int encode_adaptive_impl(rans_amd_ctx *ctx, const int format, const void *d_syms, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
+                                uint32_t scale_bits, void *d_out, uint64_t out_cap, uint64_t *d_offsets, uint32_t *d_lengths,
+                                uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream)
 {
     if (!ctx || !d_out || !d_offsets || !d_lengths || !d_chunk_freqs || (n && !d_syms) || chunk_syms == 0)
         return fail(RANS_AMD_E_ARG, "encode_adaptive: NULL argument or chunk_syms == 0");
-    if (scale_bits < 8 || scale_bits > 12)
-        return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive: scale_bits must be 8..12 (a chunk's tables live in one wave's LDS)");
+    if (int rc = adaptive_format_check(format, scale_bits, "encode_adaptive"))
+        return rc;
     if ((reinterpret_cast<uintptr_t>(d_chunk_freqs) & 7u) != 0) // (the kernels read a row with 8-byte loads per lane)
         return fail(RANS_AMD_E_ARG, "encode_adaptive: d_chunk_freqs must be 8-byte aligned");
     if (!ways_supported(RANS_AMD_FMT_BYTE, n_ways))
@@ -1403,7 +1420,7 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
     const CaptureScope capture(s);
     if (capture.active && h_total_bytes)
         return fail(RANS_AMD_E_ARG, "encode_adaptive: h_total_bytes must be NULL while the stream is capturing");
-    const uint64_t slot = encode_slot_bytes(RANS_AMD_FMT_BYTE, n, n_ways, chunk_syms);
+    const uint64_t slot = encode_slot_bytes(format, n, n_ways, chunk_syms);
     if (slot > 0xfffffff0ull)
         return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive: chunk_syms too large");
     int rc = ctx->scratch.reserve((size_t)(nchunks * slot + 64));
@@ -1436,7 +1453,8 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
         ep.sym_bytes = 1;
         ep.flags = ctx->d_enc_flags();
         ep.chunk_freqs = d_chunk_freqs;
-        HIP_TRY(launch_encode(kKernelFormatByteAdaptive, ep, ctx->num_cus, s, &ctx->last_enc_kernel));
+        HIP_TRY(launch_encode(format == RANS_AMD_FMT_WORD ? kKernelFormatWordAdaptive : kKernelFormatByteAdaptive, ep, ctx->num_cus, s,
+                              &ctx->last_enc_kernel));
         ctx->last_enc_fused = false;
         ctx->last_enc_slots = false;
     }
@@ -1485,14 +1503,14 @@ int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, 
     return RANS_AMD_OK;
 }
 
-int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_t container_bytes, const uint64_t *d_offsets,
-                             const uint32_t *d_lengths, const uint16_t *d_chunk_freqs, uint64_t n, uint32_t n_ways,
-                             uint32_t chunk_syms, uint32_t scale_bits, void *d_out, uint64_t *h_bad_chunks, void *stream)
+static int decode_adaptive_impl(rans_amd_ctx *ctx, const int format, const void *d_container, uint64_t container_bytes,
+                                const uint64_t *d_offsets, const uint32_t *d_lengths, const uint16_t *d_chunk_freqs, uint64_t n,
+                                uint32_t n_ways, uint32_t chunk_syms, uint32_t scale_bits, void *d_out, uint64_t *h_bad_chunks, void *stream)
 {
     if (!ctx || (n && (!d_container || !d_offsets || !d_lengths || !d_chunk_freqs || !d_out)) || chunk_syms == 0)
         return fail(RANS_AMD_E_ARG, "decode_adaptive: NULL argument or chunk_syms == 0");
-    if (scale_bits < 8 || scale_bits > 12)
-        return fail(RANS_AMD_E_UNSUPPORTED, "decode_adaptive: scale_bits must be 8..12");
+    if (int rc = adaptive_format_check(format, scale_bits, "decode_adaptive"))
+        return rc;
     if ((reinterpret_cast<uintptr_t>(d_chunk_freqs) & 7u) != 0)
         return fail(RANS_AMD_E_ARG, "decode_adaptive: d_chunk_freqs must be 8-byte aligned");
     if (!ways_supported(RANS_AMD_FMT_BYTE, n_ways))
@@ -1539,7 +1557,8 @@ int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_
         }
         if (ctx->timing && !t_capturing)
             HIP_TRY(hipEventRecord(ctx->ev[0], s));
-        HIP_TRY(launch_decode(kKernelFormatByteAdaptive, dp, ctx->num_cus, s, &ctx->last_kernel));
+        HIP_TRY(launch_decode(format == RANS_AMD_FMT_WORD ? kKernelFormatWordAdaptive : kKernelFormatByteAdaptive, dp, ctx->num_cus, s,
+                              &ctx->last_kernel));
         if (dp.work_counter && !capture.active)
             ctx->launch_seq++;
         if (ctx->timing && !t_capturing) {
@@ -1557,6 +1576,41 @@ int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_
             return fail(RANS_AMD_E_CORRUPT, "decode_adaptive: at least one chunk failed its integrity check");
     }
     return RANS_AMD_OK;
+}
+
+extern "C" {
+
+int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
+                             uint32_t scale_bits, void *d_out, uint64_t out_cap, uint64_t *d_offsets, uint32_t *d_lengths,
+                             uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream)
+{
+    return encode_adaptive_impl(ctx, RANS_AMD_FMT_BYTE, d_syms, n, n_ways, chunk_syms, scale_bits, d_out, out_cap, d_offsets, d_lengths,
+                                d_chunk_freqs, h_total_bytes, stream);
+}
+
+int rans_amd_encode_adaptive_fmt(rans_amd_ctx *ctx, int format, const void *d_syms, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
+                                 uint32_t scale_bits, void *d_out, uint64_t out_cap, uint64_t *d_offsets, uint32_t *d_lengths,
+                                 uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream)
+{
+    return encode_adaptive_impl(ctx, format, d_syms, n, n_ways, chunk_syms, scale_bits, d_out, out_cap, d_offsets, d_lengths,
+                                d_chunk_freqs, h_total_bytes, stream);
+}
+
+int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_t container_bytes, const uint64_t *d_offsets,
+                             const uint32_t *d_lengths, const uint16_t *d_chunk_freqs, uint64_t n, uint32_t n_ways,
+                             uint32_t chunk_syms, uint32_t scale_bits, void *d_out, uint64_t *h_bad_chunks, void *stream)
+{
+    return decode_adaptive_impl(ctx, RANS_AMD_FMT_BYTE, d_container, container_bytes, d_offsets, d_lengths, d_chunk_freqs, n, n_ways,
+                                chunk_syms, scale_bits, d_out, h_bad_chunks, stream);
+}
+
+int rans_amd_decode_adaptive_fmt(rans_amd_ctx *ctx, int format, const void *d_container, uint64_t container_bytes,
+                                 const uint64_t *d_offsets, const uint32_t *d_lengths, const uint16_t *d_chunk_freqs, uint64_t n,
+                                 uint32_t n_ways, uint32_t chunk_syms, uint32_t scale_bits, void *d_out, uint64_t *h_bad_chunks,
+                                 void *stream)
+{
+    return decode_adaptive_impl(ctx, format, d_container, container_bytes, d_offsets, d_lengths, d_chunk_freqs, n, n_ways, chunk_syms,
+                                scale_bits, d_out, h_bad_chunks, stream);
 }
 
 /* ---- host-buffer wrappers: one raw reference-format stream ----------------- */

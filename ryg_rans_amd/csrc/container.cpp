@@ -218,7 +218,8 @@ int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container
 
 /* ---- version 2: one model per chunk (rans_amd_encode_adaptive) ------------------------------
  *   [ 80-byte header (version 2, reserved = 1) | u16 chunk_freqs[n_chunks][256] | u32 lengths[n_chunks] | pad to 16 | payload ]
- * info->format is RANS_AMD_FMT_BYTE, nsyms 256, sym_bytes 1; the checksum covers header, frequencies and lengths. */
+ * info->format is RANS_AMD_FMT_BYTE (scale_bits 8..12) or RANS_AMD_FMT_WORD (scale_bits 12), nsyms 256, sym_bytes 1; the header
+ * carries the format; the checksum covers header, frequencies and lengths. */
 static uint64_t meta_bytes_v2(const rans_amd_container_info *i)
 {
     return align16(kHeaderBytes + 512ull * i->n_chunks + 4ull * i->n_chunks);
@@ -226,8 +227,9 @@ static uint64_t meta_bytes_v2(const rans_amd_container_info *i)
 
 static bool info_sane_v2(const rans_amd_container_info *i)
 {
-    return info_sane(i) && i->format == RANS_AMD_FMT_BYTE && i->nsyms == 256 && i->sym_bytes == 1 && i->scale_bits >= 8 &&
-           i->scale_bits <= 12;
+    return info_sane(i) && i->nsyms == 256 && i->sym_bytes == 1 &&
+           ((i->format == RANS_AMD_FMT_BYTE && i->scale_bits >= 8 && i->scale_bits <= 12) ||
+            (i->format == RANS_AMD_FMT_WORD && i->scale_bits == 12));
 }
 
 uint64_t rans_amd_container_bytes_adaptive(const rans_amd_container_info *info)

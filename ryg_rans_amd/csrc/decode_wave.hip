@@ -199,9 +199,9 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 
     // ---- stage the tables into LDS (once per block) ----------------------
     // (per-chunk models: no shared tables -- "table 0" is the waves' own regions, filled per chunk below)
-    const uint32_t t0_bytes = FMT == FMT_BYTEA ? (blockDim.x >> 6) * kAdaptDecWaveLds : (p.table0_bytes + 15u) & ~15u;
-    const uint32_t t1_bytes = FMT == FMT_BYTEA ? 0u : (p.table1_bytes + 15u) & ~15u;
-    if constexpr (FMT != FMT_BYTEA) {
+    const uint32_t t0_bytes = kIsAdaptive<FMT> ? (blockDim.x >> 6) * kAdaptDecWaveLds : (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1_bytes = kIsAdaptive<FMT> ? 0u : (p.table1_bytes + 15u) & ~15u;
+    if constexpr (!kIsAdaptive<FMT>) {
         const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
         uint4 *l0 = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     const uint32_t waves_per_block = blockDim.x >> 6;
 
     DecTables<FMT> T;
-    if constexpr (FMT == FMT_BYTEA) // cum2sym[M] then {freq, start}[256] of the chunk in hand, this wave's own
+    if constexpr (kIsAdaptive<FMT>) // cum2sym[M] then {freq, start}[256] of the chunk in hand, this wave's own
         T.init(smem + wave * kAdaptDecWaveLds, smem + wave * kAdaptDecWaveLds + (1u << kAdaptMaxScaleBits), p.scale_bits,
                p.log2nsyms);
     else
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
             continue;
         }
 
-        if constexpr (FMT == FMT_BYTEA) { // this chunk's model -> this wave's tables (main.cpp:139-162 per chunk)
+        if constexpr (kIsAdaptive<FMT>) { // this chunk's model -> this wave's tables (main.cpp:139-162 / main_simd.cpp:138-143 per chunk)
             if (!adapt_build_dec(p.chunk_freqs + chunk * 256u, p.scale_bits, lane, const_cast<uint8_t *>(T.t0),
                                  reinterpret_cast<uint2 *>(const_cast<uint8_t *>(T.t1)))) {
                 if (lane == 0)
@@ -775,9 +775,9 @@ template <int FMT, int K, int OUT>
 hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
     const uint32_t waves = kDecBlockThreads / 64;
-    const uint32_t t0 = FMT == FMT_BYTEA ? waves * kAdaptDecWaveLds : (p.table0_bytes + 15u) & ~15u;
-    const uint32_t t1 = FMT == FMT_BYTEA ? 0u : (p.table1_bytes + 15u) & ~15u;
-    if (FMT == FMT_BYTEA && (!p.chunk_freqs || p.scale_bits > kAdaptMaxScaleBits || p.scale_bits < 8))
+    const uint32_t t0 = kIsAdaptive<FMT> ? waves * kAdaptDecWaveLds : (p.table0_bytes + 15u) & ~15u;
+    const uint32_t t1 = kIsAdaptive<FMT> ? 0u : (p.table1_bytes + 15u) & ~15u;
+    if (kIsAdaptive<FMT> && (!p.chunk_freqs || p.scale_bits > kAdaptMaxScaleBits || p.scale_bits < 8 || (FMT == FMT_WORDA && p.scale_bits != 12)))
         return hipErrorInvalidValue;
     const size_t lds = (size_t)t0 + t1 + (size_t)waves * kRingStride + (OUT == OUT_FAST8_LDS ? waves * kOutTileBytes : 0);
     if (lds > 160 * 1024)
@@ -794,7 +794,7 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
         *name = FMT == FMT_WORD ? "k_decode<word>" : FMT == FMT_BYTE ? "k_decode<byte>" : FMT == FMT_BYTEF ? "k_decode<byte, slot records>"
                 : FMT == FMT_R64 ? "k_decode<r64>" : FMT == FMT_R64S ? "k_decode<r64 search>"
                 : FMT == FMT_WORD16 ? "k_decode<word, u16 symbols>"
-                : FMT == FMT_BYTEA ? "k_decode<byte, per-chunk models>" : "k_decode<alias>";
+                : FMT == FMT_BYTEA ? "k_decode<byte, per-chunk models>" : FMT == FMT_WORDA ? "k_decode<word, per-chunk models>" : "k_decode<alias>";
     RANS_LAUNCH(kern, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
     return hipGetLastError();
 }
@@ -881,6 +881,7 @@ hipError_t launch_decode_wave(int format, const DecParams &p, int num_cus, hipSt
     case FMT_BYTEF: return launch_decode_f<FMT_BYTEF>(p, num_cus, stream, name);
     case FMT_R64: return launch_decode_f<FMT_R64>(p, num_cus, stream, name);
     case FMT_BYTEA: return launch_decode_f<FMT_BYTEA>(p, num_cus, stream, name);
+    case FMT_WORDA: return launch_decode_f<FMT_WORDA>(p, num_cus, stream, name);
     case FMT_WORD16: { // u16 symbols: paired-round stores for full waves, element stores otherwise
         const bool aligned = ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)p.chunk_syms * 2u) & 3u) == 0;
         if (aligned && p.n_ways == 64)

@@ -54,9 +54,16 @@ template <int FMT> constexpr bool kIsAlias2 = (FMT == FMT_ALIAS2 || FMT == FMT_A
 // table fits beside the stream windows (scale_bits <= 13).  D step: v_and, v_lshlrev, ds_read_b64, v_lshrrev, v_mad_u32_u24
 // (rans_byte.h:125-128 + :291-298 as rans_word_sse41.h:123-131 does it): one gather instead of two dependent ones.
 constexpr int FMT_BYTEF = 11;
+// Internal kernel format: the WORD format (rans_word_sse41.h, 12-bit probabilities, 16-bit renormalisation) with one model
+// PER CHUNK (SURVEY 8(f)3 on the headline's format): the decoder's waves build cum2sym + {freq, start} of their chunk as
+// FMT_BYTEA does (a 4096-slot table per wave, rans_word_sse41.h:64-72, would be 32 KiB each) -- slot = x & 4095,
+// x = freq * (x >> 12) + (slot - start) is the very update of rans_word_sse41.h:123-131; the encoder's waves build the
+// general path's {freq, start, reciprocal} records.
+constexpr int FMT_WORDA = 12;
+template <int FMT> constexpr bool kIsAdaptive = (FMT == FMT_BYTEA || FMT == FMT_WORDA); // per-chunk models: per-wave tables
 template <int FMT> constexpr bool kIsByteStream = (FMT == FMT_BYTE || FMT == FMT_ALIAS || FMT == FMT_ALIAS_LDS || FMT == FMT_BYTEA ||
                                                    kIsAlias2<FMT> || FMT == FMT_BYTEF);
-template <int FMT> constexpr bool kIsWord = (FMT == FMT_WORD || FMT == FMT_WORD16);
+template <int FMT> constexpr bool kIsWord = (FMT == FMT_WORD || FMT == FMT_WORD16 || FMT == FMT_WORDA);
 
 // OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
 // symbols transposed in registers.  OUT_FAST8_NOASM: same with the compiler-scheduled renorm
@@ -105,6 +112,9 @@ template <> struct FmtTraits<FMT_ALIAS2> : FmtTraits<FMT_ALIAS> {};
 template <> struct FmtTraits<FMT_ALIAS2W> : FmtTraits<FMT_ALIAS> {};
 template <> struct FmtTraits<FMT_WORD16> : FmtTraits<FMT_WORD> {
     static constexpr int kSymByte = 0; // dec_step returns the symbol itself
+};
+template <> struct FmtTraits<FMT_WORDA> : FmtTraits<FMT_WORD> {
+    static constexpr int kSymByte = 0;
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -224,8 +234,9 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         const u32x2 e = *reinterpret_cast<RANS_LDS const u32x2 *>((uintptr_t)((x & T.maskv) << 3));
         x = (e.x & 0xffffffu) * ((x >> T.sbv) & 0xffffffu) + e.y;
         return e.x;
-    } else if constexpr (FMT == FMT_BYTEA) {
-        // the same through the wave's own table pointers (per-chunk models)
+    } else if constexpr (FMT == FMT_BYTEA || FMT == FMT_WORDA) {
+        // the same through the wave's own table pointers (per-chunk models; the word format: scale_bits is 12 and
+        // freq * (x >> 12) + (slot - start) is rans_word_sse41.h:123-131's freq * (x >> 12) + bias)
         const uint32_t cf = x & T.maskv;
         const uint32_t s = T.t0[cf];
         const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s];
@@ -374,6 +385,28 @@ __device__ __forceinline__ void adapt_build_enc(const uint16_t *chunk_freqs, uin
             const uint32_t sh = 32u - (uint32_t)__builtin_clz(f[i] - 1u); // ceil(log2 freq)
             const uint32_t rcp = (uint32_t)(((1ull << (sh + 31u)) + f[i] - 1u) / f[i]);
             r = uint4{f[i] | ((sh - 1u) << 24), c[i], rcp, 0u};
+        }
+        recs[4u * lane + i] = r;
+    }
+}
+
+// the same for the WORD format (FMT_WORDA; scale_bits = 12): the general path's records {freq, bias, m', cmpl | sh << 24}
+// with the round-up reciprocal of Granlund & Montgomery for 32-bit dividends, exactly as model.cpp builds them for a
+// whole-input model (rans_word_sse41.h:81-93's x / freq and x % freq without a division in the loop)
+__device__ __forceinline__ void adapt_build_enc_word(const uint16_t *chunk_freqs, uint32_t lane, uint4 *recs)
+{
+    uint32_t f[4], c[4];
+    adapt_load_cum(chunk_freqs, lane, f, c);
+    const uint32_t M = 1u << 12;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint4 r = {0u, 0u, 0u, 0u};
+        if (f[i] == 1u) {
+            r = uint4{1u, c[i] + M - 1u, 0xffffffffu, M - 1u};
+        } else if (f[i] >= 2u) {
+            const uint32_t l = 32u - (uint32_t)__builtin_clz(f[i] - 1u); // ceil(log2 freq)
+            const unsigned long long mprime = ((1ull << 32) * ((1ull << l) - f[i])) / f[i] + 1ull;
+            r = uint4{f[i], c[i], (uint32_t)mprime, (M - f[i]) | ((l - 1u) << 24)};
         }
         recs[4u * lane + i] = r;
     }

@@ -21,6 +21,7 @@ hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_
     if (format == kKernelFormatByteDual)
         return launch_decode_dual((int)RANS_AMD_FMT_BYTE, p, num_cus, stream, kernel_name);
     if (format != kKernelFormatR64Search && format != kKernelFormatWord16 && format != kKernelFormatByteAdaptive &&
+        format != kKernelFormatWordAdaptive &&
         format != kKernelFormatByteFused && lanes_applicable(p.nchunks, p.n_ways))
         return launch_decode_lanes(format, p, num_cus, stream, kernel_name);
     return launch_decode_wave(format, p, num_cus, stream, kernel_name);
@@ -37,7 +38,7 @@ int encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits)
     const size_t nrecs = nsyms < 256 ? 256 : nsyms;
     if (format == kKernelFormatAliasLds)
         return nrecs * 8 + ((size_t)2 << scale_bits) + 16 + kEncFusedLdsBytes <= 160 * 1024 ? 1 : 2;
-    if (format == kKernelFormatByteAdaptive) // (per-wave tables; never fused, see api.cpp)
+    if (format == kKernelFormatByteAdaptive || format == kKernelFormatWordAdaptive) // (per-wave tables; never fused, see api.cpp)
         return 0;
     const bool word_recs = format == (int)RANS_AMD_FMT_WORD || format == (int)RANS_AMD_FMT_BYTE;
     size_t tables = nrecs * 16 + (word_recs ? 256 * 16 : 0);
@@ -49,7 +50,8 @@ int encode_fused_fits(int format, uint32_t nsyms, uint32_t scale_bits)
 // true when launch_encode hands this shape to the lane-per-chunk encoders (no fused placement there)
 bool encode_uses_lanes(int format, uint64_t nchunks, uint32_t n_ways)
 {
-    return format != kKernelFormatByteAdaptive && lanes_applicable(nchunks, n_ways) && format != kKernelFormatR64Search &&
+    return format != kKernelFormatByteAdaptive && format != kKernelFormatWordAdaptive && lanes_applicable(nchunks, n_ways) &&
+           format != kKernelFormatR64Search &&
            format != kKernelFormatWord16;
 }
 
@@ -63,6 +65,8 @@ hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_
     // (the lane encoders know the public formats: a narrow alias interleave gathers alias_remap from L2)
     if (format == kKernelFormatByteAdaptive) // one model per chunk: the wave encoder builds them, whatever the interleave
         return launch_encode_wave((int)RANS_AMD_FMT_BYTE, p, num_cus, stream, name);
+    if (format == kKernelFormatWordAdaptive)
+        return launch_encode_wave(kKernelFormatWordAdaptive, p, num_cus, stream, name);
     if (!p.no_lanes && lanes_applicable(p.nchunks, p.n_ways) && format != kKernelFormatR64Search && format != kKernelFormatWord16)
         return launch_encode_lanes(format == kKernelFormatAliasLds ? (int)RANS_AMD_FMT_ALIAS : format, p, num_cus, stream, name);
     // (word format over u16 symbols: the wave encoder's general path, whatever the interleave)

@@ -153,10 +153,10 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         bad = true;
         active = false;
     }
-    if constexpr (!FULL || FMT == FMT_WORD || kIsR64<FMT>) // (the byte-stream formats' FULL form takes `dead` in its threshold)
+    if constexpr (!FULL || kIsWord<FMT> || kIsR64<FMT>) // (the byte-stream formats' FULL form takes `dead` in its threshold)
         active = active && dead == 0u;
 
-    if constexpr (FMT == FMT_WORD) {
+    if constexpr (kIsWord<FMT>) {
         // rans_word_sse41.h:81-93
         const bool emit = active && x >= (freq << 20);
         const uint64_t m = __builtin_amdgcn_ballot_w64(emit);
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         uint4 *lr = reinterpret_cast<uint4 *>(smem + (size_t)nrecs * 8u);
         for (uint32_t i = threadIdx.x; i < (2u << p.scale_bits) / 16u; i += blockDim.x)
             lr[i] = gr[i];
-    } else if (!(FMT == FMT_BYTE && p.chunk_freqs)) { // (per-chunk models: every wave builds its own records below)
+    } else if (!(FMT == FMT_BYTE && p.chunk_freqs) && FMT != FMT_WORDA) { // (per-chunk models: every wave builds its own records below)
         const uint4 *g = reinterpret_cast<const uint4 *>(p.enc_recs);
         uint4 *l = reinterpret_cast<uint4 *>(smem + kWordRecBytes);
         for (uint32_t i = threadIdx.x; i < p.nsyms; i += blockDim.x)
@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
 
     EncTables<FMT> T;
     T.recs = reinterpret_cast<const uint4 *>(smem + kWordRecBytes);
-    const bool adaptive = FMT == FMT_BYTE && p.chunk_freqs; // one model per chunk
+    const bool adaptive = (FMT == FMT_BYTE && p.chunk_freqs) || FMT == FMT_WORDA; // one model per chunk
     if (adaptive)
         T.recs = reinterpret_cast<const uint4 *>(smem + wave * kAdaptEncWaveLds);
     T.alias_remap = p.alias_remap;
@@ -742,8 +742,12 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         uint32_t dead = 0u;
         ++coded;
 
-        if (adaptive) // this chunk's model -> this wave's records (RansEncSymbolInit per chunk, main.cpp:159-162)
-            adapt_build_enc(p.chunk_freqs + chunk * 256u, p.scale_bits, lane, const_cast<uint4 *>(T.recs));
+        if (adaptive) { // this chunk's model -> this wave's records (RansEncSymbolInit per chunk, main.cpp:159-162)
+            if constexpr (FMT == FMT_WORDA)
+                adapt_build_enc_word(p.chunk_freqs + chunk * 256u, lane, const_cast<uint4 *>(T.recs));
+            else
+                adapt_build_enc(p.chunk_freqs + chunk * 256u, p.scale_bits, lane, const_cast<uint4 *>(T.recs));
+        }
 
         state_t x[K];
 #pragma unroll
@@ -1108,7 +1112,7 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 if constexpr (kIsR64<FMT>) {
                     reinterpret_cast<uint32_t RANS_GLOBAL *>(at)[0] = (uint32_t)x[k];
                     reinterpret_cast<uint32_t RANS_GLOBAL *>(at)[1] = (uint32_t)(x[k] >> 32);
-                } else if constexpr (FMT == FMT_WORD) {
+                } else if constexpr (kIsWord<FMT>) {
                     reinterpret_cast<uint16_t RANS_GLOBAL *>(at)[0] = (uint16_t)x[k];
                     reinterpret_cast<uint16_t RANS_GLOBAL *>(at)[1] = (uint16_t)(x[k] >> 16);
                 } else {
@@ -1159,7 +1163,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     const uint32_t enc_waves = fused ? waves - (waves >= 16 ? kEncFusedCopiers16 : 1) : waves;
     const size_t nrecs = p.nsyms < 256 ? 256 : p.nsyms;
     size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
-                 : (FMT == FMT_BYTE && p.chunk_freqs) ? (size_t)waves * kAdaptEncWaveLds
+                 : ((FMT == FMT_BYTE && p.chunk_freqs) || FMT == FMT_WORDA) ? (size_t)waves * kAdaptEncWaveLds
                                                       : nrecs * sizeof(EncRec) + ((FMT == FMT_WORD || FMT == FMT_BYTE) ? 256 * 16 : 0);
     if (RANS_ENC_STAGE && (FMT == FMT_WORD || (FMT == FMT_BYTE && !p.chunk_freqs)) && K == 1 && p.sym_bytes == 1 && nrecs == 256)
         lds += (size_t)waves * kEncStageBytes; // stream staging windows (4 + 4 KiB of tables in front)
@@ -1200,6 +1204,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     if (sized && p.redo) // (a handful of chunks at most, usually none: one block per CU finds that out quickly)
         cap = (uint64_t)num_cus;
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    if constexpr (FMT != FMT_WORDA) { // (per-chunk word models: the scratch-slot mode only, as rans_amd_encode_adaptive launches it)
     if (fused) {
         auto kern = k_encode<FMT, K, 1>;
         static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
@@ -1223,6 +1228,9 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
             return e;
         RANS_LAUNCH(kern, dim3(grid), dim3(threads), lds, stream, q);
         return hipGetLastError();
+    }
+    } else if (fused || slots) {
+        return hipErrorInvalidValue;
     }
     auto kern = k_encode<FMT, K, 0>;
     static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
@@ -1254,12 +1262,14 @@ hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipSt
     if (name)
         *name = format == FMT_WORD    ? "k_encode<word>"
                 : format == FMT_BYTE  ? (p.chunk_freqs ? "k_encode<byte, per-chunk models>" : "k_encode<byte>")
+                : format == FMT_WORDA ? "k_encode<word, per-chunk models>"
                 : format == FMT_R64   ? "k_encode<r64>"
                 : format == FMT_R64S  ? "k_encode<r64 full-width>"
                 : format == FMT_ALIAS_LDS ? "k_encode<alias, LDS remap>"
                                       : "k_encode<alias>";
     switch (format) {
     case FMT_WORD: return launch_encode_f<FMT_WORD>(p, num_cus, stream);
+    case FMT_WORDA: return p.chunk_freqs ? launch_encode_f<FMT_WORDA>(p, num_cus, stream) : hipErrorInvalidValue;
     case FMT_BYTE: return launch_encode_f<FMT_BYTE>(p, num_cus, stream);
     case FMT_R64: return launch_encode_f<FMT_R64>(p, num_cus, stream);
     case FMT_R64S: return launch_encode_f<FMT_R64S>(p, num_cus, stream);

@@ -65,6 +65,9 @@ constexpr int kKernelFormatByteDual = 10;
 // Kernel-side format number of the byte-format DECODER with one fused 8-byte record per slot (device_common.hpp FMT_BYTEF):
 // DecParams::table0 = {freq | sym << 24, slot - start}[1 << scale_bits], no table1.
 constexpr int kKernelFormatByteFused = 11;
+// Kernel-side format number of the WORD format with one model per chunk (device_common.hpp FMT_WORDA), decoder and encoder:
+// DecParams / EncParams::chunk_freqs holds u16[256] per chunk, scale_bits is 12.
+constexpr int kKernelFormatWordAdaptive = 12;
 constexpr uint32_t kTraceWords = 5;      // per-wave record of DecParams::trace
 
 struct DecParams {

@@ -156,8 +156,10 @@ template <int FMT> struct LaneRing {
 };
 
 // Smallest stream offset among the lanes that hold a chunk (wave-uniform): the base of the wave's 32-bit window
-// onto the container.  Offsets need not ascend with the chunk index -- any layout whose 64 chunks of a batch lie
-// within 1 GiB of each other decodes; a chunk further away is counted as bad.
+// onto the container.  Offsets need not ascend with the chunk index.  A wave addresses its batch through 32-bit offsets
+// from the batch's lowest chunk: chunks that lie 1 GiB or more above it (an overflowed chunk of a large sized-slot
+// container, a scattered hand-made index) wait for another trip of the same wave over the same batch, whose window starts
+// at the lowest of THEM (`again` below) -- every well-formed index decodes, the usual batch in one trip.
 __device__ __forceinline__ uint64_t wave_min_offset(uint64_t off, bool valid)
 {
     uint32_t lo = valid ? (uint32_t)off : 0xffffffffu, hi = valid ? (uint32_t)(off >> 32) : 0xffffffffu;
@@ -249,20 +251,23 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
     uint32_t nbad = 0;
     const uint64_t nbatches = (p.nchunks + 63u) / 64u;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
-    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += total_waves) {
+    uint64_t again = 0; // lanes of the batch in hand whose chunks lay beyond the last trip's window
+    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += again ? 0 : total_waves) {
         const uint64_t batch = uniform64(batch_v);
         const uint64_t chunk = batch * 64u + lane;
-        bool valid = chunk < p.nchunks;
+        bool valid = chunk < p.nchunks && (again == 0 || ((again >> lane) & 1u));
         const uint64_t off = valid ? p.offsets[chunk] : 0;
         const uint32_t len = valid ? p.lengths[chunk] : 0;
         const uint64_t first = chunk * p.chunk_syms;
-        // region base: the line of the batch's first chunk (lane 0 always holds a chunk)
-        const uint64_t rb = wave_min_offset(off, valid) & ~uint64_t(kLaneLine - 1);
-        if (valid && ((off & (Tr::kUnit - 1u)) != 0 || len < NW * Tr::kStateBytes || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
-                      off - rb >= (1u << 30))) {
-            nbad++;
+        if (valid && ((off & (Tr::kUnit - 1u)) != 0 || len < NW * Tr::kStateBytes || off > p.container_bytes || len > p.container_bytes - off)) {
+            nbad++; // (a malformed entry is seen in one trip only: it never joins `again`)
             valid = false;
         }
+        // region base: the line of the lowest chunk of this trip
+        const uint64_t rb = wave_min_offset(off, valid) & ~uint64_t(kLaneLine - 1);
+        const bool far = valid && off - rb >= (1u << 30);
+        again = __builtin_amdgcn_ballot_w64(far);
+        valid = valid && !far;
         const uint32_t nsym = valid ? (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms) : 0u;
         uint8_t RANS_GLOBAL *dst = (uint8_t RANS_GLOBAL *)p.out + first * p.sym_bytes;
 
@@ -735,18 +740,21 @@ template <bool PACKED> __global__ void __launch_bounds__(1024) k_decode_lanes_r6
     uint32_t nbad = 0;
     const uint64_t nbatches = (p.nchunks + 63u) / 64u;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
-    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += total_waves) {
+    uint64_t again = 0; // lanes of the batch in hand whose chunks lay beyond the last trip's window (wave_min_offset)
+    for (uint64_t batch_v = (uint64_t)blockIdx.x * waves_per_block + wave; batch_v < nbatches; batch_v += again ? 0 : total_waves) {
         const uint64_t batch = uniform64(batch_v);
         const uint64_t chunk = batch * 64u + lane;
-        bool valid = chunk < p.nchunks;
+        bool valid = chunk < p.nchunks && (again == 0 || ((again >> lane) & 1u));
         const uint64_t off = valid ? p.offsets[chunk] : 0;
         const uint32_t len = valid ? p.lengths[chunk] : 0;
-        const uint64_t rb = wave_min_offset(off, valid) & ~uint64_t(kLaneLine - 1);
-        if (valid && ((off & 3u) != 0 || len < 16u || off > p.container_bytes || len > p.container_bytes - off || off < rb ||
-                      off - rb >= (1u << 30))) {
+        if (valid && ((off & 3u) != 0 || len < 16u || off > p.container_bytes || len > p.container_bytes - off)) {
             nbad++;
             valid = false;
         }
+        const uint64_t rb = wave_min_offset(off, valid) & ~uint64_t(kLaneLine - 1);
+        const bool far = valid && off - rb >= (1u << 30);
+        again = __builtin_amdgcn_ballot_w64(far);
+        valid = valid && !far;
         // the batch's window onto the container: offsets from rb, reads past the last 16-byte granule return 0
         const uint64_t span = cbytes16 - (rb < cbytes16 ? rb : cbytes16);
         const uint32_t nrec = uniform((uint32_t)(span < 0x7ffffff0ull ? span : 0x7ffffff0ull));

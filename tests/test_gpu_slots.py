@@ -233,6 +233,39 @@ def test_compact_a_chunk_range_and_a_reordered_index(gpu, oracle):
     assert g_total == cont.size
 
 
+@pytest.mark.parametrize("fmt,sb,n_ways,chunk,kernel", [(FMT_R64, 14, 2, 512, "k_decode_lanes_r64x2"), (FMT_WORD, 12, 4, 1024, "k_decode_lanes_staged"),
+                                                         (FMT_BYTE, 14, 8, 2000, "k_decode_lanes_staged")])
+def test_lane_decoders_take_chunks_more_than_1_gib_apart(gpu, oracle, fmt, sb, n_ways, chunk, kernel):
+    """The lane decoders address a batch of 64 chunks through 32-bit offsets from its lowest chunk; chunks 1 GiB or more
+    above it (an overflowed chunk of a large sized-slot container, a scattered index) are decoded in another trip over the
+    same batch -- not counted as corrupt.  A 2.5 GiB buffer, chunks of different batches moved 1.1 and
+    2.25 GiB up, one batch with two far chunks more than 1 GiB apart from each other as well."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(200 * chunk + 17, K=256, s=1.0, seed=14)
+    om, gm = _models(ctx, oracle, fmt, sb, data)
+    cont, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
+    nchunks = len(lens)
+    big = torch.zeros((5 << 29) + 4096, dtype=torch.uint8, device="cuda")
+    big[:cont.size] = torch.from_numpy(cont).cuda()
+    o2 = offs.astype(np.int64).copy()
+    for c, where in ((3, (9 << 27) + 64), (70, (18 << 27) + 16 * 7), (71, (9 << 27) + 8192), (nchunks - 1, (5 << 29) - 256)):
+        a, ln = int(offs[c]), int(lens[c])
+        big[where:where + ln] = torch.from_numpy(cont[a:a + ln].copy()).cuda()
+        big[a:a + ln] = 0xA5  # (the old place holds garbage now)
+        o2[c] = where
+    d_offs, d_lens = torch.from_numpy(o2).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda()
+    out = ctx.decode(gm, big, big.numel(), d_offs, d_lens, data.size, n_ways, chunk)
+    assert ctx.last_decode_kernel().startswith(kernel), ctx.last_decode_kernel()
+    assert np.array_equal(out.cpu().numpy(), data)
+    # a malformed entry among them is still one bad chunk, counted once
+    o3 = o2.copy()
+    o3[70] = big.numel() + 64
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.decode(gm, big, big.numel(), torch.from_numpy(o3).cuda(), d_lens, data.size, n_ways, chunk)
+    assert e.value.status == R.E_CORRUPT
+    del big
+
+
 @pytest.mark.parametrize("n_ways,chunk", [(64, 4096), (2, 512)])  # k_compact (a wave per chunk) and k_compact_small (16 lanes)
 def test_compact_rejects_an_index_that_leaves_the_source(gpu, oracle, n_ways, chunk):
     """The source index of rans_amd_container_compact is data (it may come from a file): an (offset, length) pair outside

@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r5j
+timeout 3000 python -m pytest tests -m gpu -x -q > gpurun_out/r5j/gpu_all.log 2>&1; echo "gpu tests rc $?"
+tail -15 gpurun_out/r5j/gpu_all.log | cut -c1-300
