@@ -381,7 +381,9 @@ int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_
                              uint64_t n, uint32_t n_ways, uint32_t chunk_syms, uint32_t scale_bits, void *d_out,
                              uint64_t *h_bad_chunks, void *stream);
 /* The same with the stream format as an argument: RANS_AMD_FMT_BYTE (= the two above) or RANS_AMD_FMT_WORD (scale_bits must be
- * 12); RANS_AMD_E_UNSUPPORTED for any other format. */
+ * 12); RANS_AMD_E_UNSUPPORTED for any other format.  (Word format, a chunk that holds one symbol value only: its frequency
+ * is 4096 = M, for which rans_word_sse41.h:85's 32-bit renormalisation bound wraps to 0 -- the reference's encoder then emits
+ * a word per symbol, and so does this one, bit for bit; such chunks cost 2 bytes per symbol.) */
 int rans_amd_encode_adaptive_fmt(rans_amd_ctx *ctx, int format, const void *d_syms, uint64_t n, uint32_t n_ways,
                                  uint32_t chunk_syms, uint32_t scale_bits, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
                                  uint32_t *d_lengths, uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream);

@@ -590,12 +590,12 @@ def parse_container(blob):
     return info, freqs, lengths, payload
 
 
-def pack_container_adaptive(scale_bits, n_symbols, n_ways, chunk_syms, chunk_freqs, lengths, payload):
-    """Version-2 container (one model per chunk): chunk_freqs is u16[n_chunks * 256]."""
+def pack_container_adaptive(scale_bits, n_symbols, n_ways, chunk_syms, chunk_freqs, lengths, payload, fmt=FMT_BYTE):
+    """Version-2 container (one model per chunk): chunk_freqs is u16[n_chunks * 256]; fmt FMT_BYTE or FMT_WORD (12 bits)."""
     cf = np.ascontiguousarray(chunk_freqs, dtype=np.uint16)
     lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
     payload = np.ascontiguousarray(payload, dtype=np.uint8)
-    info = ContainerInfo(FMT_BYTE, scale_bits, 256, n_ways, chunk_syms, 1, n_symbols, num_chunks(n_symbols, chunk_syms),
+    info = ContainerInfo(fmt, scale_bits, 256, n_ways, chunk_syms, 1, n_symbols, num_chunks(n_symbols, chunk_syms),
                          payload.size)
     if lengths.size != info.n_chunks or cf.size != info.n_chunks * 256:
         raise RansAmdError(E_ARG, "container_pack_adaptive", "lengths / chunk_freqs do not match the number of chunks")

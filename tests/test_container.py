@@ -87,14 +87,14 @@ def test_gpu_encode_file_decode(tmp_path, oracle):
                           data)
 
 
-def _oracle_adaptive(oracle, data, sb, n_ways, chunk):
-    """Per-chunk models on the CPU: each chunk counted, normalised and encoded with ITS OWN table (byte format)."""
+def _oracle_adaptive(oracle, data, sb, n_ways, chunk, fmt=FMT_BYTE):
+    """Per-chunk models on the CPU: each chunk counted, normalised and encoded with ITS OWN table (byte or word format)."""
     rows, parts, lens = [], [], []
     for lo in range(0, data.size, chunk):
         piece = data[lo:lo + chunk]
         f, _ = oracle.normalize(oracle.count_freqs(piece, 256), 1 << sb)
         rows.append(f.astype(np.uint16))
-        stream = oracle.encode(FMT_BYTE, oracle.model(f, sb), piece, n_ways)
+        stream = oracle.encode(fmt, oracle.model(f, sb), piece, n_ways)
         lens.append(stream.size)
         pad = (-stream.size) % 16 if lo + chunk < data.size else 0
         parts.append(np.concatenate([stream, np.zeros(pad, np.uint8)]))
@@ -102,15 +102,16 @@ def _oracle_adaptive(oracle, data, sb, n_ways, chunk):
     return np.stack(rows) if rows else np.zeros((0, 256), np.uint16), np.array(lens, np.uint32), payload
 
 
-def test_adaptive_container_roundtrip(oracle):
+@pytest.mark.parametrize("fmt", [FMT_BYTE, FMT_WORD])
+def test_adaptive_container_roundtrip(oracle, fmt):
     rng = np.random.default_rng(3)
     # two regimes so the per-chunk models differ
     data = np.concatenate([oracle.gen_zipf(9000, K=64, s=1.2, seed=1), rng.integers(100, 256, 7001).astype(np.uint8)])
-    rows, lens, payload = _oracle_adaptive(oracle, data, 12, 32, 4096)
-    blob = R.pack_container_adaptive(12, data.size, 32, 4096, rows, lens, payload)
+    rows, lens, payload = _oracle_adaptive(oracle, data, 12, 32, 4096, fmt)
+    blob = R.pack_container_adaptive(12, data.size, 32, 4096, rows, lens, payload, fmt=fmt)
     info, f2, l2, p2 = R.parse_container_adaptive(blob)
     assert (info.format, info.scale_bits, info.nsyms, info.n_ways, info.chunk_syms, info.sym_bytes) == \
-        (FMT_BYTE, 12, 256, 32, 4096, 1)
+        (fmt, 12, 256, 32, 4096, 1)  # the header carries the stream format
     assert info.n_symbols == data.size and info.n_chunks == 4
     assert np.array_equal(f2, rows) and np.array_equal(l2, lens) and np.array_equal(p2, payload)
     assert not np.array_equal(f2[0], f2[3])
@@ -118,8 +119,12 @@ def test_adaptive_container_roundtrip(oracle):
     offs = R.offsets_from_lengths(l2)
     for c in range(info.n_chunks):
         n_c = min(4096, data.size - c * 4096)
-        got = oracle.decode(FMT_BYTE, oracle.model(f2[c].astype(np.uint32), 12), p2[offs[c]:offs[c] + l2[c]], n_c, 32)
+        got = oracle.decode(fmt, oracle.model(f2[c].astype(np.uint32), 12), p2[offs[c]:offs[c] + l2[c]], n_c, 32)
         assert np.array_equal(got, data[c * 4096:c * 4096 + n_c])
+    if fmt == FMT_WORD:  # the word format's probabilities are 12 bits, per chunk as for a whole input
+        with pytest.raises(R.RansAmdError):
+            R.pack_container_adaptive(11, data.size, 32, 4096, rows, lens, payload, fmt=FMT_WORD)
+        return
     # the two container versions do not parse as each other
     with pytest.raises(R.RansAmdError) as e:
         R.parse_container(blob)
@@ -164,10 +169,15 @@ def test_gpu_adaptive_file_roundtrip(tmp_path, oracle):
     data = np.concatenate([oracle.gen_zipf(1 << 19, K=256, s=1.0, seed=8),
                            rng.integers(0, 40, (1 << 19) + 12345).astype(np.uint8)])
     d = torch.from_numpy(data).cuda()
-    cont, offs, lens, freqs, total = ctx.encode_adaptive(d, 64, 32768, 12)
+    _gpu_adaptive_file_roundtrip(ctx, torch, tmp_path, oracle, data, d, FMT_BYTE)
+    _gpu_adaptive_file_roundtrip(ctx, torch, tmp_path, oracle, data, d, FMT_WORD)
+
+
+def _gpu_adaptive_file_roundtrip(ctx, torch, tmp_path, oracle, data, d, fmt):
+    cont, offs, lens, freqs, total = ctx.encode_adaptive(d, 64, 32768, 12, fmt=fmt)
     nch = R.num_chunks(data.size, 32768)
     blob = R.pack_container_adaptive(12, data.size, 64, 32768, freqs.cpu().numpy().view(np.uint16)[:nch * 256],
-                                     lens.cpu().numpy().astype(np.uint32)[:nch], cont[:total].cpu().numpy())
+                                     lens.cpu().numpy().astype(np.uint32)[:nch], cont[:total].cpu().numpy(), fmt=fmt)
     path = tmp_path / "mixed.rans2"
     blob.tofile(path)
 
@@ -177,12 +187,13 @@ def test_gpu_adaptive_file_roundtrip(tmp_path, oracle):
     d_offs = torch.from_numpy(o2.astype(np.int64)).cuda()
     d_lens = torch.from_numpy(l2.astype(np.int32)).cuda()
     d_f = torch.from_numpy(np.ascontiguousarray(f2).view(np.int16).reshape(-1)).cuda()
+    assert info.format == fmt
     out = ctx.decode_adaptive(d_cont, info.payload_bytes, d_offs, d_lens, d_f, info.n_symbols, info.n_ways,
-                              info.chunk_syms, info.scale_bits)
+                              info.chunk_syms, info.scale_bits, fmt=info.format)  # (the file says which coder)
     assert np.array_equal(out.cpu().numpy(), data)
     for c in (0, nch // 2, nch - 1):
         n_c = min(32768, data.size - c * 32768)
-        got = oracle.decode(FMT_BYTE, oracle.model(f2[c].astype(np.uint32), 12), p2[o2[c]:o2[c] + l2[c]], n_c, 64)
+        got = oracle.decode(fmt, oracle.model(f2[c].astype(np.uint32), 12), p2[o2[c]:o2[c] + l2[c]], n_c, 64)
         assert np.array_equal(got, data[c * 32768:c * 32768 + n_c]), c
 
 

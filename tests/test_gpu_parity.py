@@ -681,9 +681,11 @@ def test_word_format_with_u16_symbols(gpu, oracle):
         ctx.model(FMT_WORD, np.ones(8192, np.uint32), 12)
 
 
-def test_per_chunk_adaptive_models(gpu, oracle):
+@pytest.mark.parametrize("fmt", [FMT_BYTE, FMT_WORD])
+def test_per_chunk_adaptive_models(gpu, oracle, fmt):
     """one order-0 model per chunk, built as the reference builds its one model per input
-    (main.cpp:139-162) -- GPU histogram per chunk, normalize_freqs on the host, tables by the coding wavefront.
+    (main.cpp:139-162; the word format: main_simd.cpp:138-143, 12 bits) -- histogram and normalize_freqs per chunk on the
+    GPU, tables by the coding wavefront.
     Every chunk's frequencies must be the oracle's normalize(count_freqs(chunk)), every chunk's stream the oracle's
     stream for a model of that chunk alone; the input changes statistics from chunk to chunk on purpose."""
     R, ctx, torch = gpu
@@ -705,9 +707,10 @@ def test_per_chunk_adaptive_models(gpu, oracle):
     data = np.concatenate(parts).astype(np.uint8)[:37 * chunk - 1234]  # ragged last chunk
     n = data.size
     d = torch.from_numpy(data).cuda()
-    for sb in (12, 10, 8):
-        for n_ways in (64, 2, 128, 100):
-            cont, offs, lens, freqs, total = ctx.encode_adaptive(d, n_ways, chunk, sb)
+    for sb in ((12, 10, 8) if fmt == FMT_BYTE else (12,)):
+        for n_ways in (64, 2, 128, 100, 256):
+            cont, offs, lens, freqs, total = ctx.encode_adaptive(d, n_ways, chunk, sb, fmt=fmt)
+            assert ctx.last_encode_kernel()[0] == ("k_encode<byte, per-chunk models>" if fmt == FMT_BYTE else "k_encode<word, per-chunk models>")
             h_freqs = freqs.cpu().numpy().view(np.uint16).reshape(-1, 256)
             h_offs = offs.cpu().numpy().astype(np.uint64)
             h_lens = lens.cpu().numpy().astype(np.uint32)
@@ -718,23 +721,32 @@ def test_per_chunk_adaptive_models(gpu, oracle):
                 part = data[c * chunk:(c + 1) * chunk]
                 f, _ = oracle.normalize(oracle.count_freqs(part, 256), 1 << sb)
                 assert np.array_equal(h_freqs[c].astype(np.uint32), f), (sb, n_ways, c, "model")
-                want = oracle.encode(FMT_BYTE, oracle.model(f, sb), part, n_ways)
+                want = oracle.encode(fmt, oracle.model(f, sb), part, n_ways)
                 assert int(h_offs[c]) == pos and int(h_lens[c]) == want.size, (sb, n_ways, c, "index")
                 assert np.array_equal(got[pos:pos + want.size], want), (sb, n_ways, c, "stream")
                 pos += (want.size + 15) & ~15
-            out = ctx.decode_adaptive(cont, total, offs, lens, freqs, n, n_ways, chunk, sb)
+            out = ctx.decode_adaptive(cont, total, offs, lens, freqs, n, n_ways, chunk, sb, fmt=fmt)
+            assert ctx.last_decode_kernel() == ("k_decode<byte, per-chunk models>" if fmt == FMT_BYTE else "k_decode<word, per-chunk models>")
             assert np.array_equal(out.cpu().numpy(), data), (sb, n_ways, "decode")
     # adaptive beats one global model on this input, and a damaged frequency row is flagged, not decoded
-    cont, offs, lens, freqs, total = ctx.encode_adaptive(d, 64, chunk, 12)
-    gm = ctx.model_for(FMT_BYTE, data, 256, 12)
+    cont, offs, lens, freqs, total = ctx.encode_adaptive(d, 64, chunk, 12, fmt=fmt)
+    gm = ctx.model_for(fmt, data, 256, 12)
     _, _, _, total_global = ctx.encode(gm, d, 64, chunk)
-    assert total + freqs.numel() * 2 < total_global
+    if fmt == FMT_BYTE:
+        assert total + freqs.numel() * 2 < total_global
+    # (the word format: a chunk that holds ONE symbol value has freq = 4096 = M, and rans_word_sse41.h:85's renormalisation
+    #  bound (L >> 12 << 16) * freq wraps to 0 in 32 bits -- the reference then emits a word per symbol; oracle and GPU do
+    #  exactly that (the streams above are equal), so the constant chunks of this input cost 2 bytes per symbol)
     bad = freqs.clone()
     bad[5 * 256 + 3] += 1
-    out = ctx.decode_adaptive(cont, total, offs, lens, bad, n, 64, chunk, 12, sync=False)
+    out = ctx.decode_adaptive(cont, total, offs, lens, bad, n, 64, chunk, 12, sync=False, fmt=fmt)
     assert ctx.decode_errors() >= 1
+    for sb_bad in ((14,) if fmt == FMT_BYTE else (14, 11, 8)):  # (the word format's probabilities are 12 bits, rans_word_sse41.h:37)
+        with pytest.raises(R.RansAmdError) as e:
+            ctx.encode_adaptive(d, 64, chunk, sb_bad, fmt=fmt)
+        assert e.value.status == R.E_UNSUPPORTED
     with pytest.raises(R.RansAmdError) as e:
-        ctx.encode_adaptive(d, 64, chunk, 14)
+        ctx.encode_adaptive(d, 64, chunk, 12, fmt=FMT_R64)
     assert e.value.status == R.E_UNSUPPORTED
 
 
