@@ -684,6 +684,67 @@ constexpr uint32_t kR64WaveLds = 64 * kR64RingStride;
     "v_lshl_add_u64 %[at1], %[at1], 0, 64\n\t" \
     "v_lshl_add_u64 %[at2], %[at2], 0, 64\n\t" \
     "v_lshl_add_u64 %[at3], %[at3], 0, 64\n\t"
+// Paired stores (round 5): a trip leaves 64 bytes per chunk -- HALF a 128-byte line of L2 -- and the other half followed a
+// whole trip later, by when the line could have left L2 half written (WRITE_SIZE 1.34 x the symbols).
+// Now the transposed pieces of every other trip wait in v68..v83 and the pair goes out together: instruction t writes
+// bytes [0, 64) and [64, 128) of chunk (quad, t)'s line back to back.
+#ifndef RANS_R64_PAIR_STORES
+#define RANS_R64_PAIR_STORES 1
+#endif
+#define R64_HOLD                                                                                                        \
+    "v_mov_b32 v68, v8\n\tv_mov_b32 v69, v9\n\tv_mov_b32 v70, v10\n\tv_mov_b32 v71, v11\n\t"                             \
+    "v_mov_b32 v72, v12\n\tv_mov_b32 v73, v13\n\tv_mov_b32 v74, v14\n\tv_mov_b32 v75, v15\n\t"                           \
+    "v_mov_b32 v76, v16\n\tv_mov_b32 v77, v17\n\tv_mov_b32 v78, v18\n\tv_mov_b32 v79, v19\n\t"                           \
+    "v_mov_b32 v80, v20\n\tv_mov_b32 v81, v21\n\tv_mov_b32 v82, v22\n\tv_mov_b32 v83, v23\n\t"
+#define R64_STORES2                                                                                                     \
+    "s_mov_b64 exec, %[vq0]\n\t"                                                                                        \
+    "global_store_dwordx4 %[at0], v[68:71], off\n\t"                                                                    \
+    "global_store_dwordx4 %[at0], v[8:11], off offset:64\n\t"                                                           \
+    "s_mov_b64 exec, %[vq1]\n\t"                                                                                        \
+    "global_store_dwordx4 %[at1], v[72:75], off\n\t"                                                                    \
+    "global_store_dwordx4 %[at1], v[12:15], off offset:64\n\t"                                                          \
+    "s_mov_b64 exec, %[vq2]\n\t"                                                                                        \
+    "global_store_dwordx4 %[at2], v[76:79], off\n\t"                                                                    \
+    "global_store_dwordx4 %[at2], v[16:19], off offset:64\n\t"                                                          \
+    "s_mov_b64 exec, %[vq3]\n\t"                                                                                        \
+    "global_store_dwordx4 %[at3], v[80:83], off\n\t"                                                                    \
+    "global_store_dwordx4 %[at3], v[20:23], off offset:64\n\t"                                                          \
+    "s_mov_b64 exec, -1\n\t"                                                                                            \
+    "v_lshl_add_u64 %[at0], %[at0], 0, 64\n\t"                                                                          \
+    "v_lshl_add_u64 %[at1], %[at1], 0, 64\n\t"                                                                          \
+    "v_lshl_add_u64 %[at2], %[at2], 0, 64\n\t"                                                                          \
+    "v_lshl_add_u64 %[at3], %[at3], 0, 64\n\t"                                                                          \
+    "v_lshl_add_u64 %[at0], %[at0], 0, 64\n\t"                                                                          \
+    "v_lshl_add_u64 %[at1], %[at1], 0, 64\n\t"                                                                          \
+    "v_lshl_add_u64 %[at2], %[at2], 0, 64\n\t"                                                                          \
+    "v_lshl_add_u64 %[at3], %[at3], 0, 64\n\t"
+// s50 = trips decoded and not stored yet (0, 1: in v8..v23, 2: the older one transposed in v68..v83).  At the top of a trip:
+#if RANS_R64_PAIR_STORES
+#define R64_TRIP_TOP                                                                                                    \
+    "s_cmp_eq_u32 s50, 0\n\t"                                                                                           \
+    "s_cbranch_scc1 .Lr64first_%=\n\t" R64_TRANSPOSE                                                                    \
+    "s_cmp_eq_u32 s50, 1\n\t"                                                                                           \
+    "s_cbranch_scc1 .Lr64hold_%=\n\t" R64_STORES2                                                                       \
+    "s_mov_b32 s50, 0\n\t"                                                                                              \
+    "s_branch .Lr64first_%=\n\t"                                                                                        \
+    ".Lr64hold_%=:\n\t" R64_HOLD ".Lr64first_%=:\n\t"
+#define R64_TRIP_END                                                                                                    \
+    "s_add_u32 s50, s50, 1\n\t"
+#define R64_LAST                                                                                                        \
+    R64_TRANSPOSE                                                                                                       \
+    "s_cmp_eq_u32 s50, 2\n\t"                                                                                           \
+    "s_cbranch_scc1 .Lr64pair_%=\n\t" R64_STORES                                                                        \
+    "s_branch .Lr64done_%=\n\t"                                                                                         \
+    ".Lr64pair_%=:\n\t" R64_STORES2 ".Lr64done_%=:\n\t"
+#define R64_HOLD_CLOBBERS , "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83"
+#else
+#define R64_TRIP_TOP                                                                                                    \
+    "s_cmp_eq_u32 s50, 0\n\t"                                                                                           \
+    "s_cbranch_scc1 .Lr64first_%=\n\t" R64_TRANSPOSE R64_STORES ".Lr64first_%=:\n\t"
+#define R64_TRIP_END "s_mov_b32 s50, 1\n\t"
+#define R64_LAST R64_TRANSPOSE R64_STORES
+#define R64_HOLD_CLOBBERS
+#endif
 #define R64_CLOBBERS                                                                                                    \
     "vcc", "scc", "memory", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21",   \
         "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", \
@@ -800,10 +861,7 @@ template <bool PACKED> __global__ void __launch_bounds__(1024) k_decode_lanes_r6
                      "s_mov_b32 s50, 0\n\t"
                      ".Lr64trip_%=:\n\t"
                      R64_COMMIT
-                     "s_cmp_eq_u32 s50, 0\n\t"
-                     "s_cbranch_scc1 .Lr64first_%=\n\t"
-                     R64_TRANSPOSE R64_STORES
-                     ".Lr64first_%=:\n\t"
+                     R64_TRIP_TOP
 #define R64_BOUNDARY(N)                                                                                                 \
     "v_sub_u32 v46, %[ld], %[cur]\n\t"                                                                                  \
     "v_cmp_gt_i32 vcc, 48, v46\n\t"                                                                                     \
@@ -816,18 +874,18 @@ template <bool PACKED> __global__ void __launch_bounds__(1024) k_decode_lanes_r6
                      R64_COMMIT R64_BOUNDARY("1") R64P_GROUP("v12", "v13", "v14", "v15")
                      R64_COMMIT R64_BOUNDARY("2") R64P_GROUP("v16", "v17", "v18", "v19")
                      R64_COMMIT R64_BOUNDARY("3") R64P_GROUP("v20", "v21", "v22", "v23")
-                     "s_mov_b32 s50, 1\n\t"
+                     R64_TRIP_END
                      "s_sub_u32 %[trips], %[trips], 1\n\t"
                      "s_cmp_lg_u32 %[trips], 0\n\t"
                      "s_cbranch_scc1 .Lr64trip_%=\n\t"
-                     R64_TRANSPOSE R64_STORES
+                     R64_LAST
                      "s_waitcnt vmcnt(0) lgkmcnt(0)"
                      : "+{v[40:41]}"(xA), "+{v[42:43]}"(xB), "+{v[44:45]}"(win), [cur] "+v"(cur), [ld] "+v"(ld), [at0] "+v"(at[0]),
                        [at1] "+v"(at[1]), [at2] "+v"(at[2]), [at3] "+v"(at[3]), [trips] "+s"(trips)
                      : [maskv] "v"(maskv), [sbv] "v"(sbv), [m12v] "v"(m12v), [selA] "s"(0x0c0c0703u), [selB] "s"(0x07030c0cu), [row] "v"(row), [l16] "v"(l16), [rq0] "v"(rq0),
                        [kL] "s"(kL), [m0] "s"(m0), [vq0] "s"(vq[0]), [vq1] "s"(vq[1]), [vq2] "s"(vq[2]), [vq3] "s"(vq[3]),
                        [rsrc] "s"(rsrc4)
-                     : R64_CLOBBERS);
+                     : R64_CLOBBERS R64_HOLD_CLOBBERS);
         } else {
         asm volatile("s_mov_b64 s[40:41], 0\n\t"
                      "s_mov_b64 s[42:43], 0\n\t"
@@ -836,10 +894,7 @@ template <bool PACKED> __global__ void __launch_bounds__(1024) k_decode_lanes_r6
                      "s_mov_b32 s50, 0\n\t"
                      ".Lr64trip_%=:\n\t"
                      R64_COMMIT
-                     "s_cmp_eq_u32 s50, 0\n\t"
-                     "s_cbranch_scc1 .Lr64first_%=\n\t"
-                     R64_TRANSPOSE R64_STORES
-                     ".Lr64first_%=:\n\t"
+                     R64_TRIP_TOP
 #define R64_BOUNDARY(N)                                                                                                 \
     "v_sub_u32 v46, %[ld], %[cur]\n\t"                                                                                  \
     "v_cmp_gt_i32 vcc, 48, v46\n\t"                                                                                     \
@@ -852,18 +907,18 @@ template <bool PACKED> __global__ void __launch_bounds__(1024) k_decode_lanes_r6
                      R64_COMMIT R64_BOUNDARY("1") R64_GROUP("v12", "v13", "v14", "v15")
                      R64_COMMIT R64_BOUNDARY("2") R64_GROUP("v16", "v17", "v18", "v19")
                      R64_COMMIT R64_BOUNDARY("3") R64_GROUP("v20", "v21", "v22", "v23")
-                     "s_mov_b32 s50, 1\n\t"
+                     R64_TRIP_END
                      "s_sub_u32 %[trips], %[trips], 1\n\t"
                      "s_cmp_lg_u32 %[trips], 0\n\t"
                      "s_cbranch_scc1 .Lr64trip_%=\n\t"
-                     R64_TRANSPOSE R64_STORES
+                     R64_LAST
                      "s_waitcnt vmcnt(0) lgkmcnt(0)"
                      : "+{v[40:41]}"(xA), "+{v[42:43]}"(xB), "+{v[44:45]}"(win), [cur] "+v"(cur), [ld] "+v"(ld), [at0] "+v"(at[0]),
                        [at1] "+v"(at[1]), [at2] "+v"(at[2]), [at3] "+v"(at[3]), [trips] "+s"(trips)
                      : [maskv] "v"(maskv), [sbv] "v"(sbv), [t1v] "v"(t1v), [row] "v"(row), [l16] "v"(l16), [rq0] "v"(rq0),
                        [kL] "s"(kL), [m0] "s"(m0), [vq0] "s"(vq[0]), [vq1] "s"(vq[1]), [vq2] "s"(vq[2]), [vq3] "s"(vq[3]),
                        [rsrc] "s"(rsrc4)
-                     : R64_CLOBBERS);
+                     : R64_CLOBBERS R64_HOLD_CLOBBERS);
         }
         // RansDec end state: both states back at L, every byte of the chunk consumed (main64.cpp has no check; ours)
         if (valid && (xA != kL || xB != kL || cur - cur0 != len))
