@@ -41,15 +41,44 @@ def stats_rows(d):
     return [r for r in csv.DictReader(open(f[0])) if "rans_amd" in r["Name"]]
 
 
+def split_redo(rows, name_key, grid_key):
+    """The sized-slot encoder launches k_encode<.., 3> twice per call: the coders, then the (normally empty) redo pass,
+    which ends after a few microseconds.  Give the redo launches a name of their own (told apart by their duration: under a
+    tenth of the kernel's longest launch)."""
+    longest = collections.defaultdict(float)
+    for r in rows:
+        longest[short(r[name_key])] = max(longest[short(r[name_key])], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = []
+    for r in rows:
+        n = short(r[name_key])
+        if n.endswith(", 3>") and (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 0.1 * longest[n] or longest[n] < 20000):
+            n += " redo"
+        out.append((n, r))
+    return out
+
+
 def pmc_avg(d, counter):
     f = [os.path.join(d, x) for x in os.listdir(d)] if os.path.isdir(d) else []
     f = [x for x in f if x.endswith("counter_collection.csv")]
     vals = collections.defaultdict(list)
     if f:
-        for r in csv.DictReader(open(f[0])):
-            if r["Counter_Name"] == counter and "rans_amd" in r["Kernel_Name"]:
-                vals[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == counter and "rans_amd" in r["Kernel_Name"]]
+        for n, r in split_redo(rows, "Kernel_Name", "Grid_Size"):
+            vals[n].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in vals.items()}
+
+
+def trace_rows(d):
+    """Per-kernel rows from the per-dispatch trace (calls, avg / min / max us), the redo launches apart."""
+    f = [os.path.join(d, x) for x in os.listdir(d)] if os.path.isdir(d) else []
+    f = [x for x in f if x.endswith("kernel_trace.csv")]
+    if not f:
+        return []
+    rows = [r for r in csv.DictReader(open(f[0])) if "rans_amd" in r["Kernel_Name"]]
+    agg = collections.OrderedDict()
+    for n, r in split_redo(rows, "Kernel_Name", "Grid_Size_X"):
+        agg.setdefault(n, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return [(n, len(v), sum(v) / len(v), min(v), max(v)) for n, v in agg.items()]
 
 
 def main():
@@ -144,24 +173,27 @@ def main():
     rows_f = []
     out["encoders"] = {}
     for c in ("word", "byte", "c4", "c2"):
-        rows = stats_rows(os.path.join(src, "enc_%s_stats" % c))
+        rows = trace_rows(os.path.join(src, "enc_%s_stats" % c))
         fe, wr = pmc_avg(os.path.join(src, "enc_%s_fetch" % c), "FETCH_SIZE"), pmc_avg(os.path.join(src, "enc_%s_write" % c), "WRITE_SIZE")
-        for r in rows:
-            n = short(r["Name"])
+        for n, calls, avg, mn, mx in rows:
             if not (n.startswith("k_encode") or n.startswith("k_compact") or n.startswith("k_decode")):
                 continue
             mult = 1 if "lanes" in n else 2
             rd, w = fe.get(n, 0) * 1024 * mult, wr.get(n, 0) * 1024
             ratio = (rd + w) / alg[c] if (rd + w) else 0
-            layout = {"1>": "compact (fused placement)", "2>": "slots", "3>": "SIZED slots (+ redo launch)"}.get(n[-2:], "")
-            rows_f.append("| %s | `%s` | %s | %s | %.1f | %.1f | %.4g | %.4g | %.3f |" % (c, n, layout, r["Calls"], float(r["AverageNs"]) / 1e3,
-                                                                                      float(r["MinNs"]) / 1e3, rd, w, ratio))
-            out["encoders"]["%s %s" % (c, n)] = {"avg_us": float(r["AverageNs"]) / 1e3, "read": rd, "write": w, "algorithmic": alg[c], "ratio": ratio}
+            layout = ("compact (fused placement)" if n.endswith(", 1>") else "slots" if n.endswith(", 2>") else "SIZED slots: the coders"
+                      if n.endswith(", 3>") else "SIZED slots: the redo launch (nothing overflowed)" if n.endswith("redo") else
+                      "decode of the compact / slot / sized container (pooled)" if n.startswith("k_decode") else "")
+            rows_f.append("| %s | `%s` | %s | %d | %.1f | %.1f | %.4g | %.4g | %s |" % (c, n, layout, calls, avg, mn, rd, w,
+                                                                                    "%.3f" % ratio if not n.endswith("redo") else "-"))
+            out["encoders"]["%s %s" % (c, n)] = {"avg_us": avg, "min_us": mn, "read": rd, "write": w, "algorithmic": alg[c], "ratio": ratio}
     if rows_f:
         L += ["## F. encoders in the three layouts and the decoders of their containers (`tools/time_slots.py --configs X`, one X per run)", "",
-              "(`k_encode<FMT, K, MODE>`: MODE 1 = compact with fused placement, 2 = slots, 3 = sized slots -- its second row with a few "
-              "microseconds is the redo launch; the lane kernel `k_encode_lanes_r64x2` serves all three layouts of config 2 and its "
-              "row pools them; decode rows pool the three containers.)  Traffic: separate PMC passes of the same command.", "",
+              "(`k_encode<FMT, K, MODE>`: MODE 1 = compact with fused placement, 2 = slots, 3 = sized slots, whose redo launches -- a "
+              "quarter of the grid, told apart by it -- have a row of their own; the lane kernel `k_encode_lanes_r64x2` serves all three "
+              "layouts of config 2 and its row pools them, `k_encode<2, 1, 3>` there is the redo launch alone; decode rows pool the three "
+              "containers.)  Rows from the per-dispatch trace; traffic from separate PMC passes of the same command (FETCH_SIZE x 1024 x 2 "
+              "for the wave kernels, x 1 for the lane kernels' 64-byte requests; WRITE_SIZE x 1024).", "",
               "| config | kernel | layout | calls | avg us | min us | read B | write B | traffic / algorithmic |", "|---|---|---|---|---|---|---|---|---|"] + rows_f + [""]
 
     sys.path.insert(0, ROOT)
