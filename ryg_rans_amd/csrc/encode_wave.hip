@@ -124,13 +124,15 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         const uint32_t freq = r8.x & 0xffffu, start = r8.x >> 16, rcp = r8.y;
         bad = bad || (!PADDED && sym >= T.nsyms) || freq == 0u;
         const uint32_t k = 31u - T.scale_bits;
+        // (`dead`, sized slots: all ones once the slot has no room for a round -- OR-ed into the wave-uniform addend, the
+        //  saturating add then yields 0xffffffff for every lane: nothing leaves, and no instruction per symbol is spent on it)
         uint32_t x_max;
-        asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(x_max) : "v"((freq - 1u) << k), "v"(1u << k));
+        asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(x_max) : "v"((freq - 1u) << k), "v"((1u << k) | dead));
         uint32_t y = x;
         if constexpr (STAGED)
             enc_renorm_byte_full_staged(y, x_max, wp, T.split_sel);
         else
-            enc_renorm_byte_full(y, x_max | dead, wp, slot, T.swap_sel);
+            enc_renorm_byte_full(y, x_max, wp, slot, T.swap_sel);
         const uint32_t q0 = __umulhi(y, rcp);
         const uint32_t d = y - __umul24(q0, freq) - freq;          // rem0 - freq: negative iff the estimate was exact
         const uint32_t m = (uint32_t)((int32_t)d >> 31);

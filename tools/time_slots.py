@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=16384)
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--tight-slot-add", type=int, default=0, help="bytes added to rans_amd_tight_slot_bytes() (experiments with the slot stride)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = R.Context(0)
@@ -53,7 +54,7 @@ def main():
         m = ctx.model(fmt, f, sb)
         c_cont, c_offs, c_lens, c_total = ctx.encode(m, d, ways, chunk)
         s_cont, s_offs, s_lens, s_total = ctx.encode_slots(m, d, ways, chunk)
-        t_cont, t_offs, t_lens, t_total, t_slot = ctx.encode_sized(m, d, ways, chunk)  # sized slots (rans_amd_encode_slots_sized)
+        t_cont, t_offs, t_lens, t_total, t_slot = ctx.encode_sized(m, d, ways, chunk, slot=(ctx.tight_slot_bytes(m, ways, chunk) + a.tight_slot_add) if a.tight_slot_add else None)  # sized slots (rans_amd_encode_slots_sized)
         ok = bool(torch.equal(c_lens, s_lens)) and bool(torch.equal(c_lens, t_lens))
         out = torch.empty_like(d)
         try:  # (a library variant that is wrong by construction -- a dropped store, timing only -- still gets its encode times)
