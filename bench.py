@@ -1152,6 +1152,18 @@ def main():
         if not all_ok and not args.measure:
             exit_code = 1
     if use_dist:
+        # Rank 0 has just timed the reference on the host cores while the other ranks had nothing left to do: they must SLEEP
+        # through that (a barrier on the RCCL backend spins a core per rank in hipStreamSynchronize, and the container's CPU
+        # quota is shared) -- they block on a key of the rendezvous store (a socket read) that rank 0 sets when it is done.
+        try:
+            import datetime
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("bench_cpu_leg_done", "1")
+            else:
+                store.wait(["bench_cpu_leg_done"], datetime.timedelta(minutes=15))
+        except Exception:  # noqa: BLE001  (no store to be had: the barrier below still lines the ranks up)
+            pass
         barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -116,6 +116,26 @@ def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways
     assert c_total == total and torch.equal(c_offs, offs)
     assert bench.oracle_check_chunks(dict(art, cont=c_cont, offs=c_offs)) == (n + chunk - 1) // chunk
     del s_cont, c_cont
+    # 4b. SIZED slots (rans_amd_encode_slots_sized, slot = rans_amd_tight_slot_bytes()): every chunk == the oracle's stream
+    #     wherever it lies (its slot or the overflow region), the index follows the layout's rule, the container is about
+    #     the compact one's size and decodes as it is.  Then the same with slots of HALF that size: every chunk overflows
+    #     into the region behind them (the redo launch codes the whole shard) and still equals the oracle's.
+    nchunks = (n + chunk - 1) // chunk
+    worst = R.slot_bytes(fmt, n, ways, chunk)
+    t_cont, t_offs, t_lens, t_total, t_slot = ctx.encode_sized(gm, d_syms, ways, chunk)
+    assert torch.equal(t_lens, lens) and t_slot < worst
+    assert t_total <= 1.35 * total, (t_total, total)  # (config 2's 512-symbol chunks in whole 64-byte lines: 1.23 x)
+    assert bench.oracle_check_chunks(dict(art, cont=t_cont, offs=t_offs, lens=t_lens, total=t_total, slot=t_slot, worst=worst)) == nchunks
+    out = ctx.decode(gm, t_cont, t_total, t_offs, t_lens, n, ways, chunk)
+    assert torch.equal(out, d_syms)
+    del out, t_cont
+    half = max(64, (t_slot // 2) & ~63)
+    h_cont, h_offs, h_lens, h_total, _ = ctx.encode_sized(gm, d_syms, ways, chunk, slot=half, overflow_chunks=nchunks)
+    assert torch.equal(h_lens, lens) and h_total >= nchunks * half + (nchunks - 1) * worst  # (a ragged last chunk may fit)
+    assert bench.oracle_check_chunks(dict(art, cont=h_cont, offs=h_offs, lens=h_lens, total=h_total, slot=half, worst=worst)) == nchunks
+    out = ctx.decode(gm, h_cont, h_total, h_offs, h_lens, n, ways, chunk)
+    assert torch.equal(out, d_syms)
+    del out, h_cont
     # 5. a corrupted chunk is flagged (or at least does not decode to the input)
     bad = cont.clone()
     bad[int(offs[0].item()) + int(lens[0].item()) // 2] ^= 0x10
