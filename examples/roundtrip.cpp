@@ -102,11 +102,49 @@ int main(int argc, char **argv)
            (unsigned long long)n, (unsigned long long)nchunks, (unsigned long long)total, (double)total / (double)n);
     printf("encode %.3f ms (%.1f GB/s), decode %.3f ms (%.1f GB/s), kernel %s\n", enc_ms, n / enc_ms / 1e6, dec_ms,
            n / dec_ms / 1e6, rans_amd_last_decode_kernel(ctx));
-    puts(same ? "decode ok!" : "ERROR: bad decoder!");
+
+    // ---- the one-trip encoder: slots sized from the model (rans_amd_encode_slots_sized), room for a few overflowed chunks
+    //      behind them; every chunk's stream must be byte for byte the one rans_amd_encode placed in the compact container
+    bool sized_ok = true;
+    if (nchunks) {
+        const uint64_t slot = rans_amd_tight_slot_bytes(model, n_ways, chunk);
+        const uint64_t cap2 = rans_amd_encode_sized_bound(format, n, n_ways, chunk, slot, nchunks / 64 + 4);
+        uint8_t *d_cont2 = nullptr;
+        uint64_t *d_off2 = nullptr;
+        uint32_t *d_len2 = nullptr;
+        HIP(hipMalloc((void **)&d_cont2, cap2 + 256));
+        HIP(hipMalloc((void **)&d_off2, 8 * (nchunks + 1)));
+        HIP(hipMalloc((void **)&d_len2, 4 * nchunks));
+        uint64_t total2 = 0;
+        CHECK(rans_amd_encode_slots_sized(ctx, model, d_in, n, n_ways, chunk, slot, d_cont2, cap2, d_off2, d_len2, &total2, nullptr));
+        float enc2_ms = 0, dec2_ms = 0;
+        CHECK(rans_amd_last_kernel_ms(ctx, &dec2_ms, &enc2_ms));
+        HIP(hipMemset(d_out, 0, n));
+        CHECK(rans_amd_decode(ctx, model, d_cont2, total2, d_off2, d_len2, n, n_ways, chunk, d_out, &bad, nullptr));
+        HIP(hipMemcpy(back.data(), d_out, n, hipMemcpyDeviceToHost));
+        sized_ok = memcmp(back.data(), in.data(), n) == 0;
+        std::vector<uint8_t> c1(total), c2(total2);
+        std::vector<uint64_t> o1(nchunks + 1), o2(nchunks + 1);
+        std::vector<uint32_t> l1(nchunks), l2(nchunks);
+        HIP(hipMemcpy(c1.data(), d_cont, total, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(c2.data(), d_cont2, total2, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(o1.data(), d_off, 8 * (nchunks + 1), hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(o2.data(), d_off2, 8 * (nchunks + 1), hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(l1.data(), d_len, 4 * nchunks, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(l2.data(), d_len2, 4 * nchunks, hipMemcpyDeviceToHost));
+        for (uint64_t c = 0; c < nchunks && sized_ok; ++c)
+            sized_ok = l1[c] == l2[c] && memcmp(&c1[o1[c]], &c2[o2[c]], l1[c]) == 0;
+        printf("sized slots (%llu bytes each, worst case %llu): container %llu bytes = %.3f x input, encode %.3f ms, %s\n",
+               (unsigned long long)slot, (unsigned long long)rans_amd_slot_bytes(format, n, n_ways, chunk), (unsigned long long)total2,
+               (double)total2 / (double)n, enc2_ms, sized_ok ? "every chunk equals the compact container's" : "MISMATCH");
+        for (void *ptr : {(void *)d_cont2, (void *)d_off2, (void *)d_len2})
+            (void)hipFree(ptr);
+    }
+    puts(same && sized_ok ? "decode ok!" : "ERROR: bad decoder!");
 
     rans_amd_model_destroy(model);
     rans_amd_ctx_destroy(ctx);
     for (void *ptr : {(void *)d_in, (void *)d_out, (void *)d_cont, (void *)d_off, (void *)d_len})
         (void)hipFree(ptr);
-    return same ? 0 : 2;
+    return same && sized_ok ? 0 : 2;
 }
