@@ -2,7 +2,8 @@
 scale_bits, source skew, n, N (any value in 1..512), chunk size, buffer misalignment and lane-kernel
 generation; GPU encode must equal the oracle's bytes and both containers must decode to the input; since round 4 every
 case also goes through the slot layout (every chunk == the oracle's stream in its slot), its compaction (== the compact
-container) and the decode of a random chunk range of the slot container.
+container) and the decode of a random chunk range of the slot container; since round 5 also through SIZED slots (the model's
+slot size or a random one that overflows some or all chunks: every chunk == the oracle's stream wherever it lies).
 (The sweep found the N = 192/320/384/448 encoder bug that the hand-picked cases had missed.)"""
 import os
 import sys

@@ -3,7 +3,9 @@ skew, n, N, chunk size, buffer misalignment and kernel-family options of the con
   * GPU encode == oracle encode (lengths, offsets, every chunk's bytes),
   * GPU decode of the ORACLE container == input, GPU decode of its own container == input,
   * the slot layout (rans_amd_encode_slots): every chunk == the oracle's stream at the end of its slot, decode from it,
-    rans_amd_container_compact of it == the compact container, a random chunk range of it decoded on its own.
+    rans_amd_container_compact of it == the compact container, a random chunk range of it decoded on its own,
+  * sized slots (rans_amd_encode_slots_sized) with the model's slot or a random one: every chunk == the oracle's stream in
+    its slot or in the overflow region, the index rule, decode from it.
     python tools/stress.py [--cases 300] [--seed 1]
 """
 import argparse
@@ -150,9 +152,43 @@ def run(cases, seed, ctx=None, oracle=None, big=False):
                     part = ctx.decode(gm, s_cont, s_total, s_offs[lo:], s_lens[lo:], n_range, n_ways, chunk)
                     ok_slots = np.array_equal(part.cpu().numpy().view(dt), data[lo * chunk:lo * chunk + n_range])
                     desc["range"] = (lo, hi)
-            if not (ok and ok_dec and ok_slots):
+            # round 5: SIZED slots -- the model's tight slot, or a random multiple of 64 bytes between one line and the worst
+            # case (most of those overflow some or all chunks into the region behind the slots): every chunk == the
+            # oracle's stream wherever it lies, the index follows the layout's rule, the container decodes as it is
+            ok_sized = True
+            if ok and ok_slots:
+                nchunks = len(lens)
+                worst = R.slot_bytes(fmt, n, n_ways, chunk)
+                pick_slot = int(rng.integers(0, 3))
+                slot_t = None if pick_slot == 0 else 64 * int(rng.integers(1, max(2, worst // 64 + 1)))
+                t_cont, t_offs, t_lens, t_total, slot_t = ctx.encode_sized(gm, d_syms, n_ways, chunk, slot=slot_t, overflow_chunks=nchunks)
+                desc["sized_slot"] = (slot_t, worst)
+                to = t_offs.cpu().numpy().astype(np.int64)
+                eff = min(slot_t, worst)
+                ok_sized = np.array_equal(t_lens.cpu().numpy().astype(np.uint32), lens)
+                if ok_sized:
+                    ends = to[:nchunks] + lens.astype(np.int64)
+                    inside = to[:nchunks] < nchunks * eff
+                    over = int((~inside).sum())
+                    k = ends[~inside] - nchunks * eff
+                    ok_sized = np.array_equal(ends[inside], (np.nonzero(inside)[0] + 1) * eff) and np.all(k % worst == 0) and \
+                        sorted((k // worst).tolist()) == list(range(1, over + 1)) and int(to[nchunks]) == t_total == nchunks * eff + over * worst and \
+                        bool(np.all(lens[inside] <= eff))
+                    desc["overflowed"] = over
+                if ok_sized:
+                    tg = t_cont.cpu().numpy()
+                    for c in range(nchunks):
+                        a, o, ln = int(to[c]), int(offs[c]), int(lens[c])
+                        if not np.array_equal(tg[a:a + ln], want[o:o + ln]):
+                            ok_sized = False
+                            desc["bad_sized_chunk"] = c
+                            break
+                if ok_sized:
+                    out4 = ctx.decode(gm, t_cont, t_total, t_offs, t_lens, n, n_ways, chunk)
+                    ok_sized = np.array_equal(out4.cpu().numpy().view(dt), data) and ctx.decode_errors() == 0
+            if not (ok and ok_dec and ok_slots and ok_sized):
                 fails += 1
-                print("FAIL", desc, "encode_ok", ok, "decode_ok", ok_dec, "slots_ok", ok_slots, flush=True)
+                print("FAIL", desc, "encode_ok", ok, "decode_ok", ok_dec, "slots_ok", ok_slots, "sized_ok", ok_sized, flush=True)
         except Exception as e:  # noqa: BLE001
             fails += 1
             print("EXC", desc, repr(e), flush=True)
