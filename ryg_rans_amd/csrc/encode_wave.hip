@@ -32,6 +32,12 @@ template <int FMT> struct EncTables {
 // global_store_short, the one-byte lanes one global_store_byte, each under its own exec mask.  12 VALU where the
 // compiler's version (three byte stores with 64-bit address arithmetic each, the byte count by sign tricks) has ~25.
 // A lane that must not emit passes x_max = 0xffffffff.  s[34:35] holds the two-byte mask.
+#ifndef RANS_RENORM_STORE_SHORT // (experiment knobs: -DRANS_RENORM_STORE_SHORT='""' -DRANS_RENORM_STORE_BYTE='""' drop the two
+#define RANS_RENORM_STORE_SHORT "global_store_short %[r], %[t], %[base]\n\t" // stream stores of the unstaged byte-stream coders:
+#endif                                                                        // what the address unit costs config 4's encoder)
+#ifndef RANS_RENORM_STORE_BYTE
+#define RANS_RENORM_STORE_BYTE "global_store_byte %[r], %[x], %[base]\n\t"
+#endif
 __device__ __forceinline__ void enc_renorm_byte_full(uint32_t &x, uint32_t x_max, uint32_t &wp, const uint8_t RANS_GLOBAL *slot,
                                                      uint32_t swap_sel)
 {
@@ -52,10 +58,10 @@ __device__ __forceinline__ void enc_renorm_byte_full(uint32_t &x, uint32_t x_max
                  "v_add_u32_e32 %[r], %[wp], %[r]\n\t"
                  "v_perm_b32 %[t], %[x], %[x], %[sel]\n\t"
                  "s_mov_b64 exec, s[34:35]\n\t"
-                 "global_store_short %[r], %[t], %[base]\n\t"
+                 RANS_RENORM_STORE_SHORT
                  "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
                  "s_andn2_b64 exec, vcc, s[34:35]\n\t"
-                 "global_store_byte %[r], %[x], %[base]\n\t"
+                 RANS_RENORM_STORE_BYTE
                  "v_lshrrev_b32_e32 %[x], 8, %[x]\n\t"
                  "s_mov_b64 exec, -1"
                  : [x] "+v"(x), [wp] "+s"(wps), [t] "=&v"(t), [r] "=&v"(r), [c1] "=&s"(c1), [c2] "=&s"(c2)
