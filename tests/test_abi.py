@@ -246,3 +246,25 @@ def test_build_model_o0_host_only(oracle):
     assert R.lib().rans_amd_model_format(out) == FMT_BYTE and R.lib().rans_amd_model_scale_bits(out) == 14
     R.lib().rans_amd_model_destroy(out)
     assert R.lib().rans_amd_encode_workspace_bytes(FMT_WORD, 10 * 4096, 64, 4096) == 10 * R.chunk_bound(FMT_WORD, 4096, 64) + 64
+
+
+def test_sized_slot_bounds_are_pure_arithmetic():
+    """rans_amd_encode_sized_bound (no GPU needed): n_chunks sized slots + room for the named number of overflowed chunks in
+    worst-case slots; a slot at or above the worst case is the plain slot layout; rans_amd_tight_slot_bytes(NULL) = 0."""
+    import ctypes as C
+    L = R.lib()
+    for fmt, n, ways, chunk in ((R.FMT_WORD, 1 << 20, 64, 16384), (R.FMT_R64, 300000, 2, 512), (R.FMT_ALIAS, 12345, 128, 4096),
+                                (R.FMT_BYTE, 5, 64, 4096)):
+        nchunks = R.num_chunks(n, chunk)
+        worst = R.slot_bytes(fmt, n, ways, chunk)
+        assert worst % 64 == 0 and worst >= R.chunk_bound(fmt, min(n, chunk), ways)
+        assert R.encode_slots_bound(fmt, n, ways, chunk) == nchunks * worst
+        for slot in (64, 640, worst - 64):
+            if slot <= 0 or slot >= worst:
+                continue
+            for k in (0, 1, nchunks, nchunks + 7):
+                assert R.encode_sized_bound(fmt, n, ways, chunk, slot, k) == nchunks * slot + min(k, nchunks) * worst
+        for slot in (0, worst, worst + 64):
+            assert R.encode_sized_bound(fmt, n, ways, chunk, slot, 3) == nchunks * worst
+    assert R.encode_sized_bound(R.FMT_WORD, 0, 64, 4096, 640, 3) == 16
+    assert L.rans_amd_tight_slot_bytes(None, 64, 4096) == 0
