@@ -374,7 +374,7 @@ class Context:
 
     def tight_slot_bytes(self, model, n_ways, chunk_syms):
         """rans_amd_tight_slot_bytes: the slot rans_amd_encode_slots_sized is meant to run with -- the model's expected
-        chunk stream + 2 % + the flushed states + four standard deviations + a line."""
+        chunk stream + 2 % + the flushed states + four standard deviations + 16 bytes, in whole 64-byte lines."""
         return int(_lib.rans_amd_tight_slot_bytes(model._h, n_ways, chunk_syms))
 
     def encode_sized(self, model, d_syms, n_ways, chunk_syms, slot=None, overflow_chunks=None, d_out=None, sync=True,
