@@ -272,9 +272,11 @@ int rans_amd_encode_slots(rans_amd_ctx *ctx, const rans_amd_model *model, const 
  *         worst case, nothing overflows there), d_offsets[c] pointing into it
  *     d_offsets[n_chunks] = n_chunks * slot_bytes + overflowed chunks * W   (the container's size)
  *
- * Every chunk's bytes are the oracle's stream for that chunk, wherever they lie; the decoders take the index as it is.
+ * Every chunk's bytes are exactly what rans_amd_encode produces for it (the reference's stream for that chunk), wherever
+ * they lie; the decoders take the index as it is.
  * rans_amd_tight_slot_bytes() sizes a slot from the MODEL: chunk_syms times the model's expected code length (its entropy
- * under itself) plus 2 %, the N flushed states, four standard deviations of a chunk's code length and 16 bytes of slack (rounded up to whole 64-byte lines) --
+ * under itself) plus 2 %, the N flushed states, four standard deviations of a chunk's code length and 16 bytes of slack,
+ * rounded up to whole 64-byte lines --
  * input that follows the model overflows about one chunk in 30 000; input that does not (a model built from other data, an
  * incompressible stretch) overflows more often and still encodes correctly, each overflowed chunk at twice its cost.
  * out_cap must hold the slots (RANS_AMD_E_SPACE up front otherwise); whatever it has beyond them is overflow region, and a
