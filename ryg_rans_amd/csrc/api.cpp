@@ -972,11 +972,11 @@ uint64_t rans_amd_tight_slot_bytes(const rans_amd_model *model, uint32_t n_ways,
     const double var = sq > mean * mean ? sq - mean * mean : 0.0;
     const double state_bytes = h.format == RANS_AMD_FMT_R64 ? 8.0 : 4.0;
     // The coders that stage their stream in LDS (word / byte / LDS-alias format, byte symbols, 64 lanes) check the slot
-    // exactly; the others before every round, by what a round can emit at most -- their slot gets that margin
+    // exactly; the others before every pair of rounds, by what two rounds can emit at most -- their slot gets that margin
     const bool staged = h.sym_bytes == 1 && n_ways == 64 && h.nsyms <= 256 && h.scale_bits <= 16 &&
                         (h.format == RANS_AMD_FMT_WORD || h.format == RANS_AMD_FMT_BYTE || h.format == RANS_AMD_FMT_ALIAS);
     const double lanes = n_ways >= 64 ? (double)((n_ways + 63u) & ~63u) : 0.0; // (narrow interleaves: lane encoders, whole lines)
-    const double margin = staged ? 0.0 : lanes * (h.format == RANS_AMD_FMT_R64 ? 4.0 : 2.0); // (one round)
+    const double margin = staged ? 0.0 : 2.0 * lanes * (h.format == RANS_AMD_FMT_R64 ? 4.0 : 2.0); // (two rounds)
     const double bytes = 1.02 * mean * (double)chunk_syms / 8.0 + state_bytes * (double)n_ways +
                          4.0 * std::sqrt(var * (double)chunk_syms) / 8.0 + 16.0 + margin;
     const uint64_t worst = encode_slot_bytes(h.format, chunk_syms, n_ways, chunk_syms);

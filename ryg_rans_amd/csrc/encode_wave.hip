@@ -743,8 +743,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
         uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.scratch + slot_at;
         uint32_t wp = (uint32_t)p.slot_bytes;
         bool ovf = false; // SIZED, wave-uniform: the chunk's stream does not fit its slot
-        // SIZED, the coders that store every round's units themselves: 0, or ~0 from the round on before which the slot no
-        // longer had room for what a round can emit at most -- OR-ed into the renormalisation thresholds, so that nothing
+        // SIZED, the coders that store every round's units themselves: 0, or ~0 from the pair of rounds on before which the slot no
+        // longer had room for what two rounds can emit at most -- OR-ed into the renormalisation thresholds, so that nothing
         // leaves the states any more (no branch out of the unrolled loops: a `break` there cost the 4096-symbol alias coder
         // a third of its speed)
         uint32_t dead = 0u;
@@ -837,10 +837,10 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
 #pragma unroll
                         for (int k = 0; k < K; ++k)
                             t[k] = __builtin_amdgcn_perm(quad_perm<1, 0, 3, 2>(cur[j][k]), cur[j][k], sel16);
+                        if constexpr (SIZED) // (before every PAIR of rounds: a check per round is 4 of the loop's 36 instructions)
+                            dead = uniform(wp) < 2u * 64u * K * kMaxEmit ? ~0u : dead;
 #pragma unroll
                         for (int h = 1; h >= 0; --h) {
-                            if constexpr (SIZED)
-                                dead = uniform(wp) < 64u * K * kMaxEmit ? ~0u : dead; // (a round of K x 64 states)
 #pragma unroll
                             for (int k = K - 1; k >= 0; --k)
                                 enc_substep<FMT, false, true>(T, x[k], (t[k] >> (16 * h)) & 0xffffu, true, slot, wp, bad, dead);
@@ -999,8 +999,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                             enc_word_full_staged<kSmall, kTrack>(x[K - 1 - step % K], now, lp, worst);
                         } else {
                             if constexpr (SIZED) { // (the staged form is checked, exactly, where it flushes)
-                                if (step % K == 0)
-                                    dead = uniform(wp) < 64u * K * kMaxEmit ? ~0u : dead; // (a round of K x 64 states)
+                                if (step % (2 * K) == 0)
+                                    dead = uniform(wp) < 2u * 64u * K * kMaxEmit ? ~0u : dead; // (two rounds of K x 64 states)
                                 now.y |= dead; // x > threshold never holds: no word leaves
                             }
                             enc_word_full<kSmall, kTrack>(x[K - 1 - step % K], now, wp, slot, worst);
@@ -1034,8 +1034,8 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                                 enc_byte_full_staged<kTrack>(x[K - 1 - step % K], now, lp, worst);
                             } else {
                                 if constexpr (SIZED) {
-                                    if (step % K == 0)
-                                        dead = uniform(wp) < 64u * K * kMaxEmit ? ~0u : dead;
+                                    if (step % (2 * K) == 0)
+                                        dead = uniform(wp) < 2u * 64u * K * kMaxEmit ? ~0u : dead;
                                     now.w |= dead; // x >= x_max never holds: no byte leaves
                                 }
                                 enc_byte_full(x[K - 1 - step % K], now, wp, slot, worst, swap_sel);
@@ -1045,8 +1045,10 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
                 } else {
 #pragma unroll
                     for (int J = 3; J >= 0; --J) {
-                        if constexpr (SIZED && !(kStageA && kSmall))
-                            dead = uniform(wp) < 64u * K * kMaxEmit ? ~0u : dead; // (a round of K x 64 states)
+                        if constexpr (SIZED && !(kStageA && kSmall)) {
+                            if (J & 1)
+                                dead = uniform(wp) < 2u * 64u * K * kMaxEmit ? ~0u : dead; // (two rounds of K x 64 states)
+                        }
 #pragma unroll
                         for (int k = K - 1; k >= 0; --k)
                             if constexpr (kStageA && kSmall)
