@@ -222,6 +222,19 @@ def test_sized_slots_u16_symbols_and_the_4096_symbol_alias_model(gpu, oracle):
     assert {5, 6, 7} <= set(over.tolist())
 
 
+@pytest.mark.parametrize("sb", [5, 20, 31])
+def test_sized_slots_rans64_search_variant(gpu, oracle, sb):
+    """rans64 outside 7..16 probability bits (the full-width encoder, symbols found by search in the decoder): sized slots,
+    the model's own size and a forced overflow."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(150000, K=20, s=1.0, seed=9)
+    om, gm = _models(ctx, oracle, FMT_R64, sb, data, nsyms=20)
+    for n_ways, chunk in ((64, 4096), (2, 512), (100, 3000)):
+        _check_sized(R, ctx, torch, oracle, FMT_R64, om, gm, data, n_ways, chunk)
+        over, _, _ = _check_sized(R, ctx, torch, oracle, FMT_R64, om, gm, data, n_ways, chunk, slot=64)
+        assert over.size >= (data.size + chunk - 1) // chunk - 1
+
+
 def test_sized_slots_inside_a_hip_graph(gpu, oracle):
     """Both launches (the coders and the redo pass) captured into one hipGraph and replayed on other data."""
     R, ctx, torch = gpu
