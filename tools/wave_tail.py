@@ -44,3 +44,12 @@ print("rounds per wave: min %d median %d max %d (= %.1f .. %.1f chunks)" % (roun
 # per SIMD-ish view: a CU's 32 waves are two blocks of 16; when does the LAST wave of each CU end, when the first?
 per_block = rel_end.reshape(-1, 16)
 print("per block of 16 waves: first wave out at %.3f (mean), last at %.3f (mean) of the span" % (per_block.min(axis=1).mean(), per_block.max(axis=1).mean()))
+# who is fast?  rounds decoded per wave by position: wave slot inside the block (slot & 3 = SIMD), block parity, XCD
+w = rows[:, 0].astype(np.int64)
+slot, blk = w % 16, w // 16
+for name, key in (("wave slot in its block", slot), ("SIMD (slot & 3)", slot & 3), ("block parity", blk & 1), ("XCD", xcd.astype(np.int64)),
+                  ("block index mod 8", blk % 8)):
+    print("rounds per wave by %s:" % name, " ".join("%d:%.0f" % (k, rounds[key == k].mean()) for k in np.unique(key)))
+cu = blk // 2
+per_cu = np.array([rounds[cu == c].sum() for c in np.unique(cu)])
+print("rounds per CU (pair of blocks): min %.0f median %.0f max %.0f" % (per_cu.min(), np.median(per_cu), per_cu.max()))
