@@ -1048,7 +1048,10 @@ int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t sr
         cp.src_offsets = d_src_offsets;
         cp.src_limit = (reinterpret_cast<uint64_t>(d_src) + src_bytes + 15u) & ~uint64_t(15);
         cp.src_bytes = src_bytes;
-        cp.slot_bytes = n_chunks >= 4096 ? 4096 : 1u << 20; // (many chunks: most likely small ones -- 16 lanes per chunk)
+        // kernel choice (launch_compact: "slots" of at most 8 KiB take 16 lanes per chunk, larger ones a wave): the lengths
+        // live on the device, but the source cannot hold chunks longer than src_bytes / n_chunks on average -- round 4 went by
+        // the chunk COUNT alone and gave a 1 GiB container of 13 KB chunks the small-chunk kernel (0.82 ms; 0.33 with a wave each)
+        cp.slot_bytes = (src_bytes / n_chunks <= 2048) ? 4096 : 1u << 20;
         cp.lengths = d_lengths;
         cp.offsets = d_dst_offsets;
         cp.out = static_cast<uint8_t *>(d_dst);
