@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUNDS = float(1 << 24)  # 64-symbol rounds of a 1 GiB launch
+ROUNDS = float(1 << 24)  # 64-symbol rounds of a 1 GiB launch (config 4: 512 Mi symbols = 2^23 rounds: its per-round columns read double)
 
 SETS = [  # (summary file suffix, title)
     ("", "k_decode_word64 (headline)"),
@@ -17,6 +17,9 @@ SETS = [  # (summary file suffix, title)
     ("byte", "k_decode<byte> (scale_bits 14)"),
     ("encw", "k_encode<word>, slot layout (16-byte records)"),
     ("encb", "k_encode<byte>, slot layout (mirrored sub-step)"),
+    ("encw3", "k_encode<word>, SIZED slots (MODE 3: exact room check where the staged stream is flushed)"),
+    ("encc4", "k_encode<alias, LDS remap>, config 4, slot layout"),
+    ("encc43", "k_encode<alias, LDS remap>, config 4, SIZED slots (MODE 3: room check before every pair of rounds)"),
 ]
 
 
