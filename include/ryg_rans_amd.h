@@ -105,7 +105,7 @@ typedef enum rans_amd_table {
  * before switching streams).  Concurrent streams want one context each.  Models are immutable, may be
  * used from any stream, and may be destroyed after the context they were created with.
  *
- * hipGraph capture: rans_amd_encode / rans_amd_encode_slots / rans_amd_container_compact / rans_amd_decode (and the
+ * hipGraph capture: rans_amd_encode / rans_amd_encode_slots[_sized] / rans_amd_container_compact / rans_amd_decode (and the
  * _adaptive pair) may be called while `stream` is being captured -- kernels and nothing else go into the graph (workspace
  * words are cleared by a kernel of the library, not by memset nodes), and a replay does what the call did, on the same
  * buffers.  Rules: the host result pointer (h_total_bytes / h_bad_chunks) must be NULL (fetch with
@@ -302,7 +302,7 @@ int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t sr
                                const uint32_t *d_lengths, uint64_t n_chunks, void *d_dst, uint64_t dst_cap,
                                uint64_t *d_dst_offsets, uint64_t *h_total_bytes, void *stream);
 
-/* Synchronise `stream` and report how the last rans_amd_encode / rans_amd_encode_slots / rans_amd_encode_adaptive of this
+/* Synchronise `stream` and report how the last rans_amd_encode / rans_amd_encode_slots[_sized] / rans_amd_encode_adaptive[_fmt] of this
  * context -- and the last rans_amd_container_compact, which keeps a verdict of its own -- ended when they were called
  * without h_total_bytes (asynchronously, or as graph nodes): RANS_AMD_OK, RANS_AMD_E_MODEL (a symbol with frequency 0),
  * RANS_AMD_E_SPACE (out_cap / dst_cap too small) or RANS_AMD_E_HIP.  The container size is d_offsets[n_chunks]. */
