@@ -43,6 +43,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0  # measured float4 streaming copy (same guide)
 MAX_CLOCK_HZ = 2.4e9
 MAX_LINE_BYTES = 3800   # the judged stdout line (tests/test_bench_cpu.py pins it; the driver keeps ~8 KB of stdout)
+PLACEMENT_STRIDE = [24 << 30]  # bytes between placement candidates in allocation order (--placement-stride-gib)
 WAVES_PER_SIMD = 8      # resident waves per SIMD of the wave-per-chunk decoder (2 blocks x 16 waves per CU)
 
 
@@ -89,6 +90,10 @@ def parse_args():
                          "on every pair for a few launches and keep the fastest pair -- MI355X memory comes in two classes and "
                          "a kernel that streams one buffer in and another out is 4-6 %% faster when the two lie in different "
                          "ones (profiles/r04_allocation.md); 1 = take what the allocator returns first (rounds 1-3)")
+    ap.add_argument("--placement-stride-gib", type=int, default=24, metavar="G",
+                    help="allocate the placement candidates G GiB apart in allocation order (spacer allocations held during the "
+                         "probe, never touched; 0 = one after the other, what round 4 did): a class of device memory is a window of "
+                         "30-60 GiB of allocation order (profiles/r05_class_map.md)")
     ap.add_argument("--placement-spread", type=float, default=1.02, metavar="R",
                     help="setup (untimed): when the slowest probed pair is within this factor of the fastest, every candidate "
                          "lies in one class of memory -- keep them and allocate another round of candidates (twice at most)")
@@ -186,7 +191,7 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
     round trip verified.  Returns (entry, artefacts for the CPU-side oracle check).  probe > 1: every timed call first
     chooses the buffer it WRITES among `probe` candidate allocations -- the decode the (container, output) pair among two
     copies of the container and `probe` outputs (ryg_rans_amd/placement.py; untimed)."""
-    from ryg_rans_amd.placement import choose_one
+    from ryg_rans_amd.placement import choose_one, spaced
     n = 1 << log2n
     sym_bytes = 1 if K <= 256 else 2
     trace("config", short, "n", n)
@@ -203,15 +208,16 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
         # the decode reads one buffer and writes another: the PAIR decides (two memory classes, profiles/r04_allocation.md),
         # so a second copy of the container is a candidate as well
         from ryg_rans_amd.placement import choose_pair
-        conts = [cont, cont.clone()]
-        outs = [out] + [torch.empty_like(d_syms) for _ in range(probe - 1)]
+        outs, sp = spaced(torch, lambda: torch.empty_like(d_syms), probe, device, first=out, stride_bytes=PLACEMENT_STRIDE[0])
+        conts = [cont, cont.clone()]  # (the copy: at the far end of the spaced outputs)
         settle(torch, lambda: ctx.decode(model, cont, total, offs, lens, n, ways, chunk, d_out=out, sync=False))
         ci, oi, matrix = choose_pair(torch, lambda c, o: ctx.decode(model, c, total, offs, lens, n, ways, chunk, d_out=o, sync=False),
                                      conts, outs)
         cont_dec, out = conts[ci], outs[oi]
         placement["decode_probe_ms"] = [[round(v, 4) for v in row] for row in matrix]
         placement["decode_chosen"] = [ci, oi]
-        del conts, outs
+        del conts, outs, sp
+        torch.cuda.empty_cache()
     trace(" decode")
     dec_ms, dec_min = timed_launches(
         torch, lambda: ctx.decode(model, cont_dec, total, offs, lens, n, ways, chunk, d_out=out, sync=False), steps, 2)
@@ -222,13 +228,15 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
     trace(" encode (compact)")
     cont2, offs2, lens2 = torch.empty_like(cont), torch.empty_like(offs), torch.empty_like(lens)
     if probe > 1:
-        c2s = [cont2] + [torch.empty_like(cont) for _ in range(2 * probe - 1)]  # (the compact encoders are the most placement-sensitive calls: 10-12 %)
+        # (the compact encoders are the most placement-sensitive calls: 10-12 %)
+        c2s, sp = spaced(torch, lambda: torch.empty_like(cont), 2 * probe, device, first=cont2, stride_bytes=PLACEMENT_STRIDE[0])
         settle(torch, lambda: ctx.encode(model, d_syms, ways, chunk, d_out=cont2, sync=False, d_offsets=offs2, d_lengths=lens2))
         pick, ms = choose_one(torch, lambda c: ctx.encode(model, d_syms, ways, chunk, d_out=c, sync=False, d_offsets=offs2,
                                                           d_lengths=lens2), c2s)
         cont2 = c2s[pick]
         placement["encode_compact_probe_ms"] = [round(v, 4) for v in ms]
-        del c2s
+        del c2s, sp
+        torch.cuda.empty_cache()
     enc_ms, enc_min = timed_launches(
         torch, lambda: ctx.encode(model, d_syms, ways, chunk, d_out=cont2, sync=False, d_offsets=offs2, d_lengths=lens2),
         steps, 2)
@@ -244,13 +252,14 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
     s_cont, s_offs, s_lens, s_total = ctx.encode_slots(model, d_syms, ways, chunk)
     slot = R.slot_bytes(fmt, n, ways, chunk)
     if probe > 1:
-        scs = [s_cont] + [torch.empty_like(s_cont) for _ in range(min(probe, 4) - 1)]
+        scs, sp = spaced(torch, lambda: torch.empty_like(s_cont), min(probe, 4), device, first=s_cont, stride_bytes=PLACEMENT_STRIDE[0])
         settle(torch, lambda: ctx.encode_slots(model, d_syms, ways, chunk, d_out=s_cont, sync=False, d_offsets=s_offs, d_lengths=s_lens))
         pick, ms = choose_one(torch, lambda c: ctx.encode_slots(model, d_syms, ways, chunk, d_out=c, sync=False, d_offsets=s_offs,
                                                                 d_lengths=s_lens), scs)
         s_cont = scs[pick]
         placement["encode_slots_probe_ms"] = [round(v, 4) for v in ms]
-        del scs
+        del scs, sp
+        torch.cuda.empty_cache()
     s_enc_ms, s_enc_min = timed_launches(
         torch, lambda: ctx.encode_slots(model, d_syms, ways, chunk, d_out=s_cont, sync=False, d_offsets=s_offs, d_lengths=s_lens),
         steps, 2)
@@ -268,14 +277,15 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
     trace(" encode_sized")
     t_cont, t_offs, t_lens, t_total, t_slot = ctx.encode_sized(model, d_syms, ways, chunk)
     if probe > 1:
-        tcs = [t_cont] + [torch.empty_like(t_cont) for _ in range(min(probe, 4) - 1)]
+        tcs, sp = spaced(torch, lambda: torch.empty_like(t_cont), min(probe, 4), device, first=t_cont, stride_bytes=PLACEMENT_STRIDE[0])
         settle(torch, lambda: ctx.encode_sized(model, d_syms, ways, chunk, slot=t_slot, d_out=t_cont, sync=False, d_offsets=t_offs,
                                                d_lengths=t_lens))
         pick, ms = choose_one(torch, lambda c: ctx.encode_sized(model, d_syms, ways, chunk, slot=t_slot, d_out=c, sync=False,
                                                                 d_offsets=t_offs, d_lengths=t_lens), tcs)
         t_cont = tcs[pick]
         placement["encode_tight_probe_ms"] = [round(v, 4) for v in ms]
-        del tcs
+        del tcs, sp
+        torch.cuda.empty_cache()
     t_enc_ms, t_enc_min = timed_launches(
         torch, lambda: ctx.encode_sized(model, d_syms, ways, chunk, slot=t_slot, d_out=t_cont, sync=False, d_offsets=t_offs,
                                         d_lengths=t_lens), steps, 2)
@@ -645,7 +655,8 @@ def judged_line(full, details_path=None):
         n_sym = c.get("symbols_per_gpu") or 0
         line["placement"] = {"chosen_ms": pl["probe_ms_chosen"], "first_pair_ms": pl["probe_ms_first_pair"],
                              "min_ms": pl["probe_ms_min"], "max_ms": pl["probe_ms_max"],
-                             "pairs": pl["candidates"]["containers"] * pl["candidates"]["outputs"]}
+                             "pairs": pl["candidates"]["containers"] * pl["candidates"]["outputs"],
+                             "stride_gib": pl.get("stride_gib", 0)}
         if (full.get("n_gpus") or 1) == 1 and pl["probe_ms_first_pair"] > 0:
             line["value_first_pair"] = round(n_sym / pl["probe_ms_first_pair"] / 1e6, 2)
             line["frac_first_pair"] = round(rl.get("algorithmic_bytes_per_launch", 0) / pl["probe_ms_first_pair"] / 1e6
@@ -787,6 +798,9 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.all_on_device is not None:  # (ranks that share a device share its memory: no spacers)
+        args.placement_stride_gib = 0
+    PLACEMENT_STRIDE[0] = args.placement_stride_gib << 30
     fmt = {"word": R.FMT_WORD, "byte": R.FMT_BYTE, "r64": R.FMT_R64, "alias": R.FMT_ALIAS}[args.format]
     sb = args.scale_bits or {"word": 12, "byte": 14, "r64": 14, "alias": 16}[args.format]
     n = 1 << args.log2n
@@ -815,8 +829,21 @@ def main():
         # Setup, untimed: where the buffers lie is worth 4-6 % on this part (two classes of device memory; container and
         # output in DIFFERENT classes is the fast case, profiles/r04_allocation.md), and which class an allocation gets is
         # the driver's choice.  Allocate candidates, let the clocks settle on the first pair, time every pair, keep the best.
-        conts = [cont] + [cont.clone() for _ in range(2)]
-        outs = [out] + [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(args.placement_candidates - 1)]
+        # (round 5, profiles/r05_class_map.md: a class is a WINDOW of 30-60 GiB of allocation order, so candidates allocated
+        #  one after the other mostly share one -- they are allocated --placement-stride-gib apart, with copies of the
+        #  container a third and two thirds of the way; the spacers in between are never touched and freed with the rest)
+        from ryg_rans_amd.placement import spaced
+        conts, made = [cont], [1]
+
+        def next_out():
+            if made[0] in (args.placement_candidates // 3, 2 * args.placement_candidates // 3):
+                conts.append(cont.clone())
+            made[0] += 1
+            return torch.empty(n, dtype=torch.uint8, device=device)
+        outs, spacers = spaced(torch, next_out, args.placement_candidates, device, first=out,
+                               stride_bytes=args.placement_stride_gib << 30)
+        while len(conts) < 3:
+            conts.append(cont.clone())
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
             for _ in range(16):
@@ -834,14 +861,18 @@ def main():
                 break
             extended += 1
             conts += [cont.clone() for _ in range(2)]
-            outs += [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(args.placement_candidates)]
+            more, sp = spaced(torch, lambda: torch.empty(n, dtype=torch.uint8, device=device), args.placement_candidates, device,
+                              stride_bytes=args.placement_stride_gib << 30, reserve_bytes=24 << 30)
+            outs += more
+            spacers += sp
         cont, out = conts[ci], outs[oi]
         placement = {"candidates": {"containers": len(conts), "outputs": len(outs), "extended": extended}, "chosen": [ci, oi],
                      "probe_ms_chosen": round(matrix[ci][oi], 4), "probe_ms_min": round(min(flat), 4),
                      "probe_ms_max": round(max(flat), 4), "probe_ms_first_pair": round(matrix[0][0], 4),
                      "probe_ms": [[round(v, 4) for v in row] for row in matrix],
                      "note": "setup, untimed: 6 launches x 2 sweeps per pair; the other candidates are freed before the timed region"}
-        del conts, outs
+        placement["stride_gib"] = args.placement_stride_gib if spacers else 0
+        del conts, outs, spacers
         torch.cuda.empty_cache()
     if args.debug_cont_offset:
         moved = torch.empty(cont.numel() + args.debug_cont_offset, dtype=torch.uint8, device=device)[args.debug_cont_offset:]

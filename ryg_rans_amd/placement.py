@@ -8,7 +8,38 @@ the XOR pattern; the counters that move are the memory-side read latency -- TCC_
 is the driver's choice (its position in the physical address space); hipMalloc has no knob for it.  What a caller that
 owns its buffers for a while CAN do is what this module does: allocate a few candidates, time the real call on each
 pair for a few launches, keep the fastest pair, free the rest.
+
+Round 5 mapped the classes over 240 GiB of allocation order (tools/class_map.py, profiles/r05_class_map.md): they are WINDOWS
+of 30-60 GiB, a container collides (+5-6 %) with the outputs of its own window and of one or two others -- a third of all
+pairs -- and buffers allocated one after the other lie in the same window, so the pair a fresh process gets first is more
+often slow than not, and two dozen candidates allocated in a row can all be.  Candidates therefore have to be FAR apart in
+allocation order: `spaced()` below holds spacer allocations between them while they are allocated.
 """
+
+
+def spaced(torch, make, k, device, first=None, stride_bytes=24 << 30, reserve_bytes=48 << 30):
+    """k buffers -- `first` (if given) and make() for the rest -- about `stride_bytes` apart in allocation order.  Returns
+    (buffers, spacers): keep `spacers` alive until every candidate of the probe is allocated, then drop them (they are never
+    touched).  The stride shrinks so that the spacers leave `reserve_bytes` of the device's free memory alone."""
+    bufs = [first if first is not None else make()]
+    size = bufs[0].numel() * bufs[0].element_size()
+    free = torch.cuda.mem_get_info(device)[0]
+    gap = min(stride_bytes, max(0, (free - reserve_bytes) // max(k - 1, 1))) - size
+    spacers = []
+    for _ in range(k - 1):
+        if gap >= (1 << 30):
+            try:
+                spacers.append(torch.empty(gap, dtype=torch.uint8, device=device))
+            except torch.OutOfMemoryError:  # (somebody else took the memory meanwhile: the rest in a row)
+                gap = 0
+        try:
+            bufs.append(make())
+        except torch.OutOfMemoryError:  # (the candidates matter, the spacing does not)
+            del spacers[:]
+            gap = 0
+            torch.cuda.empty_cache()
+            bufs.append(make())
+    return bufs, spacers
 
 
 def time_launches(torch, fn, launches=6, warm=2):

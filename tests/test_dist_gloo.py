@@ -200,7 +200,9 @@ def test_bench_placement_probe_allocates_more_when_all_candidates_look_alike():
     assert 0 <= p["chosen"][0] < 7 and 0 <= p["chosen"][1] < 6
     assert p["probe_ms_chosen"] == p["probe_ms_min"] and line["bit_exact_roundtrip"] is True
     assert line["placement"] == {"chosen_ms": p["probe_ms_chosen"], "first_pair_ms": p["probe_ms_first_pair"],
-                                 "min_ms": p["probe_ms_min"], "max_ms": p["probe_ms_max"], "pairs": 42}
+                                 "min_ms": p["probe_ms_min"], "max_ms": p["probe_ms_max"], "pairs": 42,
+                                 "stride_gib": p["stride_gib"]}
+    assert p["stride_gib"] == 24  # (candidates 24 GiB apart in allocation order: profiles/r05_class_map.md)
     # the default spread on a small run: whatever the probe saw, the record carries the counts
     argv[-1] = "1.02"
     line, d, out = _run_bench(argv, env)
