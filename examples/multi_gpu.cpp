@@ -153,9 +153,23 @@ void run_rank(Rank &r)
         R_CHECK(rans_amd_encode(ctx, model, d_in, n, n_ways, chunk, d_cont, cap, d_off, d_len, &total, stream));
         {   // Setup: where the two buffers of a streaming decode lie is worth 4-6 % on this part and hipMalloc cannot be
             // steered (include/ryg_rans_amd.h, rans_amd_probe_placement) -- a second copy of the container and two more
-            // outputs, the library times the six pairs, the fastest pair is the one the timed loop uses.
+            // outputs, the library times the six pairs, the fastest pair is the one the timed loop uses.  The candidates
+            // are allocated ~20 GiB APART (spacer allocations nobody touches, freed after the probe): a class of device
+            // memory is a window of 20-60 GiB of allocation order, buffers allocated in a row share one
+            // (profiles/r05_class_map.md).
+            void *spacer[2] = {nullptr, nullptr};
+            auto space = [&](int i) {
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < ((size_t)96 << 30)) return;
+                if (hipMalloc(&spacer[i], (size_t)20 << 30) != hipSuccess) { // (another rank of this device was faster)
+                    spacer[i] = nullptr;
+                    (void)hipGetLastError();
+                }
+            };
+            space(0);
             R_HIP(hipMalloc((void **)&d_cont2, cap + 256));
             R_HIP(hipMalloc((void **)&d_out2, n + 256));
+            space(1);
             R_HIP(hipMalloc((void **)&d_out3, n + 256));
             R_HIP(hipMemcpyAsync(d_cont2, d_cont, total, hipMemcpyDeviceToDevice, stream));
             const void *conts[2] = {d_cont, d_cont2};
@@ -167,6 +181,8 @@ void run_rank(Rank &r)
             r.chosen_ms = ms[bc * 3 + bo];
             std::swap(d_cont, bc ? d_cont2 : d_cont); // (the kept pair in d_cont / d_out; everything is freed at the end)
             std::swap(d_out, bo == 1 ? d_out2 : (bo == 2 ? d_out3 : d_out));
+            for (void *sp : spacer)
+                if (sp) (void)hipFree(sp);
         }
         // warm-up, then `steps` timed decodes of the whole shard (device resident in, device resident out)
         for (int i = 0; i < 3; ++i)
