@@ -54,16 +54,17 @@
 extern "C" {
 #endif
 
-/* 0.5.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
+/* 0.6.0: additions only since 0.1.0 -- rans_amd_ctx_set_option, rans_amd_build_flags (0.2.0); rans_amd_encode_status, calls
  * inside a hipGraph capture (0.3.0); rans_amd_encode_slots + rans_amd_slot_bytes / rans_amd_encode_slots_bound,
  * rans_amd_container_compact, rans_amd_container_slice, chunk offsets on any multiple of the format's unit in every decoder
  * (0.4.0); rans_amd_encode_slots_sized + rans_amd_tight_slot_bytes / rans_amd_encode_sized_bound, rans_amd_probe_placement,
- * rans_amd_encode_adaptive_fmt / rans_amd_decode_adaptive_fmt (0.5.0).  A caller built
+ * rans_amd_encode_adaptive_fmt / rans_amd_decode_adaptive_fmt (0.5.0); rans_amd_encode_adaptive_sized,
+ * rans_amd_container_pack_indexed[_adaptive] (0.6.0).  A caller built
  * against an older header keeps working, with two behaviour changes it can observe: since 0.4.0
  * rans_amd_container_parse[_adaptive] want a 4-byte aligned `src` (RANS_AMD_E_ARG otherwise; an mmap at an odd offset must
  * be copied first), and since 0.5.0 rans_amd_container_compact checks its SOURCE index against src_bytes
  * (RANS_AMD_E_CORRUPT for an entry outside the source, which earlier versions read). */
-#define RANS_AMD_VERSION 500
+#define RANS_AMD_VERSION 600
 
 typedef enum rans_amd_status {
     RANS_AMD_OK = 0,
@@ -393,6 +394,28 @@ int rans_amd_decode_adaptive_fmt(rans_amd_ctx *ctx, int format, const void *d_co
                                  const uint64_t *d_offsets, const uint32_t *d_lengths, const uint16_t *d_chunk_freqs,
                                  uint64_t n, uint32_t n_ways, uint32_t chunk_syms, uint32_t scale_bits, void *d_out,
                                  uint64_t *h_bad_chunks, void *stream);
+
+/* The same encode as ONE kernel (0.6.0; the recommended entry point).  The wavefront that codes a chunk first counts it,
+ * normalises the counts, builds its records and codes the chunk -- and because it knows the chunk's histogram BEFORE it
+ * codes, it knows an upper bound of the chunk's stream (sum count[s] * log2(M / freq[s]) bits, what the floor of the rANS
+ * update can add, the flushed states) and takes exactly that much room: no scratch trip, no layout pass, no compaction, no
+ * second launch.  Where the chunks lie:
+ *   slot_bytes == 0   every chunk is a piece of `d_out` handed out in the order the coders ask (one atomic add): the
+ *                     container is about as large as the streams (+ ~1.5 %), its chunks in no particular order;
+ *   slot_bytes  > 0   (a multiple of 64) chunk c is the LAST d_lengths[c] bytes of slot c -- deterministic, as
+ *                     rans_amd_encode_slots_sized -- whenever its bound fits the slot; the others lie behind the slots,
+ *                     handed out as above.
+ * d_offsets / d_lengths say where (any decoder takes such an index; rans_amd_container_compact /
+ * rans_amd_container_pack_indexed bring the chunks into index order); d_offsets[n_chunks] = bytes of `d_out` in use.
+ * out_cap: rans_amd_encode_adaptive_sized_bound() can never be exceeded; a smaller buffer works as long as the pieces fit
+ * (RANS_AMD_E_SPACE from the call or from rans_amd_encode_status otherwise).  Every chunk's bytes and its row of
+ * d_chunk_freqs equal those of rans_amd_encode_adaptive_fmt.  (The first call of a context uploads a 32 KiB table: make
+ * one call outside a hipGraph capture first.) */
+int rans_amd_encode_adaptive_sized(rans_amd_ctx *ctx, int format, const void *d_syms, uint64_t n, uint32_t n_ways,
+                                   uint32_t chunk_syms, uint32_t scale_bits, uint64_t slot_bytes, void *d_out, uint64_t out_cap,
+                                   uint64_t *d_offsets, uint32_t *d_lengths, uint16_t *d_chunk_freqs, uint64_t *h_total_bytes,
+                                   void *stream);
+uint64_t rans_amd_encode_adaptive_sized_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms);
 
 /* ---- host-buffer convenience: one raw reference-format stream -------------- */
 

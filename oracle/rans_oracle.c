@@ -581,6 +581,82 @@ int64_t orc_compare_chunks(int fmt, const orc_model *m, const void *syms, size_t
     return bad;
 }
 
+/* one chunk as its own input: main.cpp:139-162 (count_freqs, normalize_freqs, tables), then the N-way encoder loop */
+static int adaptive_chunk(int fmt, const uint8_t *part, size_t cnt, uint32_t n_ways, uint32_t scale_bits, uint8_t *tmp,
+                          size_t bound, size_t *len, uint32_t *freqs /* [256] */)
+{
+    uint32_t cum[257];
+    orc_count_freqs(part, cnt, 1, 256, freqs);
+    int rc = orc_normalize_freqs(freqs, cum, 256, 1u << scale_bits);
+    if (rc)
+        return rc;
+    orc_model *m = orc_model_create(freqs, 256, scale_bits, 0);
+    if (!m)
+        return ORC_E_ARG;
+    rc = orc_encode(fmt, m, part, cnt, 1, n_ways, tmp, bound, len);
+    orc_model_destroy(m);
+    return rc;
+}
+
+int64_t orc_compare_chunks_adaptive(int fmt, const uint8_t *syms, size_t n, uint32_t n_ways, size_t chunk_syms,
+                                    uint32_t scale_bits, uint64_t c0, uint64_t c1, const uint8_t *container,
+                                    const uint64_t *offsets, const uint32_t *lengths, const uint16_t *rows)
+{
+    if (chunk_syms == 0 || c0 > c1 || (fmt != ORC_FMT_BYTE && fmt != ORC_FMT_WORD))
+        return -2;
+    size_t nchunks = (n + chunk_syms - 1) / chunk_syms;
+    if (c1 > nchunks)
+        return -2;
+    size_t bound = orc_stream_bound(fmt, chunk_syms < n ? chunk_syms : n, n_ways);
+    uint8_t *tmp = (uint8_t *)malloc(bound);
+    if (!tmp)
+        return -2;
+    int64_t bad = -1;
+    for (uint64_t c = c0; c < c1 && bad == -1; c++) {
+        size_t first = (size_t)c * chunk_syms;
+        size_t cnt = n - first < chunk_syms ? n - first : chunk_syms;
+        size_t len = 0;
+        uint32_t freqs[256];
+        int rc = adaptive_chunk(fmt, syms + first, cnt, n_ways, scale_bits, tmp, bound, &len, freqs);
+        if (rc) {
+            bad = -2;
+            break;
+        }
+        for (int s = 0; s < 256; s++)
+            if (rows[c * 256 + s] != freqs[s])
+                bad = (int64_t)(2 * c);
+        if (bad == -1 && (len != lengths[c] || memcmp(tmp + bound - len, container + offsets[c], len) != 0))
+            bad = (int64_t)(2 * c + 1);
+    }
+    free(tmp);
+    return bad;
+}
+
+int orc_encode_chunks_adaptive(int fmt, const uint8_t *syms, size_t n, uint32_t n_ways, size_t chunk_syms,
+                               uint32_t scale_bits, uint64_t c0, uint64_t c1, uint8_t *out, size_t slot,
+                               uint32_t *lengths, uint16_t *rows)
+{
+    if (chunk_syms == 0 || c0 > c1 || (fmt != ORC_FMT_BYTE && fmt != ORC_FMT_WORD))
+        return ORC_E_ARG;
+    size_t nchunks = (n + chunk_syms - 1) / chunk_syms;
+    size_t bound = orc_stream_bound(fmt, chunk_syms < n ? chunk_syms : n, n_ways);
+    if (c1 > nchunks || slot < bound)
+        return ORC_E_ARG;
+    for (uint64_t c = c0; c < c1; c++) {
+        size_t first = (size_t)c * chunk_syms;
+        size_t cnt = n - first < chunk_syms ? n - first : chunk_syms;
+        size_t len = 0;
+        uint32_t freqs[256];
+        int rc = adaptive_chunk(fmt, syms + first, cnt, n_ways, scale_bits, out + (c - c0) * slot, slot, &len, freqs);
+        if (rc)
+            return rc;
+        lengths[c - c0] = (uint32_t)len;
+        for (int s = 0; s < 256; s++)
+            rows[(c - c0) * 256 + s] = (uint16_t)freqs[s];
+    }
+    return ORC_OK;
+}
+
 int orc_decode_chunked(int fmt, const orc_model *m, const uint8_t *container,
                        const uint64_t *offsets, const uint32_t *lengths, size_t n, int sym_bytes,
                        uint32_t n_ways, size_t chunk_syms, void *out)

@@ -95,6 +95,19 @@ int orc_encode_chunked(int fmt, const orc_model *m, const void *syms, size_t n, 
 int64_t orc_compare_chunks(int fmt, const orc_model *m, const void *syms, size_t n, int sym_bytes, uint32_t n_ways,
                            size_t chunk_syms, uint64_t c0, uint64_t c1, const uint8_t *container,
                            const uint64_t *offsets, const uint32_t *lengths);
+/* Per-chunk models: every chunk is coded as the reference codes an input -- count_freqs, normalize_freqs to
+ * 1 << scale_bits, tables, the N-way loop (main.cpp:139-162 / main_simd.cpp:138-143 with the chunk as the input).
+ * Chunks [c0, c1) of somebody else's container: rows[c] must be normalize(count(chunk c)) (u16[256] per chunk) and the
+ * stream at offsets[c] the oracle's stream of chunk c under that model.  Returns -1 when all are equal, -2 on a bad
+ * argument, else 2 * c (row of chunk c differs) or 2 * c + 1 (stream or length of chunk c differs).  Thread-safe. */
+int64_t orc_compare_chunks_adaptive(int fmt, const uint8_t *syms, size_t n, uint32_t n_ways, size_t chunk_syms,
+                                    uint32_t scale_bits, uint64_t c0, uint64_t c1, const uint8_t *container,
+                                    const uint64_t *offsets, const uint32_t *lengths, const uint16_t *rows);
+/* The oracle's own container of per-chunk models for chunks [c0, c1): stream of chunk c at out + (c - c0) * slot (slot =
+ * orc_stream_bound of a chunk, rounded up to 16) -- lengths[c - c0] bytes ENDING at the slot's end -- and rows[c - c0]. */
+int orc_encode_chunks_adaptive(int fmt, const uint8_t *syms, size_t n, uint32_t n_ways, size_t chunk_syms,
+                               uint32_t scale_bits, uint64_t c0, uint64_t c1, uint8_t *out, size_t slot,
+                               uint32_t *lengths, uint16_t *rows);
 int orc_decode_chunked(int fmt, const orc_model *m, const uint8_t *container,
                        const uint64_t *offsets, const uint32_t *lengths, size_t n, int sym_bytes,
                        uint32_t n_ways, size_t chunk_syms, void *out);

@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "rans_amd_launch_spans",
     "rans_amd_chunk_freqs_bytes", "rans_amd_encode_adaptive", "rans_amd_decode_adaptive",
     "rans_amd_encode_adaptive_fmt", "rans_amd_decode_adaptive_fmt",
+    "rans_amd_encode_adaptive_sized", "rans_amd_encode_adaptive_sized_bound",
     "rans_amd_container_bytes_adaptive", "rans_amd_container_pack_adaptive", "rans_amd_container_parse_adaptive",
     "rans_amd_offsets_from_lengths", "rans_amd_container_bytes", "rans_amd_container_pack",
     "rans_amd_container_parse", "rans_amd_encode_workspace_bytes", "rans_amd_build_model_o0",
@@ -138,6 +139,8 @@ def _load():
         "rans_amd_decode_adaptive": (i32, [vp, vp, u64, vp, vp, vp, u64, u32, u32, u32, vp, u64p, vp]),
         "rans_amd_encode_adaptive_fmt": (i32, [vp, i32, vp, u64, u32, u32, u32, vp, u64, vp, vp, vp, u64p, vp]),
         "rans_amd_decode_adaptive_fmt": (i32, [vp, i32, vp, u64, vp, vp, vp, u64, u32, u32, u32, vp, u64p, vp]),
+        "rans_amd_encode_adaptive_sized": (i32, [vp, i32, vp, u64, u32, u32, u32, u64, vp, u64, vp, vp, vp, u64p, vp]),
+        "rans_amd_encode_adaptive_sized_bound": (u64, [i32, u64, u32, u32]),
         "rans_amd_encode_workspace_bytes": (u64, [i32, u64, u32, u32]),
         "rans_amd_build_model_o0": (i32, [vp, i32, vp, u64, i32, u32, u32, u32p, C.POINTER(vp), vp]),
         "rans_amd_offsets_from_lengths": (i32, [u32p, u64, u64p]),
@@ -467,6 +470,32 @@ class Context:
                                                    d_out.data_ptr(), d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
                                                    d_freqs.data_ptr(), C.byref(total) if sync else None, _torch_stream())
         _check(rc, "encode_adaptive")
+        return d_out, d_offsets, d_lengths, d_freqs, (total.value if sync else None)
+
+    def encode_adaptive_sized(self, d_syms, n_ways, chunk_syms, scale_bits, fmt=FMT_BYTE, slot=0, cap=None, d_out=None, sync=True,
+                              d_offsets=None, d_lengths=None, d_freqs=None):
+        """rans_amd_encode_adaptive_sized: count + normalise + code in one kernel; a chunk lies where its own bound put it
+        (slot > 0: at the end of slot c when that bound fits).  cap: bytes of the container buffer (default: the bound no
+        input can exceed).  Returns (d_container, d_offsets, d_lengths, d_chunk_freqs, total_bytes)."""
+        import torch
+        n = d_syms.numel()
+        nchunks = num_chunks(n, chunk_syms)
+        dev = d_syms.device
+        if d_out is None:
+            if cap is None:
+                cap = int(_lib.rans_amd_encode_adaptive_sized_bound(fmt, n, n_ways, chunk_syms)) + nchunks * slot
+            d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        if d_offsets is None:
+            d_offsets = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
+        if d_lengths is None:
+            d_lengths = torch.zeros(max(nchunks, 1), dtype=torch.int32, device=dev)
+        if d_freqs is None:
+            d_freqs = torch.zeros(max(nchunks, 1) * 256, dtype=torch.int16, device=dev)
+        total = C.c_uint64(0)
+        _check(_lib.rans_amd_encode_adaptive_sized(self._h, fmt, d_syms.data_ptr(), n, n_ways, chunk_syms, scale_bits, slot,
+                                                   d_out.data_ptr(), d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
+                                                   d_freqs.data_ptr(), C.byref(total) if sync else None, _torch_stream()),
+               "encode_adaptive_sized")
         return d_out, d_offsets, d_lengths, d_freqs, (total.value if sync else None)
 
     def decode_adaptive(self, d_container, container_bytes, d_offsets, d_lengths, d_freqs, n, n_ways, chunk_syms,

@@ -111,6 +111,7 @@ struct rans_amd_ctx {
     DeviceBuffer enc_status;  // fused encoder: look-back word per chunk + the claim counters (EncParams::status)
     DeviceBuffer enc_mailboxes; // fused encoder whose tables fill the LDS: one mailbox per block (EncParams::mailbox_global)
     DeviceBuffer wave_scratch; // one 64-byte line per resident decoder wave (DecParams::wave_scratch)
+    DeviceBuffer adapt_rcp;    // reciprocals by frequency for the fused per-chunk-model encoder (AdaptEncParams::rcp); built once, kept
     DeviceBuffer host_in, host_out, host_idx; // staging of the *_host wrappers, kept between calls (under host_mu)
     std::mutex host_mu;
     DeviceBuffer trace;       // per-wave clock records (rans_amd_set_timing(ctx, 2) / RANS_AMD_TRACE)
@@ -350,6 +351,7 @@ int rans_amd_ctx_destroy(rans_amd_ctx *ctx)
     ctx->host_idx.release();
     ctx->trace.release();
     ctx->wave_scratch.release();
+    ctx->adapt_rcp.release();
     if (ctx->d_words)
         (void)hipFree(ctx->d_words);
     for (int i = 0; i < 4; ++i)
@@ -1581,6 +1583,106 @@ static int decode_adaptive_impl(rans_amd_ctx *ctx, const int format, const void 
     return RANS_AMD_OK;
 }
 
+// rans_amd_encode_adaptive_sized: the whole per-chunk-model encode as ONE kernel (encode_adaptive.hip)
+static int encode_adaptive_sized_impl(rans_amd_ctx *ctx, const int format, const void *d_syms, uint64_t n, uint32_t n_ways,
+                                      uint32_t chunk_syms, uint32_t scale_bits, uint64_t slot_bytes, void *d_out, uint64_t out_cap,
+                                      uint64_t *d_offsets, uint32_t *d_lengths, uint16_t *d_chunk_freqs, uint64_t *h_total_bytes,
+                                      void *stream)
+{
+    if (!ctx || !d_out || !d_offsets || !d_lengths || !d_chunk_freqs || (n && !d_syms) || chunk_syms == 0)
+        return fail(RANS_AMD_E_ARG, "encode_adaptive_sized: NULL argument or chunk_syms == 0");
+    if (int rc = adaptive_format_check(format, scale_bits, "encode_adaptive_sized"))
+        return rc;
+    if ((reinterpret_cast<uintptr_t>(d_chunk_freqs) & 7u) != 0) // (a row is written with 8-byte stores per lane)
+        return fail(RANS_AMD_E_ARG, "encode_adaptive_sized: d_chunk_freqs must be 8-byte aligned");
+    if (!ways_supported(format, n_ways))
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive_sized: n_ways must be in 1..512");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0)
+        return fail(RANS_AMD_E_ARG, "encode_adaptive_sized: d_out must be 16-byte aligned");
+    if ((slot_bytes & 63u) != 0 || slot_bytes > 0xffffffc0ull)
+        return fail(RANS_AMD_E_ARG, "encode_adaptive_sized: slot_bytes must be 0 or a multiple of 64 below 4 GiB");
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const CaptureScope capture(s);
+    if (capture.active && h_total_bytes)
+        return fail(RANS_AMD_E_ARG, "encode_adaptive_sized: h_total_bytes must be NULL while the stream is capturing");
+    const uint64_t worst = encode_slot_bytes(format, n, n_ways, chunk_syms);
+    if (worst > 0xfffffff0ull || nchunks >= (1ull << 32))
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive_sized: chunk_syms too large, or 2^32 chunks and more");
+    if (slot_bytes && (nchunks > (~0ull) / slot_bytes || out_cap < nchunks * slot_bytes)) // (known up front: nothing is launched)
+        return fail(RANS_AMD_E_SPACE, "encode_adaptive_sized: out_cap does not hold n_chunks * slot_bytes");
+    if (!ctx->adapt_rcp.ptr) { // reciprocals by frequency (model.cpp adapt_rcp_tables): built once per context
+        if (capture.active)
+            return fail(RANS_AMD_E_ARG, "encode_adaptive_sized: make the same call once outside the capture first (a table is uploaded on first use)");
+        std::vector<uint32_t> t;
+        adapt_rcp_tables(t);
+        int rc = ctx->adapt_rcp.reserve(t.size() * 4);
+        if (rc)
+            return rc;
+        const hipError_t e = hipMemcpy(ctx->adapt_rcp.ptr, t.data(), t.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            ctx->adapt_rcp.release();
+            return hip_fail(e, "encode_adaptive_sized: table upload");
+        }
+    }
+    // claim counters (a line each), the line of the waves that are done, the line of the byte counter behind the slots
+    const size_t ctl_bytes = (size_t)(kWorkPools + 2) * kWorkPoolStride * 4;
+    int rc = ctx->enc_status.reserve(ctl_bytes);
+    if (rc)
+        return rc;
+    {
+        ZeroList zero(s);
+        HIP_TRY(zero.add(ctx->d_enc_flags(), 12)); // (with the verdict of an older compaction, as encode_impl does)
+        HIP_TRY(zero.add(ctx->enc_status.ptr, ctl_bytes));
+        if (nchunks == 0)
+            HIP_TRY(zero.add(d_offsets, 8));
+        HIP_TRY(zero.flush());
+    }
+    if (nchunks) {
+        if (ctx->timing && !t_capturing)
+            HIP_TRY(hipEventRecord(ctx->ev[2], s));
+        AdaptEncParams ap{};
+        ap.syms = static_cast<const uint8_t *>(d_syms);
+        ap.n = n;
+        ap.nchunks = nchunks;
+        ap.chunk_syms = chunk_syms;
+        ap.n_ways = n_ways;
+        ap.scale_bits = scale_bits;
+        ap.worst_slot = (uint32_t)worst;
+        ap.out = static_cast<uint8_t *>(d_out);
+        ap.out_cap = out_cap;
+        ap.slot_bytes = slot_bytes;
+        ap.offsets = d_offsets;
+        ap.lengths = d_lengths;
+        ap.chunk_freqs = d_chunk_freqs;
+        ap.flags = ctx->d_enc_flags();
+        ap.claims = static_cast<unsigned int *>(ctx->enc_status.ptr);
+        ap.bump = reinterpret_cast<unsigned long long *>(static_cast<unsigned int *>(ctx->enc_status.ptr) + (kWorkPools + 1) * kWorkPoolStride);
+        ap.rcp = static_cast<const uint32_t *>(ctx->adapt_rcp.ptr);
+        HIP_TRY(launch_encode_adaptive(format, ap, ctx->num_cus, s, &ctx->last_enc_kernel));
+        ctx->last_enc_fused = false;
+        ctx->last_enc_slots = true;
+        if (ctx->timing && !t_capturing) {
+            HIP_TRY(hipEventRecord(ctx->ev[3], s));
+            ctx->enc_timed = true;
+        }
+    }
+    if (h_total_bytes) {
+        uint32_t flags = 0;
+        uint64_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&flags, ctx->d_enc_flags(), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&total, d_offsets + nchunks, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *h_total_bytes = total;
+        if (flags & 1u)
+            return fail(RANS_AMD_E_MODEL, "encode_adaptive_sized: a chunk's counts could not be normalised");
+        return encode_flags_status(flags);
+    }
+    return RANS_AMD_OK;
+}
+
 extern "C" {
 
 int rans_amd_encode_adaptive(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
@@ -1597,6 +1699,21 @@ int rans_amd_encode_adaptive_fmt(rans_amd_ctx *ctx, int format, const void *d_sy
 {
     return encode_adaptive_impl(ctx, format, d_syms, n, n_ways, chunk_syms, scale_bits, d_out, out_cap, d_offsets, d_lengths,
                                 d_chunk_freqs, h_total_bytes, stream);
+}
+
+int rans_amd_encode_adaptive_sized(rans_amd_ctx *ctx, int format, const void *d_syms, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
+                                   uint32_t scale_bits, uint64_t slot_bytes, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
+                                   uint32_t *d_lengths, uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream)
+{
+    return encode_adaptive_sized_impl(ctx, format, d_syms, n, n_ways, chunk_syms, scale_bits, slot_bytes, d_out, out_cap, d_offsets,
+                                      d_lengths, d_chunk_freqs, h_total_bytes, stream);
+}
+
+uint64_t rans_amd_encode_adaptive_sized_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
+{
+    // every chunk in a worst-case piece (a chunk's own bound never exceeds it): what no input can overflow
+    const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
+    return nchunks ? nchunks * encode_slot_bytes(format, n, n_ways, chunk_syms) : 16;
 }
 
 int rans_amd_decode_adaptive(rans_amd_ctx *ctx, const void *d_container, uint64_t container_bytes, const uint64_t *d_offsets,

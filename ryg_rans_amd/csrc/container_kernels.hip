@@ -465,23 +465,10 @@ hipError_t launch_compact(const CompactParams &p, int num_cus, hipStream_t strea
 // One model per CHUNK, built where the symbols are: one wave per chunk of u8 symbols counts them
 // (count_freqs, main.cpp:59-66; 256 counters in the wave's LDS) and normalises the counts to 1 << scale_bits exactly
 // as SymbolStats::normalize_freqs does (main.cpp:75-129; the width-based restatement of model.cpp normalize_freqs):
-//   edge[s]  = target * (counts[0] + .. + counts[s]) / total          (64-bit product, truncating division)
-//   width[s] = edge[s] - edge[s-1]
-//   every symbol that occurs but got width 0, in ascending order, takes one slot from the narrowest symbol wider than
-//   1 (lowest index on ties) -- a sequential repair: one wave-wide arg-min per squeezed symbol.
+//   (device_common.hpp adapt_normalize: edges by 64-bit scaling, then the sequential repair of squeezed symbols)
 // Lane l owns symbols 4l .. 4l+3 (the layout adapt_load_cum reads); the result is u16[256] per chunk.  A chunk that
 // cannot be normalised (more distinct symbols than slots) sets bit 0 of *flags.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
 __global__ void __launch_bounds__(256) k_chunk_models(const uint8_t *syms, uint64_t n, uint32_t chunk_syms, uint64_t nchunks,
                                                       uint32_t scale_bits, uint16_t *chunk_freqs, uint32_t *flags)
 {
@@ -542,55 +529,7 @@ __global__ void __launch_bounds__(256) k_chunk_models(const uint8_t *syms, uint6
             for (uint32_t k = 0; k < kCopies; ++k)
                 cnt[i] += h[k * kStride + 4u * lane + i];
         }
-        // inclusive running sums in symbol order; the total is the chunk's symbol count
-        const uint32_t own = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        uint32_t incl = own;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
-            incl += lane >= (uint32_t)d ? t : 0u;
-        }
-        uint32_t run = incl - own;
-        uint32_t edge[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            run += cnt[i];
-            edge[i] = (uint32_t)(((uint64_t)target * run) / nsym); // (nsym >= 1: a chunk holds at least one symbol)
-        }
-        uint32_t prev = (uint32_t)__shfl_up((int)edge[3], 1, 64);
-        prev = lane ? prev : 0u;
-        width[0] = edge[0] - prev;
-        width[1] = edge[1] - edge[0];
-        width[2] = edge[2] - edge[1];
-        width[3] = edge[3] - edge[2];
-        // repair, in ascending symbol order
-        bool failed = false;
-        for (;;) {
-            uint32_t mine = 256u; // this lane's lowest squeezed symbol
-#pragma unroll
-            for (int i = 3; i >= 0; --i)
-                mine = (cnt[i] != 0u && width[i] == 0u) ? 4u * lane + (uint32_t)i : mine;
-            const uint32_t s = wave_min_u32(mine);
-            if (s >= 256u)
-                break;
-            uint32_t key = 0xffffffffu; // (width << 8 | symbol) of this lane's narrowest symbol wider than 1
-#pragma unroll
-            for (int i = 3; i >= 0; --i) {
-                const uint32_t k = (width[i] << 8) | (4u * lane + (uint32_t)i);
-                key = (width[i] > 1u && k < key) ? k : key;
-            }
-            const uint32_t best = wave_min_u32(key);
-            if (best == 0xffffffffu) { // nobody can give a slot away
-                failed = true;
-                break;
-            }
-            const uint32_t victim = best & 0xffu;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                width[i] -= (4u * lane + (uint32_t)i == victim) ? 1u : 0u;
-                width[i] = (4u * lane + (uint32_t)i == s) ? 1u : width[i];
-            }
-        }
+        const bool failed = !adapt_normalize(cnt, nsym, target, lane, width);
         if (failed && lane == 0)
             atomicOr(flags, 1u);
         // u16 x 4 per lane = 8 bytes at 8 * lane (adapt_load_cum's layout)

@@ -331,6 +331,89 @@ __device__ __forceinline__ void adapt_load_cum(const uint16_t *chunk_freqs, uint
     c[3] = c[2] + f[2];
 }
 
+// exclusive cumulative frequencies of a lane's four symbols from the frequencies themselves (registers)
+__device__ __forceinline__ void adapt_cum(const uint32_t (&f)[4], uint32_t lane, uint32_t (&c)[4])
+{
+    const uint32_t own = f[0] + f[1] + f[2] + f[3];
+    uint32_t incl = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+        incl += lane >= (uint32_t)d ? t : 0u;
+    }
+    c[0] = incl - own;
+    c[1] = c[0] + f[0];
+    c[2] = c[1] + f[1];
+    c[3] = c[2] + f[2];
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// SymbolStats::normalize_freqs (main.cpp:75-129) for ONE chunk on ONE wave, lane l owning symbols 4l .. 4l+3 (the width-based
+// restatement of model.cpp normalize_freqs):
+//   edge[s]  = target * (counts[0] + .. + counts[s]) / total          (64-bit product, truncating division)
+//   width[s] = edge[s] - edge[s-1]
+//   every symbol that occurs but got width 0, in ascending order, takes one slot from the narrowest symbol wider than
+//   1 (lowest index on ties) -- a sequential repair: one wave-wide arg-min per squeezed symbol.
+// Returns false (wave-uniform) when the chunk cannot be normalised (more distinct symbols than slots).
+__device__ __forceinline__ bool adapt_normalize(const uint32_t (&cnt)[4], uint32_t nsym, uint32_t target, uint32_t lane, uint32_t (&width)[4])
+{
+    // inclusive running sums in symbol order; the total is the chunk's symbol count
+    const uint32_t own = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    uint32_t incl = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+        incl += lane >= (uint32_t)d ? t : 0u;
+    }
+    uint32_t run = incl - own;
+    uint32_t edge[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        run += cnt[i];
+        edge[i] = (uint32_t)(((uint64_t)target * run) / nsym); // (nsym >= 1: a chunk holds at least one symbol)
+    }
+    uint32_t prev = (uint32_t)__shfl_up((int)edge[3], 1, 64);
+    prev = lane ? prev : 0u;
+    width[0] = edge[0] - prev;
+    width[1] = edge[1] - edge[0];
+    width[2] = edge[2] - edge[1];
+    width[3] = edge[3] - edge[2];
+    // repair, in ascending symbol order
+    for (;;) {
+        uint32_t mine = 256u; // this lane's lowest squeezed symbol
+#pragma unroll
+        for (int i = 3; i >= 0; --i)
+            mine = (cnt[i] != 0u && width[i] == 0u) ? 4u * lane + (uint32_t)i : mine;
+        const uint32_t s = wave_min_u32(mine);
+        if (s >= 256u)
+            return true;
+        uint32_t key = 0xffffffffu; // (width << 8 | symbol) of this lane's narrowest symbol wider than 1
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            const uint32_t k = (width[i] << 8) | (4u * lane + (uint32_t)i);
+            key = (width[i] > 1u && k < key) ? k : key;
+        }
+        const uint32_t best = wave_min_u32(key);
+        if (best == 0xffffffffu) // nobody can give a slot away
+            return false;
+        const uint32_t victim = best & 0xffu;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            width[i] -= (4u * lane + (uint32_t)i == victim) ? 1u : 0u;
+            width[i] = (4u * lane + (uint32_t)i == s) ? 1u : width[i];
+        }
+    }
+}
+
 // decoder tables (main.cpp:143-148 cum2sym, :159-162 RansDecSymbolInit): recs[s] = {freq, start}, cum2sym[M]
 // Returns false (wave-uniform) when the frequencies do not sum to 1 << scale_bits: they come from the caller's
 // container, and a table built from them must not be walked (the fill below relies on the sum).

@@ -328,6 +328,18 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
     return RANS_AMD_OK;
 }
 
+void adapt_rcp_tables(std::vector<uint32_t> &out)
+{
+    constexpr uint32_t kEntries = 4097;
+    out.assign(2 * kEntries, 0u);
+    out[1] = out[kEntries + 1] = 0xffffffffu; // freq 1: q = mulhi(x, 2^32 - 1) = x - 1, the bias makes up for it
+    for (uint32_t f = 2; f < kEntries; ++f) {
+        const uint32_t l = ceil_log2(f);
+        out[f] = (uint32_t)((((uint64_t)1 << (l + 31)) + f - 1) / f);
+        out[kEntries + f] = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - f)) / f + 1);
+    }
+}
+
 // make_alias_table: main_alias.cpp:147-237, for any power-of-two alphabet.
 //
 // Phase A decides, for every bucket b (bucket b nominally belongs to symbol b

@@ -169,4 +169,10 @@ struct HostModel {
     int build_alias();
 };
 
+// Reciprocals by frequency for the fused per-chunk-model encoder (encode_adaptive.hip), frequencies 0 .. 4096: first the
+// Alverson reciprocals of RansEncSymbolInit (rans_byte.h:201-243: ceil(2^(31 + ceil(log2 f)) / f); the byte format, and the word
+// format while no frequency exceeds 2048), then the round-up reciprocals for 32-bit dividends (the word format otherwise) --
+// the numbers HostModel::build puts into its records, tabulated so that a wave needs no division for its chunk's model.
+void adapt_rcp_tables(std::vector<uint32_t> &out);
+
 } // namespace rans_amd

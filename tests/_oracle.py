@@ -93,6 +93,12 @@ class Oracle:
         lib.orc_compare_chunks.restype = C.c_int64
         lib.orc_gen_zipf.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_double, C.c_uint64]
         lib.orc_gen_zipf.restype = None
+        u16p = C.POINTER(C.c_uint16)
+        lib.orc_compare_chunks_adaptive.argtypes = [C.c_int, u8p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint64,
+                                                    C.c_uint64, u8p, u64p, u32p, u16p]
+        lib.orc_compare_chunks_adaptive.restype = C.c_int64
+        lib.orc_encode_chunks_adaptive.argtypes = [C.c_int, u8p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint64,
+                                                   C.c_uint64, u8p, C.c_size_t, u32p, u16p]
         self.lib = lib
 
     # ---- model
@@ -198,6 +204,72 @@ class Oracle:
         with ThreadPoolExecutor(threads) as ex:
             res = [r for r in ex.map(run, ranges) if r != -1]
         return nchunks, (min(res) if res else -1)
+
+    def compare_container_adaptive(self, fmt, syms, n_ways, chunk_syms, scale_bits, container, offs, lens, rows, threads=None):
+        """Per-chunk models: EVERY chunk's row == normalize(count(chunk)) and EVERY chunk's stream == this oracle's stream of the
+        chunk under its own model, wherever the index puts it.  Returns (chunks compared, -1 or (chunk, "row" | "stream"))."""
+        from concurrent.futures import ThreadPoolExecutor
+        syms = np.ascontiguousarray(syms, dtype=np.uint8)
+        container = np.ascontiguousarray(container, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        rows = np.ascontiguousarray(rows).view(np.uint16).reshape(-1)
+        n = syms.size
+        nchunks = (n + chunk_syms - 1) // chunk_syms
+        assert lens.size >= nchunks and offs.size >= nchunks and rows.size >= nchunks * 256
+        assert nchunks == 0 or int((offs[:nchunks] + lens[:nchunks]).max()) <= container.size
+        threads = threads or self.host_threads()
+        per = max(1, (nchunks + threads * 4 - 1) // (threads * 4))
+        ranges = [(c, min(nchunks, c + per)) for c in range(0, nchunks, per)]
+        u16p = C.POINTER(C.c_uint16)
+
+        def run(rg):
+            return int(self.lib.orc_compare_chunks_adaptive(fmt, _ptr(syms, u8p), n, n_ways, chunk_syms, scale_bits, rg[0], rg[1],
+                                                            _ptr(container, u8p), _ptr(offs, u64p), _ptr(lens, u32p),
+                                                            _ptr(rows, u16p)))
+        with ThreadPoolExecutor(threads) as ex:
+            res = [r for r in ex.map(run, ranges) if r != -1]
+        if not res:
+            return nchunks, -1
+        assert min(res) >= 0, "orc_compare_chunks_adaptive: bad argument"
+        r = min(res)
+        return nchunks, (r >> 1, "stream" if r & 1 else "row")
+
+    def encode_chunked_adaptive(self, fmt, syms, n_ways, chunk_syms, scale_bits, align=16, threads=None):
+        """The oracle's own per-chunk-model container: (container, offs[nchunks + 1], lens, rows u16[nchunks, 256]), chunk c
+        at the sum of the aligned lengths before it."""
+        from concurrent.futures import ThreadPoolExecutor
+        syms = np.ascontiguousarray(syms, dtype=np.uint8)
+        n = syms.size
+        nchunks = (n + chunk_syms - 1) // chunk_syms
+        slot = (int(self.lib.orc_stream_bound(fmt, min(chunk_syms, n), n_ways)) + 15) & ~15
+        threads = threads or self.host_threads()
+        per = max(1, (nchunks + threads * 4 - 1) // (threads * 4))
+        ranges = [(c, min(nchunks, c + per)) for c in range(0, nchunks, per)]
+        lens = np.zeros(nchunks, dtype=np.uint32)
+        rows = np.zeros((nchunks, 256), dtype=np.uint16)
+        u16p = C.POINTER(C.c_uint16)
+
+        def run(rg):
+            tmp = np.zeros((rg[1] - rg[0]) * slot, dtype=np.uint8)
+            rc = self.lib.orc_encode_chunks_adaptive(fmt, _ptr(syms, u8p), n, n_ways, chunk_syms, scale_bits, rg[0], rg[1],
+                                                     _ptr(tmp, u8p), slot, _ptr(lens[rg[0]:rg[1]], u32p),
+                                                     _ptr(rows[rg[0]:rg[1]], u16p))
+            assert rc == 0, "orc_encode_chunks_adaptive rc=%d" % rc
+            return tmp
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(run, ranges))
+        aligned = (lens.astype(np.uint64) + np.uint64(align - 1)) & ~np.uint64(align - 1)
+        offs = np.zeros(nchunks + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(aligned)
+        if nchunks:
+            offs[nchunks] = offs[nchunks - 1] + np.uint64(lens[nchunks - 1])
+        out = np.zeros(int(offs[nchunks]) + 16, dtype=np.uint8)
+        for rg, tmp in zip(ranges, parts):
+            for c in range(rg[0], rg[1]):
+                e = (c - rg[0] + 1) * slot
+                out[int(offs[c]):int(offs[c]) + int(lens[c])] = tmp[e - int(lens[c]):e]
+        return out[:int(offs[nchunks])], offs, lens, rows
 
     def encode_chunked_mt(self, fmt, model, syms, n_ways, chunk_syms, align=16, threads=None):
         """encode_chunked over ranges of whole chunks in parallel, stitched: the same container, offsets and lengths."""

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_version_and_status_strings():
-    assert R.lib().rans_amd_version() == 500
+    assert R.lib().rans_amd_version() == 600
     for code in range(8):
         assert R.lib().rans_amd_status_string(code)
     assert R.lib().rans_amd_status_string(99) == b"unknown status"

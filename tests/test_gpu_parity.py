@@ -750,6 +750,159 @@ def test_per_chunk_adaptive_models(gpu, oracle, fmt):
     assert e.value.status == R.E_UNSUPPORTED
 
 
+def _moving_statistics(oracle, chunk, nchunks, cut=1234):
+    """every chunk its own distribution: skewed, two symbols, uniform, constant, text-like; ragged last chunk"""
+    rng = np.random.default_rng(31)
+    parts = []
+    for c in range(nchunks):
+        kind = c % 5
+        if kind == 0:
+            parts.append(np.minimum(rng.geometric(0.02 + 0.01 * (c % 40), chunk) - 1, 255))
+        elif kind == 1:
+            parts.append(rng.integers(0, 2, chunk) * ((c + 3) % 256))
+        elif kind == 2:
+            parts.append(rng.integers(0, 256, chunk))
+        elif kind == 3:
+            parts.append(np.full(chunk, c % 256))
+        else:
+            parts.append((oracle.gen_zipf(chunk, K=256, s=1.0, seed=c).astype(np.int64) + 7 * c) % 256)
+    return np.concatenate(parts).astype(np.uint8)[:nchunks * chunk - cut]
+
+
+@pytest.mark.parametrize("fmt", [FMT_BYTE, FMT_WORD])
+def test_per_chunk_models_in_one_kernel(gpu, oracle, fmt):
+    """rans_amd_encode_adaptive_sized (round 6): the wave that codes a chunk counts it, normalises, builds its records and
+    codes it into a place sized from the chunk's own histogram -- one launch.  Every chunk's row == the oracle's
+    normalize(count(chunk)) and every chunk's stream == the oracle's stream under that model (main.cpp:139-162 per chunk),
+    WHEREVER the index puts it; no two chunks overlap; with slots, a chunk whose bound fits ends at its slot's end; the
+    decoders take the container as it is; a container buffer that is too small is RANS_AMD_E_SPACE."""
+    R, ctx, torch = gpu
+    chunk = 8192
+    data = _moving_statistics(oracle, chunk, 37)
+    n = data.size
+    nchunks = (n + chunk - 1) // chunk
+    d = torch.from_numpy(data).cuda()
+    kern = "k_encode_adaptive<byte>" if fmt == FMT_BYTE else "k_encode_adaptive<word>"
+    for sb in ((12, 10, 8) if fmt == FMT_BYTE else (12,)):
+        for n_ways, slot in ((64, 0), (64, 6144), (64, 1 << 20), (2, 0), (128, 0), (100, 4096), (256, 0), (33, 0), (512, 0)):
+            cont, offs, lens, freqs, total = ctx.encode_adaptive_sized(d, n_ways, chunk, sb, fmt=fmt, slot=slot)
+            assert ctx.last_encode_kernel()[0] == kern
+            h_offs = offs.cpu().numpy().astype(np.uint64)
+            h_lens = lens.cpu().numpy().astype(np.uint32)
+            assert int(h_offs[nchunks]) == total
+            count, bad = oracle.compare_container_adaptive(fmt, data, n_ways, chunk, sb, cont[:total].cpu().numpy(), h_offs, h_lens,
+                                                           freqs.cpu().numpy())
+            assert count == nchunks and bad == -1, (sb, n_ways, slot, bad)
+            # pieces are whole 64-byte lines and no two chunks overlap; everything lies below offsets[n_chunks]
+            order = np.argsort(h_offs[:nchunks])
+            ends = h_offs[:nchunks][order] + h_lens[order]
+            assert np.all(ends[:-1] <= h_offs[:nchunks][order][1:]) and int(ends[-1]) <= total
+            assert np.all(ends % np.uint64(64) == 0)
+            if slot:
+                in_slot = h_offs[:nchunks] < np.uint64(nchunks * slot)
+                assert np.array_equal((h_offs[:nchunks] + h_lens)[in_slot], (np.nonzero(in_slot)[0].astype(np.uint64) + 1) * np.uint64(slot))
+                assert np.all(h_lens[in_slot] <= slot)
+                if slot >= (1 << 20):
+                    assert in_slot.all() and total == nchunks * slot
+                else:
+                    assert not in_slot.all()  # (the uniform chunks need 8 KiB and more)
+            out = ctx.decode_adaptive(cont, total, offs, lens, freqs, n, n_ways, chunk, sb, fmt=fmt)
+            assert np.array_equal(out.cpu().numpy(), data), (sb, n_ways, slot, "decode")
+    # the same rows and streams as the three-launch path (rans_amd_encode_adaptive_fmt)
+    c0, o0, l0, f0, t0 = ctx.encode_adaptive(d, 64, chunk, 12, fmt=fmt)
+    c1, o1, l1, f1, t1 = ctx.encode_adaptive_sized(d, 64, chunk, 12, fmt=fmt)
+    assert torch.equal(f0, f1) and torch.equal(l0, l1)
+    h0, h1, ho0, ho1, hl = c0.cpu().numpy(), c1.cpu().numpy(), o0.cpu().numpy(), o1.cpu().numpy(), l0.cpu().numpy()
+    for c in range(nchunks):
+        assert np.array_equal(h0[int(ho0[c]):int(ho0[c]) + int(hl[c])], h1[int(ho1[c]):int(ho1[c]) + int(hl[c])]), c
+    # the container is about as large as the streams: bound = stream + 1.1 % of the symbols (word) + states + a line or two
+    streams = int(hl[:nchunks].astype(np.int64).sum())
+    assert t1 <= streams + 0.02 * n + nchunks * 192, (t1, streams)
+    # unaligned input (the coders read bytes), a one-chunk input, an empty one
+    du = torch.empty(n + 1, dtype=torch.uint8, device="cuda")[1:]
+    du.copy_(d)
+    cont, offs, lens, freqs, total = ctx.encode_adaptive_sized(du, 64, chunk, 12, fmt=fmt)
+    _, bad = oracle.compare_container_adaptive(fmt, data, 64, chunk, 12, cont[:total].cpu().numpy(), offs.cpu().numpy(),
+                                               lens.cpu().numpy(), freqs.cpu().numpy())
+    assert bad == -1
+    cont, offs, lens, freqs, total = ctx.encode_adaptive_sized(d[:5000], 64, chunk, 12, fmt=fmt)
+    _, bad = oracle.compare_container_adaptive(fmt, data[:5000], 64, chunk, 12, cont[:total].cpu().numpy(), offs.cpu().numpy(),
+                                               lens.cpu().numpy(), freqs.cpu().numpy())
+    assert bad == -1
+    cont, offs, lens, freqs, total = ctx.encode_adaptive_sized(d[:0], 64, chunk, 12, fmt=fmt)
+    assert total == 0
+    # too small a buffer: RANS_AMD_E_SPACE, from the call and -- asynchronously -- from rans_amd_encode_status
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.encode_adaptive_sized(d, 64, chunk, 12, fmt=fmt, cap=t1 // 2)
+    assert e.value.status == R.E_SPACE
+    small = torch.empty(t1 // 2, dtype=torch.uint8, device="cuda")
+    ctx.encode_adaptive_sized(d, 64, chunk, 12, fmt=fmt, d_out=small, sync=False)
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.encode_status()
+    assert e.value.status == R.E_SPACE
+    with pytest.raises(R.RansAmdError) as e:  # (slots that do not fit the buffer: known up front)
+        ctx.encode_adaptive_sized(d, 64, chunk, 12, fmt=fmt, slot=8192, cap=8192 * (nchunks - 1))
+    assert e.value.status == R.E_SPACE
+    for bad_slot in (1, 100, 65):
+        with pytest.raises(R.RansAmdError) as e:
+            ctx.encode_adaptive_sized(d, 64, chunk, 12, fmt=fmt, slot=bad_slot)
+        assert e.value.status == R.E_ARG
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.encode_adaptive_sized(d, 64, chunk, 12, fmt=FMT_R64)
+    assert e.value.status == R.E_UNSUPPORTED
+    # a healthy call right behind a failed one starts clean
+    ctx.encode_adaptive_sized(d, 64, chunk, 12, fmt=fmt, sync=False)
+    ctx.encode_status()
+
+
+@pytest.mark.parametrize("fmt", [FMT_BYTE, FMT_WORD])
+def test_per_chunk_model_decoder_on_an_oracle_made_container(gpu, oracle, fmt):
+    """The per-chunk-model decoders fed a container (streams AND rows) the ORACLE made: nothing they read was written by a
+    GPU encoder."""
+    R, ctx, torch = gpu
+    chunk = 8192
+    data = _moving_statistics(oracle, chunk, 23, cut=777)
+    for n_ways in (64, 2, 128):
+        cont, offs, lens, rows = oracle.encode_chunked_adaptive(fmt, data, n_ways, chunk, 12)
+        d_cont = torch.zeros(cont.size + 64, dtype=torch.uint8, device="cuda")
+        d_cont[:cont.size] = torch.from_numpy(cont).cuda()
+        d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+        d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+        d_rows = torch.from_numpy(rows.reshape(-1).view(np.int16)).cuda()
+        out = ctx.decode_adaptive(d_cont, cont.size, d_offs, d_lens, d_rows, data.size, n_ways, chunk, 12, fmt=fmt)
+        assert np.array_equal(out.cpu().numpy(), data), n_ways
+
+
+def test_per_chunk_models_in_one_kernel_inside_a_hip_graph(gpu, oracle):
+    """The one-launch per-chunk-model encode captured into a hipGraph and replayed on other data."""
+    R, ctx, torch = gpu
+    chunk, n_ways = 8192, 64
+    datas = [_moving_statistics(oracle, chunk, 20, cut=0), oracle.gen_zipf(20 * chunk, K=256, s=1.0, seed=5),
+             np.random.default_rng(3).integers(0, 256, 20 * chunk).astype(np.uint8)]
+    d_syms = torch.from_numpy(datas[0]).cuda().clone()
+    cap = R.lib().rans_amd_encode_adaptive_sized_bound(FMT_WORD, d_syms.numel(), n_ways, chunk)
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    offs = torch.zeros(21, dtype=torch.int64, device="cuda")
+    lens = torch.zeros(20, dtype=torch.int32, device="cuda")
+    rows = torch.zeros(20 * 256, dtype=torch.int16, device="cuda")
+    ctx.encode_adaptive_sized(d_syms, n_ways, chunk, 12, fmt=FMT_WORD, d_out=out, d_offsets=offs, d_lengths=lens, d_freqs=rows)
+    g = torch.cuda.CUDAGraph()
+    stream = torch.cuda.Stream()
+    with torch.cuda.graph(g, stream=stream):
+        ctx.encode_adaptive_sized(d_syms, n_ways, chunk, 12, fmt=FMT_WORD, d_out=out, d_offsets=offs, d_lengths=lens, d_freqs=rows,
+                                  sync=False)
+    for d in datas:
+        d_syms.copy_(torch.from_numpy(d).cuda())
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ctx.encode_status()
+        total = int(offs[-1].item())
+        _, bad = oracle.compare_container_adaptive(FMT_WORD, d, n_ways, chunk, 12, out[:total].cpu().numpy(), offs.cpu().numpy(),
+                                                   lens.cpu().numpy(), rows.cpu().numpy())
+        assert bad == -1
+
+
 def test_rans64_two_way_lane_kernel(gpu, oracle):
     """BASELINE config 2's layout (the reference's 2-way rans64 loop, main64.cpp:228-282) through the dedicated
     lane-per-chunk decoder k_decode_lanes_r64x2: every scale_bits with a cum2sym table, chunk sizes of one and many
