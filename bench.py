@@ -147,6 +147,18 @@ def gen_zipf(torch, n, K, s, seed, device):
     return out
 
 
+def gen_moving(torch, n, seed, device, group=1 << 22):
+    """Bytes whose statistics MOVE (the per-chunk-model rows of `configs`, tests/test_gpu_scale.py): groups of `group`
+    symbols, group g drawn from Zipf(K_g, s_g) with K_g in {256, 64, 16, 4} and s_g in {0.5, 1.0, 1.5, 2.0} (gen_zipf: the
+    oracle's generator, seed + g) and rotated by 37 g modulo 256 -- a global model fits none of them."""
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    for g, lo in enumerate(range(0, n, group)):
+        m = min(group, n - lo)
+        part = gen_zipf(torch, m, (256, 64, 16, 4)[g % 4], (0.5, 1.0, 1.5, 2.0)[(g // 4) % 4], seed + g, device)
+        out[lo:lo + m] = ((part.to(torch.int32) + 37 * g) % 256).to(torch.uint8)
+    return out
+
+
 # ---- timing helpers ----------------------------------------------------------------------------
 
 def timed_launches(torch, fn, steps, warmup):

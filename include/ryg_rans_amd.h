@@ -399,20 +399,17 @@ int rans_amd_decode_adaptive_fmt(rans_amd_ctx *ctx, int format, const void *d_co
  * normalises the counts, builds its records and codes the chunk -- and because it knows the chunk's histogram BEFORE it
  * codes, it knows an upper bound of the chunk's stream (sum count[s] * log2(M / freq[s]) bits, what the floor of the rANS
  * update can add, the flushed states) and takes exactly that much room: no scratch trip, no layout pass, no compaction, no
- * second launch.  Where the chunks lie:
- *   slot_bytes == 0   every chunk is a piece of `d_out` handed out in the order the coders ask (one atomic add): the
- *                     container is about as large as the streams (+ ~1.5 %), its chunks in no particular order;
- *   slot_bytes  > 0   (a multiple of 64) chunk c is the LAST d_lengths[c] bytes of slot c -- deterministic, as
- *                     rans_amd_encode_slots_sized -- whenever its bound fits the slot; the others lie behind the slots,
- *                     handed out as above.
- * d_offsets / d_lengths say where (any decoder takes such an index; rans_amd_container_compact /
- * rans_amd_container_pack_indexed bring the chunks into index order); d_offsets[n_chunks] = bytes of `d_out` in use.
+ * second launch.  Chunk c's piece (a whole number of 64-byte lines) starts where the pieces of the chunks before it end
+ * -- index order, the same layout from run to run -- and its stream is the LAST d_lengths[c] bytes of the piece, so the
+ * container is about as large as the streams (+ ~1.5 %: the bound's slack).  d_offsets / d_lengths say where every stream
+ * starts (any decoder takes such an index; rans_amd_container_compact / rans_amd_container_pack_indexed_adaptive close the
+ * gaps); d_offsets[n_chunks] = bytes of `d_out` in use.
  * out_cap: rans_amd_encode_adaptive_sized_bound() can never be exceeded; a smaller buffer works as long as the pieces fit
- * (RANS_AMD_E_SPACE from the call or from rans_amd_encode_status otherwise).  Every chunk's bytes and its row of
- * d_chunk_freqs equal those of rans_amd_encode_adaptive_fmt.  (The first call of a context uploads a 32 KiB table: make
- * one call outside a hipGraph capture first.) */
+ * (RANS_AMD_E_SPACE from the call or from rans_amd_encode_status otherwise; chunks whose piece does not fit are not coded,
+ * their length is 0).  Every chunk's bytes and its row of d_chunk_freqs equal those of rans_amd_encode_adaptive_fmt.  (The
+ * first call of a context uploads a 32 KiB table: make one call outside a hipGraph capture first.) */
 int rans_amd_encode_adaptive_sized(rans_amd_ctx *ctx, int format, const void *d_syms, uint64_t n, uint32_t n_ways,
-                                   uint32_t chunk_syms, uint32_t scale_bits, uint64_t slot_bytes, void *d_out, uint64_t out_cap,
+                                   uint32_t chunk_syms, uint32_t scale_bits, void *d_out, uint64_t out_cap,
                                    uint64_t *d_offsets, uint32_t *d_lengths, uint16_t *d_chunk_freqs, uint64_t *h_total_bytes,
                                    void *stream);
 uint64_t rans_amd_encode_adaptive_sized_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms);

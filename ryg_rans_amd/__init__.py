@@ -139,7 +139,7 @@ def _load():
         "rans_amd_decode_adaptive": (i32, [vp, vp, u64, vp, vp, vp, u64, u32, u32, u32, vp, u64p, vp]),
         "rans_amd_encode_adaptive_fmt": (i32, [vp, i32, vp, u64, u32, u32, u32, vp, u64, vp, vp, vp, u64p, vp]),
         "rans_amd_decode_adaptive_fmt": (i32, [vp, i32, vp, u64, vp, vp, vp, u64, u32, u32, u32, vp, u64p, vp]),
-        "rans_amd_encode_adaptive_sized": (i32, [vp, i32, vp, u64, u32, u32, u32, u64, vp, u64, vp, vp, vp, u64p, vp]),
+        "rans_amd_encode_adaptive_sized": (i32, [vp, i32, vp, u64, u32, u32, u32, vp, u64, vp, vp, vp, u64p, vp]),
         "rans_amd_encode_adaptive_sized_bound": (u64, [i32, u64, u32, u32]),
         "rans_amd_encode_workspace_bytes": (u64, [i32, u64, u32, u32]),
         "rans_amd_build_model_o0": (i32, [vp, i32, vp, u64, i32, u32, u32, u32p, C.POINTER(vp), vp]),
@@ -472,18 +472,18 @@ class Context:
         _check(rc, "encode_adaptive")
         return d_out, d_offsets, d_lengths, d_freqs, (total.value if sync else None)
 
-    def encode_adaptive_sized(self, d_syms, n_ways, chunk_syms, scale_bits, fmt=FMT_BYTE, slot=0, cap=None, d_out=None, sync=True,
+    def encode_adaptive_sized(self, d_syms, n_ways, chunk_syms, scale_bits, fmt=FMT_BYTE, cap=None, d_out=None, sync=True,
                               d_offsets=None, d_lengths=None, d_freqs=None):
-        """rans_amd_encode_adaptive_sized: count + normalise + code in one kernel; a chunk lies where its own bound put it
-        (slot > 0: at the end of slot c when that bound fits).  cap: bytes of the container buffer (default: the bound no
-        input can exceed).  Returns (d_container, d_offsets, d_lengths, d_chunk_freqs, total_bytes)."""
+        """rans_amd_encode_adaptive_sized: count + normalise + code in one kernel; chunk c's stream ends where its piece --
+        sized from the chunk's own histogram, placed behind the pieces before it -- ends.  cap: bytes of the container
+        buffer (default: the bound no input can exceed).  Returns (d_container, d_offsets, d_lengths, d_chunk_freqs, total_bytes)."""
         import torch
         n = d_syms.numel()
         nchunks = num_chunks(n, chunk_syms)
         dev = d_syms.device
         if d_out is None:
             if cap is None:
-                cap = int(_lib.rans_amd_encode_adaptive_sized_bound(fmt, n, n_ways, chunk_syms)) + nchunks * slot
+                cap = int(_lib.rans_amd_encode_adaptive_sized_bound(fmt, n, n_ways, chunk_syms))
             d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
         if d_offsets is None:
             d_offsets = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
@@ -492,7 +492,7 @@ class Context:
         if d_freqs is None:
             d_freqs = torch.zeros(max(nchunks, 1) * 256, dtype=torch.int16, device=dev)
         total = C.c_uint64(0)
-        _check(_lib.rans_amd_encode_adaptive_sized(self._h, fmt, d_syms.data_ptr(), n, n_ways, chunk_syms, scale_bits, slot,
+        _check(_lib.rans_amd_encode_adaptive_sized(self._h, fmt, d_syms.data_ptr(), n, n_ways, chunk_syms, scale_bits,
                                                    d_out.data_ptr(), d_out.numel(), d_offsets.data_ptr(), d_lengths.data_ptr(),
                                                    d_freqs.data_ptr(), C.byref(total) if sync else None, _torch_stream()),
                "encode_adaptive_sized")

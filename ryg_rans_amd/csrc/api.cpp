@@ -1585,7 +1585,7 @@ static int decode_adaptive_impl(rans_amd_ctx *ctx, const int format, const void 
 
 // rans_amd_encode_adaptive_sized: the whole per-chunk-model encode as ONE kernel (encode_adaptive.hip)
 static int encode_adaptive_sized_impl(rans_amd_ctx *ctx, const int format, const void *d_syms, uint64_t n, uint32_t n_ways,
-                                      uint32_t chunk_syms, uint32_t scale_bits, uint64_t slot_bytes, void *d_out, uint64_t out_cap,
+                                      uint32_t chunk_syms, uint32_t scale_bits, void *d_out, uint64_t out_cap,
                                       uint64_t *d_offsets, uint32_t *d_lengths, uint16_t *d_chunk_freqs, uint64_t *h_total_bytes,
                                       void *stream)
 {
@@ -1599,8 +1599,6 @@ static int encode_adaptive_sized_impl(rans_amd_ctx *ctx, const int format, const
         return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive_sized: n_ways must be in 1..512");
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0)
         return fail(RANS_AMD_E_ARG, "encode_adaptive_sized: d_out must be 16-byte aligned");
-    if ((slot_bytes & 63u) != 0 || slot_bytes > 0xffffffc0ull)
-        return fail(RANS_AMD_E_ARG, "encode_adaptive_sized: slot_bytes must be 0 or a multiple of 64 below 4 GiB");
     const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
     DeviceGuard guard(ctx->device);
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -1611,8 +1609,6 @@ static int encode_adaptive_sized_impl(rans_amd_ctx *ctx, const int format, const
     const uint64_t worst = encode_slot_bytes(format, n, n_ways, chunk_syms);
     if (worst > 0xfffffff0ull || nchunks >= (1ull << 32))
         return fail(RANS_AMD_E_UNSUPPORTED, "encode_adaptive_sized: chunk_syms too large, or 2^32 chunks and more");
-    if (slot_bytes && (nchunks > (~0ull) / slot_bytes || out_cap < nchunks * slot_bytes)) // (known up front: nothing is launched)
-        return fail(RANS_AMD_E_SPACE, "encode_adaptive_sized: out_cap does not hold n_chunks * slot_bytes");
     if (!ctx->adapt_rcp.ptr) { // reciprocals by frequency (model.cpp adapt_rcp_tables): built once per context
         if (capture.active)
             return fail(RANS_AMD_E_ARG, "encode_adaptive_sized: make the same call once outside the capture first (a table is uploaded on first use)");
@@ -1627,8 +1623,8 @@ static int encode_adaptive_sized_impl(rans_amd_ctx *ctx, const int format, const
             return hip_fail(e, "encode_adaptive_sized: table upload");
         }
     }
-    // claim counters (a line each), the line of the waves that are done, the line of the byte counter behind the slots
-    const size_t ctl_bytes = (size_t)(kWorkPools + 2) * kWorkPoolStride * 4;
+    // a look-back word per chunk, then the claim counters (a line each)
+    const size_t ctl_bytes = (size_t)nchunks * 8 + (size_t)kWorkPools * kWorkPoolStride * 4;
     int rc = ctx->enc_status.reserve(ctl_bytes);
     if (rc)
         return rc;
@@ -1653,13 +1649,14 @@ static int encode_adaptive_sized_impl(rans_amd_ctx *ctx, const int format, const
         ap.worst_slot = (uint32_t)worst;
         ap.out = static_cast<uint8_t *>(d_out);
         ap.out_cap = out_cap;
-        ap.slot_bytes = slot_bytes;
         ap.offsets = d_offsets;
         ap.lengths = d_lengths;
         ap.chunk_freqs = d_chunk_freqs;
         ap.flags = ctx->d_enc_flags();
-        ap.claims = static_cast<unsigned int *>(ctx->enc_status.ptr);
-        ap.bump = reinterpret_cast<unsigned long long *>(static_cast<unsigned int *>(ctx->enc_status.ptr) + (kWorkPools + 1) * kWorkPoolStride);
+        ap.status = static_cast<unsigned long long *>(ctx->enc_status.ptr);
+        ap.claims = reinterpret_cast<unsigned int *>(ap.status + nchunks);
+        // (watchdog of the look-back: half a minute plus what ONE wave may need to count the call's largest chunk)
+        ap.wait_ticks = 30ull * 100000000ull + ((uint64_t)chunk_syms / 64u) * 100ull;
         ap.rcp = static_cast<const uint32_t *>(ctx->adapt_rcp.ptr);
         HIP_TRY(launch_encode_adaptive(format, ap, ctx->num_cus, s, &ctx->last_enc_kernel));
         ctx->last_enc_fused = false;
@@ -1702,16 +1699,16 @@ int rans_amd_encode_adaptive_fmt(rans_amd_ctx *ctx, int format, const void *d_sy
 }
 
 int rans_amd_encode_adaptive_sized(rans_amd_ctx *ctx, int format, const void *d_syms, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,
-                                   uint32_t scale_bits, uint64_t slot_bytes, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
+                                   uint32_t scale_bits, void *d_out, uint64_t out_cap, uint64_t *d_offsets,
                                    uint32_t *d_lengths, uint16_t *d_chunk_freqs, uint64_t *h_total_bytes, void *stream)
 {
-    return encode_adaptive_sized_impl(ctx, format, d_syms, n, n_ways, chunk_syms, scale_bits, slot_bytes, d_out, out_cap, d_offsets,
+    return encode_adaptive_sized_impl(ctx, format, d_syms, n, n_ways, chunk_syms, scale_bits, d_out, out_cap, d_offsets,
                                       d_lengths, d_chunk_freqs, h_total_bytes, stream);
 }
 
 uint64_t rans_amd_encode_adaptive_sized_bound(int format, uint64_t n, uint32_t n_ways, uint32_t chunk_syms)
 {
-    // every chunk in a worst-case piece (a chunk's own bound never exceeds it): what no input can overflow
+    // every chunk in a worst-case piece (a chunk's own bound is never larger): what no input can exceed
     const uint64_t nchunks = rans_amd_num_chunks(n, chunk_syms);
     return nchunks ? nchunks * encode_slot_bytes(format, n, n_ways, chunk_syms) : 16;
 }

@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 
         if constexpr (kIsAdaptive<FMT>) { // this chunk's model -> this wave's tables (main.cpp:139-162 / main_simd.cpp:138-143 per chunk)
             if (!adapt_build_dec(p.chunk_freqs + chunk * 256u, p.scale_bits, lane, const_cast<uint8_t *>(T.t0),
-                                 reinterpret_cast<uint2 *>(const_cast<uint8_t *>(T.t1)))) {
+                                 reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(T.t1)))) {
                 if (lane == 0)
                     atomicAdd(p.err_count, 1ull);
                 continue;
@@ -774,7 +774,13 @@ hipError_t launch_decode_word64(const DecParams &p, int num_cus, hipStream_t str
 template <int FMT, int K, int OUT>
 hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
-    const uint32_t waves = kDecBlockThreads / 64;
+    // per-chunk models: every wave owns its tables (5 KiB) and window, nothing is shared -- workgroups of FOUR waves, five of
+    // them per CU: 20 waves where one 16-wave workgroup held 16, and one wave per SIMD from every workgroup (one- and two-wave
+    // workgroups spread unevenly over the CUs when the grid does not fill them: 0.84 / 0.80 ms against 0.73 for the word
+    // format, profiles/r06_adaptive_decoder.md)
+    constexpr uint32_t kAdaptDecThreads = 256;
+    const uint32_t threads = kIsAdaptive<FMT> ? kAdaptDecThreads : kDecBlockThreads;
+    const uint32_t waves = threads / 64;
     const uint32_t t0 = kIsAdaptive<FMT> ? waves * kAdaptDecWaveLds : (p.table0_bytes + 15u) & ~15u;
     const uint32_t t1 = kIsAdaptive<FMT> ? 0u : (p.table1_bytes + 15u) & ~15u;
     if (kIsAdaptive<FMT> && (!p.chunk_freqs || p.scale_bits > kAdaptMaxScaleBits || p.scale_bits < 8 || (FMT == FMT_WORDA && p.scale_bits != 12)))
@@ -786,7 +792,11 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     static std::atomic<uint64_t> lds_ok{0}; // per instantiation, one bit per device
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 160 * 1024, lds_ok); e != hipSuccess)
         return e;
-    const int blocks_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+    int blocks_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+    if (kIsAdaptive<FMT> && threads < kDecBlockThreads) { // small workgroups: what the LDS allows, within 32 waves per CU
+        blocks_per_cu = (int)((160 * 1024) / ((lds + 255) & ~(size_t)255));
+        blocks_per_cu = blocks_per_cu * (int)waves > 32 ? 32 / (int)waves : blocks_per_cu;
+    }
     uint64_t want = (p.nchunks + waves - 1) / waves;
     uint64_t cap = (uint64_t)num_cus * blocks_per_cu;
     const uint32_t grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
@@ -795,7 +805,7 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
                 : FMT == FMT_R64 ? "k_decode<r64>" : FMT == FMT_R64S ? "k_decode<r64 search>"
                 : FMT == FMT_WORD16 ? "k_decode<word, u16 symbols>"
                 : FMT == FMT_BYTEA ? "k_decode<byte, per-chunk models>" : FMT == FMT_WORDA ? "k_decode<word, per-chunk models>" : "k_decode<alias>";
-    RANS_LAUNCH(kern, dim3(grid), dim3(kDecBlockThreads), lds, stream, p);
+    RANS_LAUNCH(kern, dim3(grid), dim3(threads), lds, stream, p);
     return hipGetLastError();
 }
 

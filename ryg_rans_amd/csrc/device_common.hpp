@@ -236,11 +236,13 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
         return e.x;
     } else if constexpr (FMT == FMT_BYTEA || FMT == FMT_WORDA) {
         // the same through the wave's own table pointers (per-chunk models; the word format: scale_bits is 12 and
-        // freq * (x >> 12) + (slot - start) is rans_word_sse41.h:123-131's freq * (x >> 12) + bias)
+        // freq * (x >> 12) + (slot - start) is rans_word_sse41.h:123-131's freq * (x >> 12) + bias).  Records packed into
+        // four bytes, freq | start << 16 (both <= 4096): a kilobyte per wave instead of two -- the LDS a wave needs is
+        // what bounds how many of these decoders a CU holds
         const uint32_t cf = x & T.maskv;
         const uint32_t s = T.t0[cf];
-        const uint2 r = reinterpret_cast<const uint2 *>(T.t1)[s];
-        x = (r.x & 0xffffffu) * ((x >> T.sbv) & 0xffffffu) + cf - r.y;
+        const uint32_t r = reinterpret_cast<const uint32_t *>(T.t1)[s];
+        x = (r & 0xffffu) * ((x >> T.sbv) & 0xffffffu) + cf - (r >> 16);
         return s;
     } else if constexpr (FMT == FMT_R64) {
         // rans64.h:118-121 (get), :286-292 (step)
@@ -307,7 +309,7 @@ __device__ __forceinline__ uint32_t dec_step(const DecTables<FMT> &T, typename F
 // of the byte coder, in its own LDS region.  Lane l owns symbols 4l .. 4l+3.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kAdaptMaxScaleBits = 12;
-constexpr uint32_t kAdaptDecWaveLds = (1u << kAdaptMaxScaleBits) + 256u * 8u; // cum2sym + {freq, start} records
+constexpr uint32_t kAdaptDecWaveLds = (1u << kAdaptMaxScaleBits) + 256u * 4u; // cum2sym + packed {freq | start << 16} records
 constexpr uint32_t kAdaptEncWaveLds = 256u * 16u;                             // EncRec per symbol
 
 // frequencies and exclusive cumulative frequencies of this lane's four symbols
@@ -414,11 +416,11 @@ __device__ __forceinline__ bool adapt_normalize(const uint32_t (&cnt)[4], uint32
     }
 }
 
-// decoder tables (main.cpp:143-148 cum2sym, :159-162 RansDecSymbolInit): recs[s] = {freq, start}, cum2sym[M]
+// decoder tables (main.cpp:143-148 cum2sym, :159-162 RansDecSymbolInit): recs[s] = freq | start << 16, cum2sym[M]
 // Returns false (wave-uniform) when the frequencies do not sum to 1 << scale_bits: they come from the caller's
 // container, and a table built from them must not be walked (the fill below relies on the sum).
 __device__ __forceinline__ bool adapt_build_dec(const uint16_t *chunk_freqs, uint32_t scale_bits, uint32_t lane,
-                                                uint8_t *cum2sym, uint2 *recs)
+                                                uint8_t *cum2sym, uint32_t *recs)
 {
     uint32_t f[4], c[4];
     adapt_load_cum(chunk_freqs, lane, f, c);
@@ -427,22 +429,22 @@ __device__ __forceinline__ bool adapt_build_dec(const uint16_t *chunk_freqs, uin
         return false;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        recs[4u * lane + i] = uint2{f[i], c[i]};
+        recs[4u * lane + i] = f[i] | (c[i] << 16); // (a frequency of 4096 = M still fits: the sum check above bounds both)
     // (LDS operations of one wave execute in order: the reads below see every lane's records)
     const uint32_t per = (1u << scale_bits) >> 6; // positions per lane: 4 .. 64
     uint32_t pos = lane * per;
     uint32_t s = 0; // the last symbol whose start is <= pos; symbols of frequency 0 are stepped over below
 #pragma unroll
     for (uint32_t half = 128; half; half >>= 1)
-        s += recs[s + half].y <= pos ? half : 0u;
-    uint32_t end = recs[s].y + recs[s].x;
+        s += (recs[s + half] >> 16) <= pos ? half : 0u;
+    uint32_t end = (recs[s] >> 16) + (recs[s] & 0xffffu);
     for (uint32_t i = 0; i < per; i += 4) {
         uint32_t w = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             while (pos >= end && s < 255u) { // next symbol with a slot at pos (pos < M = the last symbol's end)
                 ++s;
-                end = recs[s].y + recs[s].x;
+                end = (recs[s] >> 16) + (recs[s] & 0xffffu);
             }
             w |= s << (8 * b);
             ++pos;
@@ -621,6 +623,49 @@ struct SpinWatch {
         return t - t0 > limit;
     }
 };
+
+// Decoupled look-back over the status words of units [0, unit): the sum of the predecessors' values, i.e. where `unit`
+// starts.  64 predecessors per trip (lane j reads status[unit - 1 - j]) down to the first published inclusive PREFIX (unit
+// 0's virtual predecessor is one), waiting for predecessors that have not published their AGGREGATE yet.  Whole wave;
+// returns false when the wait was abandoned (`timeout_bit` of *flags set, or somebody else's protocol error seen).
+__device__ __forceinline__ bool status_lookback(const unsigned long long *status, uint64_t unit, uint32_t lane, uint32_t *flags,
+                                                unsigned long long wait_ticks, uint32_t timeout_bit, unsigned long long &base_out)
+{
+    unsigned long long base = 0;
+    SpinWatch watch(wait_ticks);
+    for (uint64_t j = unit;;) { // status[j-1], status[j-2], ... are still to be added
+        unsigned long long st = kStPrefix; // virtual predecessor of unit 0: an inclusive prefix of 0
+        if (lane < j)
+            st = __hip_atomic_load(status + (j - 1 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t ready = __builtin_amdgcn_ballot_w64((st >> 62) != 0);
+        const uint64_t pref = __builtin_amdgcn_ballot_w64((st >> 62) == 2);
+        const uint32_t first_pref = pref ? (uint32_t)__builtin_ctzll(pref) : 64u;
+        const uint64_t need = first_pref >= 63u ? ~0ull : ((2ull << first_pref) - 1ull); // lanes 0 .. first_pref
+        if ((ready & need) != need) { // a predecessor in that range has not published yet
+            if (watch.expired(flags)) { // (a protocol error must not hang the GPU)
+                if (lane == 0)
+                    atomicOr(flags, timeout_bit);
+                base_out = base;
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        unsigned long long v = lane <= first_pref ? (st & kStValue) : 0ull;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
+            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
+            v += (unsigned long long)lo | ((unsigned long long)hi << 32);
+        }
+        base += uniform64(v);
+        if (first_pref < 64u)
+            break;
+        j -= 64;
+    }
+    base_out = base;
+    return true;
+}
 
 __device__ __forceinline__ void mailbox_push(EncMailbox *mb, uint32_t unit, uint32_t len, uint32_t *flags, unsigned long long wait_ticks)
 {

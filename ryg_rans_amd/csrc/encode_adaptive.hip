@@ -7,9 +7,14 @@
 //   2. normalise  exactly as normalize_freqs does (device_common.hpp adapt_normalize); the row goes to chunk_freqs[chunk]
 //   3. place      an upper bound of the chunk's stream follows from its own histogram -- sum count[s] * log2(M / freq[s])
 //                 bits plus what the floor in C(s, x) can add per symbol, plus the flushed states -- so the wave knows how
-//                 much room it needs BEFORE it codes: slot `chunk` if the caller gave slots and the bound fits, else a
-//                 piece of the region behind the slots handed out by one atomic add.  No scratch trip, no k_layout, no
-//                 k_compact, no second launch; the container is about as large as the streams themselves.
+//                 much room it needs BEFORE it codes.  It publishes that size and finds its place by a decoupled look-back
+//                 over the sizes of the chunks before it (device_common.hpp status_lookback; the predecessors it may have to
+//                 wait for are still COUNTING, not coding): chunk c's piece starts at the sum of the pieces before it.  No
+//                 scratch trip, no k_layout, no k_compact, no second launch; the container is in index order, the same
+//                 from run to run, and about as large as the streams themselves (+ ~1.5 %).
+//                 (A bump pointer -- one atomic add per chunk on one word -- was the first version: a single word retires
+//                 ~88 atomics per microsecond and 65 536 chunks made that 0.75 ms of a 1.1 ms launch, whatever the occupancy:
+//                 profiles/r06_adaptive_encoder.md.)
 //   4. records    the hand-written sub-steps' 16-byte records of the chunk's 256 symbols at LDS address 0 (reciprocals by
 //                 frequency from a 32 KiB table in global memory: no division on the device)
 //   5. code       the chunk a second time through (the second read is served by L2 / the memory-side cache), the same
@@ -28,6 +33,10 @@ namespace {
 
 #include "encode_common.hpp"
 
+// six waves per SIMD (80 registers), 24 one-wave workgroups per CU (the LDS would allow 25): measured the same from 20 to 25
+// per CU, and with 1, 4 or 8 count loads in flight (profiles/r06_adaptive_encoder.md: the launch is bound by the LDS pipe --
+// one ds_add per symbol on top of the coder's record gather -- not by latency)
+constexpr int kAdaptWavesPerSimd = 6, kAdaptPerCu = 24;
 constexpr uint32_t kAdaptRecBytes = 256u * 16u;                     // the records, at LDS address 0
 constexpr uint32_t kAdaptWinBase = kAdaptRecBytes;                  // the stream staging window behind them
 constexpr uint32_t kAdaptEncLds = kAdaptRecBytes + kEncStageBytes; // 6 KiB; the counters of step 1 lie over the records
@@ -77,7 +86,7 @@ __device__ __forceinline__ void adapt_substep(uint32_t &x, const u32x4 rec, bool
 }
 
 template <int FMT, int K>
-__global__ void __launch_bounds__(64, K == 1 ? 6 : (K <= 4 ? 4 : 2)) k_encode_adaptive(const AdaptEncParams p)
+__global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 : 2)) k_encode_adaptive(const AdaptEncParams p)
 {
     static_assert(FMT == FMT_WORD || FMT == FMT_BYTE, "per-chunk models: the byte and the word format");
     using Tr = FmtTraits<FMT>;
@@ -123,20 +132,46 @@ __global__ void __launch_bounds__(64, K == 1 ? 6 : (K <= 4 ? 4 : 2)) k_encode_ad
             count1(v >> 24);
         };
         uint32_t done = 0;
-        if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) { // 16 bytes per lane, the next trip's load issued before this trip's counting
-            const uint32_t body16 = nsym & ~1023u;
-            if (body16) {
-                u32x4 v = *reinterpret_cast<gvec_cptr>(reinterpret_cast<uint64_t>(src) + lane * 16u);
-                for (uint32_t i = 0; i < body16; i += 1024u) {
-                    u32x4 nx = v;
-                    if (i + 1024u < body16)
-                        nx = *reinterpret_cast<gvec_cptr>(reinterpret_cast<uint64_t>(src) + i + 1024u + lane * 16u);
-                    count4(v.x);
-                    count4(v.y);
-                    count4(v.z);
-                    count4(v.w);
-                    v = nx;
+        if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+            // 16 bytes per lane and load, kCountDepth loads in flight and the next kCountDepth issued before this trip's counting:
+            // a wave that keeps ONE line per lane in flight waits a memory latency per KiB (2 us: a third of the chunk's time)
+            constexpr uint32_t kCountDepth = 4, kTrip = 1024u * kCountDepth;
+            auto at16 = [&](uint32_t byte) { return *reinterpret_cast<gvec_cptr>(reinterpret_cast<uint64_t>(src) + byte + lane * 16u); };
+            const uint32_t big = nsym & ~(kTrip - 1u);
+            if (big) {
+                u32x4 v[kCountDepth];
+#pragma unroll
+                for (uint32_t d = 0; d < kCountDepth; ++d)
+                    v[d] = at16(1024u * d);
+                for (uint32_t i = 0; i < big; i += kTrip) {
+                    u32x4 nx[kCountDepth];
+#pragma unroll
+                    for (uint32_t d = 0; d < kCountDepth; ++d)
+                        nx[d] = v[d];
+                    if (i + kTrip < big) {
+#pragma unroll
+                        for (uint32_t d = 0; d < kCountDepth; ++d)
+                            nx[d] = at16(i + kTrip + 1024u * d);
+                    }
+#pragma unroll
+                    for (uint32_t d = 0; d < kCountDepth; ++d) {
+                        count4(v[d].x);
+                        count4(v[d].y);
+                        count4(v[d].z);
+                        count4(v[d].w);
+                    }
+#pragma unroll
+                    for (uint32_t d = 0; d < kCountDepth; ++d)
+                        v[d] = nx[d];
                 }
+            }
+            const uint32_t body16 = nsym & ~1023u;
+            for (uint32_t i = big; i < body16; i += 1024u) {
+                const u32x4 v = at16(i);
+                count4(v.x);
+                count4(v.y);
+                count4(v.z);
+                count4(v.w);
             }
             done = body16;
         }
@@ -187,6 +222,8 @@ __global__ void __launch_bounds__(64, K == 1 ? 6 : (K <= 4 ? 4 : 2)) k_encode_ad
         uint64_t need = (est < 4.0e9f ? (uint64_t)est : 0xffffffffull) + slack;
         need = (need + 63u) & ~63ull;
         need = (need < p.worst_slot && !always) ? need : p.worst_slot;
+        if (lane == 0) // (the successors' look-back adds this up while the records below are being built)
+            __hip_atomic_store(p.status + chunk, kStAggregate | need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         // ---- 4. the records of this chunk (RansEncSymbolInit / the word format's round-up reciprocals, model.cpp)
         {
@@ -211,32 +248,29 @@ __global__ void __launch_bounds__(64, K == 1 ? 6 : (K <= 4 ? 4 : 2)) k_encode_ad
             }
         }
 
-        // ---- 5. code: rounds last to first, into the place the bound bought.  A second attempt (never seen: the bound is
-        // one) takes a worst-case piece.
+        // ---- 5. code: rounds last to first, into the place the bound bought
         const uint32_t rounds = uniform(nsym / N);
         const uint32_t tail = uniform(nsym - rounds * N);
         const bool fast_in = K == 1 && N == 64u && lds_at_zero && ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 3u) == 0;
         const uint32_t fast_rounds = (fast_in && !always) ? (rounds & ~15u) : 0u;
-        for (uint32_t attempt = 0; attempt < 2u; ++attempt) {
-            const uint64_t size = attempt ? p.worst_slot : need;
-            uint64_t slot_at;
-            uint64_t room = size;
-            if (attempt == 0 && p.slot_bytes && size <= p.slot_bytes) {
-                slot_at = chunk * p.slot_bytes;
-                room = p.slot_bytes;
-            } else {
-                unsigned long long at = 0;
-                if (lane == 0)
-                    at = atomicAdd(p.bump, (unsigned long long)size);
-                slot_at = p.nchunks * p.slot_bytes + uniform64(at);
+        {
+            unsigned long long base = 0;
+            const bool found = status_lookback(p.status, chunk, lane, p.flags, p.wait_ticks, 32u, base);
+            if (lane == 0) {
+                __hip_atomic_store(p.status + chunk, kStPrefix | (base + need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (chunk + 1 == p.nchunks)
+                    p.offsets[p.nchunks] = base + need; // the container's end
             }
-            if (slot_at + room > p.out_cap) { // (wave-uniform)
+            const uint64_t slot_at = base;
+            const uint64_t room = need;
+            if (!found || slot_at + room > p.out_cap) { // (wave-uniform)
                 if (lane == 0) {
-                    atomicOr(p.flags, 2u);
+                    if (found)
+                        atomicOr(p.flags, 2u);
                     p.lengths[chunk] = 0u;
                     p.offsets[chunk] = 0u;
                 }
-                break;
+                continue;
             }
             uint8_t RANS_GLOBAL *slot = (uint8_t RANS_GLOBAL *)p.out + slot_at;
             uint32_t wp = (uint32_t)room;
@@ -369,8 +403,8 @@ __global__ void __launch_bounds__(64, K == 1 ? 6 : (K <= 4 ? 4 : 2)) k_encode_ad
                 }
             }
 
-            if (ovf || wp < N * Tr::kStateBytes) { // the bound was none (never seen): once more, into a worst-case piece
-                if (attempt == 1u && lane == 0) {
+            if (ovf || wp < N * Tr::kStateBytes) { // the bound was none (never seen; the checks keep every store inside the piece)
+                if (lane == 0) {
                     atomicOr(p.flags, 1024u);
                     p.lengths[chunk] = 0u;
                     p.offsets[chunk] = 0u;
@@ -399,26 +433,16 @@ __global__ void __launch_bounds__(64, K == 1 ? 6 : (K <= 4 ? 4 : 2)) k_encode_ad
                 p.lengths[chunk] = (uint32_t)room - wp;
                 p.offsets[chunk] = slot_at + wp;
             }
-            break;
         }
     }
     if (__builtin_amdgcn_ballot_w64(failed) != 0 && lane == 0)
         atomicOr(p.flags, 1u);
-    // the last wave to leave writes the container's end: the slots and everything handed out behind them
-    if (lane == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const uint32_t before = atomicAdd(p.claims + kWorkPoolStride * kWorkPools, 1u);
-        if (before + 1u == gridDim.x) {
-            const unsigned long long used = __hip_atomic_load(p.bump, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            p.offsets[p.nchunks] = p.nchunks * p.slot_bytes + used;
-        }
-    }
 }
 
 template <int FMT, int K> hipError_t launch_t(const AdaptEncParams &p, int num_cus, hipStream_t stream)
 {
     // workgroups per CU: 6 KiB of LDS each allow 25 (profiles/r06_wg_residency.log), the 80 registers of six waves per SIMD 24
-    const uint64_t per_cu = K == 1 ? 24 : (K <= 4 ? 16 : 8);
+    const uint64_t per_cu = K == 1 ? kAdaptPerCu : (K <= 4 ? 16 : 8);
     const uint64_t cap = (uint64_t)num_cus * per_cu;
     const uint32_t grid = (uint32_t)(p.nchunks < cap ? (p.nchunks ? p.nchunks : 1) : cap);
     RANS_LAUNCH((k_encode_adaptive<FMT, K>), dim3(grid), dim3(64), kAdaptEncLds, stream, p);
@@ -442,7 +466,7 @@ template <int FMT> hipError_t launch_f(const AdaptEncParams &p, int num_cus, hip
 
 hipError_t launch_encode_adaptive(int format, const AdaptEncParams &p, int num_cus, hipStream_t stream, const char **name)
 {
-    if (!p.rcp || !p.claims || !p.bump || p.scale_bits < 8 || p.scale_bits > kAdaptMaxScaleBits ||
+    if (!p.rcp || !p.claims || !p.status || p.scale_bits < 8 || p.scale_bits > kAdaptMaxScaleBits ||
         (format == FMT_WORD && p.scale_bits != 12))
         return hipErrorInvalidValue;
     if (name)

@@ -47,36 +47,7 @@ __device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chun
 {
     const unsigned long long alen = (len + 15u) & ~15u;
     unsigned long long base = 0;
-    SpinWatch watch(p.wait_ticks);
-    for (uint64_t j = chunk;;) { // status[j-1], status[j-2], ... are still to be added
-        unsigned long long st = kStPrefix; // virtual predecessor of chunk 0: an inclusive prefix of 0
-        if (lane < j)
-            st = __hip_atomic_load(p.status + (j - 1 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t ready = __builtin_amdgcn_ballot_w64((st >> 62) != 0);
-        const uint64_t pref = __builtin_amdgcn_ballot_w64((st >> 62) == 2);
-        const uint32_t first_pref = pref ? (uint32_t)__builtin_ctzll(pref) : 64u;
-        const uint64_t need = first_pref >= 63u ? ~0ull : ((2ull << first_pref) - 1ull); // lanes 0 .. first_pref
-        if ((ready & need) != need) { // a predecessor in that range has not finished its chunk yet
-            if (watch.expired(p.flags)) { // (a protocol error must not hang the GPU)
-                if (lane == 0)
-                    atomicOr(p.flags, 32u);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-            continue;
-        }
-        unsigned long long v = lane <= first_pref ? (st & kStValue) : 0ull;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
-            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
-            v += (unsigned long long)lo | ((unsigned long long)hi << 32);
-        }
-        base += uniform64(v);
-        if (first_pref < 64u)
-            break;
-        j -= 64;
-    }
+    status_lookback(p.status, chunk, lane, p.flags, p.wait_ticks, 32u, base); // (a wait that gave up: bit 5, the launch has failed)
     if (lane == 0) {
         __hip_atomic_store(p.status + chunk, kStPrefix | (base + alen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         p.offsets[chunk] = base;

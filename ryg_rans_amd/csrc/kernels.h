@@ -260,8 +260,8 @@ hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_
 hipError_t launch_chunk_models(const void *syms, uint64_t n, uint32_t chunk_syms, uint64_t nchunks, uint32_t scale_bits,
                                uint16_t *d_chunk_freqs, uint32_t *d_flags, int num_cus, hipStream_t stream);
 // The fused per-chunk-model encoder (encode_adaptive.hip; rans_amd_encode_adaptive_sized): ONE launch -- the wave that codes
-// a chunk first counts it, normalises the counts, builds its records and codes it into a place whose size it derives from
-// the chunk's own histogram.
+// a chunk first counts it, normalises the counts, builds its records and codes it into a piece of the container whose size
+// it derives from the chunk's own histogram (pieces in index order, placed by a look-back over their sizes).
 struct AdaptEncParams {
     const uint8_t *syms;     // u8 symbols
     uint64_t n;
@@ -272,13 +272,13 @@ struct AdaptEncParams {
     uint32_t worst_slot;     // worst-case stream of a full chunk, a whole number of 64-byte lines
     uint8_t *out;            // the container
     uint64_t out_cap;
-    uint64_t slot_bytes;     // > 0: chunk c lies at the end of slot c when its bound fits the slot; 0: no slots
     uint64_t *offsets;       // out, [nchunks + 1]
     uint32_t *lengths;       // out
     uint16_t *chunk_freqs;   // out: u16[256] per chunk
     uint32_t *flags;         // bit 0: a chunk could not be normalised; bit 1: the container does not fit out_cap
-    unsigned int *claims;    // kWorkPools claim counters on a 64-byte line each, then one line {waves done}; zero at launch
-    unsigned long long *bump; // bytes handed out behind the slots; zero at launch
+    unsigned int *claims;    // kWorkPools claim counters on a 64-byte line each; zero at launch
+    unsigned long long *status; // one look-back word per chunk (AGGREGATE | piece size, then PREFIX | end of the piece); zero at launch
+    unsigned long long wait_ticks; // how long a look-back may wait (device_common.hpp SpinWatch); 0 = the default half minute
     const uint32_t *rcp;     // [2][kAdaptRcpEntries]: Alverson reciprocals by frequency, then the round-up ones (model.cpp adapt_rcp_tables)
 };
 constexpr uint32_t kAdaptRcpEntries = 4097; // frequencies 0 .. 4096 (per-chunk models: scale_bits <= 12)

@@ -144,6 +144,54 @@ def test_full_size_every_chunk_equals_oracle(gpu, oracle, name, fmt, sb, K, ways
     assert ctx.decode_errors() >= 1 or not torch.equal(out2, d_syms)
 
 
+@pytest.mark.parametrize("fmt,sb,chunk", [(FMT_WORD, 12, 16384), (FMT_BYTE, 12, 16384), (FMT_WORD, 12, 32768), (FMT_BYTE, 10, 32768)])
+def test_full_size_per_chunk_models_every_chunk_equals_oracle(gpu, oracle, fmt, sb, chunk):
+    """Per-chunk models at the BASELINE size (parity was pinned on 37 chunks): 2^30 bytes whose
+    statistics move every 4 Mi symbols, coded by the one-kernel encoder (rans_amd_encode_adaptive_sized) and by the
+    three-launch path -- EVERY chunk's row == the oracle's normalize(count(chunk)) and EVERY chunk's stream == the oracle's
+    stream of that chunk under its own model (main.cpp:139-162 with the chunk as the input); the pieces lie in index order;
+    the decoder takes the container as it is and -- independent of any GPU encoder -- a container the ORACLE made."""
+    R, ctx, torch = gpu
+    import bench
+    n = 1 << 30
+    d_syms = bench.gen_moving(torch, n, 1, "cuda")
+    # (the generator on the GPU == the oracle's on the CPU, group by group)
+    for g in (0, 5, 255):
+        part = oracle.gen_zipf(1 << 22, K=(256, 64, 16, 4)[g % 4], s=(0.5, 1.0, 1.5, 2.0)[(g // 4) % 4], seed=1 + g)
+        assert np.array_equal(d_syms[g << 22:(g + 1) << 22].cpu().numpy(), ((part.astype(np.int32) + 37 * g) % 256).astype(np.uint8))
+    h_syms = d_syms.cpu().numpy()
+    nchunks = n // chunk
+    cont, offs, lens, rows, total = ctx.encode_adaptive_sized(d_syms, 64, chunk, sb, fmt=fmt)
+    assert ctx.last_encode_kernel()[0] == ("k_encode_adaptive<word>" if fmt == FMT_WORD else "k_encode_adaptive<byte>")
+    h_offs, h_lens = offs.cpu().numpy().astype(np.uint64), lens.cpu().numpy().astype(np.uint32)
+    h_rows = rows.cpu().numpy()
+    count, bad = oracle.compare_container_adaptive(fmt, h_syms, 64, chunk, sb, cont[:total].cpu().numpy(), h_offs, h_lens, h_rows)
+    assert count == nchunks and bad == -1, bad
+    ends = h_offs[:nchunks] + h_lens
+    assert np.all(ends % np.uint64(64) == 0) and np.all(ends[:-1] <= h_offs[1:nchunks]) and int(ends[-1]) == total == int(h_offs[nchunks])
+    streams = int(h_lens.astype(np.int64).sum())
+    # (the bound's slack per chunk: 1.1 % of its symbols in the word format, the 2^-12 of the f32 sum, a line, rounding to lines)
+    assert total <= streams + nchunks * (chunk // 80 + 512), (total, streams)
+    out = ctx.decode_adaptive(cont, total, offs, lens, rows, n, 64, chunk, sb, fmt=fmt)
+    assert torch.equal(out, d_syms)
+    del out
+    # the three-launch path: the same rows and the same streams (its container: the compact layout)
+    c0, o0, l0, r0, t0 = ctx.encode_adaptive(d_syms, 64, chunk, sb, fmt=fmt)
+    assert torch.equal(r0, rows) and torch.equal(l0, lens)
+    count, bad = oracle.compare_container_adaptive(fmt, h_syms, 64, chunk, sb, c0[:t0].cpu().numpy(), o0.cpu().numpy(), h_lens, h_rows)
+    assert count == nchunks and bad == -1, bad
+    del c0, cont
+    # the decoder on a container (streams AND rows) made by the oracle alone
+    o_cont, o_offs, o_lens, o_rows = oracle.encode_chunked_adaptive(fmt, h_syms, 64, chunk, sb)
+    assert np.array_equal(o_lens, h_lens) and np.array_equal(o_rows.reshape(-1), h_rows.view(np.uint16))
+    d_cont = torch.zeros(o_cont.size + 64, dtype=torch.uint8, device="cuda")
+    d_cont[:o_cont.size] = torch.from_numpy(o_cont).cuda()
+    out = ctx.decode_adaptive(d_cont, o_cont.size, torch.from_numpy(o_offs.astype(np.int64)).cuda(),
+                              torch.from_numpy(o_lens.astype(np.int32)).cuda(), torch.from_numpy(o_rows.reshape(-1).view(np.int16)).cuda(),
+                              n, 64, chunk, sb, fmt=fmt)
+    assert torch.equal(out, d_syms)
+
+
 def test_book1_appendix_b_on_gpu(gpu):
     """SURVEY appendix B through the HIP path: decode the reference-made 64-way word stream of book1, then
     re-encode book1 into every pinned stream (sizes from the README, SHA-256 from the unmodified reference)."""

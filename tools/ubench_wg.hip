@@ -30,6 +30,47 @@ __global__ void __launch_bounds__(256) k_wait256(uint32_t *out, unsigned long lo
         out[blockIdx.x] = smem[0];
 }
 
+// where a wave runs: HW_REG_HW_ID (wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) and HW_REG_XCC_ID (3:0)
+__global__ void __launch_bounds__(256) k_where(uint32_t *out, unsigned long long ticks)
+{
+    extern __shared__ uint8_t smem[];
+    const unsigned long long t0 = wall_clock64();
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0)
+        smem[0] = 1;
+    while (wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(16);
+    if ((threadIdx.x & 63) == 0)
+        out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (hw & 0xffffu) | ((xcc & 0xfu) << 16) | (smem[0] ? 0u : 1u << 31);
+}
+
+static void where(uint32_t *out, int cus, int threads, int per_cu, int lds)
+{
+    const int waves = threads / 64, g = per_cu * cus;
+    hipMemset(out, 0xff, 1 << 22);
+    hipLaunchKernelGGL(k_where, dim3(g), dim3(threads), lds, 0, out, 20000ull);
+    hipDeviceSynchronize();
+    static uint32_t host[1 << 20];
+    hipMemcpy(host, out, (size_t)g * waves * 4, hipMemcpyDeviceToHost);
+    // waves per SIMD: key = xcc, se, sh, cu, simd
+    static int count[1 << 20];
+    for (int i = 0; i < (1 << 20); ++i) count[i] = 0;
+    for (int i = 0; i < g * waves; ++i) {
+        const uint32_t v = host[i];
+        const uint32_t key = ((v >> 16) & 0xf) << 12 | ((v >> 13) & 7) << 9 | ((v >> 12) & 1) << 8 | ((v >> 8) & 0xf) << 4 | ((v >> 4) & 3);
+        count[key]++;
+    }
+    int hist[64] = {0}, simds = 0;
+    for (int i = 0; i < (1 << 20); ++i)
+        if (count[i]) { hist[count[i] < 63 ? count[i] : 63]++; simds++; }
+    printf("%4d-thread workgroups, %2d per CU, lds %6d: %d SIMDs saw waves; SIMDs by waves hosted:", threads, per_cu, lds, simds);
+    for (int i = 1; i < 64; ++i)
+        if (hist[i]) printf("  %d waves x %d", i, hist[i]);
+    printf("\n");
+}
+
 int main()
 {
     hipDeviceProp_t prop;
@@ -61,6 +102,14 @@ int main()
         }
         printf("\n");
     }
+    // (launches that fit the chip at once: every wave of the launch is resident while it reports)
+    where(out, cus, 64, 24, 6144);
+    where(out, cus, 64, 20, 7936);
+    where(out, cus, 64, 16, 7936);
+    where(out, cus, 128, 10, 2 * 7936);
+    where(out, cus, 256, 5, 4 * 7936);
+    where(out, cus, 256, 6, 4 * 6144);
+    where(out, cus, 512, 4, 0);
     printf("256-thread workgroups (4 waves):\n");
     for (int lds : {0, 16384, 20480, 24576}) {
         printf("lds %6d:", lds);
