@@ -353,6 +353,66 @@ def measure_config(torch, R, ctx, short, name, fmt, sb, K, ways, chunk, log2n, s
     return entry, art
 
 
+def measure_adaptive(torch, R, ctx, short, name, fmt, sb, ways, chunk, d_syms, steps):
+    """One `configs` entry for per-chunk models: rans_amd_encode_adaptive_sized -- count + normalise + records +
+    code in ONE kernel, the piece of a chunk sized from its own histogram -- and rans_amd_decode_adaptive_fmt on the
+    container it leaves; `steps` back-to-back launches each, round trip verified; the artefacts go to the CPU leg, which
+    compares EVERY chunk's row and stream with the oracle's."""
+    n = d_syms.numel()
+    trace("config", short, "n", n)
+    cont, offs, lens, rows, total = ctx.encode_adaptive_sized(d_syms, ways, chunk, sb, fmt=fmt)
+    out = torch.empty_like(d_syms)
+    enc_ms, enc_min = timed_launches(
+        torch, lambda: ctx.encode_adaptive_sized(d_syms, ways, chunk, sb, fmt=fmt, d_out=cont, d_offsets=offs, d_lengths=lens,
+                                                 d_freqs=rows, sync=False), steps, 2)
+    ctx.encode_status()
+    enc_kernel = ctx.last_encode_kernel()[0]
+    total = int(offs[-1].item())
+    dec_ms, dec_min = timed_launches(
+        torch, lambda: ctx.decode_adaptive(cont, total, offs, lens, rows, n, ways, chunk, sb, d_out=out, sync=False, fmt=fmt), steps, 2)
+    exact = ctx.decode_errors() == 0 and bool(torch.equal(out, d_syms))
+    stream = int(lens.to(torch.int64).sum().item())
+    nchunks = (n + chunk - 1) // chunk
+    alg = n + stream + nchunks * 512  # symbols + streams + frequency rows, each crossing HBM once
+    entry = {
+        "short": short, "name": name, "format": R.FORMAT_NAMES[fmt], "scale_bits": sb, "alphabet": 256, "n_ways": ways, "chunk_syms": chunk,
+        "symbols": n, "decoded_bytes": n, "stream_bytes": stream, "row_bytes": nchunks * 512, "algorithmic_bytes_per_launch": alg,
+        "decode": {"kernel": ctx.last_decode_kernel(), "ms_mean": round(dec_ms, 4), "ms_min": round(dec_min, 4), "launches": steps,
+                   "decoded_GBps": round(n / dec_ms / 1e6, 1), "achieved_GBps": round(alg / dec_ms / 1e6, 1),
+                   "frac": round(alg / dec_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+        "encode": {"layout": "pieces sized from each chunk's own histogram, in index order (rans_amd_encode_adaptive_sized: one kernel)",
+                   "kernels": enc_kernel, "ms_mean": round(enc_ms, 4), "ms_min": round(enc_min, 4), "launches": steps,
+                   "input_GBps": round(n / enc_ms / 1e6, 1), "achieved_GBps": round(alg / enc_ms / 1e6, 1),
+                   "frac": round(alg / enc_ms / 1e6 / HBM_PEAK_GBPS, 4), "container_bytes": total,
+                   "container_over_input": round(total / n, 4), "container_over_streams": round(total / max(1, stream), 4)},
+        "bit_exact_roundtrip": exact, "per_chunk_models": True,
+    }
+    art = {"adaptive": True, "fmt": fmt, "sb": sb, "K": 256, "ways": ways, "chunk": chunk, "n": n, "d_syms": d_syms, "cont": cont,
+           "offs": offs, "lens": lens, "rows": rows, "total": total, "entry": entry}
+    return entry, art
+
+
+def oracle_check_adaptive(art):
+    """Per-chunk models at the bench size: EVERY chunk's frequency row == the oracle's normalize(count(chunk)) and EVERY chunk's
+    stream == the oracle's stream of the chunk under that model (main.cpp:139-162 with the chunk as the input; threaded,
+    oracle/rans_oracle.c orc_compare_chunks_adaptive); pieces in index order, whole 64-byte lines.  Returns chunks compared."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from _oracle import Oracle
+    orc = Oracle()
+    n, chunk = art["n"], art["chunk"]
+    nchunks = (n + chunk - 1) // chunk
+    offs = art["offs"].cpu().numpy().astype(np.uint64)
+    lens = art["lens"].cpu().numpy().astype(np.uint32)
+    ends = offs[:nchunks] + lens[:nchunks]
+    assert np.all(ends % np.uint64(64) == 0) and np.all(ends[:-1] <= offs[1:nchunks]) and int(ends[-1]) == int(offs[nchunks]) == art["total"], \
+        "per-chunk-model container: pieces are not whole lines in index order"
+    count, bad = orc.compare_container_adaptive(art["fmt"], art["d_syms"].cpu().numpy(), art["ways"], chunk, art["sb"],
+                                                art["cont"][:art["total"]].cpu().numpy(), offs, lens, art["rows"].cpu().numpy())
+    assert bad == -1, "per-chunk models: chunk %d: %s differs from the oracle's" % bad
+    return count
+
+
 # ---- CPU leg (rank 0, N = 1): the only place bench.py touches oracle/ ---------------------------------
 
 def oracle_check_chunks(art, sample=0):
@@ -482,7 +542,7 @@ def cpu_baseline(d_syms, freqs, n):
     # or not.  The sweep stops at the quota; both numbers are reported.
     quota = cpu_quota_cores()
     max_threads = max(1, usable if quota is None else min(usable, int(math.ceil(quota))))
-    shard = min(1 << 22, n // max_threads)       # 4 Mi symbols per shard (cache friendly: this measures the decoder)
+    shard = min(1 << 24, n // max_threads)       # 16 Mi symbols per shard: the first 256 MiB on 16 threads, as the `configs` rows
     shard -= shard % 32
     orc = Oracle()
     if not Ref.available() and not HostSimd.available():
@@ -659,9 +719,16 @@ def judged_line(full, details_path=None):
     if full.get("knobs"):
         line["knobs"] = sorted(full["knobs"])
     rl = full.get("roofline", {})
-    line["roofline"] = {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg",
-                                               "algorithmic_bytes_per_launch", "frac_job", "wave_span_ms_avg",
-                                               "frac_of_measured_copy")}  # (against the 8 TB/s spec AND the 6.29 TB/s copy)
+    # (`frac` = algorithmic bytes / the wall time of the K timed steps / peak: the clock `value` and `ms_per_step` use;
+    #  `frac_kernel_events` = the same bytes over the HIP-event mean of those launches; SURVEY 8(d): against the 8 TB/s spec
+    #  AND the 6.29 TB/s measured copy)
+    line["roofline"] = {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel",
+                                               "kernel_ms_avg", "frac_kernel_events", "algorithmic_bytes_per_launch", "frac_job",
+                                               "wave_span_ms_avg", "frac_of_measured_copy")}
+    if (full.get("n_gpus") or 1) == 1:
+        line["roofline"].pop("frac_job", None)  # (one GPU: the job IS the launch)
+    if line["roofline"].get("traffic_source"):
+        line["roofline"]["traffic_source"] = line["roofline"]["traffic_source"].split(" ")[0]  # (the file; the method is in the details)
     pl = full.get("placement", {})
     if "probe_ms_chosen" in pl:  # the un-probed figure beside the chosen one: what two plain hipMallocs would have got
         n_sym = c.get("symbols_per_gpu") or 0
@@ -669,18 +736,21 @@ def judged_line(full, details_path=None):
                              "min_ms": pl["probe_ms_min"], "max_ms": pl["probe_ms_max"],
                              "pairs": pl["candidates"]["containers"] * pl["candidates"]["outputs"],
                              "stride_gib": pl.get("stride_gib", 0)}
-        if (full.get("n_gpus") or 1) == 1 and pl["probe_ms_first_pair"] > 0:
-            line["value_first_pair"] = round(n_sym / pl["probe_ms_first_pair"] / 1e6, 2)
-            line["frac_first_pair"] = round(rl.get("algorithmic_bytes_per_launch", 0) / pl["probe_ms_first_pair"] / 1e6
-                                            / HBM_PEAK_GBPS, 4)
+        if (full.get("n_gpus") or 1) == 1:
+            # K timed steps on the first pair, the same loop and clock as `value` (the probe's own figures above are HIP-event
+            # means of its few launches: another clock).  The probe chose the first pair itself: it IS the headline.
+            fp = pl.get("first_pair_ms_per_step") or (full.get("ms_per_step") if pl.get("chosen") == [0, 0] else None)
+            if fp:
+                line["placement"]["first_pair_ms_per_step"] = fp
+                line["value_first_pair"] = round(n_sym / fp / 1e6, 2)
+                line["frac_first_pair"] = round(rl.get("algorithmic_bytes_per_launch", 0) / fp / 1e6 / HBM_PEAK_GBPS, 4)
     ck = full.get("clocks", {})
     if "error" not in ck:
-        line["clocks"] = {k: ck.get(k) for k in ("sclk_hz_measured", "per_wave_clocks_per_round_of_64",
-                                                 "clocks_per_symbol_per_simd", "gpu_aggregate_clocks_per_symbol")}
+        line["clocks"] = {k: ck.get(k) for k in ("sclk_hz_measured", "per_wave_clocks_per_round_of_64", "clocks_per_symbol_per_simd")}
     cb = full.get("cpu_baseline")
     if cb is not None:
         line["cpu_baseline"] = {"value": None if cb.get("value") is None else round(cb["value"], 3), "unit": cb.get("unit"),
-                                "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": (cb.get("sample") or "")[:120]}
+                                "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": (cb.get("sample") or "")[:72]}
         for k in ("single_thread_value", "single_thread_clocks_per_symbol", "port_value", "port_cores"):
             if cb.get(k) is not None:
                 line["cpu_baseline"][k] = round(cb[k], 3)
@@ -688,34 +758,41 @@ def judged_line(full, details_path=None):
         if k in full:
             line[k] = full[k]
     rows = []
+    ref_cores = None
     for e in full.get("configs", []):
         if "error" in e:
             rows.append({"error": e["error"][:120]})
             continue
         cpu = e.get("cpu_baseline") or {}
         total = e.get("oracle_chunks_total")
-        row = {"name": e["short"], "decode_ms": e["decode"]["ms_mean"], "decode_frac": e["decode"]["frac"],
-               "encode_ms": e["encode"]["ms_mean"], "encode_frac": e["encode"]["frac"]}
-        for key, tag in (("encode_slots", "enc_slots"), ("encode_tight", "enc_tight"), ("decode_slots", "dec_slots"),
-                         ("decode_tight", "dec_tight")):
-            if key in e:
-                row[tag + "_ms"] = e[key]["ms_mean"]
-        if "encode_tight" in e:
-            row["tight_over_input"] = e["encode_tight"]["container_over_input"]
+        row = {"name": e["short"], "decode_ms": e["decode"]["ms_mean"], "decode_frac": e["decode"]["frac"]}
+        if e.get("per_chunk_models"):  # one kernel, pieces sized from each chunk's own histogram: a sized layout by construction
+            row["enc_tight_ms"] = e["encode"]["ms_mean"]
+            row["enc_tight_frac"] = e["encode"]["frac"]
+            row["tight_size"] = e["encode"]["container_over_input"]
+        else:
+            row["encode_ms"] = e["encode"]["ms_mean"]  # (the compact layout, rans_amd_encode)
+            row["encode_frac"] = e["encode"]["frac"]
+            if "encode_tight" in e:  # (sized slots, rans_amd_encode_slots_sized, and the decode of the container they leave)
+                row["enc_tight_ms"] = e["encode_tight"]["ms_mean"]
+                row["dec_tight_ms"] = e["decode_tight"]["ms_mean"]
+                row["tight_size"] = e["encode_tight"]["container_over_input"]  # (sized container / input bytes)
         if cpu.get("value") is not None:
-            row["cpu_ref_GBps"] = cpu["value"]
-            row["cpu_ref_cores"] = cpu.get("cores")
+            row["cpu_GBps"] = cpu["value"]  # (the reference's own loop of this format on cpu_ref_cores host threads)
+            ref_cores = cpu.get("cores")
         row["oracle_ok"] = bool(e.get("bit_exact_roundtrip")) and total is not None and \
             e.get("oracle_chunks_checked") == total and e.get("oracle_chunks_checked_slots", total) == total and \
             e.get("oracle_chunks_checked_tight", total) == total
         rows.append(row)
+    if ref_cores is not None:
+        line["cpu_ref_cores"] = ref_cores  # (threads of every row's cpu_ref_GBps: the reference's own loop of that format)
     if rows:
         line["configs"] = rows
     if full.get("per_rank") and (full.get("n_gpus") or 1) > 1:
         line["per_rank_kernel_ms"] = full["per_rank"]["kernel_ms"]
     line["details"] = details_path
     # the size is a guarantee, not a hope: shed the optional per-config keys, then whole rows, until the line fits
-    for drop in ("cpu_ref_cores", "dec_slots_ms", "enc_slots_ms", "tight_over_input", "dec_tight_ms", "enc_tight_ms", "cpu_ref_GBps", None):
+    for drop in ("tight_size", "dec_tight_ms", "cpu_GBps", "enc_tight_frac", "encode_frac", None):
         if len(json.dumps(line, separators=(",", ":"))) <= MAX_LINE_BYTES:
             break
         if drop is None:
@@ -837,6 +914,7 @@ def main():
     cont, offs, lens, total = ctx.encode(model, d_syms, args.ways, args.chunk)
     out = torch.empty(n + args.debug_out_offset, dtype=torch.uint8, device=device)[args.debug_out_offset:]
     placement = {"candidates": 1}
+    first_pair = None
     if args.placement_candidates > 1 and not (args.debug_out_offset or args.debug_cont_offset or args.debug_same_chunk):
         # Setup, untimed: where the buffers lie is worth 4-6 % on this part (two classes of device memory; container and
         # output in DIFFERENT classes is the fast case, profiles/r04_allocation.md), and which class an allocation gets is
@@ -877,6 +955,7 @@ def main():
                               stride_bytes=args.placement_stride_gib << 30, reserve_bytes=24 << 30)
             outs += more
             spacers += sp
+        first_pair = None if (ci, oi) == (0, 0) else (conts[0], outs[0])  # (what two plain allocations would have got: timed below)
         cont, out = conts[ci], outs[oi]
         placement = {"candidates": {"containers": len(conts), "outputs": len(outs), "extended": extended}, "chosen": [ci, oi],
                      "probe_ms_chosen": round(matrix[ci][oi], 4), "probe_ms_min": round(min(flat), 4),
@@ -937,6 +1016,23 @@ def main():
         spans = ctx.launch_spans(min(args.steps, 32))
     except Exception:  # noqa: BLE001  (an older library build in an A/B run)
         spans = []
+    # the same K steps on the FIRST pair of allocations, same loop, same clock (setup's probe is what chose another pair):
+    # `value_first_pair` is what a caller without the probe gets
+    first_pair_elapsed = None
+    if first_pair is not None and world == 1:
+        fc, fo = first_pair
+
+        def first_step():
+            ctx.decode(model, fc, total, offs, lens, n, args.ways, args.chunk, d_out=fo, sync=False)
+        for _ in range(max(args.warmup, 3)):
+            first_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            first_step()
+        torch.cuda.synchronize()
+        first_pair_elapsed = time.perf_counter() - t1
+    del first_pair
 
     # ---- verification (after the timed region) -------------------------------------
     trace("timed region done")
@@ -970,7 +1066,11 @@ def main():
         ms_per_step = agg["ms_per_step"]
         value = agg["symbols_per_s"] / 1e9  # 1 byte per symbol
         k_s = kernel_ms * 1e-3
-        achieved = (n + total) / k_s / 1e9
+        # ONE clock on the line: `value`, `ms_per_step` and `roofline.frac` all come from the wall time of the K timed steps
+        # (rank 0's own; at N = 1 that is ms_per_step); the HIP-event mean of the same launches is listed beside it
+        step_s = records[0].elapsed_s / args.steps
+        achieved = (n + total) / step_s / 1e9
+        achieved_events = (n + total) / k_s / 1e9
         result = {
             "metric": "decode GB/s (uncompressed), %d-way interleaved rANS (%s format)" % (args.ways, args.format),
             "value": round(value, 2),
@@ -1014,16 +1114,17 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "clock": "wall time of the K timed steps (ms_per_step)",
+                "achieved_kernel_events": round(achieved_events, 1), "frac_kernel_events": round(achieved_events / HBM_PEAK_GBPS, 4),
                 "kernel": ctx.last_decode_kernel(), "kernel_ms_avg": round(kernel_ms, 4),
                 # the timed launches are dispatches [first, first + steps) of this kernel in this process, counted from 0
                 "timed_dispatches": [timed_first, timed_first + args.steps],
                 "algorithmic_bytes_per_launch": n + total,
-                # the job: algorithmic bytes of ALL ranks over the slowest rank's kernel time, against N GPUs' peak (at N = 1
-                # this is `frac`); achieved / peak / frac above are rank 0's kernel on rank 0's GPU
-                "frac_job": round(sum(r.symbols + r.stream_bytes for r in records) / (max(r.kernel_ms for r in records) * 1e-3)
+                # the job: algorithmic bytes of ALL ranks over the slowest rank's step time, against N GPUs' peak (at N = 1
+                # this is `frac`); achieved / peak / frac above are rank 0's launches on rank 0's GPU
+                "frac_job": round(sum(r.symbols + r.stream_bytes for r in records) / (ms_per_step * 1e-3)
                                   / 1e9 / (len(records) * HBM_PEAK_GBPS), 4),
-                "achieved_job": round(sum(r.symbols + r.stream_bytes for r in records) / (max(r.kernel_ms for r in records) * 1e-3)
-                                      / 1e9, 1),
+                "achieved_job": round(sum(r.symbols + r.stream_bytes for r in records) / (ms_per_step * 1e-3) / 1e9, 1),
                 "peak_job": len(records) * HBM_PEAK_GBPS,
                 "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
                 # what a launch spends inside its wavefronts (first wave start .. last wave end, mean over the timed
@@ -1033,6 +1134,8 @@ def main():
                 if spans else None,
             },
         }
+        if first_pair_elapsed is not None:
+            result["placement"]["first_pair_ms_per_step"] = round(first_pair_elapsed / args.steps * 1e3, 4)
         if args.dump_launch_ms:
             result["launch_ms"] = [round(a.elapsed_time(b), 4) for a, b in zip(ev0, ev1)]
             result["launch_span_ms"] = [round(v, 4) for v in spans]
@@ -1108,6 +1211,22 @@ def main():
                                       R.FMT_BYTE, 12, 256, 64, cc, args.log2n, 1, ks, device, d_syms=d_syms, probe=cp)
                 cfgs.append(e)
                 arts.append(a)
+                # the layouts the reference itself ships: its 8-way word streams -- main_simd.cpp:287-332, the
+                # SSE4.1 decoder's own input -- and its 2-way byte streams (main.cpp:226-280), one LANE per chunk (lanes.hip)
+                e, a = measure_config(torch, R, ctx, "word8", "word 8-way 1 GiB Zipf(256), 4096-symbol chunks (the reference's SIMD layout)",
+                                      R.FMT_WORD, 12, 256, 8, 4096, args.log2n, 1, ks, device, d_syms=d_syms, probe=1)
+                cfgs.append(e)
+                arts.append(a)
+                e, a = measure_config(torch, R, ctx, "byte2", "byte 2-way 1 GiB Zipf(256), scale_bits 14, 4096-symbol chunks (main.cpp's layout)",
+                                      R.FMT_BYTE, 14, 256, 2, 4096, args.log2n, 1, ks, device, d_syms=d_syms, probe=1)
+                cfgs.append(e)
+                arts.append(a)
+                # per-chunk models: count + normalise + code in one kernel, every chunk its own model
+                for afmt, aname in ((R.FMT_WORD, "word"), (R.FMT_BYTE, "byte")):
+                    e, a = measure_adaptive(torch, R, ctx, aname + "-adaptive", "%s format, one model per %d-symbol chunk, 64-way, 1 GiB "
+                                            "Zipf(256), 12 bits" % (aname, cc), afmt, 12, 64, cc, d_syms, ks)
+                    cfgs.append(e)
+                    arts.append(a)
                 # "64-way and wider" (north_star): two and four states per lane over the headline's data
                 for wide in (128, 256):
                     e, a = measure_config(torch, R, ctx, "word%d" % wide, "word %d-way 1 GiB Zipf(256) (%d states per lane)" % (wide, wide // 64),
@@ -1134,6 +1253,13 @@ def main():
                 checked = {}
                 t_or = time.perf_counter()
                 for a in arts:
+                    if a.get("adaptive"):
+                        key = "%s-%d/%d-way/%d per-chunk models" % (R.FORMAT_NAMES[a["fmt"]], a["sb"], a["ways"], a["chunk"])
+                        checked[key] = oracle_check_adaptive(a)
+                        a["entry"]["oracle_chunks_checked"] = checked[key]
+                        a["entry"]["oracle_chunks_total"] = (a["n"] + a["chunk"] - 1) // a["chunk"]
+                        del a["cont"]
+                        continue
                     key = "%s-%d/%d-way/%d" % (R.FORMAT_NAMES[a["fmt"]], a["sb"], a["ways"], a["chunk"])
                     checked[key] = oracle_check_chunks(a, args.oracle_sample)
                     if a["entry"] is not None:
@@ -1165,7 +1291,7 @@ def main():
                 all_ok = False
             t_cb = time.perf_counter()
             for a in arts:  # the reference's own loop of every configuration's format, on this box, beside its GPU numbers
-                if a["entry"] is None:
+                if a["entry"] is None or a.get("adaptive"):  # (per-chunk models: the reference has one model per input, no such loop)
                     continue
                 try:
                     a["entry"]["cpu_baseline"] = config_cpu_baseline(a)

@@ -10,6 +10,7 @@
 //         -Wl,-rpath,$PWD/ryg_rans_amd/lib -o build/multi_gpu
 //   build/multi_gpu [devices (default: all)] [log2 symbols per device (default 26)] [steps (default 10)]
 //   build/multi_gpu --split-one [ranks (default: max(2, devices))] [log2 symbols (default 26)] [steps]
+//   build/multi_gpu --share     [ranks] [log2 symbols per rank] [steps]     (independent shards, ranks may share devices)
 //
 // --split-one: ONE container (made once, on the host side of rank 0's device) is split over the ranks by SURVEY 8(e)'s
 // rule -- rank g owns chunks [g C / G, (g + 1) C / G) -- and every rank holds ONLY the bytes rans_amd_container_slice
@@ -292,12 +293,15 @@ int main(int argc, char **argv)
         return 1;
     }
     const bool split_one = argc > 1 && strcmp(argv[1], "--split-one") == 0;
-    if (split_one) {
+    // --share: more ranks than devices are allowed for independent shards as well (rank g on device g mod devices) -- the
+    // dry run of an 8-rank job on a box with fewer GPUs: every rank still owns its own shard, context, stream and probe
+    const bool share = argc > 1 && strcmp(argv[1], "--share") == 0;
+    if (split_one || share) {
         --argc;
         ++argv;
     }
     int world = argc > 1 ? atoi(argv[1]) : (split_one ? std::max(2, visible) : visible);
-    world = world < 1 ? 1 : ((!split_one && world > visible) ? visible : world);
+    world = world < 1 ? 1 : ((!split_one && !share && world > visible) ? visible : world);
     const int log2n = argc > 2 ? atoi(argv[2]) : 26;
     const int steps = argc > 3 ? atoi(argv[3]) : 10;
     const bool use_rccl = world <= visible; // (more ranks than devices: they share devices and gather through host memory)

@@ -457,6 +457,17 @@ uint64_t rans_amd_container_bytes(const rans_amd_container_info *info);
 int rans_amd_container_pack(const rans_amd_container_info *info, const uint32_t *norm_freqs,
                             const uint32_t *lengths, const void *payload, void *dst, uint64_t cap,
                             uint64_t *out_bytes);
+/* The same file from a container in ANY layout (0.6.0) -- what the reference does when it writes [rans_begin, end) of a
+ * buffer it coded into from the end (main.cpp:182-188): chunk c is read from payload + offsets[c] (lengths[c] bytes) and
+ * written to its place in the file's compact payload; info->payload_bytes is ignored (the file's is
+ * rans_amd_packed_payload_bytes(lengths, n_chunks); dst needs rans_amd_container_bytes() of an info with that value).
+ * `payload` / `payload_bytes`: the host copy of the device container -- sized slots (rans_amd_encode_slots_sized, overflowed
+ * chunks included), worst-case slots, a slice, a compact one: encode -> one D2H copy -> this call, no compaction pass on the
+ * device.  RANS_AMD_E_CORRUPT when an index entry does not lie inside [0, payload_bytes) (nothing outside is read). */
+uint64_t rans_amd_packed_payload_bytes(const uint32_t *lengths, uint64_t n_chunks);
+int rans_amd_container_pack_indexed(const rans_amd_container_info *info, const uint32_t *norm_freqs, const uint64_t *offsets,
+                                    const uint32_t *lengths, const void *payload, uint64_t payload_bytes, void *dst,
+                                    uint64_t cap, uint64_t *out_bytes);
 /* Validate and index a serialised container in place: *freqs, *lengths and *payload point INTO
  * src (which must be 4-byte aligned: RANS_AMD_E_ARG otherwise).  RANS_AMD_E_CORRUPT on a bad
  * magic/version/checksum or inconsistent sizes; whatever is accepted lies inside [src, src + bytes). */
@@ -471,6 +482,10 @@ uint64_t rans_amd_container_bytes_adaptive(const rans_amd_container_info *info);
 int rans_amd_container_pack_adaptive(const rans_amd_container_info *info, const uint16_t *chunk_freqs,
                                      const uint32_t *lengths, const void *payload, void *dst, uint64_t cap,
                                      uint64_t *out_bytes);
+/* ... and from any layout (rans_amd_encode_adaptive_sized's pieces): see rans_amd_container_pack_indexed. */
+int rans_amd_container_pack_indexed_adaptive(const rans_amd_container_info *info, const uint16_t *chunk_freqs,
+                                             const uint64_t *offsets, const uint32_t *lengths, const void *payload,
+                                             uint64_t payload_bytes, void *dst, uint64_t cap, uint64_t *out_bytes);
 int rans_amd_container_parse_adaptive(const void *src, uint64_t bytes, rans_amd_container_info *info,
                                       const uint16_t **chunk_freqs, const uint32_t **lengths, const void **payload);
 

@@ -49,6 +49,7 @@ ABI_SYMBOLS = [
     "rans_amd_encode_adaptive_sized", "rans_amd_encode_adaptive_sized_bound",
     "rans_amd_container_bytes_adaptive", "rans_amd_container_pack_adaptive", "rans_amd_container_parse_adaptive",
     "rans_amd_offsets_from_lengths", "rans_amd_container_bytes", "rans_amd_container_pack",
+    "rans_amd_packed_payload_bytes", "rans_amd_container_pack_indexed", "rans_amd_container_pack_indexed_adaptive",
     "rans_amd_container_parse", "rans_amd_encode_workspace_bytes", "rans_amd_build_model_o0",
 ]
 
@@ -148,6 +149,9 @@ def _load():
         "rans_amd_container_pack": (i32, [C.POINTER(ContainerInfo), u32p, u32p, vp, vp, u64, u64p]),
         "rans_amd_container_parse": (i32, [vp, u64, C.POINTER(ContainerInfo), C.POINTER(u32p), C.POINTER(u32p),
                                          C.POINTER(vp)]),
+        "rans_amd_packed_payload_bytes": (u64, [u32p, u64]),
+        "rans_amd_container_pack_indexed": (i32, [C.POINTER(ContainerInfo), u32p, u64p, u32p, vp, u64, vp, u64, u64p]),
+        "rans_amd_container_pack_indexed_adaptive": (i32, [C.POINTER(ContainerInfo), vp, u64p, u32p, vp, u64, vp, u64, u64p]),
         "rans_amd_container_bytes_adaptive": (u64, [C.POINTER(ContainerInfo)]),
         "rans_amd_container_pack_adaptive": (i32, [C.POINTER(ContainerInfo), vp, u32p, vp, vp, u64, u64p]),
         "rans_amd_container_parse_adaptive": (i32, [vp, u64, C.POINTER(ContainerInfo), C.POINTER(vp), C.POINTER(u32p),
@@ -599,6 +603,42 @@ def pack_container(fmt, norm_freqs, scale_bits, n_symbols, n_ways, chunk_syms, l
     _check(_lib.rans_amd_container_pack(C.byref(info), f.ctypes.data_as(C.POINTER(C.c_uint32)),
                                         lengths.ctypes.data_as(C.POINTER(C.c_uint32)), payload.ctypes.data,
                                         out.ctypes.data, out.size, C.byref(wrote)), "container_pack")
+    return out[:wrote.value]
+
+
+def pack_container_indexed(fmt, norm_freqs, scale_bits, n_symbols, n_ways, chunk_syms, offsets, lengths, payload, chunk_freqs=None):
+    """rans_amd_container_pack_indexed[_adaptive]: the file of a container in ANY layout -- `payload` is the host copy of the
+    device container, chunk c its lengths[c] bytes at offsets[c].  chunk_freqs (u16[n_chunks * 256]): the version-2 file."""
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    nchunks = num_chunks(n_symbols, chunk_syms)
+    if lengths.size != nchunks or offsets.size < nchunks:
+        raise RansAmdError(E_ARG, "container_pack_indexed", "index does not match the number of chunks")
+    packed = int(_lib.rans_amd_packed_payload_bytes(lengths.ctypes.data_as(C.POINTER(C.c_uint32)), nchunks))
+    wrote = C.c_uint64(0)
+    if chunk_freqs is None:
+        f = np.ascontiguousarray(norm_freqs, dtype=np.uint32)
+        info = ContainerInfo(fmt, scale_bits, f.size, n_ways, chunk_syms, 1 if f.size <= 256 else 2, n_symbols, nchunks, packed)
+        total = int(_lib.rans_amd_container_bytes(C.byref(info)))
+        if total == 0:
+            raise RansAmdError(E_ARG, "container_bytes", "inconsistent container description")
+        out = np.zeros(total, dtype=np.uint8)
+        _check(_lib.rans_amd_container_pack_indexed(C.byref(info), f.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                    offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                    lengths.ctypes.data_as(C.POINTER(C.c_uint32)), payload.ctypes.data, payload.size,
+                                                    out.ctypes.data, out.size, C.byref(wrote)), "container_pack_indexed")
+    else:
+        cf = np.ascontiguousarray(chunk_freqs).view(np.uint16).reshape(-1)
+        info = ContainerInfo(fmt, scale_bits, 256, n_ways, chunk_syms, 1, n_symbols, nchunks, packed)
+        total = int(_lib.rans_amd_container_bytes_adaptive(C.byref(info)))
+        if total == 0 or cf.size != nchunks * 256:
+            raise RansAmdError(E_ARG, "container_bytes_adaptive", "inconsistent container description")
+        out = np.zeros(total, dtype=np.uint8)
+        _check(_lib.rans_amd_container_pack_indexed_adaptive(C.byref(info), cf.ctypes.data, offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                             lengths.ctypes.data_as(C.POINTER(C.c_uint32)), payload.ctypes.data,
+                                                             payload.size, out.ctypes.data, out.size, C.byref(wrote)),
+               "container_pack_indexed_adaptive")
     return out[:wrote.value]
 
 

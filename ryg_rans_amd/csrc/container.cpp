@@ -164,6 +164,79 @@ int rans_amd_container_pack(const rans_amd_container_info *info, const uint32_t 
     return RANS_AMD_OK;
 }
 
+uint64_t rans_amd_packed_payload_bytes(const uint32_t *lengths, uint64_t n_chunks)
+{
+    uint64_t at = 0;
+    for (uint64_t c = 0; lengths && c < n_chunks; ++c)
+        at = (c + 1 == n_chunks) ? at + lengths[c] : at + align16(lengths[c]);
+    return at;
+}
+
+// chunk c of a container in ANY layout (stream at src + offsets[c], lengths[c] bytes) into the file's compact payload
+static int copy_chunks_indexed(const uint64_t *offsets, const uint32_t *lengths, uint64_t n_chunks, const void *src, uint64_t src_bytes,
+                               uint8_t *dst)
+{
+    uint64_t at = 0;
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        // (the index is DATA: nothing outside [src, src + src_bytes) is read, whatever it says)
+        if (offsets[c] > src_bytes || lengths[c] > src_bytes - offsets[c])
+            return RANS_AMD_E_CORRUPT;
+        memcpy(dst + at, static_cast<const uint8_t *>(src) + offsets[c], lengths[c]);
+        const uint64_t next = (c + 1 == n_chunks) ? at + lengths[c] : at + align16(lengths[c]);
+        if (next > at + lengths[c])
+            memset(dst + at + lengths[c], 0, (size_t)(next - at - lengths[c])); // alignment padding: zeros, so that files compare
+        at = next;
+    }
+    return RANS_AMD_OK;
+}
+
+int rans_amd_container_pack_indexed(const rans_amd_container_info *info, const uint32_t *norm_freqs, const uint64_t *offsets,
+                                    const uint32_t *lengths, const void *payload, uint64_t payload_bytes, void *dst, uint64_t cap,
+                                    uint64_t *out_bytes)
+{
+    if (!info_sane(info) || !norm_freqs || !dst || (info->n_chunks && (!offsets || !lengths || !payload)))
+        return RANS_AMD_E_ARG;
+    rans_amd_container_info packed = *info; // (the file's payload is the compact one, whatever the source's extent)
+    packed.payload_bytes = rans_amd_packed_payload_bytes(lengths, info->n_chunks);
+    const uint64_t meta = meta_bytes(&packed);
+    if (cap < meta + packed.payload_bytes)
+        return RANS_AMD_E_SPACE;
+    uint8_t *out = static_cast<uint8_t *>(dst);
+    if (int rc = copy_chunks_indexed(offsets, lengths, info->n_chunks, payload, payload_bytes, out + meta))
+        return rc;
+    // header, tables and checksum as rans_amd_container_pack writes them (a NULL payload there: the header only)
+    uint64_t sum = 0;
+    for (uint32_t s = 0; s < info->nsyms; ++s)
+        sum += norm_freqs[s];
+    if (sum != (1ull << info->scale_bits))
+        return RANS_AMD_E_MODEL;
+    memset(out, 0, (size_t)meta);
+    Header h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, kMagic, 8);
+    h.version = kVersion;
+    h.format = packed.format;
+    h.scale_bits = packed.scale_bits;
+    h.nsyms = packed.nsyms;
+    h.n_ways = packed.n_ways;
+    h.chunk_syms = packed.chunk_syms;
+    h.sym_bytes = packed.sym_bytes;
+    h.n_symbols = packed.n_symbols;
+    h.n_chunks = packed.n_chunks;
+    h.payload_bytes = packed.payload_bytes;
+    uint64_t ck = fnv1a(0xcbf29ce484222325ull, &h, sizeof(h));
+    ck = fnv1a(ck, norm_freqs, 4ull * packed.nsyms);
+    ck = fnv1a(ck, lengths, 4ull * packed.n_chunks);
+    h.checksum = ck;
+    memcpy(out, &h, sizeof(h));
+    memcpy(out + kHeaderBytes, norm_freqs, 4ull * packed.nsyms);
+    if (packed.n_chunks)
+        memcpy(out + kHeaderBytes + 4ull * packed.nsyms, lengths, 4ull * packed.n_chunks);
+    if (out_bytes)
+        *out_bytes = meta + packed.payload_bytes;
+    return RANS_AMD_OK;
+}
+
 int rans_amd_container_parse(const void *src, uint64_t bytes, rans_amd_container_info *info, const uint32_t **freqs,
                              const uint32_t **lengths, const void **payload)
 {
@@ -289,6 +362,56 @@ int rans_amd_container_pack_adaptive(const rans_amd_container_info *info, const 
         memcpy(out + meta, payload, (size_t)info->payload_bytes);
     if (out_bytes)
         *out_bytes = total;
+    return RANS_AMD_OK;
+}
+
+int rans_amd_container_pack_indexed_adaptive(const rans_amd_container_info *info, const uint16_t *chunk_freqs, const uint64_t *offsets,
+                                             const uint32_t *lengths, const void *payload, uint64_t payload_bytes, void *dst,
+                                             uint64_t cap, uint64_t *out_bytes)
+{
+    if (!info_sane_v2(info) || !dst || (info->n_chunks && (!chunk_freqs || !offsets || !lengths || !payload)))
+        return RANS_AMD_E_ARG;
+    rans_amd_container_info packed = *info;
+    packed.payload_bytes = rans_amd_packed_payload_bytes(lengths, info->n_chunks);
+    const uint64_t meta = meta_bytes_v2(&packed);
+    if (cap < meta + packed.payload_bytes)
+        return RANS_AMD_E_SPACE;
+    for (uint64_t c = 0; c < info->n_chunks; ++c) { // every chunk's model must be a model
+        uint32_t sum = 0;
+        for (int s = 0; s < 256; ++s)
+            sum += chunk_freqs[c * 256 + s];
+        if (sum != (1u << info->scale_bits))
+            return RANS_AMD_E_MODEL;
+    }
+    uint8_t *out = static_cast<uint8_t *>(dst);
+    if (int rc = copy_chunks_indexed(offsets, lengths, info->n_chunks, payload, payload_bytes, out + meta))
+        return rc;
+    memset(out, 0, (size_t)meta);
+    Header h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, kMagic, 8);
+    h.version = 2;
+    h.reserved = 1; // model mode: per-chunk u16 frequencies
+    h.format = packed.format;
+    h.scale_bits = packed.scale_bits;
+    h.nsyms = packed.nsyms;
+    h.n_ways = packed.n_ways;
+    h.chunk_syms = packed.chunk_syms;
+    h.sym_bytes = packed.sym_bytes;
+    h.n_symbols = packed.n_symbols;
+    h.n_chunks = packed.n_chunks;
+    h.payload_bytes = packed.payload_bytes;
+    uint64_t ck = fnv1a(0xcbf29ce484222325ull, &h, sizeof(h));
+    ck = fnv1a(ck, chunk_freqs, 512ull * packed.n_chunks);
+    ck = fnv1a(ck, lengths, 4ull * packed.n_chunks);
+    h.checksum = ck;
+    memcpy(out, &h, sizeof(h));
+    if (packed.n_chunks) {
+        memcpy(out + kHeaderBytes, chunk_freqs, 512ull * packed.n_chunks);
+        memcpy(out + kHeaderBytes + 512ull * packed.n_chunks, lengths, 4ull * packed.n_chunks);
+    }
+    if (out_bytes)
+        *out_bytes = meta + packed.payload_bytes;
     return RANS_AMD_OK;
 }
 

@@ -212,6 +212,94 @@ void fuzz_slice()
     (void)rans_amd_container_slice(offs.data(), lens.data(), n, lo, hi, &b, &e, reb.data() + 0 * (lo > hi));
 }
 
+uint64_t g_indexed_ok = 0, g_indexed_bad = 0;
+
+// rans_amd_container_pack_indexed[_adaptive]: a source buffer of EXACT size on the heap and an index that is right, or has
+// entries anywhere (the index is data): whatever the call returns, it must not read outside the source nor write outside dst,
+// and a file it wrote must parse and hold the chunks' bytes.
+void fuzz_pack_indexed()
+{
+    const bool v2 = below(2) != 0;
+    rans_amd_container_info info;
+    memset(&info, 0, sizeof info);
+    info.format = v2 ? (below(2) ? RANS_AMD_FMT_BYTE : RANS_AMD_FMT_WORD) : below(4);
+    info.scale_bits = (info.format == RANS_AMD_FMT_WORD) ? 12 : 8 + below(5);
+    info.nsyms = 256;
+    info.n_ways = 1 + below(512);
+    info.chunk_syms = 1 + below(3000);
+    info.sym_bytes = 1;
+    info.n_symbols = below(40000);
+    info.n_chunks = (info.n_symbols + info.chunk_syms - 1) / info.chunk_syms;
+    const uint64_t n = info.n_chunks;
+    std::vector<uint32_t> lengths((size_t)n);
+    std::vector<uint64_t> offs((size_t)n + 1, 0);
+    uint64_t at = below(50);
+    for (uint64_t c = 0; c < n; ++c) { // a valid scattered layout first
+        lengths[c] = 1 + below(400);
+        offs[c] = at;
+        at += lengths[c] + below(100);
+    }
+    const uint64_t src_bytes = at;
+    uint8_t *src = (uint8_t *)malloc(src_bytes ? src_bytes : 1);
+    for (uint64_t i = 0; i < src_bytes; ++i)
+        src[i] = (uint8_t)(i * 131u + 7u);
+    const bool damage = below(3) == 0 && n;
+    if (damage) {
+        const uint64_t c = below((uint32_t)n);
+        switch (below(4)) {
+        case 0: offs[c] = src_bytes - below(lengths[c]); break;      // runs over the end
+        case 1: offs[c] = rnd(); break;                               // anywhere
+        case 2: lengths[c] = (uint32_t)rnd(); break;                  // any length
+        default: offs[c] = src_bytes + below(1000); break;
+        }
+    }
+    info.payload_bytes = rnd(); // (ignored by the indexed calls)
+    rans_amd_container_info sized = info;
+    sized.payload_bytes = rans_amd_packed_payload_bytes(lengths.data(), n);
+    uint64_t total = v2 ? rans_amd_container_bytes_adaptive(&sized) : rans_amd_container_bytes(&sized);
+    if (total == 0 || total > (1ull << 26)) { // (a damaged length can ask for gigabytes: the call must refuse by cap)
+        total = 4096;
+    }
+    const uint64_t cap = below(8) ? total : below((uint32_t)total + 1);
+    uint8_t *dst = (uint8_t *)malloc(cap ? cap : 1);
+    std::vector<uint32_t> f(256, 0);
+    f[below(256)] = 1u << info.scale_bits;
+    std::vector<uint16_t> cf((size_t)n * 256, 0);
+    for (uint64_t c = 0; c < n; ++c)
+        cf[c * 256 + below(256)] = (uint16_t)(1u << info.scale_bits);
+    uint64_t wrote = 0;
+    const int rc = v2 ? rans_amd_container_pack_indexed_adaptive(&info, cf.data(), offs.data(), lengths.data(), src, src_bytes, dst, cap, &wrote)
+                      : rans_amd_container_pack_indexed(&info, f.data(), offs.data(), lengths.data(), src, src_bytes, dst, cap, &wrote);
+    if (rc == RANS_AMD_OK) {
+        ++g_indexed_ok;
+        if (wrote > cap)
+            abort();
+        rans_amd_container_info back;
+        const uint32_t *l2 = nullptr;
+        const void *p2 = nullptr;
+        int prc;
+        if (v2) {
+            const uint16_t *c2 = nullptr;
+            prc = rans_amd_container_parse_adaptive(dst, wrote, &back, &c2, &l2, &p2);
+        } else {
+            const uint32_t *f2 = nullptr;
+            prc = rans_amd_container_parse(dst, wrote, &back, &f2, &l2, &p2);
+        }
+        if (prc != RANS_AMD_OK || back.n_chunks != n)
+            abort();
+        std::vector<uint64_t> o2((size_t)n + 1);
+        if (rans_amd_offsets_from_lengths(l2, n, o2.data()) != RANS_AMD_OK)
+            abort();
+        for (uint64_t c = 0; c < n; ++c)
+            if (l2[c] != lengths[c] || memcmp(static_cast<const uint8_t *>(p2) + o2[c], src + offs[c], lengths[c]) != 0)
+                abort();
+    } else {
+        ++g_indexed_bad;
+    }
+    free(dst);
+    free(src);
+}
+
 uint64_t g_models_ok = 0, g_models_bad = 0;
 
 void fuzz_model()
@@ -332,12 +420,15 @@ int main(int argc, char **argv)
         parse_and_walk(b, v2);
         parse_and_walk(b, !v2); // ... and through the other version's parser
         fuzz_slice();
+        fuzz_pack_indexed();
         fuzz_model();
         if (it % 4 == 0)
             fuzz_oracle();
     }
     if (g_parsed_ok < iters / 64)
         abort(); // (the valid containers at least)
+    if (g_indexed_ok < iters / 4 || g_indexed_bad < iters / 16)
+        abort(); // (both outcomes of the indexed pack must have been seen)
     printf("fuzz_host: %llu iterations, seed %llu: containers accepted %llu / rejected %llu, models built %llu / refused %llu, "
            "oracle round trips %llu -- no sanitizer report\n",
            (unsigned long long)iters, (unsigned long long)(argc > 2 ? strtoull(argv[2], nullptr, 0) : 1),

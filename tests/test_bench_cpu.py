@@ -122,15 +122,16 @@ def test_reference_loops_of_the_cpu_baseline_are_the_oracles_streams(oracle, ref
 def test_judged_line_is_short_and_complete():
     """bench.py's LAST stdout line is what the driver parses, and the driver keeps only the last few KB of stdout: round 4's
     20.6 KB line came back `parsed: null`.  judged_line() is a pure function of the full record; here it runs on a canned
-    full record (round 4's, renamed to this round's keys) and on a worst case (12 configs with every optional key, 8 ranks,
-    an error string), and must stay under 4096 bytes with every field the contract and the judge ask for."""
+    full record (this round's, from the GPU box: gpurun_out -> tests/golden/bench_record_r06.json, probe matrices stripped),
+    on an 8-rank record and on a worst case, and must stay under bench.MAX_LINE_BYTES with every field the contract and the
+    judge ask for -- and with ONE clock: value, ms_per_step, roofline.frac and value_first_pair all come from timed steps."""
     import copy
 
     import bench
-    full = json.load(open(os.path.join(HERE, "golden", "bench_record_r04.json")))
+    full = json.load(open(os.path.join(HERE, "golden", "bench_record_r06.json")))
     line = bench.judged_line(full, "bench_details.json")
     text = json.dumps(line, separators=(",", ":"))
-    assert len(text) <= bench.MAX_LINE_BYTES < 4096, len(text)
+    assert len(text) <= bench.MAX_LINE_BYTES <= 3800, len(text)
     assert "\n" not in text and json.loads(text) == line
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "clocks", "configs", "details"):
@@ -138,33 +139,74 @@ def test_judged_line_is_short_and_complete():
     assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
     assert line["config"]["workload"] == full["config"]["workload"] and "model" not in line["config"]
     rl = line["roofline"]
-    assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and rl["unit"] == "GB/s" and rl["traffic"] == full["roofline"]["traffic"]
+    assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and rl["unit"] == "GB/s" and "traffic" in rl and "traffic_source" in rl
     assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+    # one clock: the line's frac is the algorithmic bytes over ms_per_step (what the judge recomputes), the HIP-event figure beside it
+    assert abs(rl["frac"] - rl["algorithmic_bytes_per_launch"] / line["ms_per_step"] / 1e6 / 8000.0) < 2e-4
+    assert abs(rl["frac_kernel_events"] - rl["algorithmic_bytes_per_launch"] / rl["kernel_ms_avg"] / 1e6 / 8000.0) < 2e-4
+    assert rl["frac_kernel_events"] >= rl["frac"]  # (events bracket the launches, the steps also hold the gaps between them)
     cb = line["cpu_baseline"]
     assert cb["kind"] == "reference" and cb["value"] == round(full["cpu_baseline"]["value"], 3) and cb["cores"] >= 1 and cb["sample"]
+    assert "16 MiB shards" in cb["sample"]                      # the first 256 MiB, as the `configs` rows
     assert cb["port_value"] > cb["value"]                       # the AVX-512 port is extra, never `value`
-    # the un-probed placement beside the chosen one, and no matrix
-    assert line["placement"]["first_pair_ms"] >= line["placement"]["chosen_ms"] and "probe_ms" not in line["placement"]
-    assert line["value_first_pair"] == round((1 << 30) / line["placement"]["first_pair_ms"] / 1e6, 2)
-    assert line["value_first_pair"] <= line["value"] * 1.02
+    # the un-probed placement beside the chosen one: K timed steps of the same loop, no matrix
+    pl = line["placement"]
+    assert "probe_ms" not in pl and pl["first_pair_ms_per_step"] >= line["ms_per_step"]
+    assert line["value_first_pair"] == round((1 << 30) / pl["first_pair_ms_per_step"] / 1e6, 2)
+    assert line["value_first_pair"] <= line["value"] and line["frac_first_pair"] <= rl["frac"]
     rows = line["configs"]
-    assert [r["name"] for r in rows] == ["C3-word64", "C2-r64x2", "C4-alias4096", "byte14", "byte12", "word128", "word256"]
+    assert [r["name"] for r in rows] == ["C3-word64", "C2-r64x2", "C4-alias4096", "byte14", "byte12", "word8", "byte2",
+                                         "word-adaptive", "byte-adaptive", "word128", "word256"]
     for r, e in zip(rows, full["configs"]):
-        assert r["decode_ms"] == e["decode"]["ms_mean"] and r["encode_ms"] == e["encode"]["ms_mean"]
-        assert r["enc_slots_ms"] == e["encode_slots"]["ms_mean"] and r["oracle_ok"] is True
-        assert r["cpu_ref_GBps"] == e["cpu_baseline"]["value"]
+        assert r["decode_ms"] == e["decode"]["ms_mean"] and r["decode_frac"] == e["decode"]["frac"] and r["oracle_ok"] is True
+        if e.get("per_chunk_models"):  # one kernel: count + normalise + code; the container is sized from the chunks' own histograms
+            assert r["enc_tight_ms"] == e["encode"]["ms_mean"] and r["enc_tight_frac"] == e["encode"]["frac"] and "encode_ms" not in r
+            assert r["tight_size"] == e["encode"]["container_over_input"]
+        else:
+            assert r["encode_ms"] == e["encode"]["ms_mean"] and r["enc_tight_ms"] == e["encode_tight"]["ms_mean"]
+            assert r["dec_tight_ms"] == e["decode_tight"]["ms_mean"] and r["tight_size"] == e["encode_tight"]["container_over_input"]
+            assert r["cpu_GBps"] == e["cpu_baseline"]["value"]
+    assert line["cpu_ref_cores"] == full["configs"][0]["cpu_baseline"]["cores"]
+    # the probe chose the first pair itself: the headline IS the first pair
+    same = copy.deepcopy(full)
+    same["placement"]["chosen"] = [0, 0]
+    same["placement"].pop("first_pair_ms_per_step", None)
+    assert bench.judged_line(same)["value_first_pair"] == round((1 << 30) / same["ms_per_step"] / 1e6, 2)
     # a config whose oracle check did not cover every chunk is not "ok"
     broken = copy.deepcopy(full)
     broken["configs"][1]["oracle_chunks_checked"] -= 1
     assert bench.judged_line(broken)["configs"][1]["oracle_ok"] is False
+    broken = copy.deepcopy(full)
+    broken["configs"][7]["oracle_chunks_checked"] -= 1
+    assert bench.judged_line(broken)["configs"][7]["oracle_ok"] is False
+    # a measured traffic figure and its source fit as well
+    tr = copy.deepcopy(full)
+    tr["roofline"]["traffic"] = 2007767255.2727275
+    tr["roofline"]["traffic_source"] = "profiles/r06_traffic.json (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes, same kernel sources)"
+    t2 = bench.judged_line(tr, "bench_details.json")
+    assert t2["roofline"]["traffic_source"] == "profiles/r06_traffic.json"
+    assert len(json.dumps(t2, separators=(",", ":"))) <= bench.MAX_LINE_BYTES
+    # eight ranks (BASELINE configs[4]; the driver's SCALE run): no `configs`, per-rank kernel times, the summed oracle sample
+    eight = copy.deepcopy(full)
+    eight.pop("configs")
+    eight["n_gpus"] = 8
+    eight["value"] = 8 * full["value"]
+    eight["per_rank"] = {"kernel_ms": [0.38123 + 0.001 * i for i in range(8)], "elapsed_ms_per_step": [0.39] * 8,
+                         "stream_bytes": [841767114] * 8, "roofline_frac": [0.62] * 8}
+    eight["oracle_chunks_checked"] = 8 * 266
+    eight["oracle_chunks_total"] = 8 * 32768
+    eight["oracle_chunks_checked_per_rank"] = [266] * 8
+    eight["placement"].pop("first_pair_ms_per_step", None)
+    l8 = bench.judged_line(eight, "bench_details.json")
+    t8 = json.dumps(l8, separators=(",", ":"))
+    assert len(t8) <= bench.MAX_LINE_BYTES and l8["n_gpus"] == 8 and len(l8["per_rank_kernel_ms"]) == 8
+    assert "cpu_baseline" in l8 and "roofline" in l8 and "frac_job" in l8["roofline"] and "value_first_pair" not in l8
+    assert json.loads(t8[-4096:] if len(t8) > 4096 else t8) == l8  # (parsable from the last 4 KB of stdout)
     # worst case
     worst = copy.deepcopy(full)
-    for e in worst["configs"]:
-        e["encode_tight"] = dict(e["encode_slots"], container_over_input=0.8512)
-        e["decode_tight"] = e["decode_slots"]
-    worst["configs"] = (worst["configs"] * 2)[:12]
+    worst["configs"] = (worst["configs"] * 2)[:16]
     worst["n_gpus"] = 8
     worst["per_rank"] = {"kernel_ms": [0.38123] * 8}
     worst["error"] = "round trip mismatch, corrupt chunk reported, or a chunk differs from the oracle"
     worst["knobs"] = {"RANS_AMD_LIB": "x" * 100}
-    assert len(json.dumps(bench.judged_line(worst, "bench_details.json"), separators=(",", ":"))) < 4096
+    assert len(json.dumps(bench.judged_line(worst, "bench_details.json"), separators=(",", ":"))) <= bench.MAX_LINE_BYTES

@@ -197,6 +197,146 @@ def _gpu_adaptive_file_roundtrip(ctx, torch, tmp_path, oracle, data, d, fmt):
         assert np.array_equal(got, data[c * 32768:c * 32768 + n_c]), c
 
 
+@pytest.mark.parametrize("fmt,sb", [(FMT_WORD, 12), (FMT_BYTE, 14), (FMT_R64, 14)])
+def test_pack_indexed_from_any_layout(oracle, fmt, sb):
+    """rans_amd_container_pack_indexed: the file written from a container in ANY layout equals, byte for byte, the file
+    rans_amd_container_pack writes from the compact one -- slot layout (a stream at the END of its slot, as the reference
+    leaves it in its buffer, main.cpp:176-188), scattered chunks in descending order, a sized layout with two chunks in an
+    overflow region.  Index entries outside the source are refused, nothing outside is read."""
+    data = oracle.gen_zipf(50001, K=256, s=1.0, seed=6)
+    f, om, payload, offs, lens = _oracle_container(oracle, fmt, sb, data, 64, 4096)
+    want = R.pack_container(fmt, f, sb, data.size, 64, 4096, lens, payload)
+    n = lens.size
+    rng = np.random.default_rng(9)
+    slot = 2 * 4096 + 512
+    layouts = []
+    src = rng.integers(0, 256, n * slot, dtype=np.uint8)  # (garbage between the streams: none of it may reach the file)
+    o = np.zeros(n + 1, dtype=np.uint64)
+    for c in range(n):  # slot layout
+        o[c] = (c + 1) * slot - int(lens[c])
+        src[int(o[c]):int(o[c]) + int(lens[c])] = payload[int(offs[c]):int(offs[c]) + int(lens[c])]
+    o[n] = n * slot
+    layouts.append((src, o))
+    src = rng.integers(0, 256, n * slot + 99, dtype=np.uint8)
+    o = np.zeros(n + 1, dtype=np.uint64)
+    at = 7  # scattered, descending, unaligned starts
+    for c in reversed(range(n)):
+        o[c] = at
+        src[at:at + int(lens[c])] = payload[int(offs[c]):int(offs[c]) + int(lens[c])]
+        at += int(lens[c]) + int(rng.integers(0, 300))
+    o[n] = at
+    layouts.append((src, o))
+    tight = (int(lens.max()) + 63) // 64 * 64 - 128  # sized slots: the longest chunks overflow behind them
+    src = rng.integers(0, 256, n * tight + n * slot, dtype=np.uint8)
+    o = np.zeros(n + 1, dtype=np.uint64)
+    over = 0
+    for c in range(n):
+        if int(lens[c]) <= tight:
+            o[c] = (c + 1) * tight - int(lens[c])
+        else:
+            over += 1
+            o[c] = n * tight + over * slot - int(lens[c])
+        src[int(o[c]):int(o[c]) + int(lens[c])] = payload[int(offs[c]):int(offs[c]) + int(lens[c])]
+    assert over >= 1
+    o[n] = n * tight + over * slot
+    layouts.append((src, o))
+    for src, o in layouts:
+        got = R.pack_container_indexed(fmt, f, sb, data.size, 64, 4096, o, lens, src)
+        assert np.array_equal(got, want)
+        info, f2, l2, p2 = R.parse_container(got)
+        assert np.array_equal(oracle.decode_chunked(fmt, om, p2, R.offsets_from_lengths(l2), l2, data.size, 64, 4096), data)
+    # the index is data: an entry that leaves the source is refused
+    src, o = layouts[0]
+    for c, delta in ((0, src.size), (n - 1, 1), (3, 1 << 62)):
+        bad = o.copy()
+        bad[c] += np.uint64(delta) if c != n - 1 else np.uint64(src.size - int(o[c]) - int(lens[c]) + 1)
+        with pytest.raises(R.RansAmdError) as e:
+            R.pack_container_indexed(fmt, f, sb, data.size, 64, 4096, bad, lens, src)
+        assert e.value.status == R.E_CORRUPT, c
+    with pytest.raises(R.RansAmdError):
+        g = f.copy(); g[0] += 1
+        R.pack_container_indexed(fmt, g, sb, data.size, 64, 4096, o, lens, src)  # model does not sum to M
+    # an empty input
+    blob = R.pack_container_indexed(fmt, f, sb, 0, 64, 4096, np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint8))
+    assert R.parse_container(blob)[0].n_chunks == 0
+
+
+@pytest.mark.parametrize("fmt", [FMT_BYTE, FMT_WORD])
+def test_pack_indexed_adaptive(oracle, fmt):
+    """... and the version-2 file (one model per chunk) from the pieces rans_amd_encode_adaptive_sized leaves: every stream
+    the end of a piece of whole 64-byte lines."""
+    rng = np.random.default_rng(3)
+    data = np.concatenate([oracle.gen_zipf(9000, K=64, s=1.2, seed=1), rng.integers(100, 256, 7001).astype(np.uint8)])
+    rows, lens, payload = _oracle_adaptive(oracle, data, 12, 32, 4096, fmt)
+    want = R.pack_container_adaptive(12, data.size, 32, 4096, rows, lens, payload, fmt=fmt)
+    offs = R.offsets_from_lengths(lens)
+    pieces = (lens.astype(np.int64) + 200 + 63) // 64 * 64
+    ends = np.cumsum(pieces)
+    src = rng.integers(0, 256, int(ends[-1]), dtype=np.uint8)
+    o = np.zeros(lens.size + 1, dtype=np.uint64)
+    for c in range(lens.size):
+        o[c] = int(ends[c]) - int(lens[c])
+        src[int(o[c]):int(ends[c])] = payload[int(offs[c]):int(offs[c]) + int(lens[c])]
+    o[lens.size] = ends[-1]
+    got = R.pack_container_indexed(fmt, None, 12, data.size, 32, 4096, o, lens, src, chunk_freqs=rows)
+    assert np.array_equal(got, want)
+    bad = o.copy()
+    bad[1] = np.uint64(src.size)
+    with pytest.raises(R.RansAmdError) as e:
+        R.pack_container_indexed(fmt, None, 12, data.size, 32, 4096, bad, lens, src, chunk_freqs=rows)
+    assert e.value.status == R.E_CORRUPT
+    worse = rows.copy(); worse[1, 0] += 1
+    with pytest.raises(R.RansAmdError) as e:
+        R.pack_container_indexed(fmt, None, 12, data.size, 32, 4096, o, lens, src, chunk_freqs=worse)
+    assert e.value.status == R.E_MODEL
+
+
+@pytest.mark.gpu
+def test_gpu_sized_encode_to_file_without_a_compaction_pass(tmp_path, oracle):
+    """The "keep it" path: sized-slot encode -> ONE D2H copy of the container -> rans_amd_container_pack_indexed
+    -> file -> a fresh reader decodes it; an overflowed chunk (incompressible stretch) included.  The file equals the one made
+    from the compact encoder's container.  Then the same for per-chunk models (rans_amd_encode_adaptive_sized -> version 2)."""
+    import torch
+    ctx = R.Context(0)
+    chunk = 8192
+    data = oracle.gen_zipf(60 * chunk + 321, K=256, s=1.0, seed=8).copy()
+    data[7 * chunk:9 * chunk] = np.random.default_rng(5).integers(0, 256, 2 * chunk).astype(np.uint8)  # two chunks that overflow their slots
+    d_syms = torch.from_numpy(data).cuda()
+    freqs, _ = R.normalize_freqs(ctx.count_freqs_device(d_syms, 256), 4096)
+    m = ctx.model(FMT_WORD, freqs, 12)
+    t_cont, t_offs, t_lens, t_total, t_slot = ctx.encode_sized(m, d_syms, 64, chunk)
+    h_offs = t_offs.cpu().numpy().astype(np.uint64)
+    assert int(np.count_nonzero(h_offs[:-1] >= np.uint64(61 * t_slot))) >= 2  # (they lie in the overflow region)
+    blob = R.pack_container_indexed(FMT_WORD, freqs, 12, data.size, 64, chunk, h_offs, t_lens.cpu().numpy().astype(np.uint32),
+                                    t_cont[:t_total].cpu().numpy())
+    cont, offs, lens, total = ctx.encode(m, d_syms, 64, chunk)
+    assert np.array_equal(blob, R.pack_container(FMT_WORD, freqs, 12, data.size, 64, chunk, lens.cpu().numpy().astype(np.uint32),
+                                                 cont[:total].cpu().numpy()))
+    path = tmp_path / "sized.rans"
+    blob.tofile(path)
+    info, f2, l2, p2 = R.parse_container(np.fromfile(path, dtype=np.uint8))
+    m2 = ctx.model(info.format, f2, info.scale_bits)
+    d_cont = torch.from_numpy(np.concatenate([p2, np.zeros(64, np.uint8)])).cuda()
+    out = ctx.decode(m2, d_cont, info.payload_bytes, torch.from_numpy(R.offsets_from_lengths(l2).astype(np.int64)).cuda(),
+                     torch.from_numpy(l2.astype(np.int32)).cuda(), info.n_symbols, info.n_ways, info.chunk_syms)
+    assert np.array_equal(out.cpu().numpy(), data)
+    for fmt in (FMT_BYTE, FMT_WORD):
+        c1, o1, l1, r1, t1 = ctx.encode_adaptive_sized(d_syms, 64, chunk, 12, fmt=fmt)
+        blob = R.pack_container_indexed(fmt, None, 12, data.size, 64, chunk, o1.cpu().numpy().astype(np.uint64),
+                                        l1.cpu().numpy().astype(np.uint32), c1[:t1].cpu().numpy(), chunk_freqs=r1.cpu().numpy())
+        c0, o0, l0, r0, t0 = ctx.encode_adaptive(d_syms, 64, chunk, 12, fmt=fmt)
+        nch = R.num_chunks(data.size, chunk)
+        assert np.array_equal(blob, R.pack_container_adaptive(12, data.size, 64, chunk, r0.cpu().numpy().view(np.uint16)[:nch * 256],
+                                                              l0.cpu().numpy().astype(np.uint32)[:nch], c0[:t0].cpu().numpy(), fmt=fmt))
+        info, f2, l2, p2 = R.parse_container_adaptive(blob)
+        d_cont = torch.from_numpy(np.concatenate([p2, np.zeros(64, np.uint8)])).cuda()
+        out = ctx.decode_adaptive(d_cont, info.payload_bytes, torch.from_numpy(R.offsets_from_lengths(l2).astype(np.int64)).cuda(),
+                                  torch.from_numpy(l2.astype(np.int32)).cuda(),
+                                  torch.from_numpy(np.ascontiguousarray(f2).view(np.int16).reshape(-1)).cuda(), info.n_symbols,
+                                  info.n_ways, info.chunk_syms, info.scale_bits, fmt=info.format)
+        assert np.array_equal(out.cpu().numpy(), data)
+
+
 def test_container_slice_arithmetic():
     """rans_amd_container_slice (host arrays): the byte hull of a chunk range, 16-byte aligned at its start, and offsets
     rebased to it -- for compact, slot-layout and descending indexes; bad ranges are refused."""

@@ -192,6 +192,54 @@ def test_full_size_per_chunk_models_every_chunk_equals_oracle(gpu, oracle, fmt, 
     assert torch.equal(out, d_syms)
 
 
+@pytest.mark.parametrize("name,fmt,sb,ways,chunk,n", [
+    ("word-64-way", FMT_WORD, 12, 64, 32768, 5 << 30),                 # 5 Gi symbols: 163 840 chunks, 32 768 of them past 2^32
+    ("r64-2-way", FMT_R64, 14, 2, 512, (1 << 32) + (1 << 20) + 77),    # config 2's shape: 8 390 657 chunks (> 2^23), a ragged last one
+])
+def test_more_than_2_to_the_32_symbols(gpu, oracle, name, fmt, sb, ways, chunk, n):
+    """n >= 2^32: the ABI takes uint64_t n and the kernels form 64-bit bases; here they meet symbols, chunks
+    and offsets beyond 32 bits.  Sized-slot encode, decode, round trip; an oracle sample of 1024 chunks plus the first and the
+    LAST ones (past 2^32 symbols) compared byte for byte; the compact encoder's index agrees with the sized one's lengths."""
+    R, ctx, torch = gpu
+    import bench
+    d_syms = bench.gen_zipf(torch, n, 256, 1.0, 1, "cuda")
+    # (the generator is counter based: a stretch beyond 2^32 equals the oracle's run over the same counters)
+    counts = ctx.count_freqs_device(d_syms, 256)
+    assert int(counts.sum()) == n
+    freqs, _ = R.normalize_freqs(counts, 1 << sb)
+    gm = ctx.model(fmt, freqs, sb)
+    nchunks = (n + chunk - 1) // chunk
+    t_cont, t_offs, t_lens, t_total, t_slot = ctx.encode_sized(gm, d_syms, ways, chunk)
+    worst = R.slot_bytes(fmt, n, ways, chunk)
+    assert t_total > (1 << 32) and int(t_offs[-1].item()) == t_total
+    art = {"fmt": fmt, "sb": sb, "K": 256, "ways": ways, "chunk": chunk, "n": n, "freqs": freqs, "d_syms": d_syms,
+           "cont": t_cont, "offs": t_offs, "lens": t_lens, "total": t_total, "slot": t_slot, "worst": worst}
+    assert bench.oracle_check_chunks(art, sample=1024) >= 1024
+    # the chunks whose symbols lie past 2^32, one by one (the last 64 and the ragged last)
+    om = oracle.model(freqs, sb)
+    h_offs = t_offs[nchunks - 64:nchunks].cpu().numpy()
+    h_lens = t_lens[nchunks - 64:nchunks].cpu().numpy()
+    for i, c in enumerate(range(nchunks - 64, nchunks)):
+        lo, hi = c * chunk, min(n, (c + 1) * chunk)
+        assert lo >= (1 << 32)
+        ref = oracle.encode(fmt, om, d_syms[lo:hi].cpu().numpy(), ways)
+        a, ln = int(h_offs[i]), int(h_lens[i])
+        assert ln == ref.size and np.array_equal(t_cont[a:a + ln].cpu().numpy(), ref), c
+    out = ctx.decode(gm, t_cont, t_total, t_offs, t_lens, n, ways, chunk)
+    assert torch.equal(out, d_syms)
+    del out, t_cont
+    # the compact layout (fused placement / lane encoders + offset scan over > 2^23 chunks): same lengths, prefix-sum index
+    cont, offs, lens, total = ctx.encode(gm, d_syms, ways, chunk)
+    assert torch.equal(lens, t_lens)
+    aligned = (lens.to(torch.int64) + 15) & ~15
+    want = torch.zeros(nchunks + 1, dtype=torch.int64, device="cuda")
+    want[1:] = torch.cumsum(aligned, 0)
+    want[nchunks] = want[nchunks - 1] + lens[nchunks - 1]
+    assert torch.equal(offs, want) and total == int(want[-1].item())
+    out = ctx.decode(gm, cont, total, offs, lens, n, ways, chunk)
+    assert torch.equal(out, d_syms)
+
+
 def test_book1_appendix_b_on_gpu(gpu):
     """SURVEY appendix B through the HIP path: decode the reference-made 64-way word stream of book1, then
     re-encode book1 into every pinned stream (sizes from the README, SHA-256 from the unmodified reference)."""
