@@ -162,7 +162,9 @@ int rans_amd_ctx_set_option(rans_amd_ctx *ctx, int option, int value);
 /* ---- model building (SymbolStats, main.cpp:49-129) ---------------------- */
 
 /* Histogram of n symbols (sym_bytes 1 or 2) into freqs[nsyms]; symbols >= nsyms
- * are an error.  Host version replaces count_freqs (main.cpp:59-66). */
+ * are an error.  Host version replaces count_freqs (main.cpp:59-66).  The counters are the reference's 32-bit ones
+ * (main.cpp:49-57): n >= 2^32 is RANS_AMD_E_UNSUPPORTED, not a wrapped count -- the coders take any n, the model of such
+ * an input comes from a part of it (or from per-chunk models). */
 int rans_amd_count_freqs_host(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *freqs);
 /* Device version: d_syms on the GPU, result copied to host freqs (synchronises `stream`). */
 int rans_amd_count_freqs(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, int sym_bytes, uint32_t nsyms,

@@ -432,8 +432,16 @@ int rans_amd_ctx_set_option(rans_amd_ctx *ctx, int option, int value)
 
 /* ---- model ------------------------------------------------------------ */
 
+// The model builder's counters are 32 bits wide, as the reference's (SymbolStats: uint32_t freqs[], cum_freqs[], main.cpp:49-57;
+// normalize_freqs sums them in 32 bits as well): a histogram of 2^32 symbols and more is refused, not wrapped.  The coders
+// take any n (uint64_t); such an input needs its model from a part of it -- or per-chunk models.
+static const char *kCountTooMany = "count_freqs: 2^32 symbols and more do not fit the model builder's 32-bit counters (SymbolStats, "
+                                   "main.cpp:49-57): count a part of the input, or use per-chunk models";
+
 int rans_amd_count_freqs_host(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *freqs)
 {
+    if (n > 0xffffffffull)
+        return fail(RANS_AMD_E_UNSUPPORTED, kCountTooMany);
     int rc = count_freqs_host(syms, n, sym_bytes, nsyms, freqs);
     return rc ? fail(rc, "count_freqs_host: bad argument or symbol outside the alphabet") : rc;
 }
@@ -443,6 +451,8 @@ int rans_amd_count_freqs(rans_amd_ctx *ctx, const void *d_syms, uint64_t n, int 
 {
     if (!ctx || !freqs || (n && !d_syms) || (sym_bytes != 1 && sym_bytes != 2) || nsyms == 0 || nsyms > 16384)
         return fail(RANS_AMD_E_ARG, "count_freqs: bad argument");
+    if (n > 0xffffffffull)
+        return fail(RANS_AMD_E_UNSUPPORTED, kCountTooMany);
     DeviceGuard guard(ctx->device);
     std::lock_guard<std::mutex> lock(ctx->mu);
     hipStream_t s = static_cast<hipStream_t>(stream);

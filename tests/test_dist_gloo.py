@@ -153,7 +153,7 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert line["n_gpus"] == min(64, torch.cuda.device_count())
     assert d["launch"] == {"self_launched": True, "gpus_requested": 64, "gpus_visible": torch.cuda.device_count(),
                            "all_on_device": None}
-    assert line["roofline"]["frac_job"] > 0
+    assert d["roofline"]["frac_job"] > 0 and line["roofline"]["frac"] > 0  # (one GPU: the job IS the launch, the line carries `frac`)
 
 
 @pytest.mark.gpu
@@ -182,8 +182,10 @@ def test_bench_default_command_line_survives_the_drivers_stdout_window():
     assert all(r["oracle_ok"] is True and r["decode_ms"] > 0 and r["enc_tight_ms"] > 0 for r in rows)
     assert all(r["encode_ms"] > 0 for r in rows if not r["name"].endswith("-adaptive"))
     assert line["oracle_chunks_checked"] == line["oracle_chunks_total"] and line["decodes_oracle_container"] is True
-    # the un-probed pair: K timed steps of the same loop -- never faster than the headline it was not chosen for
-    assert line["placement"]["first_pair_ms"] > 0 and 0 < line["value_first_pair"] <= line["value"] * 1.05
+    # the un-probed pair: K timed steps of the same loop and clock (at this size -- 16 MiB, two steps of 0.08 ms -- the order of
+    # the two is noise; at 1 GiB the canned record of tests/test_bench_cpu.py pins first pair <= headline)
+    assert line["placement"]["first_pair_ms"] > 0 and line["value_first_pair"] > 0
+    assert line["value_first_pair"] == pytest.approx((1 << 24) / line["placement"]["first_pair_ms_per_step"] / 1e6, rel=1e-3)
     # and the file has what the line dropped
     assert len(d["placement"]["probe_ms"]) >= 3 and len(d["configs"]) == len(rows) and "decoders" in d["cpu_baseline"]
 
