@@ -279,7 +279,10 @@ int rans_amd_encode_slots(rans_amd_ctx *ctx, const rans_amd_model *model, const 
  * they lie; the decoders take the index as it is.
  * rans_amd_tight_slot_bytes() sizes a slot from the MODEL: chunk_syms times the model's expected code length (its entropy
  * under itself) plus 2 %, the N flushed states, four standard deviations of a chunk's code length and 16 bytes of slack,
- * rounded up to whole 64-byte lines --
+ * rounded up to whole 64-byte lines (the 64-way byte-symbol coders check their slot exactly where they flush their staging
+ * window; they do so for symbol buffers and chunk_syms that are multiples of 4 -- any other shape, and every other coder,
+ * checks by what two rounds can emit at most, and gets that margin added here when the model's shape alone decides it; an
+ * unaligned buffer of a staged shape overflows a little more often, each overflowed chunk at twice its cost) --
  * input that follows the model overflows about one chunk in 30 000; input that does not (a model built from other data, an
  * incompressible stretch) overflows more often and still encodes correctly, each overflowed chunk at twice its cost.
  * out_cap must hold the slots (RANS_AMD_E_SPACE up front otherwise); whatever it has beyond them is overflow region, and a
@@ -305,10 +308,13 @@ int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t sr
                                const uint32_t *d_lengths, uint64_t n_chunks, void *d_dst, uint64_t dst_cap,
                                uint64_t *d_dst_offsets, uint64_t *h_total_bytes, void *stream);
 
-/* Synchronise `stream` and report how the last rans_amd_encode / rans_amd_encode_slots[_sized] / rans_amd_encode_adaptive[_fmt] of this
- * context -- and the last rans_amd_container_compact, which keeps a verdict of its own -- ended when they were called
- * without h_total_bytes (asynchronously, or as graph nodes): RANS_AMD_OK, RANS_AMD_E_MODEL (a symbol with frequency 0),
- * RANS_AMD_E_SPACE (out_cap / dst_cap too small) or RANS_AMD_E_HIP.  The container size is d_offsets[n_chunks]. */
+/* Synchronise `stream` and report how the last rans_amd_encode / rans_amd_encode_slots[_sized] / rans_amd_encode_adaptive[_fmt|_sized]
+ * of this context ended when it was called without h_total_bytes (asynchronously, or as a graph node): RANS_AMD_OK,
+ * RANS_AMD_E_MODEL (a symbol with frequency 0), RANS_AMD_E_SPACE (out_cap too small) or RANS_AMD_E_HIP -- and, when that is
+ * RANS_AMD_OK, what the last asynchronous rans_amd_container_compact had to say (RANS_AMD_E_SPACE, RANS_AMD_E_CORRUPT): it
+ * keeps its verdict in a word of its own that the next compaction replaces and that this call and a compaction's own
+ * synchronous return read and reset -- an encode queued behind a compaction does not discard it (0.6.0; before, every
+ * encode did).  The container size is d_offsets[n_chunks]. */
 int rans_amd_encode_status(rans_amd_ctx *ctx, void *stream);
 
 /* Decode a container.  d_out receives n symbols.  Chunk c is the d_lengths[c] bytes at d_container + d_offsets[c];
@@ -353,8 +359,10 @@ int rans_amd_container_slice(const uint64_t *offsets, const uint32_t *lengths, u
  * the clocks favours nobody; times come from HIP events on `stream`.  *best_container / *best_out name the fastest pair;
  * ms_matrix (NULL, or n_containers * n_outs floats, row = container) receives the mean milliseconds of every pair, so the
  * caller sees what the choice was worth (ms_matrix[0] is the pair two plain allocations would have got).  Synchronous;
- * every decode is checked (RANS_AMD_E_CORRUPT if one fails).  launches = 0 -> 6, sweeps = 0 -> 2.  The caller frees the
- * candidates it does not keep. */
+ * every decode is checked (RANS_AMD_E_CORRUPT if one fails) through the context's failed-chunk counter, which the probe
+ * reads and resets: call it with no asynchronous decode of this context pending (rans_amd_decode_errors first), or a
+ * failure of that earlier decode is reported here, as the probe's.  launches = 0 -> 6, sweeps = 0 -> 2.  The caller frees
+ * the candidates it does not keep. */
 int rans_amd_probe_placement(rans_amd_ctx *ctx, const rans_amd_model *model, const void *const *d_containers,
                              uint32_t n_containers, uint64_t container_bytes, const uint64_t *d_offsets,
                              const uint32_t *d_lengths, uint64_t n, uint32_t n_ways, uint32_t chunk_syms,

@@ -739,8 +739,10 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
                                             : "encode_slots: out_cap is below rans_amd_encode_slots_bound()");
     int rc = RANS_AMD_OK;
     ZeroList zero(s); // (everything the kernels below expect to find zero: one launch)
-    HIP_TRY(zero.add(ctx->d_enc_flags(), 12)); // encode flags, histogram flags (unused by an encode), and the compaction's verdict:
-                                              // rans_amd_encode_status after THIS call must not report an older compaction
+    HIP_TRY(zero.add(ctx->d_enc_flags(), 8)); // encode flags and histogram flags (unused by an encode).  NOT the compaction's word:
+                                             // a compaction's verdict stays until it has been reported (rans_amd_encode_status, or the
+                                             // compaction's own synchronous return) -- an encode queued behind an asynchronous
+                                             // compaction must not wipe what nobody has seen yet
 
     // The wave-per-chunk encoders place and copy their chunks themselves (EncParams::status; encode_wave.hip
     // place_and_copy): no k_layout / k_compact.  The lane-per-chunk encoders (N = 1, 2, 4, 8 with many chunks) and the
@@ -1035,7 +1037,8 @@ int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t sr
     const CaptureScope capture(s);
     if (capture.active && h_total_bytes)
         return fail(RANS_AMD_E_ARG, "container_compact: h_total_bytes must be NULL while the stream is capturing");
-    {
+    {   // (this compaction's verdict replaces an older compaction's: the kernels below skip their work while the word says
+        //  "no room" -- but no ENCODE clears it any more, see encode_impl)
         ZeroList zero(s);
         HIP_TRY(zero.add(ctx->d_compact_flags(), 4));
         HIP_TRY(zero.flush());
@@ -1076,6 +1079,11 @@ int rans_amd_container_compact(rans_amd_ctx *ctx, const void *d_src, uint64_t sr
         uint64_t total = 0;
         HIP_TRY(hipMemcpyAsync(&flags, ctx->d_compact_flags(), 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(&total, d_dst_offsets + n_chunks, 8, hipMemcpyDeviceToHost, s));
+        {   // reported with this return: the word starts over
+            ZeroList zero(s);
+            HIP_TRY(zero.add(ctx->d_compact_flags(), 4));
+            HIP_TRY(zero.flush());
+        }
         HIP_TRY(hipStreamSynchronize(s));
         *h_total_bytes = total;
         return encode_flags_status(flags);
@@ -1093,10 +1101,14 @@ int rans_amd_encode_status(rans_amd_ctx *ctx, void *stream)
     uint32_t flags = 0, cflags = 0;
     HIP_TRY(hipMemcpyAsync(&flags, ctx->d_enc_flags(), 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&cflags, ctx->d_compact_flags(), 4, hipMemcpyDeviceToHost, s));
+    {   // the compactions' verdict is reported by this call: the word starts over
+        ZeroList zero(s);
+        HIP_TRY(zero.add(ctx->d_compact_flags(), 4));
+        HIP_TRY(zero.flush());
+    }
     HIP_TRY(hipStreamSynchronize(s));
     const int rc = encode_flags_status(flags);
-    // (a compaction whose destination was too small or whose source index was corrupt -- the verdict of the LAST compaction
-    //  only as long as no encode followed it: every encode call clears the word)
+    // (the last compaction's verdict -- destination too small, source index corrupt -- whatever encodes ran behind it)
     return rc != RANS_AMD_OK ? rc : encode_flags_status(cflags & (2u | 512u));
 }
 
@@ -1443,7 +1455,7 @@ static int encode_adaptive_impl(rans_amd_ctx *ctx, const int format, const void 
         return rc;
     {
         ZeroList zero(s);
-        HIP_TRY(zero.add(ctx->d_enc_flags(), 12)); // (with the verdict of an older compaction, as encode_impl does)
+        HIP_TRY(zero.add(ctx->d_enc_flags(), 8)); // (encode + histogram flags; a compaction's verdict stays until reported, as in encode_impl)
         HIP_TRY(zero.flush());
     }
     if (nchunks) {
@@ -1640,7 +1652,7 @@ static int encode_adaptive_sized_impl(rans_amd_ctx *ctx, const int format, const
         return rc;
     {
         ZeroList zero(s);
-        HIP_TRY(zero.add(ctx->d_enc_flags(), 12)); // (with the verdict of an older compaction, as encode_impl does)
+        HIP_TRY(zero.add(ctx->d_enc_flags(), 8)); // (encode + histogram flags; a compaction's verdict stays until reported, as in encode_impl)
         HIP_TRY(zero.add(ctx->enc_status.ptr, ctl_bytes));
         if (nchunks == 0)
             HIP_TRY(zero.add(d_offsets, 8));

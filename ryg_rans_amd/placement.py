@@ -21,6 +21,7 @@ def spaced(torch, make, k, device, first=None, stride_bytes=24 << 30, reserve_by
     """k buffers -- `first` (if given) and make() for the rest -- about `stride_bytes` apart in allocation order.  Returns
     (buffers, spacers): keep `spacers` alive until every candidate of the probe is allocated, then drop them (they are never
     touched).  The stride shrinks so that the spacers leave `reserve_bytes` of the device's free memory alone."""
+    oom = getattr(torch, "OutOfMemoryError", None) or torch.cuda.OutOfMemoryError  # (older PyTorch has only the cuda one)
     bufs = [first if first is not None else make()]
     size = bufs[0].numel() * bufs[0].element_size()
     free = torch.cuda.mem_get_info(device)[0]
@@ -30,12 +31,12 @@ def spaced(torch, make, k, device, first=None, stride_bytes=24 << 30, reserve_by
         if gap >= (1 << 30):
             try:
                 spacers.append(torch.empty(gap, dtype=torch.uint8, device=device))
-            except torch.OutOfMemoryError:  # (somebody else took the memory meanwhile: the rest in a row)
+            except oom:  # (somebody else took the memory meanwhile: the rest in a row)
                 gap = 0
         try:
             bufs.append(make())
-        except torch.OutOfMemoryError:  # (the candidates matter, the spacing does not)
-            del spacers[:]
+        except oom:  # (the candidates matter, the spacing does not: from here on in a row -- the caller sees an empty
+            spacers = []  #  `spacers` and reports a stride of 0)
             gap = 0
             torch.cuda.empty_cache()
             bufs.append(make())

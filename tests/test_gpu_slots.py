@@ -227,10 +227,19 @@ def test_compact_a_chunk_range_and_a_reordered_index(gpu, oracle):
     with pytest.raises(R.RansAmdError) as e:
         ctx.compact(d_cont, cont.size, d_offs, d_lens, nchunks, d_dst=tiny)
     assert e.value.status == R.E_SPACE and int(tiny.sum()) == 0
-    # ... and that verdict does not outlive the compaction: an encode that follows starts with a clean word
+    # ... and that verdict was REPORTED with the synchronous return: an encode that follows and its status are clean
     g_cont, g_offs, g_lens, g_total = ctx.encode(gm, torch.from_numpy(data).cuda(), n_ways, chunk)
     ctx.encode_status()
     assert g_total == cont.size
+    # an ASYNCHRONOUS compaction that fails, an asynchronous encode queued behind it, then the status call: the compaction's
+    # verdict must still be there (every encode used to wipe it) -- and it is reported once
+    dd = torch.zeros(nchunks + 1, dtype=torch.int64, device="cuda")
+    ctx.compact(d_cont, cont.size, d_offs, d_lens, nchunks, d_dst=tiny, sync=False, d_dst_offsets=dd)
+    ctx.encode(gm, torch.from_numpy(data).cuda(), n_ways, chunk, sync=False)
+    with pytest.raises(R.RansAmdError) as e:
+        ctx.encode_status()
+    assert e.value.status == R.E_SPACE
+    ctx.encode_status()
 
 
 @pytest.mark.parametrize("fmt,sb,n_ways,chunk,kernel", [(FMT_R64, 14, 2, 512, "k_decode_lanes_r64x2"), (FMT_WORD, 12, 4, 1024, "k_decode_lanes_staged"),
