@@ -141,11 +141,14 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx);
 /* Kernel-family choices of a context.  Every setting produces the same bytes -- the alternatives exist because
  * they were measured against each other and the tests run all of them; the defaults are the fast
  * ones.  The library reads no environment variable: this call is the only way to change what it launches.
- * (Knobs that change what a kernel WRITES -- dropped stores, skipped copies, for the experiments DESIGN.md quotes --
- * exist only in the separate -DRANS_AMD_MEASURE build, never in this library.) */
+ * (The separate -DRANS_AMD_MEASURE build adds a watchdog base and a per-wave trace file through the environment; the
+ * experiment knobs of rounds 1-5 -- dropped stores, skipped copies, alternative kernels -- were removed in round 6, their
+ * patches and logs live under profiles/.) */
 enum rans_amd_option {
-    RANS_AMD_OPT_LANE_KERNELS = 0,         /* narrow interleaves (N = 1, 2, 4, 8): 0 = automatic (default), 1 = the staged
-                                              generation only, 2 = the per-lane register-window generation */
+    RANS_AMD_OPT_LANE_KERNELS = 0,         /* RETIRED in 0.6.0: only 0 (automatic) is accepted, any other value is
+                                              RANS_AMD_E_UNSUPPORTED.  (It pinned a generation of the narrow-interleave
+                                              kernels; the first generation is now the fallback for the shapes only it
+                                              serves -- huge chunks, chunk sizes off 16, u16 symbols, a handful of chunks.) */
     RANS_AMD_OPT_LANE_FUSED_PLACEMENT = 1, /* 1 = the lane-per-chunk encoders place their chunks themselves (default 0:
                                               layout + compaction kernels behind them) */
     RANS_AMD_OPT_FUSED_PLACEMENT = 2,      /* 0 = wave-per-chunk encoders followed by layout + compaction kernels

@@ -22,7 +22,6 @@ FMT_BYTE, FMT_WORD, FMT_R64, FMT_ALIAS = 0, 1, 2, 3
 FORMAT_NAMES = {FMT_BYTE: "byte", FMT_WORD: "word", FMT_R64: "r64", FMT_ALIAS: "alias"}
 
 OPT_LANE_KERNELS, OPT_LANE_FUSED_PLACEMENT, OPT_FUSED_PLACEMENT, OPT_DUAL_DECODE, OPT_ENC_SCRATCH_RING = range(5)
-LANE_KERNELS = {"auto": 0, "staged": 1, "regwin": 2}
 
 OK, E_ARG, E_MODEL, E_SPACE, E_CORRUPT, E_UNSUPPORTED, E_HIP, E_NOMEM = range(8)
 

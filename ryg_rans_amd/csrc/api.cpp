@@ -125,7 +125,6 @@ struct rans_amd_ctx {
     uint32_t variant = 0;    // kVar* bits (rans_amd_ctx_set_option)
     bool unfused = false;    // RANS_AMD_OPT_FUSED_PLACEMENT = 0: k_encode + k_layout + k_compact
     bool scratch_ring = false; // RANS_AMD_OPT_ENC_SCRATCH_RING = 1
-    size_t scratch_shift = 0, status_shift = 0; // measure build: where in their allocations the two start (placement sweeps)
     const char *last_kernel = "";
     const char *last_enc_kernel = ""; // the coding kernel of the last encode call
     bool last_enc_fused = false;      // ... and whether it placed its chunks itself (no k_layout / k_compact)
@@ -382,21 +381,6 @@ int rans_amd_ctx_trim(rans_amd_ctx *ctx)
     return RANS_AMD_OK;
 }
 
-#ifdef RANS_AMD_MEASURE
-// Measure build only (not in the header, not in the shipped library): where the encoder's workspaces lie, and a byte
-// offset (a multiple of 256) for each inside its allocation -- tools/dbg_enc_placement.py sweeps them.
-extern "C" __attribute__((visibility("default"))) unsigned long long rans_amd_measure_ptr(rans_amd_ctx *ctx, int which)
-{
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    return which == 0 ? (unsigned long long)(uintptr_t)ctx->scratch.ptr + ctx->scratch_shift
-                      : (unsigned long long)(uintptr_t)ctx->enc_status.ptr + ctx->status_shift;
-}
-extern "C" __attribute__((visibility("default"))) void rans_amd_measure_shift(rans_amd_ctx *ctx, int which, unsigned long long bytes)
-{
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    (which == 0 ? ctx->scratch_shift : ctx->status_shift) = (size_t)bytes & ~(size_t)255;
-}
-#endif
 
 int rans_amd_ctx_set_option(rans_amd_ctx *ctx, int option, int value)
 {
@@ -404,11 +388,9 @@ int rans_amd_ctx_set_option(rans_amd_ctx *ctx, int option, int value)
         return fail(RANS_AMD_E_ARG, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     switch (option) {
-    case RANS_AMD_OPT_LANE_KERNELS:
-        if (value < 0 || value > 2)
-            return fail(RANS_AMD_E_ARG, "set_option: RANS_AMD_OPT_LANE_KERNELS takes 0 (auto), 1 (staged) or 2 (register window)");
-        ctx->variant &= ~(kVarLanesStaged | kVarLanesRegwin);
-        ctx->variant |= value == 1 ? kVarLanesStaged : value == 2 ? kVarLanesRegwin : 0u;
+    case RANS_AMD_OPT_LANE_KERNELS: // (0.6.0: no choice any more -- the first generation is the fallback for the shapes only it serves)
+        if (value != 0)
+            return fail(RANS_AMD_E_UNSUPPORTED, "set_option: RANS_AMD_OPT_LANE_KERNELS was retired in 0.6.0 (only 0 = automatic is accepted)");
         return RANS_AMD_OK;
     case RANS_AMD_OPT_LANE_FUSED_PLACEMENT:
         ctx->variant = value ? (ctx->variant | kVarLanesFused) : (ctx->variant & ~kVarLanesFused);
@@ -749,12 +731,12 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
     // 160 KiB alias model keep the three-kernel path.
     // (context option RANS_AMD_OPT_FUSED_PLACEMENT = 0 restores the three-kernel path)
     const bool unfused_env = ctx->unfused;
-    // RANS_AMD_ALIAS_L2=1 (measure build): A/B knob, the general alias encoder (alias_remap gathered from L2)
-    static const bool alias_l2 = measure_knob("RANS_AMD_ALIAS_L2") != nullptr;
     const int enc_format = model->host.r64_search ? kKernelFormatR64Search
                            : (format == RANS_AMD_FMT_WORD && model->host.sym_bytes == 2) ? kKernelFormatWord16
-                           : (format == RANS_AMD_FMT_ALIAS && model->d_alias_remap16 && !alias_l2) ? kKernelFormatAliasLds
+                           : (format == RANS_AMD_FMT_ALIAS && model->d_alias_remap16) ? kKernelFormatAliasLds
                                                                                                   : format;
+    if (enc_format == RANS_AMD_FMT_ALIAS && !encode_uses_lanes(enc_format, nchunks, n_ways))
+        return fail(RANS_AMD_E_UNSUPPORTED, "encode: this alias model has no LDS tables (cannot happen for a model rans_amd_model_create accepted)");
     EncParams ep{};
     ep.syms = static_cast<const uint8_t *>(d_syms);
     ep.n = n;
@@ -824,20 +806,20 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
         if (nchunks == 0)
             HIP_TRY(zero.add(d_offsets, 8));
     } else {
-        rc = ctx->scratch.reserve((size_t)((ring ? ring_waves * kEncRingSlots : nchunks) * slot + 64) + ctx->scratch_shift);
+        rc = ctx->scratch.reserve((size_t)((ring ? ring_waves * kEncRingSlots : nchunks) * slot + 64));
         if (rc)
             return rc;
-        ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr) + ctx->scratch_shift;
+        ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr);
     }
     ep.ring_slots = ring ? kEncRingSlots : 0u;
     if (fused) {
         // (wave encoders: a word per chunk; lane encoders: a word per round of a block, at most one per batch of 64
         //  chunks; then the claim counters)
         const size_t status_bytes = (size_t)(nchunks + 8u * kWorkPools) * 8;
-        rc = ctx->enc_status.reserve(status_bytes + ctx->status_shift);
+        rc = ctx->enc_status.reserve(status_bytes);
         if (rc)
             return rc;
-        HIP_TRY(zero.add(static_cast<uint8_t *>(ctx->enc_status.ptr) + ctx->status_shift, status_bytes));
+        HIP_TRY(zero.add(static_cast<uint8_t *>(ctx->enc_status.ptr), status_bytes));
         if (fits == 2) { // the tables fill the LDS: one mailbox per block in global memory
             const size_t mb_bytes = (size_t)ctx->num_cus * kEncMailboxStride;
             rc = ctx->enc_mailboxes.reserve(mb_bytes);
@@ -870,12 +852,8 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
         ep.scale_bits = model->host.scale_bits;
         ep.sym_bytes = (uint32_t)model->host.sym_bytes;
         ep.flags = ctx->d_enc_flags();
-        {
-            static const char *dbg = measure_knob("RANS_AMD_ENC_DEBUG"); // (measure build only: output wrong by construction)
-            ep.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
-        }
         if (fused) {
-            ep.status = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(ctx->enc_status.ptr) + ctx->status_shift);
+            ep.status = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(ctx->enc_status.ptr));
             ep.claims = reinterpret_cast<unsigned int *>(ep.status + nchunks); // (wave encoders; the lane encoders' scanners count behind their own status words)
             ep.offsets = d_offsets;
             ep.out = static_cast<uint8_t *>(d_out);
@@ -1162,8 +1140,6 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         dp.sym_bytes = (uint32_t)model->host.sym_bytes;
         dp.err_count = ctx->d_err();
         // dynamic chunk hand-out: a 4-byte counter zeroed in stream order ahead of the kernel
-        // A/B knob (RANS_AMD_STATIC_SCHED=1 restores static striding).
-        static const bool static_sched = measure_knob("RANS_AMD_STATIC_SCHED") != nullptr;
         // Counters form a ring of 64 slots (all zero at context creation); launch i uses slot
         // i % 64 and re-zeroes slot (i + 32) % 64 from inside the kernel, so no memset node is
         // needed and up to 32 decode launches of one context may be in flight at once.
@@ -1177,13 +1153,10 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
                 return wrc;
             dp.wave_scratch = static_cast<uint8_t *>(ctx->wave_scratch.ptr);
         }
-        static const char *debug_env = measure_knob("RANS_AMD_DEBUG"); // (measure build only, see kernels.h)
-        dp.debug = debug_env ? (uint32_t)strtoul(debug_env, nullptr, 0) : 0u;
         dp.variant = ctx->variant;
-        if (!static_sched && nchunks < 0xffffffffull) {
+        if (nchunks < 0xffffffffull) {
             unsigned int *ring = reinterpret_cast<unsigned int *>(ctx->d_words + 256);
             const uint32_t per_slot = kWorkSlotWords;
-            static const bool no_span = measure_knob("RANS_AMD_NO_SPAN") != nullptr; // A/B: cost of the span record
             if (capture.active) {
                 // A launch that becomes a graph node runs again and again with these very arguments: its counters are one
                 // of kCaptureSlots slots of their own, zeroed by a k_zero node in front of the kernel (so every replay
@@ -1194,16 +1167,13 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
                     HIP_TRY(zero.add(dp.work_counter, (uint64_t)per_slot * 4));
                     HIP_TRY(zero.flush());
                 }
-                if (!no_span)
-                    dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
+                dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
             } else {
                 dp.work_counter = ring + (size_t)(ctx->launch_seq % kWorkSlots) * per_slot;
                 dp.work_counter_reset = ring + (size_t)((ctx->launch_seq + kWorkSlots / 2) % kWorkSlots) * per_slot;
                 // the slot's last line: first wave start / last wave end of the launch (rans_amd_launch_spans)
-                if (!no_span) {
-                    dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
-                    dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
-                }
+                dp.span = reinterpret_cast<unsigned long long *>(dp.work_counter + kWorkPools * kWorkPoolStride);
+                dp.span_reset = reinterpret_cast<unsigned long long *>(dp.work_counter_reset + kWorkPools * kWorkPoolStride);
             }
         }
         // wave clocks (rans_amd_set_timing(ctx, 2)) and the debug timeline (RANS_AMD_TRACE=<file>): per-wave
@@ -1242,24 +1212,15 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         }
         // Byte format, wave-per-chunk decoders: the fused slot records (one gather per symbol) where the model has them and
         // the table leaves room for two blocks per CU (scale_bits <= 12: 32 KiB; at 13 bits one block per CU -- four waves
-        // per SIMD -- loses to eight with the two-gather tables; RANS_AMD_BYTE_FUSED13=1 in the measure build tries it).
+        // per SIMD -- loses to eight with the two-gather tables: profiles/r04_byte_decoder_variants.log).
         // The lane-per-chunk kernels and the two-chunk kernel keep cum2sym + records.
-        static const bool fused13 = measure_knob("RANS_AMD_BYTE_FUSED13") != nullptr;
-        static const bool no_fused = measure_knob("RANS_AMD_NO_BYTE_FUSED") != nullptr;
-        if (dec_format == RANS_AMD_FMT_BYTE && model->d_fused && !no_fused && !lanes_applicable(nchunks, n_ways) &&
-            (model->host.scale_bits <= 12 || fused13)) {
+        if (dec_format == RANS_AMD_FMT_BYTE && model->d_fused && !lanes_applicable(nchunks, n_ways) && model->host.scale_bits <= 12) {
             dp.table0 = model->d_fused;
             dp.table0_bytes = (uint32_t)(model->host.byte_slots.size() * sizeof(WordSlot));
             dp.table1 = model->d_fused;
             dp.table1_bytes = 0;
             dec_format = kKernelFormatByteFused;
         }
-        // (measure build, RANS_AMD_BYTE_DUAL=1: the byte format through the same kernel -- A/B runs)
-        static const bool byte_dual = measure_knob("RANS_AMD_BYTE_DUAL") != nullptr;
-        if (byte_dual && dec_format == RANS_AMD_FMT_BYTE && n_ways == 64 && nchunks >= 2 && !(ctx->variant & kVarNoDual) &&
-            decode_dual_fits(dp.table0_bytes, dp.table1_bytes) && !dp.trace &&
-            ((reinterpret_cast<uintptr_t>(d_out) | (uintptr_t)chunk_syms) & 3u) == 0)
-            dec_format = kKernelFormatByteDual;
         HIP_TRY(launch_decode(dec_format, dp, ctx->num_cus, s, &ctx->last_kernel));
         // the launch that uses slot i zeroes slot i + 32: move on only once it really is in the stream,
         // or a later launch would start from a counter nobody reset

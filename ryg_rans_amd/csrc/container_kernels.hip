@@ -255,33 +255,21 @@ __global__ void __launch_bounds__(256) k_compact_small(const CompactParams p)
 // Round 4: the copies belong to the BLOCK, not to each of its waves (atomics from different waves never meet inside one
 // LDS instruction, so private copies per wave bought nothing and cost LDS): 32 copies 2 banks apart, a lane uses copy
 // (lane & 31), 33 KiB per block, twice as many blocks -- 1 GiB of Zipf(256) bytes 0.358 -> 0.281 ms per call, uniform bytes
-// 0.303 -> 0.283, one repeated byte 0.495 -> 0.228 (tools/r4w_call.sh; the knobs are for such A/B builds).
-#ifndef RANS_HIST_COPIES
-#define RANS_HIST_COPIES 32
-#endif
-#ifndef RANS_HIST_PAD
-#define RANS_HIST_PAD 2
-#endif
-#ifndef RANS_HIST_SHARED // 1: the copies belong to the block (all its waves), 0: to each wave (rounds 1-3 with 8 copies, pad 8)
-#define RANS_HIST_SHARED 1
-#endif
-#ifndef RANS_HIST_BLOCKS // blocks per CU in the grid
-#define RANS_HIST_BLOCKS 8
-#endif
-constexpr uint32_t kHistCopies = RANS_HIST_COPIES;
-constexpr uint32_t kHistCopyStride = 256 + RANS_HIST_PAD; // dwords: copy c starts in bank RANS_HIST_PAD * c
+// 0.303 -> 0.283, one repeated byte 0.495 -> 0.228 (tools/history/r4w_call.sh).
+constexpr uint32_t kHistCopies = 32, kHistBlocksPerCu = 8;
+constexpr uint32_t kHistCopyStride = 256 + 2; // dwords: copy c starts in bank 2 c
 
 __global__ void __launch_bounds__(256) k_histogram_u8(const void *syms, uint64_t n, uint32_t nsyms, uint32_t *hist,
                                                       uint32_t *flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *all = reinterpret_cast<uint32_t *>(smem);
-    const uint32_t waves = RANS_HIST_SHARED ? 1u : blockDim.x >> 6;
+    const uint32_t waves = 1u; // (the copies belong to the block)
     const uint32_t total = waves * kHistCopies * kHistCopyStride;
     for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
         all[i] = 0;
     __syncthreads();
-    uint32_t *h = all + ((RANS_HIST_SHARED ? 0u : (threadIdx.x >> 6) * kHistCopies) + (threadIdx.x & (kHistCopies - 1))) * kHistCopyStride;
+    uint32_t *h = all + (threadIdx.x & (kHistCopies - 1)) * kHistCopyStride;
 
     const uint8_t *p = static_cast<const uint8_t *>(syms);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -552,9 +540,9 @@ hipError_t launch_chunk_models(const void *syms, uint64_t n, uint32_t chunk_syms
 hipError_t launch_histogram(const void *syms, uint64_t n, int sym_bytes, uint32_t nsyms, uint32_t *d_hist,
                             uint32_t *d_flags, int num_cus, hipStream_t stream)
 {
-    const uint32_t grid = (uint32_t)num_cus * (sym_bytes == 1 ? RANS_HIST_BLOCKS : 4);
+    const uint32_t grid = (uint32_t)num_cus * (sym_bytes == 1 ? kHistBlocksPerCu : 4);
     if (sym_bytes == 1) {
-        const size_t lds = (size_t)(RANS_HIST_SHARED ? 1 : 256 / 64) * kHistCopies * kHistCopyStride * 4;
+        const size_t lds = (size_t)kHistCopies * kHistCopyStride * 4;
         RANS_LAUNCH(k_histogram_u8, dim3(grid), dim3(256), lds, stream, syms, n, nsyms, d_hist, d_flags);
     } else {
         uint32_t copies = 8; // a power of two, as many as fit 33 KiB (four blocks per CU stay resident; one copy above 4096 symbols)

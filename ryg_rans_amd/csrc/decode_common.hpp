@@ -33,10 +33,7 @@ namespace {
 constexpr uint32_t kMaxAdvance = 512;
 static_assert(kRingMirror >= kMaxAdvance + 256, "mirror must cover one checkpoint interval plus one sub-step");
 constexpr uint32_t kRsrcFlags = 0x00020000u; // raw buffer, 32-bit data format (gfx9 family)
-#ifndef RANS_LOAD_AUX
-#define RANS_LOAD_AUX 2
-#endif
-constexpr int kAuxNt = RANS_LOAD_AUX;        // 2 = non-temporal: every stream byte is read exactly once
+constexpr int kAuxNt = 2;                    // 2 = non-temporal: every stream byte is read exactly once
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
@@ -129,14 +126,7 @@ struct StreamWindow {
             }
             pre = fetch(lane);
             if constexpr (kMarker) {
-#ifdef RANS_TOUCH_AHEAD // (experiment) pull the block AFTER the one just requested into L2: one dword per 16 bytes,
-                        // into a register nobody reads; invisible to the compiler, never waited for on its own
-                asm volatile("buffer_load_dword v63, %0, %1, 0 offen" ::"v"(gnext + lane * 16u), "s"(rsrc4) : "v63", "memory");
-#endif
                 __builtin_amdgcn_raw_buffer_store_b32(gnext, marker_rsrc, lane * 4u, 0, 0);
-#ifdef RANS_TWO_MARKERS // (experiment: vmcnt(2), i.e. the two newest operations may stay in flight)
-                __builtin_amdgcn_raw_buffer_store_b32(gnext, marker_rsrc, lane * 4u, 0, 0);
-#endif
             }
         }
     }
@@ -228,37 +218,6 @@ __device__ __forceinline__ void renorm_word_full(uint32_t &x, uint32_t &cur, uin
 __device__ __forceinline__ void renorm_byte_full(uint32_t &x, uint32_t &cur, uint32_t k2p23, uint32_t k2p15)
 {
     uint32_t t, b0, b1, c1, c2;
-#ifdef RANS_BYTE_RENORM_R1 // round 1's sequence (11 SALU): kept for A/B runs
-    uint64_t m1;
-    asm volatile("v_cmp_gt_u32_e32 vcc, %[l23], %[x]\n\t"
-                 "s_nop 1\n\t"
-                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                 "s_mov_b64 %[m1], vcc\n\t"
-                 "s_bcnt1_i32_b64 %[c1], vcc\n\t"
-                 "v_cmp_gt_u32_e32 vcc, %[l15], %[x]\n\t"
-                 "v_add_u32_e32 %[t], %[cur], %[t]\n\t"
-                 "s_add_i32 %[cur], %[cur], %[c1]\n\t"
-                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, %[t]\n\t"
-                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                 "s_bcnt1_i32_b64 %[c2], vcc\n\t"
-                 "s_mov_b64 exec, %[m1]\n\t"
-                 "ds_read_u8 %[b0], %[t]\n\t"
-                 "s_mov_b64 exec, vcc\n\t"
-                 "ds_read_u8 %[b1], %[t] offset:1\n\t"
-                 "s_mov_b64 exec, %[m1]\n\t"
-                 "s_add_i32 %[cur], %[cur], %[c2]\n\t"
-                 "s_waitcnt lgkmcnt(1)\n\t"
-                 "v_lshl_or_b32 %[x], %[x], 8, %[b0]\n\t"
-                 "s_mov_b64 exec, vcc\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 "v_lshl_or_b32 %[x], %[x], 8, %[b1]\n\t"
-                 "s_mov_b64 exec, -1"
-                 : [x] "+v"(x), [t] "=&v"(t), [b0] "=&v"(b0), [b1] "=&v"(b1), [c1] "=&s"(c1), [c2] "=&s"(c2),
-                   [m1] "=&s"(m1), [cur] "+s"(cur)
-                 : [l23] "v"(k2p23), [l15] "v"(k2p15)
-                 : "vcc", "scc", "memory");
-#else
     // s[52:53] = lanes that take at least one byte, vcc = lanes that take two (a subset).  Lane i's bytes are
     // consecutive (rans_byte.h:307-318 reads them in one loop), at cur + (bytes taken by the lanes below it); both
     // bytes are read under the first mask (the second read of a one-byte lane is dropped by the exec mask of its
@@ -285,16 +244,13 @@ __device__ __forceinline__ void renorm_byte_full(uint32_t &x, uint32_t &cur, uin
                  : [x] "+v"(x), [t] "=&v"(t), [b0] "=&v"(b0), [b1] "=&v"(b1), [c1] "=&s"(c1), [c2] "=&s"(c2), [cur] "+s"(cur)
                  : [l23] "v"(k2p23), [l15] "v"(k2p15)
                  : "vcc", "scc", "memory", "s52", "s53");
-#endif
 }
 
 // Cache policy of the symbol stores: non-temporal, system scope -- decoded symbols are written once and not
 // read back by this kernel, so they should stream through instead of sitting dirty in L2 / Infinity Cache until the
 // next launch has to push them out.  Measured on the headline workload (1 GiB, sustained launches): plain stores
 // 0.438 ms, nt 0.412, sc1 0.422, nt sc1 0.409 (the policy of the stream LOADS makes no difference).
-#ifndef RANS_STORE_MODS
 #define RANS_STORE_MODS " nt sc1"
-#endif
 constexpr int kAuxStore = 2 | 16; // the same for stores issued through builtins: nt | sc1
 
 // Descriptor of this wave's marker word (StreamWindow::checkpoint<true>): 4 records, i.e. lane 0 only.

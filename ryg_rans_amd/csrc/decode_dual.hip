@@ -330,7 +330,7 @@ bool decode_dual_fits(uint32_t table0_bytes, uint32_t table1_bytes)
     return t0 + t1 + (size_t)(kDecBlockThreads / 64) * 2u * kRingStride <= 160 * 1024;
 }
 
-// format: kKernelFormatAlias2 / kKernelFormatAlias2W (tables in the FMT_ALIAS2 form) or RANS_AMD_FMT_BYTE.
+// format: kKernelFormatAlias2 / kKernelFormatAlias2W (tables in the FMT_ALIAS2 form).
 // The caller has checked n_ways == 64 and the alignment of the output.
 hipError_t launch_decode_dual(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
@@ -342,8 +342,6 @@ hipError_t launch_decode_dual(int format, const DecParams &p, int num_cus, hipSt
     case FMT_ALIAS2W:
         return sym16 ? launch_dual_t<FMT_ALIAS2W, true>(p, num_cus, stream, name, "k_decode_dual<alias>")
                      : launch_dual_t<FMT_ALIAS2W, false>(p, num_cus, stream, name, "k_decode_dual<alias>");
-    case FMT_BYTE:
-        return sym16 ? hipErrorInvalidValue : launch_dual_t<FMT_BYTE, false>(p, num_cus, stream, name, "k_decode_dual<byte>");
     default:
         return hipErrorInvalidValue;
     }

@@ -73,23 +73,6 @@ namespace {
     "ds_read_b64 " E ", v56\n\t"                           \
     "v_lshrrev_b32_e32 v57, 12, %[x]\n\t"
 
-// Code placement (experiment knob, see DESIGN): RANS_GROUP_ALIGN = log2 of the alignment of the sequence's
-// first instruction (padding is s_nop, executed once per group), RANS_GROUP_PAD = extra 4-byte s_nops after it.
-#ifndef RANS_GROUP_ALIGN
-#define RANS_GROUP_ALIGN 0
-#endif
-#ifndef RANS_GROUP_PAD
-#define RANS_GROUP_PAD 0
-#endif
-#define RANS_STR2(x) #x
-#define RANS_STR(x) RANS_STR2(x)
-#if RANS_GROUP_PAD == 1
-#define RANS_GROUP_HEAD ".p2align " RANS_STR(RANS_GROUP_ALIGN) "\n\ts_nop 0\n\t"
-#else
-#define RANS_GROUP_HEAD ".p2align " RANS_STR(RANS_GROUP_ALIGN) "\n\t"
-#endif
-
-
 template <bool kStorePrev>
 __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uint32_t &cur, uint32_t m12,
                                                   uint32_t k65536, uint32_t sel1, uint32_t sel2, uint32_t selA,
@@ -99,18 +82,8 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
     uint32_t cnt;
     if constexpr (kStorePrev) {
         asm volatile(
-            RANS_GROUP_HEAD
             // ---- round 0 (+ the previous group's transposition and store)
             RANS_WORD_LOOKUP("v[58:59]")
-#ifdef RANS_OLD_TEMPS
-            "v_mov_b32_dpp v62, %[pa] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_perm_b32 v63, v62, %[pa], %[sel1]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_mad_u32_u24 %[x], v58, v57, v59\n\t"
-            "v_mov_b32_dpp v62, v63 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_perm_b32 v62, v62, v63, %[sel2]\n\t"
-            "buffer_store_dword v62, %[ooff], %[orsrc], %[osoff] offen\n\t"
-#else
             "v_mov_b32_dpp v60, %[pa] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
             "v_perm_b32 v61, v60, %[pa], %[sel1]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
@@ -118,7 +91,6 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
             "v_mov_b32_dpp v60, v61 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
             "v_perm_b32 v62, v60, v61, %[sel2]\n\t"
             "buffer_store_dword v62, %[ooff], %[orsrc], %[osoff] offen" RANS_STORE_MODS "\n\t"
-#endif
             RANS_WORD_RENORM
             // ---- round 1
             RANS_WORD_LOOKUP("v[60:61]")
@@ -143,9 +115,6 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
               [selC] "v"(selC), [selm] "s"(0x05040100u), [orsrc] "s"(orsrc), [ooff] "v"(out_lane_off),
               [osoff] "s"(osoff_prev)
             : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62"
-#ifdef RANS_OLD_TEMPS
-              , "v63"
-#endif
             );
         // (The store is deliberately inside the sequence, in round 0.  The compiler does not see it, so the
         // s_waitcnt vmcnt(0) it puts in front of a window refill -- which happens after round 3 -- also waits
@@ -176,9 +145,6 @@ __device__ __forceinline__ void decode_group_word(uint32_t &x, uint32_t &pa, uin
             : [m12] "v"(m12), [lim] "v"(k65536), [selA] "v"(selA), [selB] "v"(selB), [selC] "v"(selC),
               [selm] "s"(0x05040100u)
             : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62"
-#ifdef RANS_OLD_TEMPS
-              , "v63"
-#endif
             );
     }
 }
@@ -230,8 +196,6 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     }
 
     uint8_t *ring = smem + t0_bytes + t1_bytes + wave * kRingStride;
-    uint8_t *tile = smem + t0_bytes + t1_bytes + waves_per_block * kRingStride + wave * kOutTileBytes; // OUT_FAST8_LDS
-    static_assert(OUT != OUT_FAST8_LDS || K == 1, "the LDS output tile holds 4 rounds of 64 symbols");
     const uint32_t N = (OUT != OUT_SLOW) ? 64u * K : p.n_ways;
     const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
 
@@ -367,43 +331,9 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                 gdst += 4u * N;
             }
             r = pairs << 1;
-        } else if constexpr (OUT == OUT_FAST8_GROUP) {
-            // ---- groups of 4 full rounds, one hand-scheduled sequence each (decode_group_word); the
-            // transposition and store of a group's symbols ride in the next group's first round
-            static_assert(FMT == FMT_WORD && K == 1, "the hand-scheduled group is the 64-way word decoder");
-            const uint32_t groups = rounds >> 2;
-            if (groups) {
-                const uint64_t dsta = reinterpret_cast<uint64_t>(dst);
-                const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu,
-                                     (kMeasureBuild && (p.debug & 1u)) ? 0u : uniform(nsym), kRsrcFlags};
-                uint32_t selA = 0x03020703u, selB = 0x03070100u, selC = 0x07020100u; // acc_symbol<3, 1..3>
-                uint32_t k65536 = 0x10000u, m12 = 0xfffu;
-                asm volatile("v_mov_b32 %0, %0" : "+v"(selA)); // opaque: live in VGPRs, never rematerialised in the loop
-                asm volatile("v_mov_b32 %0, %0" : "+v"(selB));
-                asm volatile("v_mov_b32 %0, %0" : "+v"(selC));
-                asm volatile("v_mov_b32 %0, %0" : "+v"(k65536));
-                asm volatile("v_mov_b32 %0, %0" : "+v"(m12));
-                uint32_t pa = 0;
-                W.marker_rsrc = marker_rsrc(p, blockIdx.x * waves_per_block + wave);
-                W.template checkpoint<true>(lane);
-                decode_group_word<false>(x[0], pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc,
-                                         out_lane_off, 0u);
-                const uint32_t oend = (groups - 1u) * 256u;
-                uint32_t osoff = 0;
-                for (; osoff != oend; osoff += 256u) {
-                    W.template checkpoint<true>(lane);
-                    decode_group_word<true>(x[0], pa, W.cur, m12, k65536, sel1, sel2, selA, selB, selC, orsrc,
-                                            out_lane_off, osoff);
-                }
-                const uint32_t v = quad_transpose(pa, sel1, sel2);
-                __builtin_nontemporal_store(v, reinterpret_cast<uint32_t RANS_GLOBAL *>(dst + osoff + out_lane_off));
-            }
-            r = groups << 2;
-        } else
-        if constexpr (OUT != OUT_SLOW) {
+        } else if constexpr (OUT != OUT_SLOW) {
             // ---- groups of 4 full rounds, symbols transposed in registers ----
             const uint32_t groups = rounds >> 2;
-            uint8_t RANS_GLOBAL *gdst = dst;
             // symbol stores go through a descriptor of the chunk's output with the running offset in an SGPR
             // (soffset): no 64-bit VALU pointer arithmetic in the loop
             const rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -414,21 +344,14 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
             for (uint32_t g = 0; g < groups; ++g) {
                 uint32_t acc[K];
 #define RANS_ROUND(J)                                                              \
-    _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
-        const uint32_t raw = dec_step<FMT>(T, x[k]);                               \
-        if constexpr (OUT == OUT_FAST8_LDS)                                        \
-            tile[J * 64 + lane] = (uint8_t)(raw >> (8 * Tr::kSymByte));            \
-        else if constexpr (OUT == OUT_FAST8_BYTE)                                  \
-            gdst[J * N + k * 64 + lane] = (uint8_t)(raw >> (8 * Tr::kSymByte));    \
-        else                                                                       \
-            acc[k] = acc_symbol<Tr::kSymByte, J>(raw, acc[k]);                     \
-    }                                                                              \
+    _Pragma("unroll") for (int k = 0; k < K; ++k)                                  \
+        acc[k] = acc_symbol<Tr::kSymByte, J>(dec_step<FMT>(T, x[k]), acc[k]);      \
     _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
         if ((J * K + k) % kCheckEvery == 0)                                        \
             W.checkpoint(lane);                                                    \
-        if constexpr (FMT == FMT_WORD && (OUT == OUT_FAST8 || OUT == OUT_FAST8_LDS || OUT == OUT_FAST8_BYTE)) \
+        if constexpr (FMT == FMT_WORD)                                             \
             renorm_word_full(x[k], W.cur, k65536);                                 \
-        else if constexpr (kIsByteStream<FMT> && (OUT == OUT_FAST8 || OUT == OUT_FAST8_BYTE)) \
+        else if constexpr (kIsByteStream<FMT>)                                     \
             renorm_byte_full(x[k], W.cur, k2p23, k2p15);                           \
         else                                                                       \
             W.consume(dec_renorm<FMT>(W, x[k], true));                             \
@@ -438,18 +361,11 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                 RANS_ROUND(2)
                 RANS_ROUND(3)
 #undef RANS_ROUND
-                if constexpr (OUT == OUT_FAST8_LDS) {
-                    // LDS ops of one wave execute in order: the read sees the four writes
-                    const uint32_t v = reinterpret_cast<const uint32_t *>(tile)[lane];
-                    __builtin_nontemporal_store(v, reinterpret_cast<uint32_t RANS_GLOBAL *>(gdst + lane * 4u));
-                } else if constexpr (OUT != OUT_FAST8_BYTE) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const uint32_t v = quad_transpose(acc[k], sel1, sel2);
-                        __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, out_lane_off + k * 64u, osoff, kAuxStore);
-                    }
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t v = quad_transpose(acc[k], sel1, sel2);
+                    __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, out_lane_off + k * 64u, osoff, kAuxStore);
                 }
-                gdst += 4u * N;
                 osoff += 4u * N;
             }
             r = groups << 2;
@@ -504,7 +420,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 
 // ---------------------------------------------------------------------------
 // k_decode_word64 -- the headline configuration on its own: word format, 64-way, u8 symbols, 4-byte aligned
-// output (main_simd.cpp:313-332 for 64 lanes).  Same decoding as k_decode<FMT_WORD, 1, OUT_FAST8_GROUP>,
+// output (main_simd.cpp:313-332 for 64 lanes).  Same decoding as k_decode<FMT_WORD, 1, OUT_FAST8>, four rounds as ONE asm sequence,
 // plus the hand-over between chunks taken off the critical path: a wave that stops to claim a chunk, read
 // its index entry, then its initial states and first stream blocks sits through three dependent memory
 // round trips (~3 us, and every SIMD has 8 waves doing that once per chunk).  Here the three steps of the
@@ -515,11 +431,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
 // so the switch itself is two LDS block writes.  Claims are made late on purpose: a claimed chunk is work
 // committed to this wave, and the slow (young) waves of a SIMD should not sit on chunks at the end.
 // ---------------------------------------------------------------------------
-#ifndef RANS_CLAIM_AHEAD
-#define RANS_CLAIM_AHEAD 10
-#define RANS_DATA_AHEAD 5
-#endif
-constexpr uint32_t kClaimAhead = RANS_CLAIM_AHEAD, kDataAhead = RANS_DATA_AHEAD; // in groups of 4 rounds
+constexpr uint32_t kClaimAhead = 10, kDataAhead = 5; // in groups of 4 rounds
 
 // buffer descriptor of one 64-way word chunk's stream (StreamWindow::stream_rsrc): what may be fetched is the
 // chunk's length rounded up to the 16-byte granule, clipped to the container's last granule
@@ -537,14 +449,10 @@ __device__ __forceinline__ rsrc_t chunk_rsrc(uint64_t cbase, uint64_t cbytes16, 
     return StreamWindow::stream_rsrc(cbase + (off - skip), skip + 64u * 4u, climit < room ? climit : (uint32_t)room);
 }
 
-// (experiment knob, profiles/r04_word64_launch_bounds.md: -DRANS_WORD64_WAVES=14 -DRANS_WORD64_MIN_WAVES=7 builds the kernel
-//  with 72 VGPRs -- no spills -- in blocks of 14 waves, two per CU: seven waves per SIMD instead of eight)
-#ifndef RANS_WORD64_WAVES
-#define RANS_WORD64_WAVES (kDecBlockThreads / 64)
-#define RANS_WORD64_MIN_WAVES 8
-#endif
-constexpr int kWord64Threads = 64 * RANS_WORD64_WAVES;
-__global__ void __launch_bounds__(kWord64Threads, RANS_WORD64_MIN_WAVES) k_decode_word64(const DecParams p)
+// (eight waves per SIMD at 64 VGPRs with a few spills; a spill-free 72-VGPR build in blocks of 14 waves -- seven per SIMD -- was
+//  1.47 x slower: profiles/r04_word64_launch_bounds.md)
+constexpr int kWord64Threads = kDecBlockThreads;
+__global__ void __launch_bounds__(kWord64Threads, 8) k_decode_word64(const DecParams p)
 {
     using Tr = FmtTraits<FMT_WORD>;
     constexpr uint32_t N = 64;
@@ -661,15 +569,6 @@ __global__ void __launch_bounds__(kWord64Threads, RANS_WORD64_MIN_WAVES) k_decod
         const uint32_t c_len = uniform(n_len) + c_skip; // (where the cursor must end up, counted from the first granule)
         StreamWindow W;
         W.install(ring, chunk_rsrc(cbase, cbytes16, n_off, n_len), c_skip + N * Tr::kStateBytes, lane, n_b0, n_b1);
-#ifdef RANS_TOUCH_AHEAD
-        {
-            const uint64_t sa = cbase + uniform64(n_off) + N * Tr::kStateBytes;
-            const uint64_t room = cbytes16 - uniform64(n_off);
-            const uint32_t climit = (uniform(n_len) + 15u) & ~15u;
-            W.rsrc4 = u32x4{uniform((uint32_t)sa), uniform((uint32_t)(sa >> 32)) & 0xffffu,
-                            (climit < room ? climit : (uint32_t)room) - N * Tr::kStateBytes, kRsrcFlags};
-        }
-#endif
         uint32_t x = n_x;
         const uint64_t first_sym = c_idx * p.chunk_syms;
         const uint32_t nsym = uniform((uint32_t)((p.n - first_sym) < p.chunk_syms ? (p.n - first_sym) : p.chunk_syms));
@@ -685,7 +584,7 @@ __global__ void __launch_bounds__(kWord64Threads, RANS_WORD64_MIN_WAVES) k_decod
         if (groups) {
             const uint64_t dsta = reinterpret_cast<uint64_t>(dst);
             const u32x4 orsrc = {uniform((uint32_t)dsta), uniform((uint32_t)(dsta >> 32)) & 0xffffu,
-                                 (kMeasureBuild && (p.debug & 1u)) ? 0u : uniform(nsym), kRsrcFlags};
+                                 uniform(nsym), kRsrcFlags};
             uint32_t pa = 0;
             W.marker_rsrc = marker_rsrc(p, blockIdx.x * waves_per_block + wave);
             W.template checkpoint<true>(lane);
@@ -785,7 +684,7 @@ hipError_t launch_decode_t(const DecParams &p, int num_cus, hipStream_t stream, 
     const uint32_t t1 = kIsAdaptive<FMT> ? 0u : (p.table1_bytes + 15u) & ~15u;
     if (kIsAdaptive<FMT> && (!p.chunk_freqs || p.scale_bits > kAdaptMaxScaleBits || p.scale_bits < 8 || (FMT == FMT_WORDA && p.scale_bits != 12)))
         return hipErrorInvalidValue;
-    const size_t lds = (size_t)t0 + t1 + (size_t)waves * kRingStride + (OUT == OUT_FAST8_LDS ? waves * kOutTileBytes : 0);
+    const size_t lds = (size_t)t0 + t1 + (size_t)waves * kRingStride;
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
     auto kern = k_decode<FMT, K, OUT>;
@@ -821,37 +720,12 @@ template <int FMT> hipError_t launch_decode_f(const DecParams &p, int num_cus, h
         default: break;
         }
     }
-    // A/B knobs (word format, 64-way only): alternatives that were measured and lost, kept so the
-    // measurements in DESIGN.md can be repeated.
-    static const bool no_asm = measure_knob("RANS_AMD_NO_ASM") != nullptr;   // compiler-scheduled renorm: -2 %
-    static const bool lds_out = measure_knob("RANS_AMD_LDS_OUT") != nullptr;  // output via an LDS tile: -7 %
-    static const bool byte_out = measure_knob("RANS_AMD_BYTE_OUT") != nullptr; // per-round byte stores: -5 %
-    if constexpr (FMT == FMT_BYTE || FMT == FMT_BYTEF) { // (measure build: per-round byte stores instead of the register transpose)
-        static const bool byte_fmt_out = measure_knob("RANS_AMD_BYTE_FMT_OUT") != nullptr;
-        if (fast && byte_fmt_out && p.n_ways == 64)
-            return launch_decode_t<FMT, 1, OUT_FAST8_BYTE>(p, num_cus, s, name);
-    }
+    // (alternatives that were measured and lost -- compiler-scheduled renormalisation -2 %, output through an LDS tile -7 %,
+    //  per-round byte stores -5 %, groups without the pipelined chunk hand-over, the byte format's byte stores: HISTORY.md,
+    //  profiles/r04_byte_decoder_variants.log -- are no longer in the sources)
     if constexpr (FMT == FMT_WORD) {
-        if (fast && lds_out && p.n_ways == 64)
-            return launch_decode_t<FMT_WORD, 1, OUT_FAST8_LDS>(p, num_cus, s, name);
-        if (fast && byte_out && p.n_ways == 64)
-            return launch_decode_t<FMT_WORD, 1, OUT_FAST8_BYTE>(p, num_cus, s, name);
-    }
-    if (FMT == FMT_WORD && fast && no_asm) {
-        switch (p.n_ways) {
-        case 64: return launch_decode_t<FMT_WORD, 1, OUT_FAST8_NOASM>(p, num_cus, s, name);
-        case 128: return launch_decode_t<FMT_WORD, 2, OUT_FAST8_NOASM>(p, num_cus, s, name);
-        case 256: return launch_decode_t<FMT_WORD, 4, OUT_FAST8_NOASM>(p, num_cus, s, name);
-        default: break;
-        }
-    }
-    if constexpr (FMT == FMT_WORD) {
-        static const bool no_group = measure_knob("RANS_AMD_NO_GROUP") != nullptr; // A/B: the per-round asm of round 1
-        static const bool no_pipe = measure_knob("RANS_AMD_NO_PIPE") != nullptr;   // A/B: groups, but serial chunk hand-over
-        if (fast && p.n_ways == 64 && !no_group && !no_pipe)
+        if (fast && p.n_ways == 64)
             return launch_decode_word64(p, num_cus, s, name);
-        if (fast && p.n_ways == 64 && !no_group)
-            return launch_decode_t<FMT_WORD, 1, OUT_FAST8_GROUP>(p, num_cus, s, name);
     }
     switch (p.n_ways) {
     case 64:

@@ -65,17 +65,10 @@ template <int FMT> constexpr bool kIsByteStream = (FMT == FMT_BYTE || FMT == FMT
                                                    kIsAlias2<FMT> || FMT == FMT_BYTEF);
 template <int FMT> constexpr bool kIsWord = (FMT == FMT_WORD || FMT == FMT_WORD16 || FMT == FMT_WORDA);
 
-// OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8
-// symbols transposed in registers.  OUT_FAST8_NOASM: same with the compiler-scheduled renorm
-// (A/B knob).  OUT_FAST8_LDS: symbols staged through a 256-byte LDS tile per wave
-// (ds_write_b8 per round, one ds_read_b32 + global_store_dword per 4 rounds; K == 1 only).
-// OUT_FAST16: u16 symbols, 2 rounds packed per dword and swapped between lane pairs.
-// OUT_FAST8_BYTE: one global_store_byte per lane and round (64 contiguous bytes per wave), no transpose.
-// OUT_FAST8_GROUP: word format, 64-way: four rounds + the previous group's transposition and store as ONE
-// hand-scheduled instruction sequence (decode_wave.hip, decode_group_word).
-enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST8_NOASM = 2, OUT_FAST8_LDS = 3, OUT_FAST16 = 4, OUT_FAST8_BYTE = 5,
-               OUT_FAST8_GROUP = 6 };
-constexpr uint32_t kOutTileBytes = 256;
+// OUT_SLOW: element stores (any N, any alignment, u16 symbols).  OUT_FAST8: 4 rounds of u8 symbols transposed in
+// registers, one dword store per lane.  OUT_FAST16: u16 symbols, 2 rounds packed per dword and swapped between lane pairs.
+// (The 64-way word decoder has a kernel of its own: decode_wave.hip k_decode_word64.)
+enum OutMode { OUT_SLOW = 0, OUT_FAST8 = 1, OUT_FAST16 = 4 };
 
 template <int FMT> struct FmtTraits;
 template <> struct FmtTraits<FMT_WORD> {

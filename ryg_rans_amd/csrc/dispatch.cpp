@@ -18,8 +18,6 @@ hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_
 {
     if (format == kKernelFormatAlias2 || format == kKernelFormatAlias2W) // (api.cpp has checked the shape)
         return launch_decode_dual(format, p, num_cus, stream, kernel_name);
-    if (format == kKernelFormatByteDual)
-        return launch_decode_dual((int)RANS_AMD_FMT_BYTE, p, num_cus, stream, kernel_name);
     if (format != kKernelFormatR64Search && format != kKernelFormatWord16 && format != kKernelFormatByteAdaptive &&
         format != kKernelFormatWordAdaptive &&
         format != kKernelFormatByteFused && lanes_applicable(p.nchunks, p.n_ways))

@@ -6,7 +6,6 @@
 
 template <int FMT> struct EncTables {
     const uint4 *recs; // LDS: EncRec {freq, start, rcp, remap}  (FMT_ALIAS_LDS: uint2 {freq | start << 16, rcp})
-    const uint32_t *alias_remap; // global
     const uint16_t *remap16;     // LDS (FMT_ALIAS_LDS)
     uint32_t scale_bits;
     uint32_t nsyms;
@@ -20,12 +19,10 @@ template <int FMT> struct EncTables {
 // global_store_short, the one-byte lanes one global_store_byte, each under its own exec mask.  12 VALU where the
 // compiler's version (three byte stores with 64-bit address arithmetic each, the byte count by sign tricks) has ~25.
 // A lane that must not emit passes x_max = 0xffffffff.  s[34:35] holds the two-byte mask.
-#ifndef RANS_RENORM_STORE_SHORT // (experiment knobs: -DRANS_RENORM_STORE_SHORT='""' -DRANS_RENORM_STORE_BYTE='""' drop the two
-#define RANS_RENORM_STORE_SHORT "global_store_short %[r], %[t], %[base]\n\t" // stream stores of the unstaged byte-stream coders:
-#endif                                                                        // what the address unit costs config 4's encoder)
-#ifndef RANS_RENORM_STORE_BYTE
+// (with both stores dropped the 4096-symbol alias coder still takes 0.477 of its 0.536 ms: the address unit's share is 11 %,
+//  profiles/r05_c4_encoder_no_stores.log)
+#define RANS_RENORM_STORE_SHORT "global_store_short %[r], %[t], %[base]\n\t"
 #define RANS_RENORM_STORE_BYTE "global_store_byte %[r], %[x], %[base]\n\t"
-#endif
 __device__ __forceinline__ void enc_renorm_byte_full(uint32_t &x, uint32_t x_max, uint32_t &wp, const uint8_t RANS_GLOBAL *slot,
                                                      uint32_t swap_sel)
 {
@@ -207,13 +204,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
         y = x >> (nb << 3);
         }
         uint32_t xn;
-        if constexpr (FMT == FMT_ALIAS) {
-            uint32_t q, rem;
-            divmod_rcp(y, freq, rcp, q, rem);
-            // (`dead`, sized slots: the states are no longer renormalised and `rem` is no remainder any more -- the chunk is
-            //  abandoned, nothing of it counts, and the gather from global memory must not follow a wild index)
-            xn = (q << T.scale_bits) + ((active && dead == 0u) ? T.alias_remap[rem + start] : 0u);
-        } else if constexpr (FMT == FMT_ALIAS_LDS) {
+        if constexpr (FMT == FMT_ALIAS_LDS) {
             // main_alias.cpp:249 with alias_remap in LDS (u16: slots are < M <= 2^16); the index of an inactive
             // or invalid lane is garbage, hence the mask -- its result is discarded below
             uint32_t q, rem;
@@ -237,12 +228,7 @@ __device__ __forceinline__ void enc_substep(const EncTables<FMT> &T, typename Fm
 //               compare/select; x' = x + bias + q * cmpl in one v_mad_u32_u24 + add
 // 10 VALU (13 with the round-up reciprocal), no v_cndmask, no branch.  `wp` is the byte offset of the lowest word written.
 // (One state per lane -- every 64-way launch -- runs enc_word_full_staged below instead: the words go to LDS first.)
-#ifndef RANS_ENC_STAGE // (experiment knob: -DRANS_ENC_STAGE=0 = the word encoder stores every round's words itself)
-#define RANS_ENC_STAGE 1
-#endif
-#ifndef RANS_ENC_STORE // (experiment knob: -DRANS_ENC_STORE='""' drops the stream stores of the word encoder)
 #define RANS_ENC_STORE "global_store_short %[t], %[x], %[base]\n\t"
-#endif
 // rec = WordEncRec {m', (freq << 20) - 1, cmpl | sh << 24, bias} (model.h; sixteen bytes: one ds_read_b128, nothing to take
 // apart).  SMALL: no frequency of the model exceeds 2048, the renormalised state is below 2^31 and q = mulhi(x, m') >> sh
 // is exact (Alverson, rans_byte.h:201-243): 10 VALU.  Otherwise the round-up method of Granlund & Montgomery for 32-bit

@@ -61,28 +61,18 @@ __device__ __forceinline__ void place_and_copy(const EncParams &p, uint64_t chun
     }
     u32x4 RANS_GLOBAL *dst = reinterpret_cast<u32x4 RANS_GLOBAL *>(reinterpret_cast<uint64_t>(p.out) + base);
     const uint32_t n16 = (len + 15u) >> 4; // (the last piece may read up to 15 bytes of the next slot: scratch is padded)
-#ifndef RANS_COPY_DEPTH
-#define RANS_COPY_DEPTH 8
-#endif
-    for (uint32_t i0 = lane; i0 < n16; i0 += 64u * RANS_COPY_DEPTH) { // (nt: the slot is read once, the container written once)
-        u32x4 v[RANS_COPY_DEPTH];
+    constexpr int kCopyDepth = 8; // (16-byte loads a lane keeps in flight)
+    for (uint32_t i0 = lane; i0 < n16; i0 += 64u * kCopyDepth) { // (nt: the slot is read once, the container written once)
+        u32x4 v[kCopyDepth];
 #pragma unroll
-        for (int j = 0; j < RANS_COPY_DEPTH; ++j)
+        for (int j = 0; j < kCopyDepth; ++j)
             if (i0 + 64u * j < n16) {
-#ifndef RANS_COPY_PLAIN_LOAD
                 v[j] = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(sa + 16ull * (i0 + 64u * j)));
-#else
-                v[j] = *reinterpret_cast<gvec_cptr>(sa + 16ull * (i0 + 64u * j)); // unaligned 16-byte load
-#endif
             }
 #pragma unroll
-        for (int j = 0; j < RANS_COPY_DEPTH; ++j)
+        for (int j = 0; j < kCopyDepth; ++j)
             if (i0 + 64u * j < n16) {
-#ifndef RANS_COPY_PLAIN_STORE
                 __builtin_nontemporal_store(v[j], dst + i0 + 64u * j);
-#else
-                dst[i0 + 64u * j] = v[j];
-#endif
             }
     }
 }
@@ -219,7 +209,6 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
     const bool adaptive = (FMT == FMT_BYTE && p.chunk_freqs) || FMT == FMT_WORDA; // one model per chunk
     if (adaptive)
         T.recs = reinterpret_cast<const uint4 *>(smem + wave * kAdaptEncWaveLds);
-    T.alias_remap = p.alias_remap;
     T.remap16 = reinterpret_cast<const uint16_t *>(smem + (size_t)nrecs * 8u);
     T.scale_bits = p.scale_bits;
     T.nsyms = p.nsyms;
@@ -402,9 +391,6 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             uint32_t rec_mask = 0xff0u, swap_sel = 0x0c0c0001u; // (v_perm selector: the low two bytes swapped, zeros above)
             uint32_t k3v = 4u; // (word and byte format: 16-byte records; the name is round 3's, when the word format had eight)
             asm volatile("" : "+v"(k3v)); // (SDWA takes no literal; a VGPR operand is also the faster VALU form)
-            if (kMeasureBuild && (p.debug & 4u)) // measurement only: every lane reads record 0 (word format: or, symbols with bit 0
-                rec_mask = 0u, k3v = 31u;        // set, an address beyond the LDS, which reads zeros) -- what the bank conflicts of
-                                                 // the record gather cost; the output is wrong by construction
             (void)k3v;
             asm volatile("" : "+v"(rec_mask)); // keep the mask in a VGPR (a literal operand costs a slower VALU form)
             asm volatile("" : "+v"(swap_sel));
@@ -415,13 +401,13 @@ __global__ void __launch_bounds__(FMT == FMT_ALIAS_LDS ? kEncAliasLdsThreads : (
             // word format, one state per lane: stream staging (enc_word_full_staged).  Invariant between groups of four
             // rounds: memory holds the stream from wp up; what a flush writes below wp (< 16 bytes, whatever the window
             // held) is written again, correctly, by the next flush, and at the end by the state flush.
-            constexpr bool kStageW = RANS_ENC_STAGE && FMT == FMT_WORD && K == 1;
+            constexpr bool kStageW = FMT == FMT_WORD && K == 1;
             // (byte format: 16 rounds emit at most (8 + 16 scale_bits) / 8 bytes per lane, 31 at 15 bits: 1984 bytes fit the
             //  window, the 33 x 64 of 16-bit probabilities do not -- those models flush every eight rounds: 17 x 64)
-            constexpr bool kStageB = RANS_ENC_STAGE && FMT == FMT_BYTE && K == 1;
+            constexpr bool kStageB = FMT == FMT_BYTE && K == 1;
             const bool stage_b = kStageB && byte_asm && p.scale_bits <= 16u;
             // (alias tables in LDS, byte symbols: windows where the launcher found room behind the tables, EncParams::stage_off)
-            constexpr bool kStageA = RANS_ENC_STAGE && FMT == FMT_ALIAS_LDS && K == 1;
+            constexpr bool kStageA = FMT == FMT_ALIAS_LDS && K == 1;
             const bool stage_a = kStageA && p.stage_off != 0u && p.scale_bits <= 16u;
             const bool flush8 = kStageA || (kStageB && p.scale_bits == 16u); // (alias: two bytes per lane and round at most, whatever the input)
             (void)flush8;
@@ -720,7 +706,7 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
     size_t lds = FMT == FMT_ALIAS_LDS ? nrecs * 8 + ((size_t)2 << p.scale_bits)
                  : ((FMT == FMT_BYTE && p.chunk_freqs) || FMT == FMT_WORDA) ? (size_t)waves * kAdaptEncWaveLds
                                                       : nrecs * sizeof(EncRec) + ((FMT == FMT_WORD || FMT == FMT_BYTE) ? 256 * 16 : 0);
-    if (RANS_ENC_STAGE && (FMT == FMT_WORD || (FMT == FMT_BYTE && !p.chunk_freqs)) && K == 1 && p.sym_bytes == 1 && nrecs == 256)
+    if ((FMT == FMT_WORD || (FMT == FMT_BYTE && !p.chunk_freqs)) && K == 1 && p.sym_bytes == 1 && nrecs == 256)
         lds += (size_t)waves * kEncStageBytes; // stream staging windows (4 + 4 KiB of tables in front)
     EncParams q = p;
     if (fused && !p.mailbox_global) {
@@ -729,18 +715,12 @@ template <int FMT, int K> hipError_t launch_encode_t(const EncParams &p, int num
         lds += kEncFusedLdsBytes;
     }
     q.stage_off = 0;
-    if (RANS_ENC_STAGE && FMT == FMT_ALIAS_LDS && K == 1 && p.sym_bytes == 1) { // windows of the coding waves, where there is room
+    if (FMT == FMT_ALIAS_LDS && K == 1 && p.sym_bytes == 1) { // windows of the coding waves, where there is room
         const size_t at = (lds + 15) & ~(size_t)15;
         if (at + (size_t)enc_waves * kEncStageBytes <= 160 * 1024) {
             q.stage_off = (uint32_t)at;
             lds = at + (size_t)enc_waves * kEncStageBytes;
         }
-    }
-    {   // measure build, RANS_AMD_ENC_LDS_MIN=bytes: ask for at least that much LDS per block -- fewer resident blocks per CU,
-        // the occupancy scan of profiles/r05_encoder_occupancy.md (what an encoder that kept whole chunks in LDS would run at)
-        static const char *lds_min = measure_knob("RANS_AMD_ENC_LDS_MIN");
-        if (lds_min && (size_t)atoi(lds_min) > lds && FMT != FMT_ALIAS_LDS)
-            lds = (size_t)atoi(lds_min);
     }
     const size_t lds_cap = FMT == FMT_ALIAS_LDS ? 160 * 1024 : 128 * 1024;
     if (lds > lds_cap || (FMT == FMT_WORD && !p.word_enc_recs && p.sym_bytes == 1) ||
@@ -820,8 +800,7 @@ hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipSt
                 : format == FMT_WORDA ? "k_encode<word, per-chunk models>"
                 : format == FMT_R64   ? "k_encode<r64>"
                 : format == FMT_R64S  ? "k_encode<r64 full-width>"
-                : format == FMT_ALIAS_LDS ? "k_encode<alias, LDS remap>"
-                                      : "k_encode<alias>";
+                                      : "k_encode<alias, LDS remap>";
     switch (format) {
     case FMT_WORD: return launch_encode_f<FMT_WORD>(p, num_cus, stream);
     case FMT_WORDA: return p.chunk_freqs ? launch_encode_f<FMT_WORDA>(p, num_cus, stream) : hipErrorInvalidValue;
@@ -829,7 +808,8 @@ hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipSt
     case FMT_R64: return launch_encode_f<FMT_R64>(p, num_cus, stream);
     case FMT_R64S: return launch_encode_f<FMT_R64S>(p, num_cus, stream);
     case FMT_ALIAS_LDS: return launch_encode_f<FMT_ALIAS_LDS>(p, num_cus, stream);
-    case FMT_ALIAS: return launch_encode_f<FMT_ALIAS>(p, num_cus, stream);
+    // (FMT_ALIAS, alias_remap gathered from global memory: retired in round 6 -- every alias model the library can create has
+    //  its encoder tables in LDS form, model.cpp; the lane encoders keep their own gather for narrow interleaves)
     default: return hipErrorInvalidValue;
     }
 }

@@ -22,8 +22,6 @@ inline const char *measure_knob(const char *) { return nullptr; }
 #endif
 
 // DecParams::variant / EncParams::variant: kernel-family choices of the context (rans_amd_ctx_set_option)
-constexpr uint32_t kVarLanesStaged = 1u;   // lane-per-chunk kernels: the staged generation only
-constexpr uint32_t kVarLanesRegwin = 2u;   // ... the first generation (per-lane register window)
 constexpr uint32_t kVarLanesFused = 4u;    // lane-per-chunk encoders place their chunks themselves
 constexpr uint32_t kVarNoDual = 8u;        // alias decoders: always one chunk per wave (k_decode)
 constexpr uint32_t kVarDualAlways = 16u;   // ... two chunks per wave (k_decode_dual) whenever the tables fit, not only when
@@ -60,8 +58,6 @@ constexpr int kKernelFormatByteAdaptive = 7;
 // DecParams::table0 = {sym | (M - freq) << 16, adjust} per half bucket, table1 = own-slot count per bucket (u8 / u16).
 constexpr int kKernelFormatAlias2 = 8;
 constexpr int kKernelFormatAlias2W = 9;
-// The byte format (tables as for RANS_AMD_FMT_BYTE) through the two-chunks-per-wave decoder.
-constexpr int kKernelFormatByteDual = 10;
 // Kernel-side format number of the byte-format DECODER with one fused 8-byte record per slot (device_common.hpp FMT_BYTEF):
 // DecParams::table0 = {freq | sym << 24, slot - start}[1 << scale_bits], no table1.
 constexpr int kKernelFormatByteFused = 11;
@@ -94,8 +90,6 @@ struct DecParams {
     unsigned int *work_counter_reset; // a counter slot of a LATER launch that this launch zeroes
     const uint16_t *chunk_freqs;      // FMT_BYTEA: normalised frequencies, u16[256] per chunk (else NULL)
     uint8_t *wave_scratch;            // one 64-byte line per resident wave (marker stores of the window refills), or NULL
-    uint32_t debug;                   // RANS_AMD_MEASURE builds only (RANS_AMD_DEBUG): bit 0 = drop the symbol stores of
-                                      // the 64-way word decoders (their descriptor gets zero records); else 0
     uint32_t variant;                 // kVar* bits
     unsigned long long *span;         // this launch's {max of ~(wave start), max of wave end} in 100 MHz ticks, or NULL
     unsigned long long *span_reset;   // the span record of a LATER launch that this launch zeroes
@@ -149,8 +143,6 @@ struct EncParams {
     uint64_t batch_begin, batch_end, unit_base; // set by the launcher
     uint32_t claim_slot;
     uint32_t variant;           // kVar* bits
-    uint32_t debug;             // RANS_AMD_MEASURE builds only (RANS_AMD_ENC_DEBUG): bit 0 = the lane encoders' fused placement skips the copy
-                                //   itself, bit 1 = ... does not wait for a batch's place (uses 0); output is wrong by construction
     // Slot layout (rans_amd_encode_slots): the chunks STAY where they are coded -- `scratch` is the caller's container, chunk
     // c's stream ends at the end of slot c exactly as the reference's encoder ends at the end of its buffer
     // (rans_byte.h:22-26, main.cpp:176-188), and the coding kernel writes offsets[c] = c * slot_bytes + (slot_bytes - len)
@@ -173,14 +165,8 @@ struct EncParams {
     uint64_t ovf_base;          // redo: byte offset of the overflow region (= nchunks * the first launch's slot_bytes)
     uint32_t no_lanes;          // the request goes to the wave encoders whatever its interleave (sized slots the lane encoders cannot take)
 };
-#ifndef RANS_FUSED_THREADS
-#define RANS_FUSED_THREADS 512
-#endif
-#ifndef RANS_FUSED_COPIERS16
-#define RANS_FUSED_COPIERS16 2
-#endif
-constexpr uint32_t kEncFusedThreads = RANS_FUSED_THREADS; // 7 encoder waves + 1 copier wave; 4 blocks per CU
-constexpr uint32_t kEncFusedCopiers16 = RANS_FUSED_COPIERS16; // copier waves of a 16-wave block
+constexpr uint32_t kEncFusedThreads = 512; // 7 encoder waves + 1 copier wave; 4 blocks per CU
+constexpr uint32_t kEncFusedCopiers16 = 2; // copier waves of a 16-wave block
 constexpr uint32_t kEncMailboxBytes = 16 + 64 * 8;
 // Wave-per-chunk encoders, fused placement: behind the mailbox, one "drained" counter per coding wave of the block (the
 // scratch ring protocol, EncParams::ring_slots)
@@ -194,10 +180,7 @@ constexpr uint32_t kEncMailboxStride = 640; // a block's mailbox in global memor
 // into them in turn (a slot is reused once the block's copier has moved its previous occupant to the container), so the
 // scratch a launch touches is (coding waves) x (slots) x (stream of a chunk) instead of the whole container once more --
 // small enough to stay in the 256 MiB Infinity Cache, which is what takes the second trip through HBM out of the encoders.
-#ifndef RANS_ENC_RING_SLOTS
-#define RANS_ENC_RING_SLOTS 2
-#endif
-constexpr uint32_t kEncRingSlots = RANS_ENC_RING_SLOTS;
+constexpr uint32_t kEncRingSlots = 2;
 constexpr uint32_t kEncRingMaxWavesPerCu = 32;          // resident waves of a CU: upper bound of the coding waves
 constexpr uint64_t kEncRingMaxSlotBytes = (1ull << 26) - 64; // mailbox entries of the ring protocol keep 26 bits of length: a
                                                              // stream that fills its slot must still be below 2^26 bytes

@@ -304,9 +304,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
             for (int j = 0; j < 4; ++j) {
                 r[j] = req[16 * j + grp]; // LDS ops of one wave execute in order: sees the writes above
                 v[j] = u32x4{0u, 0u, 0u, 0u};
-                uint64_t a = cbase + rb + (r[j] & ~(kLaneLine - 1u)) + part * 16u;
-                if (kMeasureBuild && (p.debug & 2u)) // measurement only: every refill hits the same (cached) line
-                    a = cbase + part * 16u;
+                const uint64_t a = cbase + rb + (r[j] & ~(kLaneLine - 1u)) + part * 16u;
                 if ((r[j] & 1u) && a < glimit)
                     v[j] = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(a));
             }
@@ -373,7 +371,7 @@ __global__ void __launch_bounds__(1024) k_decode_lanes_staged(const DecParams p)
                     q3 = decode16();
                 // (every valid lane has its 64 symbols here; lanes without a chunk carry zeros)
                 quad_transpose(q0, q1, q2, q3, lane);
-                const uint32_t o = (kMeasureBuild && (p.debug & 4u)) ? (i0 & 64u) : i0;
+                const uint32_t o = i0;
                 if (vq[0])
                     *reinterpret_cast<u32x4 RANS_GLOBAL *>(at[0] + o) = q0;
                 if (vq[1])
@@ -688,9 +686,6 @@ constexpr uint32_t kR64WaveLds = 64 * kR64RingStride;
 // whole trip later, by when the line could have left L2 half written (WRITE_SIZE 1.34 x the symbols).
 // Now the transposed pieces of every other trip wait in v68..v83 and the pair goes out together: instruction t writes
 // bytes [0, 64) and [64, 128) of chunk (quad, t)'s line back to back.
-#ifndef RANS_R64_PAIR_STORES
-#define RANS_R64_PAIR_STORES 1
-#endif
 #define R64_HOLD                                                                                                        \
     "v_mov_b32 v68, v8\n\tv_mov_b32 v69, v9\n\tv_mov_b32 v70, v10\n\tv_mov_b32 v71, v11\n\t"                             \
     "v_mov_b32 v72, v12\n\tv_mov_b32 v73, v13\n\tv_mov_b32 v74, v14\n\tv_mov_b32 v75, v15\n\t"                           \
@@ -719,7 +714,6 @@ constexpr uint32_t kR64WaveLds = 64 * kR64RingStride;
     "v_lshl_add_u64 %[at2], %[at2], 0, 64\n\t"                                                                          \
     "v_lshl_add_u64 %[at3], %[at3], 0, 64\n\t"
 // s50 = trips decoded and not stored yet (0, 1: in v8..v23, 2: the older one transposed in v68..v83).  At the top of a trip:
-#if RANS_R64_PAIR_STORES
 #define R64_TRIP_TOP                                                                                                    \
     "s_cmp_eq_u32 s50, 0\n\t"                                                                                           \
     "s_cbranch_scc1 .Lr64first_%=\n\t" R64_TRANSPOSE                                                                    \
@@ -737,14 +731,6 @@ constexpr uint32_t kR64WaveLds = 64 * kR64RingStride;
     "s_branch .Lr64done_%=\n\t"                                                                                         \
     ".Lr64pair_%=:\n\t" R64_STORES2 ".Lr64done_%=:\n\t"
 #define R64_HOLD_CLOBBERS , "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83"
-#else
-#define R64_TRIP_TOP                                                                                                    \
-    "s_cmp_eq_u32 s50, 0\n\t"                                                                                           \
-    "s_cbranch_scc1 .Lr64first_%=\n\t" R64_TRANSPOSE R64_STORES ".Lr64first_%=:\n\t"
-#define R64_TRIP_END "s_mov_b32 s50, 1\n\t"
-#define R64_LAST R64_TRANSPOSE R64_STORES
-#define R64_HOLD_CLOBBERS
-#endif
 #define R64_CLOBBERS                                                                                                    \
     "vcc", "scc", "memory", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21",   \
         "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", \
@@ -1310,7 +1296,7 @@ __device__ __forceinline__ void lanes_copy_batch(const EncParams &p, uint64_t ba
         const uint32_t o = (uint32_t)__shfl_xor((int)most, d, 64);
         most = o > most ? o : most;
     }
-    most = (kMeasureBuild && (p.debug & 1u)) ? 0u : uniform(most);
+    most = uniform(most);
     for (uint32_t i0 = 0; i0 < most; i0 += 4u * kLaneCopyDepth) {
         u32x4 v[4][kLaneCopyDepth];
 #pragma unroll
@@ -2017,27 +2003,20 @@ __global__ void __launch_bounds__(256) k_encode_lanes16(const EncParams p)
         atomicOr(p.flags, 1u);
 }
 
-// Context option RANS_AMD_OPT_LANE_KERNELS (kVarLanesStaged / kVarLanesRegwin in Params::variant): pin the
-// lane-per-stream kernel generation (tests run both; every generation writes the same bytes)
-static int lanes_force(uint32_t variant)
-{
-    return (variant & kVarLanesStaged) ? 1 : ((variant & kVarLanesRegwin) ? -1 : 0);
-}
-
 template <int FMT, int NW>
 hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
     const uint32_t t0 = (p.table0_bytes + 15u) & ~15u, t1 = (p.table1_bytes + 15u) & ~15u;
-    // kVarLanesRegwin: the per-lane register window this kernel replaced (>= 4x over-fetch)
-    const int force = lanes_force(p.variant);
-    const bool reg_window = force < 0;
     // staged kernel: the tables are shared by the block, every wave adds kLaneWaveLds of rings, so one
     // large block per CU keeps the most waves resident (rans64, 14 bits: 15 waves; 4-wave blocks: 12)
     const size_t table_lds = (size_t)t0 + t1;
     uint32_t sw = table_lds + kLaneWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - table_lds) / kLaneWaveLds) : 0;
     sw = sw > 16 ? 16 : sw;
     // 64 chunks of one wave must lie within 2^30 bytes (32-bit ring positions): any sane chunk size
-    const bool staged = !reg_window && sw >= 1 && (uint64_t)p.chunk_syms * 8u < (1u << 22);
+    // NAMED FALLBACK: chunks of 512 Ki symbols and more, or tables that leave no room for a wave's rings, go to the first
+    // generation's per-lane register window (k_decode_lanes: >= 4 x over-fetch, one chunk per lane all the same -- a wave per
+    // chunk would leave 62 of 64 lanes idle on a 2-way stream); tests/test_gpu_parity.py test_lane_decoder_fallback_*
+    const bool staged = sw >= 1 && (uint64_t)p.chunk_syms * 8u < (1u << 22);
     {   // One batch (64 chunks) is a long latency-bound job, so a last round with a few waves per CU
         // costs as much as a full one: take the fewest rounds the LDS allows and split the batches
         // evenly over them (16 batches per CU: 16 waves x 1 round, or 8 x 2 -- never 14 + 2).
@@ -2052,31 +2031,22 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
     if constexpr (FMT == FMT_R64 && NW == 2) {
         // third generation for the reference's own 2-way rans64 layout (config 2): full 64-symbol trips only; a ragged
         // last chunk is decoded by the staged kernel in a second launch
-        static const bool off = measure_knob("RANS_AMD_NO_R64X2") != nullptr;
         const bool aligned = p.sym_bytes == 1 && ((reinterpret_cast<uintptr_t>(p.out) | p.chunk_syms) & 63u) == 0 &&
                              (reinterpret_cast<uintptr_t>(p.container) & 15u) == 0;
-        if (!off && force == 0 && staged && aligned && p.nchunks >= 64 && !p.trace) {
+        if (staged && aligned && p.nchunks >= 64 && !p.trace) {
             const uint64_t full = p.n / p.chunk_syms; // chunks with chunk_syms symbols
             // packed slot records (one gather per symbol) where the model has them and at least 8 waves' rings fit beside
             // the table
-            static const bool no_packed = measure_knob("RANS_AMD_NO_R64_PACKED") != nullptr; // (A/B runs)
             const size_t packed_lds = (p.packed_bytes + 15u) & ~(size_t)15;
-            const bool packed = p.packed && !no_packed && packed_lds + 8u * kR64WaveLds <= 160 * 1024;
+            const bool packed = p.packed && packed_lds + 8u * kR64WaveLds <= 160 * 1024;
             const size_t table_lds3 = packed ? packed_lds : table_lds;
             uint32_t sw3 = (uint32_t)((160 * 1024 - table_lds3) / kR64WaveLds);
             sw3 = sw3 > 16 ? 16 : sw3;
-            // (measure build, RANS_AMD_R64_WAVES=n: fewer resident waves per CU than the LDS allows -- the occupancy scan of
-            //  profiles/r04_c2_bound.md)
-            static const char *cap_waves = measure_knob("RANS_AMD_R64_WAVES");
-            const bool capped = cap_waves && atoi(cap_waves) > 0 && (uint32_t)atoi(cap_waves) < sw3;
-            if (capped)
-                sw3 = (uint32_t)atoi(cap_waves);
             const uint64_t batches = (full + 63) / 64;
             const uint64_t per_cu = (batches + (uint64_t)num_cus - 1) / (uint64_t)num_cus;
             const uint64_t rounds = (per_cu + sw3 - 1) / sw3;
             const uint64_t even = rounds ? (per_cu + rounds - 1) / rounds : 1;
-            if (!capped) // (a capped scan keeps the wave count it asked for: its last round may be ragged)
-                sw3 = (uint32_t)(even ? even : 1);
+            sw3 = (uint32_t)(even ? even : 1);
             auto kern3 = packed ? k_decode_lanes_r64x2<true> : k_decode_lanes_r64x2<false>;
             static std::atomic<uint64_t> lds_ok3[2] = {{0}, {0}};
             if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern3), 160 * 1024, lds_ok3[packed]); e != hipSuccess)
@@ -2141,21 +2111,21 @@ hipError_t launch_decode_lanes_t(const DecParams &p, int num_cus, hipStream_t st
 }
 
 // The staged lane encoder (coalesced symbol loads, whole-line stream stores, fused placement) takes u8 symbols in
-// 16-byte aligned chunks with slots made of whole lines; RANS_AMD_LANES=regwin keeps the per-lane kernel (A/B runs),
-// =staged forces the staged one whatever the batch count (tests).  Returns the waves per block the LDS allows, 0 = no.
+// 16-byte aligned chunks with slots made of whole lines, from six batches per CU on.  Everything else -- u16 symbols, chunk
+// sizes that are not multiples of 16, unaligned buffers, a handful of batches -- is the NAMED FALLBACK's: the first generation's
+// per-lane encoder k_encode_lanes16 (one chunk per lane, unit-by-unit stores).  Returns the waves per block the LDS allows, 0 = no.
 static uint32_t encode_lanes_staged_waves(const EncParams &p, int num_cus, uint64_t min_batches_per_cu = 6)
 {
     const size_t table_lds = (size_t)p.nsyms * sizeof(EncRec);
-    const int force = lanes_force(p.variant);
     // (room for the scanner wave and the control words of the fused placement, whether or not this launch uses them)
     const size_t fixed_lds = table_lds + 16 + kEncMailboxBytes;
     uint32_t sw = fixed_lds + kEncWaveLds <= 160 * 1024 ? (uint32_t)((160 * 1024 - fixed_lds) / kEncWaveLds) : 0;
     sw = sw > 16 - kLaneCopiers ? 16 - kLaneCopiers : sw;
-    const bool staged = force >= 0 && sw >= 1 && p.sym_bytes == 1 && (p.slot_bytes % kLaneLine) == 0 &&
+    const bool staged = sw >= 1 && p.sym_bytes == 1 && (p.slot_bytes % kLaneLine) == 0 &&
                         ((reinterpret_cast<uintptr_t>(p.syms) | p.chunk_syms) & 15u) == 0 &&
                         (reinterpret_cast<uintptr_t>(p.scratch) & 15u) == 0 &&
                         // fewer, longer batches: the per-lane kernel's many small blocks hide latency better
-                        (force > 0 || (p.nchunks + 63) / 64 >= (uint64_t)num_cus * min_batches_per_cu);
+                        (p.nchunks + 63) / 64 >= (uint64_t)num_cus * min_batches_per_cu;
     return staged ? sw : 0u;
 }
 
@@ -2184,9 +2154,8 @@ template <int FMT, int NW> hipError_t launch_encode_lanes_t(const EncParams &p_i
         if constexpr (FMT == FMT_R64 && NW == 2) {
             // the reference's 2-way rans64 layout (config 2) on its own kernel: whole batches of full chunks; what is
             // left (fewer than 64 chunks, the last one perhaps ragged) goes through the staged kernel below
-            static const bool off = measure_knob("RANS_AMD_NO_R64X2_ENC") != nullptr;
             const uint64_t full_batches = (p.n / p.chunk_syms) / 64;
-            if (!off && lanes_force(p.variant) == 0 && (p.chunk_syms & 63u) == 0 && p.scale_bits >= 7 && p.scale_bits <= 16 &&
+            if ((p.chunk_syms & 63u) == 0 && p.scale_bits >= 7 && p.scale_bits <= 16 &&
                 p.nsyms <= 256 && full_batches >= (uint64_t)num_cus) {
                 // 8 KiB of table + 8 KiB of ring per coding wave (+ the scanner wave and its LDS words when it places the chunks)
                 uint32_t sw3 = p.status ? 16 - kLaneCopiers : 16;

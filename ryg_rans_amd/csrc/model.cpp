@@ -293,10 +293,6 @@ int HostModel::build(int fmt, const uint32_t *norm_freqs, uint32_t ns, uint32_t 
         word_small = true;
         for (uint32_t s = 0; s < ns; ++s)
             word_small = word_small && freqs[s] <= 2048u;
-#ifdef RANS_AMD_MEASURE // (A/B runs: the round-up reciprocals whatever the model)
-        if (getenv("RANS_AMD_WORD_NO_SMALL"))
-            word_small = false;
-#endif
         if (ns <= 256)
             word_enc_recs.assign(256, WordEncRec{0u, 0xffffffffu, 0x80000000u, 0u});
         auto rec16 = [M](uint32_t mprime, uint32_t cmpl, uint32_t bias, uint32_t sh) { // (freq = M - cmpl; thresh = (freq << 20) - 1)

@@ -459,28 +459,34 @@ def test_many_chunks_layout(gpu, oracle):
         assert np.array_equal(out.cpu().numpy(), data)
 
 
-@pytest.mark.parametrize("generation", ["staged", "regwin", "staged+fused"])
+@pytest.mark.parametrize("generation", ["auto", "auto+fused"])
 def test_lane_kernels_both_generations(gpu, oracle, generation):
-    """Narrow interleaves (N = 1, 2, 4, 8): the wave-cooperative staged kernels and the per-lane
-    register-window kernels they replaced, pinned through the context option RANS_AMD_OPT_LANE_KERNELS, every format,
-    ragged last chunk, chunk sizes that are and are not multiples of 16 / 64, against the oracle byte for byte."""
+    """Narrow interleaves (N = 1, 2, 4, 8): the wave-cooperative staged kernels and -- for the shapes only they serve: chunk
+    sizes that are not multiples of 16, a handful of batches -- the first generation's per-lane kernels (the named fallback;
+    the option that pinned a generation was retired in round 6), every format, ragged last chunk, against the oracle byte
+    for byte."""
     R, _, torch = gpu
     ctx = R.Context(0)  # (its own context: the options must not leak into the other tests)
-    ctx.set_option(R.OPT_LANE_KERNELS, R.LANE_KERNELS[generation.split("+")[0]])
+    ctx.set_option(R.OPT_LANE_KERNELS, 0)
+    with pytest.raises(R.RansAmdError) as e:  # (retired: only "automatic" is left)
+        ctx.set_option(R.OPT_LANE_KERNELS, 2)
+    assert e.value.status == R.E_UNSUPPORTED
     # "+fused": the staged encoders placing their chunks themselves (no k_layout / k_compact_small)
     ctx.set_option(R.OPT_LANE_FUSED_PLACEMENT, int(generation.endswith("+fused")))
     data = oracle.gen_zipf(200000 + 37, K=256, s=1.0, seed=17)
     d_syms = torch.from_numpy(data).cuda()
+    seen = set()
     for fmt, sb in FORMATS:
         om, gm = _models(R, ctx, oracle, fmt, sb, data)
-        for n_ways, chunk in ((2, 512), (1, 256), (4, 1024), (8, 2048), (2, 80), (2, 1000), (1, 48), (8, 64)):
+        for n_ways, chunk in ((2, 512), (1, 256), (4, 1024), (8, 2048), (2, 80), (2, 1000), (1, 48), (8, 64), (2, 16), (1, 32)):
             want, offs, lens = oracle.encode_chunked(fmt, om, data, n_ways, chunk, align=16)
             cont, d_offs, d_lens, total = ctx.encode(gm, d_syms, n_ways, chunk)
             assert total == want.size, (fmt, n_ways, chunk)
             assert np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens), (fmt, n_ways, chunk)
             assert np.array_equal(d_offs.cpu().numpy().astype(np.uint64), offs), (fmt, n_ways, chunk)
-            if generation != "regwin" and chunk % 16 == 0:  # (other chunk sizes: the per-lane kernel, three-kernel path)
-                assert ctx.last_encode_kernel() == ("k_encode_lanes_staged", generation.endswith("+fused"))
+            seen.add(ctx.last_encode_kernel()[0])
+            if generation.endswith("+fused") and chunk % 16 == 0 and ctx.last_encode_kernel()[0] == "k_encode_lanes_staged":
+                assert ctx.last_encode_kernel()[1] is True
             got = cont[:total].cpu().numpy()
             for c in (0, 1, len(lens) // 2, len(lens) - 2, len(lens) - 1):
                 o, ln = int(offs[c]), int(lens[c])
@@ -492,7 +498,9 @@ def test_lane_kernels_both_generations(gpu, oracle, generation):
             assert np.array_equal(out.cpu().numpy(), data), (fmt, n_ways, chunk)
             out = ctx.decode(gm, cont, total, d_offs, d_lens, data.size, n_ways, chunk)
             assert np.array_equal(out.cpu().numpy(), data), (fmt, n_ways, chunk)
-    # unaligned symbol buffers fall back inside the library, whatever is pinned
+    # both generations of the encoder have run (the staged one from six batches per CU on: 16- and 32-symbol chunks here)
+    assert "k_encode_lanes16" in seen and "k_encode_lanes_staged" in seen, seen
+    # unaligned symbol buffers fall back inside the library
     om, gm = _models(R, ctx, oracle, FMT_R64, 14, data)
     backing = torch.zeros(data.size + 16, dtype=torch.uint8, device="cuda")
     backing[3:3 + data.size] = d_syms
@@ -500,6 +508,29 @@ def test_lane_kernels_both_generations(gpu, oracle, generation):
     out_b = torch.zeros(data.size + 16, dtype=torch.uint8, device="cuda")
     ctx.decode(gm, cont, total, d_offs, d_lens, data.size, 2, 512, d_out=out_b[5:5 + data.size])
     assert np.array_equal(out_b[5:5 + data.size].cpu().numpy(), data)
+
+
+@pytest.mark.parametrize("fmt,sb,n_ways", [(FMT_BYTE, 14, 2), (FMT_WORD, 12, 8)])
+def test_lane_decoder_fallback_for_huge_chunks(gpu, oracle, fmt, sb, n_ways):
+    """The first generation's per-lane decoder (k_decode_lanes) is the NAMED FALLBACK for what the staged decoder cannot
+    take: chunks of 512 Ki symbols and more (its ring positions are 32-bit offsets inside a batch).  64 + 1 chunks of 512 Ki
+    symbols in the reference's own narrow layouts: a container the ORACLE made decodes to the input, and the GPU encoder's
+    container (wave encoder or per-lane encoder, whichever the shape gets) equals it chunk by chunk."""
+    R, ctx, torch = gpu
+    chunk = 1 << 19
+    data = oracle.gen_zipf(64 * chunk + 12345, K=256, s=1.0, seed=21)
+    om, gm = _models(R, ctx, oracle, fmt, sb, data)
+    want, offs, lens = oracle.encode_chunked_mt(fmt, om, data, n_ways, chunk, align=16)
+    d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
+    out = ctx.decode(gm, d_cont, want.size, torch.from_numpy(offs.astype(np.int64)).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda(),
+                     data.size, n_ways, chunk)
+    assert ctx.last_decode_kernel() == "k_decode_lanes", ctx.last_decode_kernel()
+    assert np.array_equal(out.cpu().numpy(), data)
+    cont, d_offs, d_lens, total = ctx.encode(gm, torch.from_numpy(data).cuda(), n_ways, chunk)
+    assert total == want.size and np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens)
+    assert np.array_equal(cont[:total].cpu().numpy(), want)
+    out = ctx.decode(gm, cont, total, d_offs, d_lens, data.size, n_ways, chunk)
+    assert np.array_equal(out.cpu().numpy(), data)
 
 
 def test_model_may_outlive_its_context(gpu, oracle):

@@ -110,14 +110,10 @@ def test_slot_layout_word_u16_symbols_and_lane_generations(gpu, oracle):
     om, gm = oracle.model(f, 12), ctx.model(FMT_WORD, f, 12)
     _check_slots(R, ctx, torch, oracle, FMT_WORD, om, gm, d16, 64, 8192)
     data = oracle.gen_zipf(200000, K=256, s=1.0, seed=9)
-    for opt in (1, 2, 0):  # staged generation, per-lane register windows, automatic
-        ctx.set_option(R.OPT_LANE_KERNELS, opt)
-        try:
-            for fmt, sb in ((FMT_BYTE, 14), (FMT_WORD, 12), (FMT_R64, 14)):
-                om, gm = _models(ctx, oracle, fmt, sb, data)
-                _check_slots(R, ctx, torch, oracle, fmt, om, gm, data, 2, 512)
-        finally:
-            ctx.set_option(R.OPT_LANE_KERNELS, 0)
+    for chunk in (512, 500, 64):  # (the per-lane encoder for few batches / chunk sizes off 16, the staged one for many)
+        for fmt, sb in ((FMT_BYTE, 14), (FMT_WORD, 12), (FMT_R64, 14)):
+            om, gm = _models(ctx, oracle, fmt, sb, data)
+            _check_slots(R, ctx, torch, oracle, fmt, om, gm, data, 2, chunk)
 
 
 def test_slot_layout_capacity_is_checked_up_front(gpu, oracle):
@@ -179,7 +175,7 @@ def test_decoders_take_chunks_on_every_unit_boundary(gpu, oracle, fmt, sb, n_way
         d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
         sweeps = [(None, None)]
         if n_ways <= 8:
-            sweeps = [(R.OPT_LANE_KERNELS, v) for v in (0, 1, 2)]
+            sweeps = [(None, None)]
         elif fmt == FMT_ALIAS:
             sweeps = [(R.OPT_DUAL_DECODE, v) for v in (1, 0, 2)]
         for opt, val in sweeps:
