@@ -498,8 +498,23 @@ def test_lane_kernels_both_generations(gpu, oracle, generation):
             assert np.array_equal(out.cpu().numpy(), data), (fmt, n_ways, chunk)
             out = ctx.decode(gm, cont, total, d_offs, d_lens, data.size, n_ways, chunk)
             assert np.array_equal(out.cpu().numpy(), data), (fmt, n_ways, chunk)
-    # both generations of the encoder have run (the staged one from six batches per CU on: 16- and 32-symbol chunks here)
-    assert "k_encode_lanes16" in seen and "k_encode_lanes_staged" in seen, seen
+    assert "k_encode_lanes16" in seen, seen  # (few batches: the per-lane encoder, the named fallback)
+    # ... and the staged generation, which takes over from six batches of 64 chunks per CU on: 16-symbol chunks of a larger input
+    big = oracle.gen_zipf(6 * 256 * 64 * 16 + 16 * 999 + 5, K=256, s=1.0, seed=18)
+    d_big = torch.from_numpy(big).cuda()
+    for fmt, sb, n_ways in ((FMT_WORD, 12, 8), (FMT_BYTE, 14, 2), (FMT_R64, 14, 1), (FMT_ALIAS, 16, 4)):
+        om, gm = _models(R, ctx, oracle, fmt, sb, big)
+        want, offs, lens = oracle.encode_chunked_mt(fmt, om, big, n_ways, 16, align=16)
+        cont, d_offs, d_lens, total = ctx.encode(gm, d_big, n_ways, 16)
+        assert ctx.last_encode_kernel() == ("k_encode_lanes_staged", generation.endswith("+fused")), ctx.last_encode_kernel()
+        assert total == want.size and np.array_equal(d_offs.cpu().numpy().astype(np.uint64), offs)
+        assert np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens)
+        got = cont[:total].cpu().numpy()
+        for c in list(range(0, len(lens), 997)) + [len(lens) - 2, len(lens) - 1]:  # (bytes between chunks are alignment padding)
+            o, ln = int(offs[c]), int(lens[c])
+            assert np.array_equal(got[o:o + ln], want[o:o + ln]), (fmt, n_ways, c)
+        out = ctx.decode(gm, cont, total, d_offs, d_lens, big.size, n_ways, 16)
+        assert ctx.last_decode_kernel() == "k_decode_lanes_staged" and np.array_equal(out.cpu().numpy(), big)
     # unaligned symbol buffers fall back inside the library
     om, gm = _models(R, ctx, oracle, FMT_R64, 14, data)
     backing = torch.zeros(data.size + 16, dtype=torch.uint8, device="cuda")
@@ -528,7 +543,10 @@ def test_lane_decoder_fallback_for_huge_chunks(gpu, oracle, fmt, sb, n_ways):
     assert np.array_equal(out.cpu().numpy(), data)
     cont, d_offs, d_lens, total = ctx.encode(gm, torch.from_numpy(data).cuda(), n_ways, chunk)
     assert total == want.size and np.array_equal(d_lens.cpu().numpy().astype(np.uint32), lens)
-    assert np.array_equal(cont[:total].cpu().numpy(), want)
+    got = cont[:total].cpu().numpy()
+    for c in range(len(lens)):  # (bytes between chunks are alignment padding, not stream)
+        o, ln = int(offs[c]), int(lens[c])
+        assert np.array_equal(got[o:o + ln], want[o:o + ln]), c
     out = ctx.decode(gm, cont, total, d_offs, d_lens, data.size, n_ways, chunk)
     assert np.array_equal(out.cpu().numpy(), data)
 
