@@ -1164,7 +1164,7 @@ def main():
         # (tools/profile.sh -> tools/summarize_profile.py -> profiles/<tag>_traffic.json); PMC passes cannot
         # share a process with the timed run, so a committed measurement is quoted only when it was taken on
         # this workload AND on the kernel sources of this checkout (its `kernel_source_tag`), else null.
-        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r05_traffic.json"))
+        tj = os.environ.get("RANS_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r06_traffic.json"))
         default_workload = (args.format == "word" and args.ways == 64 and args.chunk == 32768 and args.log2n == 30)
         if os.path.exists(tj) and default_workload:
             try:
@@ -1213,12 +1213,14 @@ def main():
                 arts.append(a)
                 # the layouts the reference itself ships: its 8-way word streams -- main_simd.cpp:287-332, the
                 # SSE4.1 decoder's own input -- and its 2-way byte streams (main.cpp:226-280), one LANE per chunk (lanes.hip)
-                e, a = measure_config(torch, R, ctx, "word8", "word 8-way 1 GiB Zipf(256), 4096-symbol chunks (the reference's SIMD layout)",
-                                      R.FMT_WORD, 12, 256, 8, 4096, args.log2n, 1, ks, device, d_syms=d_syms, probe=1)
+                # (1024-symbol chunks: a wave of these kernels walks 64 streams at once, and streams that lie more than a DRAM page
+                #  apart cost it the row locality -- 0.91 ms at 1 Ki symbols, 1.27 at 4 Ki, 2.2 at 16 Ki: profiles/r06_lanes_chunk_sweep.log)
+                e, a = measure_config(torch, R, ctx, "word8", "word 8-way 1 GiB Zipf(256), 1024-symbol chunks (the reference's SIMD layout)",
+                                      R.FMT_WORD, 12, 256, 8, 1024, args.log2n, 1, ks, device, d_syms=d_syms, probe=1)
                 cfgs.append(e)
                 arts.append(a)
-                e, a = measure_config(torch, R, ctx, "byte2", "byte 2-way 1 GiB Zipf(256), scale_bits 14, 4096-symbol chunks (main.cpp's layout)",
-                                      R.FMT_BYTE, 14, 256, 2, 4096, args.log2n, 1, ks, device, d_syms=d_syms, probe=1)
+                e, a = measure_config(torch, R, ctx, "byte2", "byte 2-way 1 GiB Zipf(256), scale_bits 14, 1024-symbol chunks (main.cpp's layout)",
+                                      R.FMT_BYTE, 14, 256, 2, 1024, args.log2n, 1, ks, device, d_syms=d_syms, probe=1)
                 cfgs.append(e)
                 arts.append(a)
                 # per-chunk models: count + normalise + code in one kernel, every chunk its own model
