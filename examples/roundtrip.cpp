@@ -137,6 +137,44 @@ int main(int argc, char **argv)
         printf("sized slots (%llu bytes each, worst case %llu): container %llu bytes = %.3f x input, encode %.3f ms, %s\n",
                (unsigned long long)slot, (unsigned long long)rans_amd_slot_bytes(format, n, n_ways, chunk), (unsigned long long)total2,
                (double)total2 / (double)n, enc2_ms, sized_ok ? "every chunk equals the compact container's" : "MISMATCH");
+        // ---- "keep it": what the reference does with fwrite(rans_begin, ...) (main.cpp:182-188).  The sized container went to
+        //      the host in ONE copy above (c2); rans_amd_container_pack_indexed writes the self-describing file from it chunk by
+        //      chunk -- no compaction pass on the device -- and a reader needs nothing but that file.
+        if (sized_ok) {
+            rans_amd_container_info info;
+            memset(&info, 0, sizeof info);
+            info.format = (uint32_t)format;
+            info.scale_bits = scale_bits;
+            info.nsyms = 256;
+            info.n_ways = n_ways;
+            info.chunk_syms = chunk;
+            info.sym_bytes = 1;
+            info.n_symbols = n;
+            info.n_chunks = nchunks;
+            info.payload_bytes = rans_amd_packed_payload_bytes(l2.data(), nchunks);
+            std::vector<uint8_t> file((size_t)rans_amd_container_bytes(&info));
+            uint64_t wrote = 0;
+            CHECK(rans_amd_container_pack_indexed(&info, freqs, o2.data(), l2.data(), c2.data(), total2, file.data(), file.size(), &wrote));
+            rans_amd_container_info back_info;
+            const uint32_t *f_freqs = nullptr, *f_lens = nullptr;
+            const void *f_payload = nullptr;
+            CHECK(rans_amd_container_parse(file.data(), wrote, &back_info, &f_freqs, &f_lens, &f_payload));
+            std::vector<uint64_t> f_offs(nchunks + 1);
+            CHECK(rans_amd_offsets_from_lengths(f_lens, nchunks, f_offs.data()));
+            rans_amd_model *m2 = nullptr;
+            CHECK(rans_amd_model_create(ctx, (int)back_info.format, f_freqs, back_info.nsyms, back_info.scale_bits, &m2));
+            HIP(hipMemcpy(d_cont2, f_payload, back_info.payload_bytes, hipMemcpyHostToDevice));
+            HIP(hipMemcpy(d_off2, f_offs.data(), 8 * (nchunks + 1), hipMemcpyHostToDevice));
+            HIP(hipMemcpy(d_len2, f_lens, 4 * nchunks, hipMemcpyHostToDevice));
+            HIP(hipMemset(d_out, 0, n));
+            CHECK(rans_amd_decode(ctx, m2, d_cont2, back_info.payload_bytes, d_off2, d_len2, back_info.n_symbols, back_info.n_ways,
+                                  back_info.chunk_syms, d_out, &bad, nullptr));
+            HIP(hipMemcpy(back.data(), d_out, n, hipMemcpyDeviceToHost));
+            sized_ok = memcmp(back.data(), in.data(), n) == 0;
+            printf("file from the sized container (rans_amd_container_pack_indexed): %llu bytes, decodes %s\n", (unsigned long long)wrote,
+                   sized_ok ? "to the input" : "WRONG");
+            rans_amd_model_destroy(m2);
+        }
         for (void *ptr : {(void *)d_cont2, (void *)d_off2, (void *)d_len2})
             (void)hipFree(ptr);
     }

@@ -189,7 +189,7 @@ def main():
         fe = pmc_avg(os.path.join(src, "lanes_%s_fetch" % tag), "FETCH_SIZE")
         wr = pmc_avg(os.path.join(src, "lanes_%s_write" % tag), "WRITE_SIZE")
         for nme, calls, avg, mn, mx in trace_rows(os.path.join(src, "lanes_%s_stats" % tag)):
-            if not (nme.startswith("k_decode_lanes") or nme.startswith("k_encode_lanes") or nme.startswith("k_compact") or nme.startswith("k_layout")):
+            if not (nme.startswith("k_decode_lanes") or nme.startswith("k_encode_lanes") or nme.startswith("k_compact")):
                 continue
             rd, w = fe.get(nme, 0) * 1024, wr.get(nme, 0) * 1024  # (x 1: 64-byte quad requests, calibrated in round 4)
             rows_h.append("| %s | `%s` | %d | %.1f | %.1f | %.4f | %.4g | %.4g | %s |" % (
