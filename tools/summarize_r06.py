@@ -199,7 +199,34 @@ def main():
         L += ["## H. the reference's own layouts: 1 GiB Zipf(256), one LANE per chunk (`tools/time_lanes.py --chunk 1024 --encode`)", "",
               "| layout | kernel | calls | avg us | min us | frac of 8 TB/s | read B | write B | traffic / algorithmic |", "|---|---|---|---|---|---|---|---|---|"] + rows_h + [""]
 
-    # I: counters of the kernels whose bound DESIGN states
+    # I: counters of the kernels whose bound DESIGN states -- derived as in rounds 2-5 (tools/summarize_counters.py)
+    def read_counters(path):
+        vals = {}
+        for line in open(path):
+            m = re.match(r"(\w+)\s+n=\d+\s+avg=([0-9.e+\-]+)", line)
+            if m:
+                vals[m.group(1)] = float(m.group(2))
+        return vals
+    derived = ["## I. counters (separate `--pmc` passes, `tools/pmc_kernel.sh`): derived", "",
+               "cycles = GRBM_GUI_ACTIVE / 8 (per XCD); VALU busy = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / cycles; LDS pipe = SQ_LDS_IDX_ACTIVE / 256 CUs / "
+               "cycles; per-round counts = SQ_INSTS_* / 2^24 (64-symbol rounds of a 1 GiB launch); waves per CU = SQ_WAVES / 256 (persistent grids).", "",
+               "| kernel | ms under counters | waves per CU | VALU busy | LDS pipe | conflict share | waiting / issue stall / issuing (share of wave cycles) | VALU / SALU / LDS instr per round |",
+               "|---|---|---|---|---|---|---|---|"]
+    for tag, what in (("cnt_word8", "`k_decode_lanes_staged`, word 8-way, 1024-symbol chunks"), ("cnt_byte2", "`k_decode_lanes_staged`, byte 2-way"),
+                      ("cnt_adec", "`k_decode<word, per-chunk models>`"), ("cnt_aenc", "`k_encode_adaptive<word>`")):
+        f = os.path.join(src, tag + "_sq_summary.txt")
+        if not os.path.exists(f):
+            continue
+        v = read_counters(f)
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        ms = re.search(r"avg duration under counters ([0-9.]+) us", open(f).read())
+        derived.append("| %s | %.3f | %.0f | %.0f %% | %.0f %% | %.0f %% | %.0f / %.0f / %.0f %% | %.2f / %.2f / %.2f |" % (
+            what, float(ms.group(1)) / 1e3 if ms else 0, v["SQ_WAVES"] / 256, 100 * 4 * v["SQ_ACTIVE_INST_VALU"] / 1024 / cyc,
+            100 * v["SQ_LDS_IDX_ACTIVE"] / 256 / cyc, 100 * v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"],
+            100 * v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 100 * v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"],
+            100 * v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_INSTS_VALU"] / 2 ** 24, v["SQ_INSTS_SALU"] / 2 ** 24, v["SQ_INSTS_LDS"] / 2 ** 24))
+    if len(derived) > 6:
+        L += derived + [""]
     for tag, what in (("cnt_word8", "k_decode_lanes_staged, word 8-way"), ("cnt_byte2", "k_decode_lanes_staged, byte 2-way"),
                       ("cnt_adec", "k_decode<word, per-chunk models>"), ("cnt_aenc", "k_encode_adaptive<word>")):
         f = os.path.join(src, tag + "_sq_summary.txt")
