@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
     _Pragma("unroll") for (int k = 0; k < K; ++k) {                                \
         if ((J * K + k) % kCheckEvery == 0)                                        \
             W.checkpoint(lane);                                                    \
-        if constexpr (FMT == FMT_WORD)                                             \
+        if constexpr (FMT == FMT_WORD || FMT == FMT_WORDA)                         \
             renorm_word_full(x[k], W.cur, k65536);                                 \
         else if constexpr (kIsByteStream<FMT>)                                     \
             renorm_byte_full(x[k], W.cur, k2p23, k2p15);                           \
