@@ -295,8 +295,10 @@ def test_native_example_with_eight_ranks_sharing_a_device():
 @pytest.mark.gpu
 def test_force_dist_agrees_with_the_plain_run():
     """SCALE's N = 1 (real RCCL at world size 1: init_process_group, two barriers, the on-device all-gather) must agree with
-    BENCH's N = 1 (no process group): the same timed region either way.  Two processes each, the faster of each kind within
-    2 % (placement is a per-process lottery the probe narrows to about a per cent)."""
+    BENCH's N = 1 (no process group): the same timed region either way.  What the process group could add is time BETWEEN the
+    launches of the timed loop -- so the test pins exactly that: ms_per_step minus the HIP-event mean of the same launches
+    (0.007 ms of launch gaps) may not grow by more than 0.004 ms, i.e. 1 % of a step.  The step times themselves also carry
+    each process's placement lottery (the probe narrows it to a few per cent: DESIGN 5), hence the wider bound on them."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -305,13 +307,14 @@ def test_force_dist_agrees_with_the_plain_run():
     for _ in range(2):
         line, d, out = _run_bench(argv, env, timeout=900)
         assert out.returncode == 0, out.stderr[-2000:]
-        plain.append(line["ms_per_step"])
+        plain.append((line["ms_per_step"], line["ms_per_step"] - line["roofline"]["kernel_ms_avg"]))
         env["MASTER_PORT"] = str(_free_port())
         line, d, out = _run_bench(argv + ["--force-dist"], env, timeout=900)
         assert out.returncode == 0, out.stderr[-2000:]
         assert d["distributed"]["backend"] == "nccl" and line["n_gpus"] == 1
-        forced.append(line["ms_per_step"])
-    assert min(forced) == pytest.approx(min(plain), rel=0.02), (plain, forced)
+        forced.append((line["ms_per_step"], line["ms_per_step"] - line["roofline"]["kernel_ms_avg"]))
+    assert min(g for _, g in forced) <= min(g for _, g in plain) + 0.004, (plain, forced)
+    assert min(m for m, _ in forced) == pytest.approx(min(m for m, _ in plain), rel=0.06), (plain, forced)
 
 
 @pytest.mark.gpu
