@@ -325,7 +325,9 @@ __global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 
                         auto piece = [&](int32_t at) {
                             if (at >= (int32_t)lo) {
                                 const u32x4 v = *lds_u32x4((uint32_t)at);
-                                *reinterpret_cast<u32x4 RANS_GLOBAL *>(slot + ((uint32_t)at + to_slot)) = v;
+                                // (nt: the stream is written once and not read by this launch -- it should not push the
+                                //  chunks that wait for their second read out of L2)
+                                __builtin_nontemporal_store(v, reinterpret_cast<u32x4 RANS_GLOBAL *>(slot + ((uint32_t)at + to_slot)));
                                 if ((uint32_t)at == lo)
                                     *lds_u32x4(kAdaptWinBase + kTopPiece) = v;
                             }
@@ -346,7 +348,8 @@ __global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 
                     auto load_super = [&](uint32_t (&dstq)[4], uint32_t sg) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            dstq[j] = *reinterpret_cast<const uint32_t RANS_GLOBAL *>(src + (uint64_t)(sg * 16u + j * 4u) * N + in_off);
+                            // (nt: the chunk's LAST use; the count pass above reads with plain loads so that the lines stay)
+                            dstq[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t RANS_GLOBAL *>(src + (uint64_t)(sg * 16u + j * 4u) * N + in_off));
                     };
                     auto fast_loop = [&](auto small_tag) {
                         constexpr bool kSmall = decltype(small_tag)::value;
