@@ -85,10 +85,22 @@ __device__ __forceinline__ void adapt_substep(uint32_t &x, const u32x4 rec, bool
     }
 }
 
-template <int FMT, int K>
-__global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 : 2)) k_encode_adaptive(const AdaptEncParams p)
+// RR > 0: REGISTER-RESIDENT chunks -- a full chunk of RR x 1024 symbols (RR = 4, 8, 16) is loaded ONCE, four dwords per lane and
+// super-group of sixteen rounds in exactly the layout the coding loop wants them (the 4 x 4 transpose's input), all RR x 4 loads
+// in flight together; the counters are fed from those registers and so is the coding loop, unrolled over the super-groups: the
+// chunk crosses the fabric once (the two-pass form reads it twice: 1.62 x the algorithmic bytes) and the coding loop holds no
+// loads at all.  The price is occupancy (64 more VGPRs at RR = 16: four waves per SIMD).  Ragged chunks (the last one of an
+// input) and one-symbol word chunks take the two-pass form inside the same kernel.  The word format codes with the round-up
+// reciprocals here whatever the frequencies (exact for every frequency; 3 VALU more than Alverson's, in a launch the LDS pipe
+// bounds): one unrolled loop instead of two.
+constexpr int adapt_waves_per_simd(int K, int RR) { return K != 1 ? (K <= 4 ? 4 : 2) : RR >= 16 ? 4 : RR >= 8 ? 5 : kAdaptWavesPerSimd; }
+
+template <int FMT, int K, int RR>
+__global__ void __launch_bounds__(64, adapt_waves_per_simd(K, RR)) k_encode_adaptive(const AdaptEncParams p)
 {
     static_assert(FMT == FMT_WORD || FMT == FMT_BYTE, "per-chunk models: the byte and the word format");
+    static_assert(RR == 0 || K == 1, "register-resident chunks: one state per lane");
+    constexpr bool kRR = RR > 0;
     using Tr = FmtTraits<FMT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = lane_id();
@@ -116,6 +128,22 @@ __global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 
         const uint32_t nsym = (uint32_t)((p.n - first) < p.chunk_syms ? (p.n - first) : p.chunk_syms);
         const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + first;
 
+        // (register-resident form: the whole chunk, in the coding loop's layout -- lane l holds row 4 j + (l & 3), columns
+        //  4 (l >> 2) .. + 3 of super-group sg; the byte format's lanes mirrored, enc_byte_full_staged)
+        const bool rr_chunk = kRR && N == 64u && lds_at_zero && nsym == (uint32_t)RR * 1024u && p.chunk_syms == (uint32_t)RR * 1024u &&
+                              (reinterpret_cast<uintptr_t>(p.syms) & 3u) == 0;
+        uint32_t d[kRR ? RR : 1][4];
+        if constexpr (kRR) {
+            if (rr_chunk) {
+                const uint32_t off = FMT == FMT_BYTE ? (lane & 3u) * 64u + (60u - (lane & ~3u)) : in_lane_off;
+#pragma unroll
+                for (int sg = 0; sg < RR; ++sg)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        d[sg][j] = *reinterpret_cast<const uint32_t RANS_GLOBAL *>(src + (uint32_t)(sg * 16 + j * 4) * 64u + off);
+            }
+        }
+
         // ---- 1. count (count_freqs, main.cpp:59-66).  Counter (s, k) at byte 16 s + 4 k: the four copies of a symbol side by
         // side, so that the sums below are one ds_read_b128 per symbol.
 #pragma unroll
@@ -132,7 +160,17 @@ __global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 
             count1(v >> 24);
         };
         uint32_t done = 0;
-        if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        if constexpr (kRR) {
+            if (rr_chunk) { // from the registers (the order does not matter to a histogram)
+#pragma unroll
+                for (int sg = 0; sg < RR; ++sg)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        count4(d[sg][j]);
+                done = nsym;
+            }
+        }
+        if (done == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
             // 16 bytes per lane and load, kCountDepth loads in flight and the next kCountDepth issued before this trip's counting:
             // a wave that keeps ONE line per lane in flight waits a memory latency per KiB (2 us: a third of the chunk's time)
             constexpr uint32_t kCountDepth = 4, kTrip = 1024u * kCountDepth;
@@ -176,7 +214,7 @@ __global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 
             done = body16;
         }
         const bool aligned4 = (reinterpret_cast<uintptr_t>(src) & 3u) == 0;
-        const uint32_t body = aligned4 ? (nsym & ~3u) : done;
+        const uint32_t body = (kRR && rr_chunk) ? nsym : aligned4 ? (nsym & ~3u) : done;
         for (uint32_t i = done + lane * 4u; i < body; i += 256u)
             count4(*reinterpret_cast<const uint32_t RANS_GLOBAL *>(src + i));
         for (uint32_t i = body + lane; i < nsym; i += 64u)
@@ -214,7 +252,9 @@ __global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 
             wmax = o > wmax ? o : wmax;
         }
         bits = __builtin_bit_cast(float, uniform(__builtin_bit_cast(uint32_t, bits)));
-        const bool small = uniform(wmax) <= 2048u; // word format: Alverson reciprocals (the renormalised state stays below 2^31)
+        // word format: Alverson reciprocals while the renormalised state stays below 2^31 (no frequency above 2048); the
+        // register-resident kernels code with the round-up reciprocals throughout
+        const bool small = !kRR && uniform(wmax) <= 2048u;
         const bool always = FMT == FMT_WORD && uniform(wmax) == M; // (one symbol value: see adapt_substep)
         // (f32: 2^-12 of the sum and a line cover the rounding of 256 products and their sum)
         const float est = bits * (0.125f * (1.0f + 1.0f / 4096.0f));
@@ -397,9 +437,55 @@ __global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 
                                 cur[j] = nxt[j];
                         }
                     };
-                    if (FMT == FMT_WORD && !small)
+                    // symbol byte 3 - step of t -> its record (table at LDS address 0), the next record read before the current one is used
+                    auto code4 = [&](uint32_t t, uint32_t &lp) {
+                        auto rec_at = [&](int step) {
+                            uint32_t at;
+                            if (step == 0)
+                                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(at) : "v"(k3v), "v"(t));
+                            else if (step == 1)
+                                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(at) : "v"(k3v), "v"(t));
+                            else if (step == 2)
+                                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(at) : "v"(k3v), "v"(t));
+                            else
+                                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(at) : "v"(k3v), "v"(t));
+                            return *reinterpret_cast<const RANS_LDS u32x4 *>((uintptr_t)at);
+                        };
+                        u32x4 rec = rec_at(0);
+                        lp = uniform(lp);
+#pragma unroll
+                        for (int step = 0; step < 4; ++step) {
+                            const u32x4 now = rec;
+                            if (step + 1 < 4)
+                                rec = rec_at(step + 1);
+                            if constexpr (FMT == FMT_WORD)
+                                enc_word_full_staged<false, false>(x[0], now, lp, worst);
+                            else
+                                enc_byte_full_staged<false>(x[0], now, lp, worst);
+                        }
+                        lp = uniform(lp);
+                    };
+                    bool from_registers = false;
+                    if constexpr (kRR) {
+                        if (rr_chunk) { // every super-group from the registers, last to first; nothing is loaded in this loop
+                            from_registers = true;
+#pragma unroll
+                            for (int sg = RR - 1; sg >= 0; --sg) {
+                                if (!ovf) {
+                                    const uint32_t win_top = kAdaptWinBase + kTopPiece + (uniform(wp) & 15u);
+                                    uint32_t lp = FMT == FMT_WORD ? win_top >> 1 : win_top;
+#pragma unroll
+                                    for (int j = 3; j >= 0; --j)
+                                        code4(quad_transpose(d[sg][j], tsel1, sel2), lp);
+                                    stage_flush(win_top, FMT == FMT_WORD ? uniform(lp) << 1 : uniform(lp));
+                                }
+                            }
+                        }
+                    }
+                    if (from_registers) {
+                    } else if (FMT == FMT_WORD && !small)
                         fast_loop(std::false_type{});
-                    else
+                    else if (!kRR || FMT == FMT_BYTE) // (register-resident word kernels: the round-up records only)
                         fast_loop(std::true_type{});
                     if constexpr (FMT == FMT_BYTE) // back to lane l = stream l
                         x[0] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((63u - lane) * 4u), (int)x[0]);
@@ -442,26 +528,34 @@ __global__ void __launch_bounds__(64, K == 1 ? kAdaptWavesPerSimd : (K <= 4 ? 4 
         atomicOr(p.flags, 1u);
 }
 
-template <int FMT, int K> hipError_t launch_t(const AdaptEncParams &p, int num_cus, hipStream_t stream)
+template <int FMT, int K, int RR> hipError_t launch_t(const AdaptEncParams &p, int num_cus, hipStream_t stream)
 {
-    // workgroups per CU: 6 KiB of LDS each allow 25 (profiles/r06_wg_residency.log), the 80 registers of six waves per SIMD 24
-    const uint64_t per_cu = K == 1 ? kAdaptPerCu : (K <= 4 ? 16 : 8);
-    const uint64_t cap = (uint64_t)num_cus * per_cu;
+    // workgroups per CU: 6 KiB of LDS each allow 25 (profiles/r06_wg_residency.log), the registers kAdaptPerCu and fewer
+    const uint64_t per_cu = K != 1 ? (K <= 4 ? 16 : 8) : (uint64_t)adapt_waves_per_simd(K, RR) * 4;
+    const uint64_t cap = (uint64_t)num_cus * (per_cu < (uint64_t)kAdaptPerCu ? per_cu : (uint64_t)kAdaptPerCu);
     const uint32_t grid = (uint32_t)(p.nchunks < cap ? (p.nchunks ? p.nchunks : 1) : cap);
-    RANS_LAUNCH((k_encode_adaptive<FMT, K>), dim3(grid), dim3(64), kAdaptEncLds, stream, p);
+    RANS_LAUNCH((k_encode_adaptive<FMT, K, RR>), dim3(grid), dim3(64), kAdaptEncLds, stream, p);
     return hipGetLastError();
 }
 
 template <int FMT> hipError_t launch_f(const AdaptEncParams &p, int num_cus, hipStream_t s)
 {
+    if (p.n_ways == 64 && (reinterpret_cast<uintptr_t>(p.syms) & 3u) == 0 && p.n >= p.chunk_syms) { // register-resident chunks
+        if (p.chunk_syms == 16384u)
+            return launch_t<FMT, 1, 16>(p, num_cus, s);
+        if (p.chunk_syms == 8192u)
+            return launch_t<FMT, 1, 8>(p, num_cus, s);
+        if (p.chunk_syms == 4096u)
+            return launch_t<FMT, 1, 4>(p, num_cus, s);
+    }
     if (p.n_ways >= 1 && p.n_ways <= 64)
-        return launch_t<FMT, 1>(p, num_cus, s);
+        return launch_t<FMT, 1, 0>(p, num_cus, s);
     if (p.n_ways <= 128)
-        return launch_t<FMT, 2>(p, num_cus, s);
+        return launch_t<FMT, 2, 0>(p, num_cus, s);
     if (p.n_ways <= 256)
-        return launch_t<FMT, 4>(p, num_cus, s);
+        return launch_t<FMT, 4, 0>(p, num_cus, s);
     if (p.n_ways <= 512)
-        return launch_t<FMT, 8>(p, num_cus, s);
+        return launch_t<FMT, 8, 0>(p, num_cus, s);
     return hipErrorInvalidValue;
 }
 

@@ -853,6 +853,17 @@ def test_per_chunk_models_in_one_kernel(gpu, oracle, fmt):
             layouts[key] = h_offs
             out = ctx.decode_adaptive(cont, total, offs, lens, freqs, n, n_ways, chunk, sb, fmt=fmt)
             assert np.array_equal(out.cpu().numpy(), data), (sb, n_ways, "decode")
+    # the register-resident forms of the kernel (full chunks of 4 / 8 / 16 Ki symbols live in registers between the count and
+    # the coding pass; the ragged last chunk takes the two-pass form inside the same kernel) and a chunk size without one
+    big = _moving_statistics(oracle, 4096, 90, cut=3000)
+    d_big = torch.from_numpy(big).cuda()
+    for ch in (4096, 16384, 12288):
+        cont, offs, lens, freqs, total = ctx.encode_adaptive_sized(d_big, 64, ch, 12, fmt=fmt)
+        cnt, bad = oracle.compare_container_adaptive(fmt, big, 64, ch, 12, cont[:total].cpu().numpy(), offs.cpu().numpy(), lens.cpu().numpy(),
+                                                     freqs.cpu().numpy())
+        assert bad == -1 and cnt == (big.size + ch - 1) // ch, (ch, bad)
+        out = ctx.decode_adaptive(cont, total, offs, lens, freqs, big.size, 64, ch, 12, fmt=fmt)
+        assert np.array_equal(out.cpu().numpy(), big), ch
     # the same rows and streams as the three-launch path (rans_amd_encode_adaptive_fmt)
     c0, o0, l0, f0, t0 = ctx.encode_adaptive(d, 64, chunk, 12, fmt=fmt)
     c1, o1, l1, f1, t1 = ctx.encode_adaptive_sized(d, 64, chunk, 12, fmt=fmt)
