@@ -309,7 +309,10 @@ def test_gpu_sized_encode_to_file_without_a_compaction_pass(tmp_path, oracle):
     assert int(np.count_nonzero(h_offs[:-1] >= np.uint64(61 * t_slot))) >= 2  # (they lie in the overflow region)
     blob = R.pack_container_indexed(FMT_WORD, freqs, 12, data.size, 64, chunk, h_offs, t_lens.cpu().numpy().astype(np.uint32),
                                     t_cont[:t_total].cpu().numpy())
-    cont, offs, lens, total = ctx.encode(m, d_syms, 64, chunk)
+    # the same file as the one made from the compact encoder's container (whose alignment padding between chunks is whatever the
+    # device buffer held: zeroed here, as rans_amd_container_pack_indexed writes it)
+    cap = R.encode_bound(FMT_WORD, data.size, 64, chunk) + 16
+    cont, offs, lens, total = ctx.encode(m, d_syms, 64, chunk, d_out=torch.zeros(cap, dtype=torch.uint8, device="cuda"))
     assert np.array_equal(blob, R.pack_container(FMT_WORD, freqs, 12, data.size, 64, chunk, lens.cpu().numpy().astype(np.uint32),
                                                  cont[:total].cpu().numpy()))
     path = tmp_path / "sized.rans"
@@ -326,9 +329,14 @@ def test_gpu_sized_encode_to_file_without_a_compaction_pass(tmp_path, oracle):
                                         l1.cpu().numpy().astype(np.uint32), c1[:t1].cpu().numpy(), chunk_freqs=r1.cpu().numpy())
         c0, o0, l0, r0, t0 = ctx.encode_adaptive(d_syms, 64, chunk, 12, fmt=fmt)
         nch = R.num_chunks(data.size, chunk)
-        assert np.array_equal(blob, R.pack_container_adaptive(12, data.size, 64, chunk, r0.cpu().numpy().view(np.uint16)[:nch * 256],
-                                                              l0.cpu().numpy().astype(np.uint32)[:nch], c0[:t0].cpu().numpy(), fmt=fmt))
+        blob0 = R.pack_container_adaptive(12, data.size, 64, chunk, r0.cpu().numpy().view(np.uint16)[:nch * 256],
+                                          l0.cpu().numpy().astype(np.uint32)[:nch], c0[:t0].cpu().numpy(), fmt=fmt)
+        i0, f0, ll0, p0 = R.parse_container_adaptive(blob0)
         info, f2, l2, p2 = R.parse_container_adaptive(blob)
+        assert blob.size == blob0.size and np.array_equal(f0, f2) and np.array_equal(ll0, l2)
+        oo = R.offsets_from_lengths(l2)
+        for c in range(nch):  # (the bytes between chunks are alignment padding: zeros here, whatever the device buffer held there)
+            assert np.array_equal(p0[int(oo[c]):int(oo[c]) + int(l2[c])], p2[int(oo[c]):int(oo[c]) + int(l2[c])]), c
         d_cont = torch.from_numpy(np.concatenate([p2, np.zeros(64, np.uint8)])).cuda()
         out = ctx.decode_adaptive(d_cont, info.payload_bytes, torch.from_numpy(R.offsets_from_lengths(l2).astype(np.int64)).cuda(),
                                   torch.from_numpy(l2.astype(np.int32)).cuda(),
