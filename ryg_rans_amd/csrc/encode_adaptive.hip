@@ -89,11 +89,14 @@ __device__ __forceinline__ void adapt_substep(uint32_t &x, const u32x4 rec, bool
 // super-group of sixteen rounds in exactly the layout the coding loop wants them (the 4 x 4 transpose's input), all RR x 4 loads
 // in flight together; the counters are fed from those registers and so is the coding loop, unrolled over the super-groups: the
 // chunk crosses the fabric once (the two-pass form reads it twice: 1.62 x the algorithmic bytes) and the coding loop holds no
-// loads at all.  The price is occupancy (64 more VGPRs at RR = 16: four waves per SIMD).  Ragged chunks (the last one of an
+// loads at all.  The price is occupancy (64 more VGPRs at RR = 16: three waves per SIMD, 12 per CU -- and still 2 % faster than the
+// two-pass form at 24, whose second read waits on the memory side).  Ragged chunks (the last one of an
 // input) and one-symbol word chunks take the two-pass form inside the same kernel.  The word format codes with the round-up
 // reciprocals here whatever the frequencies (exact for every frequency; 3 VALU more than Alverson's, in a launch the LDS pipe
 // bounds): one unrolled loop instead of two.
-constexpr int adapt_waves_per_simd(int K, int RR) { return K != 1 ? (K <= 4 ? 4 : 2) : RR >= 16 ? 4 : RR >= 8 ? 5 : kAdaptWavesPerSimd; }
+// (waves per SIMD by the registers a resident chunk needs -- 64 / 32 / 16 VGPRs of symbols beside ~90 of working set, no spills:
+//  at RR = 16 three spill-free waves beat four that spill 22 registers, 0.874 against 0.984 ms for the word format)
+constexpr int adapt_waves_per_simd(int K, int RR) { return K != 1 ? (K <= 4 ? 4 : 2) : RR >= 16 ? 3 : RR >= 4 ? 4 : kAdaptWavesPerSimd; }
 
 template <int FMT, int K, int RR>
 __global__ void __launch_bounds__(64, adapt_waves_per_simd(K, RR)) k_encode_adaptive(const AdaptEncParams p)

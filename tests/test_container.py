@@ -309,12 +309,16 @@ def test_gpu_sized_encode_to_file_without_a_compaction_pass(tmp_path, oracle):
     assert int(np.count_nonzero(h_offs[:-1] >= np.uint64(61 * t_slot))) >= 2  # (they lie in the overflow region)
     blob = R.pack_container_indexed(FMT_WORD, freqs, 12, data.size, 64, chunk, h_offs, t_lens.cpu().numpy().astype(np.uint32),
                                     t_cont[:t_total].cpu().numpy())
-    # the same file as the one made from the compact encoder's container (whose alignment padding between chunks is whatever the
-    # device buffer held: zeroed here, as rans_amd_container_pack_indexed writes it)
-    cap = R.encode_bound(FMT_WORD, data.size, 64, chunk) + 16
-    cont, offs, lens, total = ctx.encode(m, d_syms, 64, chunk, d_out=torch.zeros(cap, dtype=torch.uint8, device="cuda"))
-    assert np.array_equal(blob, R.pack_container(FMT_WORD, freqs, 12, data.size, 64, chunk, lens.cpu().numpy().astype(np.uint32),
-                                                 cont[:total].cpu().numpy()))
+    # the same file as the one made from the compact encoder's container, up to the alignment padding between chunks (zeros here;
+    # whatever its copier waves dragged along there)
+    cont, offs, lens, total = ctx.encode(m, d_syms, 64, chunk)
+    blob0 = R.pack_container(FMT_WORD, freqs, 12, data.size, 64, chunk, lens.cpu().numpy().astype(np.uint32), cont[:total].cpu().numpy())
+    i0, f0, l0, p0 = R.parse_container(blob0)
+    i1, f1, l1, p1 = R.parse_container(blob)
+    assert blob.size == blob0.size and np.array_equal(f0, f1) and np.array_equal(l0, l1)
+    oo = R.offsets_from_lengths(l1)
+    for c in range(l1.size):
+        assert np.array_equal(p0[int(oo[c]):int(oo[c]) + int(l1[c])], p1[int(oo[c]):int(oo[c]) + int(l1[c])]), c
     path = tmp_path / "sized.rans"
     blob.tofile(path)
     info, f2, l2, p2 = R.parse_container(np.fromfile(path, dtype=np.uint8))

@@ -171,19 +171,16 @@ def main():
             continue
         fmt, what = names[nme]
         alg = n + streams.get(fmt, 0.79 * n) + rows_b
-        # (FETCH_SIZE reports wide 16-byte-per-lane reads at half their bytes on gfx950 and dword reads in full: the
-        #  register-resident encoder loads its chunk dword by dword -- x 1: it reads every input byte exactly once, and x 2
-        #  would make that two)
-        rd, w = fe.get(nme, 0) * 1024 * (1 if nme.startswith("k_encode_adaptive") else 2), wr.get(nme, 0) * 1024
+        rd, w = fe.get(nme, 0) * 1024 * 2, wr.get(nme, 0) * 1024
         rows_g.append("| `%s` | %s, %s | %d | %.1f | %.1f | %.4f | %.4g | %.4g | %s |" % (
             nme, fmt, what, calls, avg, mn, alg / (avg * 1e-6) / 8e12, rd, w, "%.3f" % ((rd + w) / alg) if rd + w else "-"))
         out["adaptive"][nme] = {"avg_us": avg, "min_us": mn, "read": rd, "write": w, "algorithmic": alg}
     if rows_g:
         L += ["## G. per-chunk models, 1 GiB Zipf(256), 16 Ki-symbol chunks, 64-way, 12 bits (`tools/time_adaptive.py 30`)", "",
               "(algorithmic bytes = symbols + streams + frequency rows, each once; FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate PMC "
-              "passes; x 1 for the one-kernel encoder's dword loads.  That kernel keeps a 4 / 8 / 16 Ki-symbol chunk in registers between the "
-              "count and the coding pass: every input byte crosses the fabric once.  Its two-pass form -- other chunk sizes, ragged chunks "
-              "-- reads the chunk twice: profiles/r06_adaptive_encoder_variants.log.)", "",
+              "passes.  The one-kernel encoder keeps a 4 / 8 / 16 Ki-symbol chunk in registers between the count and the coding pass: every "
+              "input byte crosses the fabric once.  Its two-pass form -- other chunk sizes, ragged chunks -- reads the chunk twice: 1.62 x, "
+              "1.54 x with non-temporal coding-pass loads and stream stores: profiles/r06_adaptive_encoder_variants.log.)", "",
               "| kernel | what | calls | avg us | min us | frac of 8 TB/s | read B | write B | traffic / algorithmic |", "|---|---|---|---|---|---|---|---|---|"] + rows_g + [""]
 
     # H: the reference's own layouts on the lane kernels
