@@ -243,6 +243,26 @@ def test_more_than_2_to_the_32_symbols(gpu, oracle, name, fmt, sb, ways, chunk, 
     assert torch.equal(out, d_syms)
 
 
+def test_per_chunk_models_past_2_to_the_32_symbols(gpu, oracle):
+    """The one-kernel per-chunk-model encoder beyond 32 bits: 2^32 + 3 x 16384 + 77 symbols of moving statistics in 262 148
+    chunks (the register-resident form, a ragged last chunk in the two-pass form, look-back sums beyond 2^32 bytes) -- every
+    chunk's row and stream == the oracle's, the pieces in index order, decoded back."""
+    R, ctx, torch = gpu
+    import bench
+    n, chunk = (1 << 32) + 3 * 16384 + 77, 16384
+    d_syms = bench.gen_moving(torch, n, 3, "cuda")
+    nchunks = (n + chunk - 1) // chunk
+    cont, offs, lens, rows, total = ctx.encode_adaptive_sized(d_syms, 64, chunk, 12, fmt=FMT_WORD, cap=n + (n >> 3))
+    h_offs, h_lens = offs.cpu().numpy().astype(np.uint64), lens.cpu().numpy().astype(np.uint32)
+    ends = h_offs[:nchunks] + h_lens
+    assert np.all(ends % np.uint64(64) == 0) and np.all(ends[:-1] <= h_offs[1:nchunks]) and int(ends[-1]) == total == int(h_offs[nchunks])
+    count, bad = oracle.compare_container_adaptive(FMT_WORD, d_syms.cpu().numpy(), 64, chunk, 12, cont[:total].cpu().numpy(), h_offs, h_lens,
+                                                   rows.cpu().numpy())
+    assert count == nchunks and bad == -1, bad
+    out = ctx.decode_adaptive(cont, total, offs, lens, rows, n, 64, chunk, 12, fmt=FMT_WORD)
+    assert torch.equal(out, d_syms)
+
+
 def test_book1_appendix_b_on_gpu(gpu):
     """SURVEY appendix B through the HIP path: decode the reference-made 64-way word stream of book1, then
     re-encode book1 into every pinned stream (sizes from the README, SHA-256 from the unmodified reference)."""
