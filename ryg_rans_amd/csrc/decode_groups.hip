@@ -1,0 +1,373 @@
+// decode_groups.hip -- the reference's 8-way word layout (rans_word_sse41.h:151-227: two SSE registers of four states,
+// one shared cursor), EIGHT chunks per wave: lane 8 g + i holds state i of chunk g of the wave's octet.
+//
+// The lane-per-chunk kernels (lanes.hip) give every lane a whole chunk: 64 private streams per wave, a 136-byte ring
+// row per lane in LDS (8.7 KiB per wave beside the 32 KiB slot table: 13..14 waves per CU), and their pace is set by
+// how few waves a CU can hold (profiles/r06_small_abs.md).  Here a chunk is decoded the way the wave-per-chunk
+// kernels do it (decode_wave.hip) -- one symbol per lane per round, "who renormalises" is a ballot, a lane's place in
+// its stream is a population count over the lanes below it -- only that the ballot is cut into eight bytes, one per
+// chunk:
+//   * mask_g = ballot & (bits of group g), held per lane in a VGPR; v_mbcnt counts ITS bits below the lane, and with
+//     the group's cursor as the instruction's addend the result is the lane's word position outright; v_bcnt with the
+//     cursor as addend is the group's next cursor (every lane of the group computes the same);
+//   * a group's stream goes through a 256-byte ring in LDS (2 KiB per wave: 32 waves per CU beside the table), fetched
+//     in aligned 128-byte blocks, 16 bytes per lane, the next block parked in registers one refill ahead.  Eight rounds
+//     consume at most 8 x 8 x 2 = 128 bytes per group, so a group needs at most one block per eight rounds: one
+//     compare per lane every eight rounds, the refill itself runs under the exec mask of the groups that need it;
+//   * four rounds of symbols are transposed inside the quads (as in decode_wave.hip) and every lane stores a dword:
+//     32 contiguous bytes per group and store.
+// Full chunks of a multiple of 32 symbols only (the launcher hands everything else to the lane kernel).
+//
+// No MFMA: integer, table-driven, serial per state.
+
+#include "decode_common.hpp"
+
+namespace rans_amd {
+
+namespace {
+
+constexpr uint32_t kGrpBlock = 128;             // bytes a group fetches at a time: 8 lanes x 16 B
+constexpr uint32_t kGrpRing = 2 * kGrpBlock;    // per group
+constexpr uint32_t kGrpWaveLds = 8 * kGrpRing;  // per wave
+constexpr uint32_t kGrpThreads = 1024;
+constexpr uint32_t kGrpClaimSyms = 8192;        // symbols one claim of the work counter covers, at least
+
+__device__ __forceinline__ uint32_t lds_u16(uint32_t addr)
+{
+    return *reinterpret_cast<RANS_LDS const uint16_t *>((uintptr_t)addr);
+}
+
+// Eight rounds of the eight chunks as one hand-scheduled sequence: rans_word_sse41.h:123-141 (the D step and the
+// renormalisation of RansWordDecSym / RansWordDecRenorm), 14 VALU + 2 LDS per round:
+//   v_and, v_lshlrev            slot = x & 4095 -> LDS byte address of the slot record (the table starts at LDS address 0)
+//   ds_read_b64                 {freq | sym << 24, bias}
+//   v_lshrrev, v_mad_u32_u24    x = freq * (x >> 12) + bias
+//   v_cmp                       vcc = the lanes that renormalise (x < 2^16)
+//   v_perm                      the symbol joins its accumulator (rounds 2..7; it also is one of the two wait states a
+//                               VALU read of a VALU-written vcc needs on gfx940+, s_nop the other)
+//   v_and, v_and_or             t_lo = vcc_lo & my group's bits, t = (vcc_hi & my group's bits) | t_lo -- a group lies in
+//                               one half of the wave, so t is the group's byte of the ballot in place
+//   v_mbcnt_lo(t_lo, cursor), v_mbcnt_hi(t, .)   cursor + renormalising lanes of MY group below me: for lanes 0..31
+//                               v_mbcnt_hi adds nothing, for lanes 32..63 t_lo is zero and v_mbcnt_lo adds nothing
+//   v_bcnt(t, cursor)           the group's next cursor (words)
+//   v_lshlrev, v_and_or         word position -> LDS byte address inside the group's 256-byte ring
+//   ds_read_u16, v_perm         under exec = vcc: x = (x << 16) | word
+// Rounds alternate between two accumulators (A: rounds 0, 2, 4, 6; B: 1, 3, 5, 7), see the output transposition below.
+// Fixed registers v56..v63: the halves of a 64-bit asm operand cannot be named.
+#define RANS_G_LOOKUP(PAIR, LO, HI)                        \
+    "v_and_b32_e32 v62, %[m12], %[x]\n\t"                  \
+    "v_lshlrev_b32_e32 v62, 3, v62\n\t"                    \
+    "ds_read_b64 " PAIR ", v62\n\t"                        \
+    "v_lshrrev_b32_e32 v63, 12, %[x]\n\t"                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                             \
+    "v_mad_u32_u24 %[x], " LO ", v63, " HI "\n\t"
+#define RANS_G_RENORM(FILL)                                \
+    "v_cmp_gt_u32_e32 vcc, %[lim], %[x]\n\t"               \
+    FILL                                                   \
+    "v_and_b32_e32 v62, vcc_lo, %[gmlo]\n\t"               \
+    "v_and_or_b32 v63, vcc_hi, %[gmhi], v62\n\t"           \
+    "v_mbcnt_lo_u32_b32 v62, v62, %[cur]\n\t"              \
+    "v_mbcnt_hi_u32_b32 v62, v63, v62\n\t"                 \
+    "v_bcnt_u32_b32 %[cur], v63, %[cur]\n\t"               \
+    "v_lshlrev_b32_e32 v62, 1, v62\n\t"                    \
+    "v_and_or_b32 v62, v62, %[k255], %[ring]\n\t"          \
+    "s_mov_b64 exec, vcc\n\t"                              \
+    "ds_read_u16 v63, v62\n\t"                             \
+    "s_waitcnt lgkmcnt(0)\n\t"                             \
+    "v_perm_b32 %[x], %[x], v63, %[selm]\n\t"              \
+    "s_mov_b64 exec, -1\n\t"
+__device__ __forceinline__ void decode_octet_8rounds(uint32_t &x, uint32_t &curw, uint32_t &acc_a, uint32_t &acc_b, uint32_t m12,
+                                                     uint32_t lim, uint32_t gm_lo, uint32_t gm_hi, uint32_t k255, uint32_t ring,
+                                                     uint32_t sel_a, uint32_t sel_b, uint32_t sel_c)
+{
+    asm volatile(
+        RANS_G_LOOKUP("v[56:57]", "v56", "v57") RANS_G_RENORM("s_nop 1\n\t")
+        RANS_G_LOOKUP("v[58:59]", "v58", "v59") RANS_G_RENORM("s_nop 1\n\t")
+        RANS_G_LOOKUP("v[60:61]", "v60", "v61") RANS_G_RENORM("v_perm_b32 %[pa], v60, v56, %[selA]\n\ts_nop 0\n\t")
+        RANS_G_LOOKUP("v[60:61]", "v60", "v61") RANS_G_RENORM("v_perm_b32 %[pb], v60, v58, %[selA]\n\ts_nop 0\n\t")
+        RANS_G_LOOKUP("v[60:61]", "v60", "v61") RANS_G_RENORM("v_perm_b32 %[pa], v60, %[pa], %[selB]\n\ts_nop 0\n\t")
+        RANS_G_LOOKUP("v[60:61]", "v60", "v61") RANS_G_RENORM("v_perm_b32 %[pb], v60, %[pb], %[selB]\n\ts_nop 0\n\t")
+        RANS_G_LOOKUP("v[60:61]", "v60", "v61") RANS_G_RENORM("v_perm_b32 %[pa], v60, %[pa], %[selC]\n\ts_nop 0\n\t")
+        RANS_G_LOOKUP("v[60:61]", "v60", "v61") RANS_G_RENORM("v_perm_b32 %[pb], v60, %[pb], %[selC]\n\ts_nop 0\n\t")
+        : [x] "+v"(x), [cur] "+v"(curw), [pa] "=&v"(acc_a), [pb] "=&v"(acc_b)
+        : [m12] "v"(m12), [lim] "v"(lim), [gmlo] "v"(gm_lo), [gmhi] "v"(gm_hi), [k255] "v"(k255), [ring] "v"(ring),
+          [selA] "v"(sel_a), [selB] "v"(sel_b), [selC] "v"(sel_c), [selm] "s"(0x05040100u)
+        : "vcc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+}
+#undef RANS_G_LOOKUP
+#undef RANS_G_RENORM
+
+__global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const DecParams p)
+{
+    using Tr = FmtTraits<FMT_WORD>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u; // WordSlot[4096]: 32 KiB, a multiple of the ring size
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+    }
+    __syncthreads();
+    DecTables<FMT_WORD> T;
+    T.init(smem, smem + t0_bytes, p.scale_bits, p.log2nsyms);
+    if (!lds_starts_at_zero(smem)) { // cannot happen without static LDS; never decode on a wrong assumption
+        if (threadIdx.x == 0)
+            atomicAdd(p.err_count, 1ull << 32);
+        return;
+    }
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u;
+    if (p.span_reset && blockIdx.x == 0 && threadIdx.x < 2)
+        p.span_reset[threadIdx.x] = 0ull;
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t g = lane >> 3, i = lane & 7u;
+    // raw LDS byte address of this group's ring (LDS starts at zero; 256-byte aligned: positions wrap with an and-or)
+    const uint32_t ring = t0_bytes + wave * kGrpWaveLds + g * kGrpRing;
+    // Ring positions carry a per-group bias of 16 g bytes: the groups' cursors move at the same average pace, and eight
+    // rings 256 bytes apart would otherwise sit on the same banks.
+    const uint32_t bias = 16u * g;
+    // this group's bits of the ballot's halves (one of the two is zero)
+    uint32_t gm_lo = g < 4 ? 0xffu << (8u * g) : 0u, gm_hi = g >= 4 ? 0xffu << (8u * (g - 4u)) : 0u;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(gm_lo)); // opaque: keep them in VGPRs
+    asm volatile("v_mov_b32 %0, %0" : "+v"(gm_hi));
+    uint32_t k255 = 255u, k65536 = 0x10000u;
+    // v_perm selectors of the symbol accumulators (decode_common.hpp acc_symbol for byte 3 of the slot record's first word)
+    uint32_t sel_a = 0x03020703u, sel_b = 0x03070100u, sel_c = 0x07020100u;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(sel_a));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(sel_b));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(sel_c));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(k255));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(k65536));
+
+    const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
+    const uint64_t glo = cbase & ~uint64_t(15), glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
+    const uint32_t sel1 = (lane & 1u) ? 0x03070105u : 0x06020400u;
+    const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
+    const uint32_t groups16 = uniform(p.chunk_syms >> 7);      // 16 rounds of 8 symbols
+    const uint32_t rem4 = uniform((p.chunk_syms >> 5) & 3u);   // + up to three times 4 rounds
+    const uint64_t octets = (p.nchunks + 7u) >> 3; // (the last one may hold fewer than eight chunks)
+    const uint32_t per_claim = uniform(p.chunk_syms >= kGrpClaimSyms / 8u ? 1u : (kGrpClaimSyms / 8u + p.chunk_syms - 1u) / p.chunk_syms);
+    const uint64_t claims = (octets + per_claim - 1u) / per_claim;
+
+    auto load16 = [&](uint64_t a) -> u32x4 { // 16 bytes of the container, zeros beyond its granules
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (a >= glo && a < glimit)
+            v = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(a));
+        return v;
+    };
+
+    uint32_t nbad = 0;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    uint64_t claim_v = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint32_t npools = gridDim.x < kWorkPools ? gridDim.x : kWorkPools;
+    const uint32_t pool = blockIdx.x % npools;
+    // Work is handed out dynamically, as in decode_wave.hip k_decode (pool = blockIdx % 8 owns the claims c with c % 8 == pool).
+    // Nothing is claimed or fetched ahead of its octet: the kernel is bound by VALU and LDS issue (eight waves per SIMD), a
+    // wave's trips to memory in front of an octet are covered by the other seven, and measured (profiles/r06_word8_groups.md)
+    // a claim held while another octet is decoded keeps work from the waves that run dry: + 6 % at 16 octets per wave, + 15 %
+    // at one; index entries fetched during the last rounds only add to what the refills' s_waitcnt vmcnt(0) waits for.
+    auto claim_take = [&]() -> uint64_t {
+        if (p.work_counter) {
+            uint32_t got = 0;
+            if (lane == 0)
+                got = atomicAdd(p.work_counter + pool * kWorkPoolStride, 1u);
+            return (uint64_t)uniform(got) * npools + pool;
+        }
+        const uint64_t c = claim_v;
+        claim_v += total_waves;
+        return uniform64(c);
+    };
+    uint64_t octet, o_end;
+    bool have;
+    {
+        const uint64_t c = claim_take();
+        have = c < claims;
+        octet = c * per_claim;
+        o_end = (c + 1u) * per_claim < octets ? (c + 1u) * per_claim : octets;
+    }
+    uint64_t off = 0;
+    uint32_t len = 0;
+    if (have && octet * 8u + g < p.nchunks) {
+        off = p.offsets[octet * 8u + g];
+        len = p.lengths[octet * 8u + g];
+    }
+    while (have) {
+        {
+            const bool exists = octet * 8u + g < p.nchunks;
+            const bool valid = exists && (off & 1u) == 0 && len >= 8u * 4u && off <= p.container_bytes && len <= p.container_bytes - off;
+            if (exists && !valid && i == 0)
+                nbad++;
+            const uint64_t src = cbase + (valid ? off : 0u);
+            uint32_t x = Tr::kL;
+            if (valid) // RansDecInit order: state 0 first (rans_word_sse41.h:104-113)
+                x = reinterpret_cast<const uint32_t RANS_GLOBAL *>(src)[i];
+            // positions count from the 128-byte line of the chunk's first byte
+            const uint64_t abase = src & ~uint64_t(kGrpBlock - 1u);
+            const uint32_t start = (uint32_t)(src - abase) + 8u * 4u; // < 160
+            uint32_t curw = (start + bias) >> 1; // the cursor in words (biased)
+            uint64_t ld = abase + 16u * i;
+            const u32x4 b0 = load16(ld), b1 = load16(ld + kGrpBlock);
+            u32x4 pend = load16(ld + 2u * kGrpBlock); // block 2; the ring holds blocks nb - 2 and nb - 1, pend is block nb
+            ld += 3u * kGrpBlock;
+            *reinterpret_cast<RANS_LDS u32x4 *>((uintptr_t)(ring | ((16u * i + bias) & 255u))) = b0;
+            *reinterpret_cast<RANS_LDS u32x4 *>((uintptr_t)(ring | ((kGrpBlock + 16u * i + bias) & 255u))) = b1;
+            uint32_t wr = ring | ((16u * i + bias) & 255u); // where block nb goes
+            uint32_t thr = (kGrpBlock + bias) >> 1;         // cursor (words) from which block nb has to be in the ring
+            auto checkpoint = [&]() {
+                if (curw >= thr) { // (the same for the eight lanes of a group)
+                    *reinterpret_cast<RANS_LDS u32x4 *>((uintptr_t)wr) = pend;
+                    wr ^= kGrpBlock;
+                    thr += kGrpBlock / 2u;
+                    pend = load16(ld);
+                    ld += kGrpBlock;
+                }
+            };
+            checkpoint(); // the states may end in block 1
+
+            // symbol stores through a descriptor of the octet's output: the running offset is an SGPR
+            const rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>(reinterpret_cast<uint64_t>(p.out) + octet * 8u * p.chunk_syms), 0, 8u * p.chunk_syms, kRsrcFlags);
+            const uint32_t out_off16 = valid ? g * p.chunk_syms + 16u * i : 0x80000000u; // (an invalid chunk's stores: dropped by the range check)
+            uint32_t osoff = 0;
+#define RANS_GROUP_ROUND(ACC, J)                                                                        \
+    {                                                                                                   \
+        ACC = acc_symbol<Tr::kSymByte, J>(dec_step<FMT_WORD>(T, x), ACC);                               \
+        const bool need = x < k65536;                                                                   \
+        const uint64_t m = __builtin_amdgcn_ballot_w64(need);                                           \
+        const uint32_t t_lo = (uint32_t)m & gm_lo, t_hi = (uint32_t)(m >> 32) & gm_hi;                  \
+        /* the cursor + this group's renormalising lanes below me (v_mbcnt adds its second operand) */  \
+        const uint32_t at = __builtin_amdgcn_mbcnt_hi(t_hi, __builtin_amdgcn_mbcnt_lo(t_lo, curw));     \
+        curw += __builtin_popcount(t_lo) + __builtin_popcount(t_hi);                                    \
+        if (need)                                                                                       \
+            x = (x << 16) | lds_u16(((at << 1) & k255) | ring);                                         \
+    }
+            // Sixteen rounds = one 128-byte line per group.  Round r's symbols go to byte (r >> 1) & 3 of accumulator
+            // (r & 1) + 2 (r >> 3): after the quad transposes lane (m = i & 3, h = i >> 2) holds the dwords (row 2 m, half h),
+            // (row 2 m + 1, half h), (row 8 + 2 m, h), (row 9 + 2 m, h) of the line's sixteen 8-byte rows; the halves h = 0
+            // keep the first two and take their other halves from lane i + 4, the halves h = 1 the last two from lane i - 4:
+            // lane i then holds bytes [16 i, 16 i + 16) of the line, one 16-byte store per lane.
+            for (uint32_t q = 0; q < groups16; ++q) {
+                uint32_t a0, a1, a2, a3;
+                checkpoint();
+                decode_octet_8rounds(x, curw, a0, a1, T.mask12v, k65536, gm_lo, gm_hi, k255, ring, sel_a, sel_b, sel_c);
+                checkpoint();
+                decode_octet_8rounds(x, curw, a2, a3, T.mask12v, k65536, gm_lo, gm_hi, k255, ring, sel_a, sel_b, sel_c);
+                a0 = quad_transpose(a0, sel1, sel2);
+                a1 = quad_transpose(a1, sel1, sel2);
+                a2 = quad_transpose(a2, sel1, sel2);
+                a3 = quad_transpose(a3, sel1, sel2);
+                // (v_cndmask_b32_dpp by hand: left to the compiler, the select becomes a branch around the DPP move, and a DPP
+                // move under an exec mask reads zeros from the lanes the mask has switched off -- the very lanes it is after)
+                u32x4 v;
+                asm volatile("s_nop 1\n\t"
+                             "s_mov_b64 vcc, %[lower]\n\t"
+                             "v_cndmask_b32_dpp %[vx], %[a2], %[a0], vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" // lower ? a0 : a2 of lane - 4
+                             "v_cndmask_b32_dpp %[vz], %[a3], %[a1], vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "s_mov_b64 vcc, %[upper]\n\t"
+                             "v_cndmask_b32_dpp %[vy], %[a0], %[a2], vcc row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" // upper ? a2 : a0 of lane + 4
+                             "v_cndmask_b32_dpp %[vw], %[a1], %[a3], vcc row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                             : [vx] "=&v"(v.x), [vy] "=&v"(v.y), [vz] "=&v"(v.z), [vw] "=&v"(v.w)
+                             : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [lower] "s"(0x0f0f0f0f0f0f0f0full),
+                               [upper] "s"(0xf0f0f0f0f0f0f0f0ull)
+                             : "vcc");
+                __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, out_off16, osoff, kAuxStore);
+                osoff += 128u;
+            }
+            for (uint32_t q = 0; q < rem4; ++q) { // what is left of a chunk that is not a multiple of 128 symbols: 4 rounds a time
+                if ((q & 1u) == 0)
+                    checkpoint();
+                uint32_t acc = 0;
+                RANS_GROUP_ROUND(acc, 0)
+                RANS_GROUP_ROUND(acc, 1)
+                RANS_GROUP_ROUND(acc, 2)
+                RANS_GROUP_ROUND(acc, 3)
+                const uint32_t v = quad_transpose(acc, sel1, sel2);
+                const uint32_t li = lane_id() & 7u; // lane (m, h) of the group holds row m, states 4 h .. 4 h + 3
+                __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, out_off16 - 16u * li + (li & 3u) * 8u + (li >> 2) * 4u, osoff, 0);
+                osoff += 32u;
+            }
+#undef RANS_GROUP_ROUND
+            // integrity: every state back at L, the cursor exactly at the end of the chunk's stream
+            const bool bad = valid && (x != Tr::kL || 2u * curw - bias - (start - 8u * 4u) != len);
+            const uint64_t bm = __builtin_amdgcn_ballot_w64(bad);
+            if (i == 0 && ((bm >> (8u * g)) & 0xffu) != 0)
+                nbad++;
+            // the octet after this one
+            uint64_t n_octet = octet + 1u, n_end = o_end;
+            bool n_have = true;
+            if (n_octet >= o_end) {
+                const uint64_t c = claim_take();
+                n_have = c < claims;
+                n_octet = c * per_claim;
+                n_end = (c + 1u) * per_claim < octets ? (c + 1u) * per_claim : octets;
+            }
+            uint64_t n_off = 0;
+            uint32_t n_len = 0;
+            if (n_have && n_octet * 8u + g < p.nchunks) {
+                n_off = p.offsets[n_octet * 8u + g];
+                n_len = p.lengths[n_octet * 8u + g];
+            }
+            octet = n_octet;
+            o_end = n_end;
+            have = n_have;
+            off = n_off;
+            len = n_len;
+        }
+    }
+    if (nbad)
+        atomicAdd(p.err_count, (unsigned long long)nbad);
+}
+
+} // namespace
+
+// Every full chunk goes through k_decode_word_groups; a ragged last chunk through the wave-per-chunk decoder in a second launch
+// (one wave, eight of its lanes at work: a chunk's rounds one after the other, ~20 us per thousand symbols -- the lane kernel,
+// one LANE for the whole chunk, takes four times that).
+bool decode_word_groups_applicable(const DecParams &p)
+{
+    return p.n_ways == 8 && p.sym_bytes == 1 && p.scale_bits == 12 && (p.chunk_syms & 31u) == 0 && p.chunk_syms <= (1u << 20) &&
+           (reinterpret_cast<uintptr_t>(p.out) & 3u) == 0 && p.n / p.chunk_syms >= 8 && !p.trace &&
+           ((p.table0_bytes + 15u) & ~15u) % kGrpRing == 0;
+}
+
+hipError_t launch_decode_word_groups(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
+{
+    const uint64_t full = p.n / p.chunk_syms; // chunks the group kernel takes
+    const size_t table_lds = (p.table0_bytes + 15u) & ~15u;
+    const size_t lds = table_lds + (size_t)(kGrpThreads / 64) * kGrpWaveLds;
+    auto kern = k_decode_word_groups;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 160 * 1024, lds_ok); e != hipSuccess)
+        return e;
+    DecParams q = p;
+    q.nchunks = full;
+    q.n = full * p.chunk_syms;
+    const uint32_t per_cu = 2u * lds <= 160u * 1024u ? 2u : 1u;
+    const uint64_t want_blocks = ((full + 7u) / 8u + kGrpThreads / 64 - 1) / (kGrpThreads / 64);
+    const uint64_t cap = (uint64_t)num_cus * per_cu;
+    const uint32_t grid = (uint32_t)(want_blocks < cap ? want_blocks : cap);
+    if (name)
+        *name = "k_decode_word_groups";
+    RANS_LAUNCH(kern, dim3(grid), dim3(kGrpThreads), lds, stream, q);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess)
+        return e;
+    if (full == p.nchunks)
+        return hipSuccess;
+    DecParams r = p; // the ragged last chunk
+    r.offsets = p.offsets + full;
+    r.lengths = p.lengths + full;
+    r.out = static_cast<uint8_t *>(p.out) + full * p.chunk_syms;
+    r.n = p.n - full * p.chunk_syms;
+    r.nchunks = p.nchunks - full;
+    r.work_counter = nullptr;
+    r.work_counter_reset = nullptr;
+    r.span = nullptr;
+    r.span_reset = nullptr;
+    return launch_decode_wave(FMT_WORD, r, num_cus, stream, nullptr);
+}
+
+} // namespace rans_amd

@@ -525,14 +525,15 @@ def test_lane_kernels_both_generations(gpu, oracle, generation):
     assert np.array_equal(out_b[5:5 + data.size].cpu().numpy(), data)
 
 
-@pytest.mark.parametrize("fmt,sb,n_ways", [(FMT_BYTE, 14, 2), (FMT_WORD, 12, 8)])
-def test_lane_decoder_fallback_for_huge_chunks(gpu, oracle, fmt, sb, n_ways):
+@pytest.mark.parametrize("fmt,sb,n_ways,extra", [(FMT_BYTE, 14, 2, 0), (FMT_WORD, 12, 8, 8)])
+def test_lane_decoder_fallback_for_huge_chunks(gpu, oracle, fmt, sb, n_ways, extra):
     """The first generation's per-lane decoder (k_decode_lanes) is the NAMED FALLBACK for what the staged decoder cannot
     take: chunks of 512 Ki symbols and more (its ring positions are 32-bit offsets inside a batch).  64 + 1 chunks of 512 Ki
     symbols in the reference's own narrow layouts: a container the ORACLE made decodes to the input, and the GPU encoder's
-    container (wave encoder or per-lane encoder, whichever the shape gets) equals it chunk by chunk."""
+    container (wave encoder or per-lane encoder, whichever the shape gets) equals it chunk by chunk.  (The 8-way word layout
+    has its own decoder for chunks of a multiple of 32 symbols, k_decode_word_groups: the case here is 8 symbols off.)"""
     R, ctx, torch = gpu
-    chunk = 1 << 19
+    chunk = (1 << 19) + extra
     data = oracle.gen_zipf(64 * chunk + 12345, K=256, s=1.0, seed=21)
     om, gm = _models(R, ctx, oracle, fmt, sb, data)
     want, offs, lens = oracle.encode_chunked_mt(fmt, om, data, n_ways, chunk, align=16)
@@ -1042,6 +1043,98 @@ def test_rans64_two_way_lane_kernel(gpu, oracle):
         ctx.decode(gm, torch.from_numpy(np.concatenate([bad, np.zeros(64, np.uint8)])).cuda(), want.size,
                    torch.from_numpy(o).cuda(), torch.from_numpy(l).cuda(), data.size, 2, chunk, sync=False)
         assert ctx.decode_errors() >= 1, kind
+
+
+def test_word_eight_way_octet_decoder(gpu, oracle):
+    """The reference's 8-way word layout (rans_word_sse41.h:151-227, main_simd.cpp:313-332) through k_decode_word_groups, eight
+    chunks per wave: chunk sizes of one and many 16-round lines, sizes that leave one to three 4-round groups behind the last
+    line, chunk counts that are no multiple of eight and a ragged last chunk (the lane kernel's second launch), chunks that
+    start on any 2-byte boundary, in any order; the ORACLE's container and the GPU's own; streams that consume the most a
+    valid one can (16 bytes per round) and next to nothing; damage is flagged, never a crash."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(8)
+    zipf = oracle.gen_zipf(700000 + 77, K=256, s=1.0, seed=31)
+    flat = rng.integers(0, 256, 260000).astype(np.uint8)
+    heavy = np.where(rng.random(260000) < 0.93, 7, rng.integers(0, 256, 260000)).astype(np.uint8)  # ~0.1 byte per symbol
+    cases = [(zipf, 1024), (zipf, 128), (zipf, 32), (zipf, 96), (zipf, 160), (zipf, 4000), (zipf, 16384), (zipf[:8 * 1024], 1024),
+             (zipf[:71 * 256 + 9], 256), (flat, 1024), (flat, 224), (heavy, 512), (heavy, 16384)]
+    for data, chunk in cases:
+        om, gm = _models(R, ctx, oracle, FMT_WORD, 12, data)
+        want, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, 8, chunk, align=16)
+        d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
+        d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+        d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+        back = torch.full((data.size + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+        out = back[128:128 + data.size]
+        ctx.decode(gm, d_cont, want.size, d_offs, d_lens, data.size, 8, chunk, d_out=out)
+        assert ctx.last_decode_kernel() == "k_decode_word_groups", (ctx.last_decode_kernel(), chunk)
+        assert np.array_equal(out.cpu().numpy(), data), (chunk, data.size)
+        host = back.cpu().numpy()
+        assert (host[:128] == 0xA5).all() and (host[128 + data.size:] == 0xA5).all(), chunk  # nothing outside the output
+        cont, o2, l2, total = ctx.encode(gm, torch.from_numpy(data).cuda(), 8, chunk)
+        out = ctx.decode(gm, cont, total, o2, l2, data.size, 8, chunk)
+        assert ctx.last_decode_kernel() == "k_decode_word_groups" and np.array_equal(out.cpu().numpy(), data), (chunk, "own container")
+    # output on a 4-byte boundary is enough; on any other the lane kernel takes over
+    data, chunk = zipf[:100 * 256], 256
+    om, gm = _models(R, ctx, oracle, FMT_WORD, 12, data)
+    want, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, 8, chunk, align=16)
+    d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
+    d_offs, d_lens = torch.from_numpy(offs.astype(np.int64)).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda()
+    for shift, kernel in ((4, "k_decode_word_groups"), (12, "k_decode_word_groups"), (2, "k_decode_lanes_staged"), (1, "k_decode_lanes_staged")):
+        back = torch.zeros(data.size + 64, dtype=torch.uint8, device="cuda")
+        ctx.decode(gm, d_cont, want.size, d_offs, d_lens, data.size, 8, chunk, d_out=back[shift:shift + data.size])
+        assert ctx.last_decode_kernel() == kernel, (shift, ctx.last_decode_kernel())
+        assert np.array_equal(back[shift:shift + data.size].cpu().numpy(), data), shift
+    # chunks packed back to front on 2-byte boundaries (the format's unit)
+    rev = np.zeros(want.size + 256, np.uint8)
+    roffs = np.zeros_like(offs)
+    pos = 2
+    for c in range(len(lens) - 1, -1, -1):
+        roffs[c] = pos
+        rev[pos:pos + lens[c]] = want[int(offs[c]):int(offs[c]) + int(lens[c])]
+        pos += int(lens[c]) + 2 * (c % 5)
+    d_rev = torch.from_numpy(rev).cuda()
+    out = ctx.decode(gm, d_rev, pos, torch.from_numpy(roffs.astype(np.int64)).cuda(), d_lens, data.size, 8, chunk)
+    assert ctx.last_decode_kernel() == "k_decode_word_groups" and np.array_equal(out.cpu().numpy(), data)
+    # rare symbols only (12 bits each, the most the format's 12-bit models can ask for): three of four states renormalise per
+    # round on average, rounds in which all eight do (16 stream bytes, the refill invariant's bound) are common
+    f = np.ones(256, np.uint32)
+    f[0] = 4096 - 255
+    rare = rng.integers(1, 256, 64 * 2048).astype(np.uint8)
+    om, gm2 = oracle.model(f, 12), ctx.model(FMT_WORD, f, 12)
+    w2, of2, le2 = oracle.encode_chunked(FMT_WORD, om, rare, 8, 2048, align=16)
+    assert w2.size > 3 * rare.size // 2 - 4096
+    out = ctx.decode(gm2, torch.from_numpy(np.concatenate([w2, np.zeros(64, np.uint8)])).cuda(), w2.size,
+                     torch.from_numpy(of2.astype(np.int64)).cuda(), torch.from_numpy(le2.astype(np.int32)).cuda(), rare.size, 8, 2048)
+    assert ctx.last_decode_kernel() == "k_decode_word_groups" and np.array_equal(out.cpu().numpy(), rare)
+    # damage: flipped stream bytes, a length that lies, an odd offset, an offset beyond the container
+    for kind in range(4):
+        bad, o, l = want.copy(), offs.astype(np.int64).copy(), lens.astype(np.int32).copy()
+        if kind == 0:
+            for at in rng.integers(0, want.size, 20):
+                bad[at] ^= 0x40
+        elif kind == 1:
+            l[7] += 2
+        elif kind == 2:
+            o[9] += 1
+        else:
+            o[11] = want.size + 1000
+        ctx.decode(gm, torch.from_numpy(np.concatenate([bad, np.zeros(64, np.uint8)])).cuda(), want.size,
+                   torch.from_numpy(o).cuda(), torch.from_numpy(l).cuda(), data.size, 8, chunk, sync=False)
+        assert ctx.decode_errors() >= 1, kind
+    # ... and random damage of every kind never hangs or faults
+    for trial in range(9):
+        bad, l = want.copy(), lens.astype(np.int32).copy()
+        if trial % 3 == 0:
+            at = rng.integers(0, bad.size, 40)
+            bad[at] ^= rng.integers(1, 256, 40).astype(np.uint8)
+        elif trial % 3 == 1:
+            bad[rng.integers(0, bad.size):] = 0
+        else:
+            l[rng.integers(0, l.size, 3)] = rng.integers(0, 1 << 20, 3).astype(np.int32)
+        out = ctx.decode(gm, torch.from_numpy(np.concatenate([bad, np.zeros(64, np.uint8)])).cuda(), bad.size, d_offs,
+                         torch.from_numpy(l).cuda(), data.size, 8, chunk, sync=False)
+        assert ctx.decode_errors() > 0 or np.array_equal(out.cpu().numpy(), data), trial
 
 
 @pytest.mark.parametrize("placement", ["kernels", "fused"])
