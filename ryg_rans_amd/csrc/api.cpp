@@ -1213,8 +1213,9 @@ int rans_amd_decode(rans_amd_ctx *ctx, const rans_amd_model *model, const void *
         // Byte format, wave-per-chunk decoders: the fused slot records (one gather per symbol) where the model has them and
         // the table leaves room for two blocks per CU (scale_bits <= 12: 32 KiB; at 13 bits one block per CU -- four waves
         // per SIMD -- loses to eight with the two-gather tables: profiles/r04_byte_decoder_variants.log).
-        // The lane-per-chunk kernels and the two-chunk kernel keep cum2sym + records.
-        if (dec_format == RANS_AMD_FMT_BYTE && model->d_fused && !lanes_applicable(nchunks, n_ways) && model->host.scale_bits <= 12) {
+        // The lane-per-chunk kernels, the 2-way pair kernel (decode_groups.hip) and the two-chunk kernel keep cum2sym + records.
+        if (dec_format == RANS_AMD_FMT_BYTE && model->d_fused && !lanes_applicable(nchunks, n_ways) && !decode_byte_pairs_applicable(dp) &&
+            model->host.scale_bits <= 12) {
             dp.table0 = model->d_fused;
             dp.table0_bytes = (uint32_t)(model->host.byte_slots.size() * sizeof(WordSlot));
             dp.table1 = model->d_fused;

@@ -322,6 +322,341 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
         atomicAdd(p.err_count, (unsigned long long)nbad);
 }
 
+// ---------------------------------------------------------------------------
+// Byte format, 2-way (main.cpp:226-280: two states, one pointer): THIRTY-TWO chunks per wave, lane 2 g + i holds state i of
+// chunk g of the wave's batch.  The same plan as above with the group cut down to a pair:
+//   * a state takes 0, 1 or 2 bytes (rans_byte.h:307-318, scale_bits <= 16); state 1's bytes follow state 0's, so the odd
+//     lane's position is the cursor + what the even lane takes (its count through a DPP swap of the pair, masked to the even
+//     lanes' counts beforehand), and the next cursor is the odd lane's position + count, broadcast to the pair (DPP);
+//   * a pair's stream goes through a 64-byte ring in LDS (rows 68 bytes apart: byte 64 mirrors byte 0, so that the second
+//     byte of a lane can be read at offset 1 without wrapping), fetched in aligned 32-byte blocks, 16 bytes per lane, the
+//     next block parked in registers.  Eight rounds consume at most 8 x 2 x 2 = 32 bytes per pair: the refill check again is
+//     one compare per lane every eight rounds;
+//   * tables as in the lane kernels: cum2sym (LDS address 0) and {freq, start} records -- two dependent gathers per symbol;
+//   * four rounds of a state's symbols are one dword; the pair interleaves them (DPP swap + v_perm), sixteen rounds are 32
+//     bytes of the chunk, 16 per lane, and after thirty-two rounds two 16-byte stores per lane leave back to back: 64
+//     contiguous bytes per chunk.
+// Full chunks of a multiple of 64 symbols.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kPairBlock = 32;              // bytes a pair fetches at a time: 2 lanes x 16 B
+constexpr uint32_t kPairRing = 2 * kPairBlock;   // per pair
+constexpr uint32_t kPairRow = kPairRing + 4;     // ring + the mirror byte; 17 dwords: equal positions of the 32 pairs on 32 banks
+constexpr uint32_t kPairWaveLds = 32 * kPairRow; // per wave
+constexpr int kPairAux = kAuxStore; // nt sc1, as the other decoders' symbol stores (plain stores: 0.94 ms against 0.73)
+
+// Eight rounds (one symbol per lane and round) as one hand-scheduled sequence; rans_byte.h:125-128 (get), :291-298 (advance),
+// :307-318 (renormalise).  17 VALU + 4 LDS per round:
+//   v_and                       cf = x & mask
+//   ds_read_u8                  s = cum2sym[cf]
+//   v_lshrrev                   q = x >> scale_bits
+//   v_lshl_or                   the symbol joins its accumulator (rounds 1..3 of four; round 0's lands there directly)
+//   v_lshl_add, ds_read_b64     {freq, start} of s
+//   v_mad_u32_u24, v_sub        x = freq * q + cf - start
+//   v_cmp x2                    n1 = x < 2^23 (at least one byte), n2 = x < 2^15 (two)
+//   v_addc x2                   t = cursor + n1 + n2: where this lane's bytes END if it is the pair's first
+//   v_cndmask_dpp               my position = even lane: the cursor; odd lane: the even lane's t (vcc = the even lanes)
+//   v_add_dpp, v_sub            the pair's next cursor = t + the other lane's t - cursor
+//   v_and, v_add                position -> LDS address in the pair's ring
+//   ds_read_u8 x2, v_lshl_or x2 under exec = n1 / n2: x = (x << 8) | byte
+#define RANS_P_RECORD(SREG)                                                                        \
+    "v_lshl_add_u32 %[t1], " SREG ", 3, %[rec]\n\t"                                                \
+    "ds_read_b64 v[60:61], %[t1]\n\t"                                                              \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                     \
+    "v_mad_u32_u24 %[x], v60, %[t2], %[t0]\n\t"                                                    \
+    "v_sub_u32_e32 %[x], %[x], v61\n\t"
+#define RANS_P_ROUND(SREG, FILL)                                                                   \
+    "v_and_b32_e32 %[t0], %[maskv], %[x]\n\t"                                                      \
+    "ds_read_u8 " SREG ", %[t0]\n\t"                                                               \
+    "v_lshrrev_b32_e32 %[t2], %[sbv], %[x]\n\t"                                                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                     \
+    RANS_P_RECORD(SREG)                                                                            \
+    "v_cmp_gt_u32_e64 %[n1], %[l23], %[x]\n\t"                                                     \
+    "v_cmp_gt_u32_e64 %[n2], %[l15], %[x]\n\t"                                                     \
+    FILL                                                                                           \
+    "v_addc_co_u32_e64 %[t1], %[dm], %[cur], 0, %[n1]\n\t"                                         \
+    "v_addc_co_u32_e64 %[t1], %[dm], %[t1], 0, %[n2]\n\t"                                          \
+    "s_nop 1\n\t"                                                                                  \
+    "v_cndmask_b32_dpp %[t2], %[t1], %[cur], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_u32_dpp %[t0], %[t1], %[t1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_sub_u32_e32 %[cur], %[t0], %[cur]\n\t"                                                      \
+    "v_and_b32_e32 %[t2], 63, %[t2]\n\t"                                                           \
+    "v_add_u32_e32 %[t2], %[ring], %[t2]\n\t"                                                      \
+    "s_mov_b64 exec, %[n1]\n\t"                                                                    \
+    "ds_read_u8 %[t1], %[t2]\n\t"                                                                  \
+    "s_mov_b64 exec, %[n2]\n\t"                                                                    \
+    "ds_read_u8 %[t0], %[t2] offset:1\n\t"                                                         \
+    "s_mov_b64 exec, %[n1]\n\t"                                                                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                     \
+    "v_lshl_or_b32 %[x], %[x], 8, %[t1]\n\t"                                                       \
+    "s_mov_b64 exec, %[n2]\n\t"                                                                    \
+    "v_lshl_or_b32 %[x], %[x], 8, %[t0]\n\t"                                                       \
+    "s_mov_b64 exec, -1\n\t"
+#define RANS_P_FOUR(ACC)                                                                           \
+    RANS_P_ROUND(ACC, "s_nop 0\n\t")                                                               \
+    RANS_P_ROUND("%[t3]", "v_lshl_or_b32 " ACC ", %[t3], 8, " ACC "\n\t")                          \
+    RANS_P_ROUND("%[t3]", "v_lshl_or_b32 " ACC ", %[t3], 16, " ACC "\n\t")                         \
+    RANS_P_ROUND("%[t3]", "v_lshl_or_b32 " ACC ", %[t3], 24, " ACC "\n\t")
+__device__ __forceinline__ void decode_pairs_8rounds(uint32_t &x, uint32_t &cur, uint32_t &acc_a, uint32_t &acc_b, uint32_t maskv,
+                                                     uint32_t sbv, uint32_t rec, uint32_t l23, uint32_t l15, uint32_t ring)
+{
+    uint32_t t0, t1, t2, t3;
+    uint64_t n1, n2, dm;
+    asm volatile("s_mov_b64 vcc, %[evens]\n\t" // the even lanes (the pair's state 0), for the whole sequence
+                 RANS_P_FOUR("%[pa]") RANS_P_FOUR("%[pb]")
+                 : [x] "+v"(x), [cur] "+v"(cur), [pa] "=&v"(acc_a), [pb] "=&v"(acc_b), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                   [t3] "=&v"(t3), [n1] "=&s"(n1), [n2] "=&s"(n2), [dm] "=&s"(dm)
+                 : [maskv] "v"(maskv), [sbv] "v"(sbv), [rec] "v"(rec), [l23] "v"(l23), [l15] "v"(l15), [ring] "v"(ring),
+                   [evens] "s"(0x5555555555555555ull)
+                 : "vcc", "memory", "v60", "v61");
+}
+#undef RANS_P_FOUR
+#undef RANS_P_RECORD
+#undef RANS_P_ROUND
+
+// sixteen rounds of a pair -> 32 bytes of its chunk, 16 per lane: d0..d3 are the four 4-round accumulators of this lane's
+// state.  Pair-interleave (the even lane keeps the first dword of every eight bytes, the odd lane the second), then the even
+// lane collects bytes [0, 16) and the odd lane [16, 32).
+__device__ __forceinline__ u32x4 pair_lines(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t sel_p)
+{
+    u32x4 v;
+    uint32_t e0, e1, e2, e3;
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %[e0], %[d0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %[e1], %[d1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %[e2], %[d2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %[e3], %[d3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_perm_b32 %[e0], %[e0], %[d0], %[sel]\n\t" // even: [mine0, theirs0, mine1, theirs1]; odd: [theirs2, mine2, theirs3, mine3]
+                 "v_perm_b32 %[e1], %[e1], %[d1], %[sel]\n\t"
+                 "v_perm_b32 %[e2], %[e2], %[d2], %[sel]\n\t"
+                 "v_perm_b32 %[e3], %[e3], %[d3], %[sel]\n\t"
+                 "s_mov_b64 vcc, %[evens]\n\t"
+                 "v_cndmask_b32_dpp %[vx], %[e2], %[e0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" // even ? mine : the even lane's
+                 "v_cndmask_b32_dpp %[vz], %[e3], %[e1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_mov_b64 vcc, %[odds]\n\t"
+                 "v_cndmask_b32_dpp %[vy], %[e0], %[e2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" // odd ? mine : the odd lane's
+                 "v_cndmask_b32_dpp %[vw], %[e1], %[e3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                 : [vx] "=&v"(v.x), [vy] "=&v"(v.y), [vz] "=&v"(v.z), [vw] "=&v"(v.w), [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2),
+                   [e3] "=&v"(e3)
+                 : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [sel] "v"(sel_p), [evens] "s"(0x5555555555555555ull),
+                   [odds] "s"(0xaaaaaaaaaaaaaaaaull)
+                 : "vcc");
+    return v;
+}
+
+// Four lanes (two pairs, chunks A and B) hold, per chunk, the eight 16-byte pieces of a 128-byte line: piece 2 r + i in
+// register set r of the pair's lane i.  quad_half<HI, R> gathers what lane t of the quad stores with ONE instruction so that the
+// quad writes 64 contiguous bytes: piece t of half R (pieces 4 R .. 4 R + 3) of chunk HI -- lane (2 HI + (t & 1))'s register set
+// 2 R + (t >> 1).  Two DPP operations per dword.
+template <int HI>
+__device__ __forceinline__ u32x4 quad_half(const u32x4 &lo, const u32x4 &hi)
+{
+    u32x4 o;
+    uint32_t t0, t1, t2, t3;
+    if constexpr (HI) {
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b32_dpp %[t0], %[h0] quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %[t1], %[h1] quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %[t2], %[h2] quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %[t3], %[h3] quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_mov_b64 vcc, %[upper]\n\t" // lanes 2, 3 of every quad: the register set 2 R + 1
+                     "v_cndmask_b32_dpp %[o0], %[l0], %[t0], vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_cndmask_b32_dpp %[o1], %[l1], %[t1], vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_cndmask_b32_dpp %[o2], %[l2], %[t2], vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_cndmask_b32_dpp %[o3], %[l3], %[t3], vcc quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf"
+                     : [o0] "=&v"(o.x), [o1] "=&v"(o.y), [o2] "=&v"(o.z), [o3] "=&v"(o.w), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                       [t3] "=&v"(t3)
+                     : [l0] "v"(lo.x), [l1] "v"(lo.y), [l2] "v"(lo.z), [l3] "v"(lo.w), [h0] "v"(hi.x), [h1] "v"(hi.y), [h2] "v"(hi.z),
+                       [h3] "v"(hi.w), [upper] "s"(0xccccccccccccccccull)
+                     : "vcc");
+    } else {
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b32_dpp %[t0], %[h0] quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %[t1], %[h1] quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %[t2], %[h2] quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mov_b32_dpp %[t3], %[h3] quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_mov_b64 vcc, %[upper]\n\t"
+                     "v_cndmask_b32_dpp %[o0], %[l0], %[t0], vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_cndmask_b32_dpp %[o1], %[l1], %[t1], vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_cndmask_b32_dpp %[o2], %[l2], %[t2], vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_cndmask_b32_dpp %[o3], %[l3], %[t3], vcc quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf"
+                     : [o0] "=&v"(o.x), [o1] "=&v"(o.y), [o2] "=&v"(o.z), [o3] "=&v"(o.w), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                       [t3] "=&v"(t3)
+                     : [l0] "v"(lo.x), [l1] "v"(lo.y), [l2] "v"(lo.z), [l3] "v"(lo.w), [h0] "v"(hi.x), [h1] "v"(hi.y), [h2] "v"(hi.z),
+                       [h3] "v"(hi.w), [upper] "s"(0xccccccccccccccccull)
+                     : "vcc");
+    }
+    return o;
+}
+
+__global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecParams p)
+{
+    using Tr = FmtTraits<FMT_BYTE>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t t0_bytes = (p.table0_bytes + 15u) & ~15u; // cum2sym u8[M]
+    const uint32_t t1_bytes = (p.table1_bytes + 15u) & ~15u; // {freq, start}[nsyms]
+    {
+        const uint4 *g0 = reinterpret_cast<const uint4 *>(p.table0);
+        uint4 *l0 = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < t0_bytes / 16u; i += blockDim.x)
+            l0[i] = g0[i];
+        const uint4 *g1 = reinterpret_cast<const uint4 *>(p.table1);
+        uint4 *l1 = reinterpret_cast<uint4 *>(smem + t0_bytes);
+        for (uint32_t i = threadIdx.x; i < t1_bytes / 16u; i += blockDim.x)
+            l1[i] = g1[i];
+    }
+    __syncthreads();
+    if (!lds_starts_at_zero(smem)) { // cannot happen without static LDS; never decode on a wrong assumption
+        if (threadIdx.x == 0)
+            atomicAdd(p.err_count, 1ull << 32);
+        return;
+    }
+    if (p.work_counter_reset && blockIdx.x == 0 && threadIdx.x < kWorkPools)
+        p.work_counter_reset[threadIdx.x * kWorkPoolStride] = 0u;
+    if (p.span_reset && blockIdx.x == 0 && threadIdx.x < 2)
+        p.span_reset[threadIdx.x] = 0ull;
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t g = lane >> 1, i = lane & 1u;
+    const uint32_t ring_c = t0_bytes + t1_bytes + wave * kPairWaveLds + g * kPairRow; // raw LDS byte address of the pair's ring
+    // per-lane constants in VGPRs (a VALU operand from an SGPR or a literal issues slower: profiles/r01_ubench.log)
+    uint32_t ring = ring_c, maskv = (1u << p.scale_bits) - 1u, sbv = p.scale_bits, rec = t0_bytes;
+    uint32_t l23 = 1u << 23, l15 = 1u << 15;
+    uint32_t sel_p = i ? 0x03070206u : 0x05010400u; // v_perm(theirs, mine): the pair's bytes in stream order
+    asm volatile("v_mov_b32 %0, %0" : "+v"(ring));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(maskv));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(sbv));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(rec));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(l23));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(l15));
+
+    const uint64_t cbase = reinterpret_cast<uint64_t>(p.container);
+    const uint64_t glo = cbase & ~uint64_t(15), glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
+    const uint32_t groups64 = uniform(p.chunk_syms >> 7);    // 64 rounds of 2 symbols
+    const uint32_t rem32 = uniform((p.chunk_syms >> 6) & 1u); // + 32 rounds
+    const uint64_t batches = (p.nchunks + 31u) >> 5;      // (the last one may hold fewer than 32 chunks)
+    const uint32_t per_claim = uniform(p.chunk_syms >= kGrpClaimSyms / 32u ? 1u : (kGrpClaimSyms / 32u + p.chunk_syms - 1u) / p.chunk_syms);
+    const uint64_t claims = (batches + per_claim - 1u) / per_claim;
+
+    auto load16 = [&](uint64_t a) -> u32x4 { // 16 bytes of the container, zeros beyond its granules
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (a >= glo && a < glimit)
+            v = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(a));
+        return v;
+    };
+
+    uint32_t nbad = 0;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    uint64_t claim_v = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint32_t npools = gridDim.x < kWorkPools ? gridDim.x : kWorkPools;
+    const uint32_t pool = blockIdx.x % npools;
+    auto claim_take = [&]() -> uint64_t { // (as in k_decode_word_groups)
+        if (p.work_counter) {
+            uint32_t got = 0;
+            if (lane == 0)
+                got = atomicAdd(p.work_counter + pool * kWorkPoolStride, 1u);
+            return (uint64_t)uniform(got) * npools + pool;
+        }
+        const uint64_t c = claim_v;
+        claim_v += total_waves;
+        return uniform64(c);
+    };
+    for (;;) {
+        const uint64_t claim = claim_take();
+        if (claim >= claims)
+            break;
+        const uint64_t b_end = (claim + 1u) * per_claim < batches ? (claim + 1u) * per_claim : batches;
+        for (uint64_t batch = claim * per_claim; batch < b_end; ++batch) {
+            const uint64_t chunk = batch * 32u + g;
+            const bool exists = chunk < p.nchunks;
+            const uint64_t off = exists ? p.offsets[chunk] : 0u;
+            const uint32_t len = exists ? p.lengths[chunk] : 0u;
+            const bool valid = exists && len >= 2u * 4u && off <= p.container_bytes && len <= p.container_bytes - off;
+            if (exists && !valid && i == 0)
+                nbad++;
+            const uint64_t src = cbase + (valid ? off : 0u);
+            uint32_t x = Tr::kL;
+            if (valid) // RansDecInit order: state 0 first (main.cpp:261-262)
+                x = reinterpret_cast<const uint32_t RANS_GLOBAL *>(src)[i];
+            // positions count from the 32-byte block of the chunk's first byte
+            const uint64_t abase = src & ~uint64_t(kPairBlock - 1u);
+            const uint32_t start = (uint32_t)(src - abase) + 2u * 4u; // < 40
+            uint32_t cur = start;
+            uint64_t ld = abase + 16u * i;
+            const u32x4 b0 = load16(ld), b1 = load16(ld + kPairBlock);
+            u32x4 pend = load16(ld + 2u * kPairBlock); // block 2; the ring holds blocks nb - 2 and nb - 1, pend is block nb
+            ld += 3u * kPairBlock;
+            auto put = [&](uint32_t at, const u32x4 &v) { // (rows are 4-byte aligned: four dword writes)
+                RANS_LDS uint32_t *d = reinterpret_cast<RANS_LDS uint32_t *>((uintptr_t)(ring_c + at + 16u * i));
+                d[0] = v.x;
+                d[1] = v.y;
+                d[2] = v.z;
+                d[3] = v.w;
+                if (at == 0 && i == 0)
+                    *reinterpret_cast<RANS_LDS uint8_t *>((uintptr_t)(ring_c + kPairRing)) = (uint8_t)v.x;
+            };
+            put(0, b0);
+            put(kPairBlock, b1);
+            uint32_t thr = kPairBlock; // cursor from which block nb has to be in the ring; block nb goes to ring offset ~thr & 32
+            auto checkpoint = [&]() {
+                if (cur >= thr) { // (the same for both lanes of a pair)
+                    put(~thr & kPairBlock, pend);
+                    thr += kPairBlock;
+                    pend = load16(ld);
+                    ld += kPairBlock;
+                }
+            };
+            checkpoint(); // the states may end in block 1
+
+            const rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>(reinterpret_cast<uint64_t>(p.out) + batch * 32u * p.chunk_syms), 0, 32u * p.chunk_syms, kRsrcFlags);
+            const uint32_t out_off16 = valid ? g * p.chunk_syms + 16u * i : 0x80000000u; // (an invalid chunk's stores: dropped by the range check)
+            // the quad's two chunks A = g & ~1 and B = A + 1, as lane t = lane & 3 of the quad addresses them: 16 t bytes in
+            const bool valid_a = __shfl((int)valid, (int)(lane & ~3u)) != 0, valid_b = __shfl((int)valid, (int)(lane | 2u)) != 0;
+            const uint32_t off_a = valid_a ? (g & ~1u) * p.chunk_syms + 16u * (lane & 3u) : 0x80000000u;
+            const uint32_t off_b = valid_b ? (g | 1u) * p.chunk_syms + 16u * (lane & 3u) : 0x80000000u;
+            uint32_t osoff = 0;
+            auto sixteen = [&]() -> u32x4 { // 16 rounds -> this lane's 16 of the pair's 32 bytes
+                uint32_t a0, a1, a2, a3;
+                checkpoint();
+                decode_pairs_8rounds(x, cur, a0, a1, maskv, sbv, rec, l23, l15, ring);
+                checkpoint();
+                decode_pairs_8rounds(x, cur, a2, a3, maskv, sbv, rec, l23, l15, ring);
+                return pair_lines(a0, a1, a2, a3, sel_p);
+            };
+            // 64 rounds = one 128-byte line of the chunk: four 16-byte stores per lane leave back to back (a pair writes 32
+            // contiguous bytes per instruction; pieces of a line that leave 16 or 32 rounds apart reach memory as partial
+            // lines -- measured 1.18 ms against 0.70 without stores)
+            for (uint32_t q = 0; q < groups64; ++q) {
+                const u32x4 v0 = sixteen();
+                const u32x4 v1 = sixteen();
+                const u32x4 v2 = sixteen();
+                const u32x4 v3 = sixteen();
+                // a quad writes 64 contiguous bytes per instruction, a chunk's line with two instructions back to back
+                __builtin_amdgcn_raw_buffer_store_b128(quad_half<0>(v0, v1), orsrc, off_a, osoff, kPairAux);
+                __builtin_amdgcn_raw_buffer_store_b128(quad_half<0>(v2, v3), orsrc, off_a, osoff + 64u, kPairAux);
+                __builtin_amdgcn_raw_buffer_store_b128(quad_half<1>(v0, v1), orsrc, off_b, osoff, kPairAux);
+                __builtin_amdgcn_raw_buffer_store_b128(quad_half<1>(v2, v3), orsrc, off_b, osoff + 64u, kPairAux);
+                osoff += 128u;
+            }
+            if (rem32) { // a chunk of an odd multiple of 64 symbols: its last half line
+                const u32x4 v0 = sixteen();
+                const u32x4 v1 = sixteen();
+                __builtin_amdgcn_raw_buffer_store_b128(v0, orsrc, out_off16, osoff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v1, orsrc, out_off16, osoff + 32u, 0);
+            }
+            // integrity: both states back at L, the cursor exactly at the end of the chunk's stream
+            const bool bad = valid && (x != Tr::kL || cur - (start - 2u * 4u) != len);
+            const uint64_t bm = __builtin_amdgcn_ballot_w64(bad);
+            if (i == 0 && ((bm >> (2u * g)) & 3u) != 0)
+                nbad++;
+        }
+    }
+    if (nbad)
+        atomicAdd(p.err_count, (unsigned long long)nbad);
+}
+
 } // namespace
 
 // Every full chunk goes through k_decode_word_groups; a ragged last chunk through the wave-per-chunk decoder in a second launch
@@ -368,6 +703,51 @@ hipError_t launch_decode_word_groups(const DecParams &p, int num_cus, hipStream_
     r.span = nullptr;
     r.span_reset = nullptr;
     return launch_decode_wave(FMT_WORD, r, num_cus, stream, nullptr);
+}
+
+// The same for the byte format's 2-way layout (cum2sym tables, scale_bits 8..16, u8 symbols).
+bool decode_byte_pairs_applicable(const DecParams &p)
+{
+    const size_t tables = (size_t)((p.table0_bytes + 15u) & ~15u) + ((p.table1_bytes + 15u) & ~15u);
+    return p.n_ways == 2 && p.sym_bytes == 1 && p.scale_bits >= 8 && p.scale_bits <= 16 && (p.chunk_syms & 63u) == 0 &&
+           p.chunk_syms <= (1u << 20) && (reinterpret_cast<uintptr_t>(p.out) & 3u) == 0 && p.n / p.chunk_syms >= 32 && !p.trace &&
+           tables + (size_t)(kGrpThreads / 64) * kPairWaveLds <= 160u * 1024u;
+}
+
+hipError_t launch_decode_byte_pairs(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
+{
+    const uint64_t full = p.n / p.chunk_syms;
+    const size_t tables = (size_t)((p.table0_bytes + 15u) & ~15u) + ((p.table1_bytes + 15u) & ~15u);
+    const size_t lds = tables + (size_t)(kGrpThreads / 64) * kPairWaveLds;
+    auto kern = k_decode_byte_pairs;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 160 * 1024, lds_ok); e != hipSuccess)
+        return e;
+    DecParams q = p;
+    q.nchunks = full;
+    q.n = full * p.chunk_syms;
+    const uint32_t per_cu = 2u * lds <= 160u * 1024u ? 2u : 1u;
+    const uint64_t want_blocks = ((full + 31u) / 32u + kGrpThreads / 64 - 1) / (kGrpThreads / 64);
+    const uint64_t cap = (uint64_t)num_cus * per_cu;
+    const uint32_t grid = (uint32_t)(want_blocks < cap ? want_blocks : cap);
+    if (name)
+        *name = "k_decode_byte_pairs";
+    RANS_LAUNCH(kern, dim3(grid), dim3(kGrpThreads), lds, stream, q);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess)
+        return e;
+    if (full == p.nchunks)
+        return hipSuccess;
+    DecParams r = p; // the ragged last chunk
+    r.offsets = p.offsets + full;
+    r.lengths = p.lengths + full;
+    r.out = static_cast<uint8_t *>(p.out) + full * p.chunk_syms;
+    r.n = p.n - full * p.chunk_syms;
+    r.nchunks = p.nchunks - full;
+    r.work_counter = nullptr;
+    r.work_counter_reset = nullptr;
+    r.span = nullptr;
+    r.span_reset = nullptr;
+    return launch_decode_wave(FMT_BYTE, r, num_cus, stream, nullptr);
 }
 
 } // namespace rans_amd

@@ -21,6 +21,8 @@ hipError_t launch_decode(int format, const DecParams &p, int num_cus, hipStream_
     // the reference's 8-way word layout, u8 symbols, from eight full chunks on: eight chunks per wave (decode_groups.hip)
     if (format == (int)RANS_AMD_FMT_WORD && decode_word_groups_applicable(p))
         return launch_decode_word_groups(p, num_cus, stream, kernel_name);
+    if (format == (int)RANS_AMD_FMT_BYTE && decode_byte_pairs_applicable(p))
+        return launch_decode_byte_pairs(p, num_cus, stream, kernel_name);
     if (format != kKernelFormatR64Search && format != kKernelFormatWord16 && format != kKernelFormatByteAdaptive &&
         format != kKernelFormatWordAdaptive &&
         format != kKernelFormatByteFused && lanes_applicable(p.nchunks, p.n_ways))

@@ -44,6 +44,9 @@ hipError_t launch_decode_dual(int format, const DecParams &p, int num_cus, hipSt
 // take (fewer than eight full chunks at the end, a ragged last one) goes on to launch_decode_lanes from inside
 bool decode_word_groups_applicable(const DecParams &p);
 hipError_t launch_decode_word_groups(const DecParams &p, int num_cus, hipStream_t stream, const char **name);
+// 32 chunks per wave, the byte format's 2-way layout over u8 symbols (cum2sym tables), same file
+bool decode_byte_pairs_applicable(const DecParams &p);
+hipError_t launch_decode_byte_pairs(const DecParams &p, int num_cus, hipStream_t stream, const char **name);
 
 // lane-per-stream kernels (N = 1, 2, 4, 8 with at least kLaneKernelMinChunks chunks): lanes.hip
 constexpr uint64_t kLaneKernelMinChunks = 64;

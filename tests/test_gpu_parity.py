@@ -525,13 +525,14 @@ def test_lane_kernels_both_generations(gpu, oracle, generation):
     assert np.array_equal(out_b[5:5 + data.size].cpu().numpy(), data)
 
 
-@pytest.mark.parametrize("fmt,sb,n_ways,extra", [(FMT_BYTE, 14, 2, 0), (FMT_WORD, 12, 8, 8)])
+@pytest.mark.parametrize("fmt,sb,n_ways,extra", [(FMT_BYTE, 14, 2, 8), (FMT_WORD, 12, 8, 8)])
 def test_lane_decoder_fallback_for_huge_chunks(gpu, oracle, fmt, sb, n_ways, extra):
     """The first generation's per-lane decoder (k_decode_lanes) is the NAMED FALLBACK for what the staged decoder cannot
     take: chunks of 512 Ki symbols and more (its ring positions are 32-bit offsets inside a batch).  64 + 1 chunks of 512 Ki
     symbols in the reference's own narrow layouts: a container the ORACLE made decodes to the input, and the GPU encoder's
-    container (wave encoder or per-lane encoder, whichever the shape gets) equals it chunk by chunk.  (The 8-way word layout
-    has its own decoder for chunks of a multiple of 32 symbols, k_decode_word_groups: the case here is 8 symbols off.)"""
+    container (wave encoder or per-lane encoder, whichever the shape gets) equals it chunk by chunk.  (Both layouts
+    have decoders of their own for chunks of a multiple of 32 / 64 symbols, k_decode_word_groups / k_decode_byte_pairs: the
+    cases here are 8 symbols off.)"""
     R, ctx, torch = gpu
     chunk = (1 << 19) + extra
     data = oracle.gen_zipf(64 * chunk + 12345, K=256, s=1.0, seed=21)
@@ -1134,6 +1135,94 @@ def test_word_eight_way_octet_decoder(gpu, oracle):
             l[rng.integers(0, l.size, 3)] = rng.integers(0, 1 << 20, 3).astype(np.int32)
         out = ctx.decode(gm, torch.from_numpy(np.concatenate([bad, np.zeros(64, np.uint8)])).cuda(), bad.size, d_offs,
                          torch.from_numpy(l).cuda(), data.size, 8, chunk, sync=False)
+        assert ctx.decode_errors() > 0 or np.array_equal(out.cpu().numpy(), data), trial
+
+
+@pytest.mark.parametrize("sb", [14, 8, 12, 16])
+def test_byte_two_way_pair_decoder(gpu, oracle, sb):
+    """The reference's 2-way byte layout (main.cpp:226-280) through k_decode_byte_pairs, 32 chunks per wave: chunk sizes of one
+    and many 64-round lines and of an odd number of half lines, chunk counts that are no multiple of 32 and a ragged last
+    chunk (the wave decoder's second launch), chunks on any byte boundary and in any order, the ORACLE's container and the
+    GPU's own, streams that take two bytes per state and round and streams that take next to none; damage is flagged."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(80 + sb)
+    zipf = oracle.gen_zipf(700000 + 55, K=256, s=1.0, seed=33)
+    flat = rng.integers(0, 256, 260000).astype(np.uint8)
+    heavy = np.where(rng.random(260000) < 0.93, 7, rng.integers(0, 256, 260000)).astype(np.uint8)
+    cases = [(zipf, 1024), (zipf, 128), (zipf, 64), (zipf, 192), (zipf, 4032), (zipf, 16384), (zipf[:32 * 1024], 1024),
+             (zipf[:71 * 256 + 9], 256), (flat, 1024), (flat, 320), (heavy, 512), (heavy, 4096)]
+    for data, chunk in cases:
+        om, gm = _models(R, ctx, oracle, FMT_BYTE, sb, data)
+        want, offs, lens = oracle.encode_chunked(FMT_BYTE, om, data, 2, chunk, align=16)
+        d_cont = torch.from_numpy(np.concatenate([want, np.zeros(64, np.uint8)])).cuda()
+        d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+        d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+        back = torch.full((data.size + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+        out = back[128:128 + data.size]
+        ctx.decode(gm, d_cont, want.size, d_offs, d_lens, data.size, 2, chunk, d_out=out)
+        assert ctx.last_decode_kernel() == "k_decode_byte_pairs", (ctx.last_decode_kernel(), chunk)
+        assert np.array_equal(out.cpu().numpy(), data), (chunk, data.size)
+        host = back.cpu().numpy()
+        assert (host[:128] == 0xA5).all() and (host[128 + data.size:] == 0xA5).all(), chunk  # nothing outside the output
+        cont, o2, l2, total = ctx.encode(gm, torch.from_numpy(data).cuda(), 2, chunk)
+        out = ctx.decode(gm, cont, total, o2, l2, data.size, 2, chunk)
+        assert ctx.last_decode_kernel() == "k_decode_byte_pairs" and np.array_equal(out.cpu().numpy(), data), (chunk, "own container")
+    # chunks packed back to front on odd byte boundaries; output 4 bytes into a line (2 bytes: the lane kernel)
+    data, chunk = zipf[:100 * 256], 256
+    om, gm = _models(R, ctx, oracle, FMT_BYTE, sb, data)
+    want, offs, lens = oracle.encode_chunked(FMT_BYTE, om, data, 2, chunk, align=16)
+    d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+    rev = np.zeros(want.size + 1024, np.uint8)
+    roffs = np.zeros_like(offs)
+    pos = 1
+    for c in range(len(lens) - 1, -1, -1):
+        roffs[c] = pos
+        rev[pos:pos + lens[c]] = want[int(offs[c]):int(offs[c]) + int(lens[c])]
+        pos += int(lens[c]) + (c % 7)
+    for shift, kernel in ((4, "k_decode_byte_pairs"), (2, "k_decode_lanes_staged")):
+        back = torch.zeros(data.size + 64, dtype=torch.uint8, device="cuda")
+        ctx.decode(gm, torch.from_numpy(rev).cuda(), pos, torch.from_numpy(roffs.astype(np.int64)).cuda(), d_lens, data.size, 2, chunk,
+                   d_out=back[shift:shift + data.size])
+        assert ctx.last_decode_kernel() == kernel, (shift, ctx.last_decode_kernel())
+        assert np.array_equal(back[shift:shift + data.size].cpu().numpy(), data), shift
+    # rare symbols only: scale_bits bits per symbol, two bytes per state in most rounds at 16 bits
+    f = np.ones(256, np.uint32)
+    f[0] = (1 << sb) - 255
+    rare = rng.integers(1, 256, 64 * 2048).astype(np.uint8)
+    om2, gm2 = oracle.model(f, sb), ctx.model(FMT_BYTE, f, sb)
+    w2, of2, le2 = oracle.encode_chunked(FMT_BYTE, om2, rare, 2, 2048, align=16)
+    assert w2.size > rare.size * sb // 8 - 4096
+    out = ctx.decode(gm2, torch.from_numpy(np.concatenate([w2, np.zeros(64, np.uint8)])).cuda(), w2.size,
+                     torch.from_numpy(of2.astype(np.int64)).cuda(), torch.from_numpy(le2.astype(np.int32)).cuda(), rare.size, 2, 2048)
+    assert ctx.last_decode_kernel() == "k_decode_byte_pairs" and np.array_equal(out.cpu().numpy(), rare)
+    # damage: flipped stream bytes, a length that lies, an offset beyond the container; then random damage.  (Not at 8 bits:
+    # 256 symbols of frequency 1 make the state a shift register -- a flipped byte is one wrong symbol and nothing else.)
+    if sb < 12:
+        return
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    for kind in range(3):
+        bad, o, l = want.copy(), offs.astype(np.int64).copy(), lens.astype(np.int32).copy()
+        if kind == 0:
+            for at in rng.integers(0, want.size, 20):
+                bad[at] ^= 0x40
+        elif kind == 1:
+            l[7] += 1
+        else:
+            o[11] = want.size + 1000
+        ctx.decode(gm, torch.from_numpy(np.concatenate([bad, np.zeros(64, np.uint8)])).cuda(), want.size,
+                   torch.from_numpy(o).cuda(), torch.from_numpy(l).cuda(), data.size, 2, chunk, sync=False)
+        assert ctx.decode_errors() >= 1, kind
+    for trial in range(9):
+        bad, l = want.copy(), lens.astype(np.int32).copy()
+        if trial % 3 == 0:
+            at = rng.integers(0, bad.size, 40)
+            bad[at] ^= rng.integers(1, 256, 40).astype(np.uint8)
+        elif trial % 3 == 1:
+            bad[rng.integers(0, bad.size):] = 0
+        else:
+            l[rng.integers(0, l.size, 3)] = rng.integers(0, 1 << 20, 3).astype(np.int32)
+        out = ctx.decode(gm, torch.from_numpy(np.concatenate([bad, np.zeros(64, np.uint8)])).cuda(), bad.size, d_offs,
+                         torch.from_numpy(l).cuda(), data.size, 2, chunk, sync=False)
         assert ctx.decode_errors() > 0 or np.array_equal(out.cpu().numpy(), data), trial
 
 
