@@ -4,7 +4,7 @@
 #   B  rocprofv3 --kernel-trace --stats over the HEADLINE ALONE, cut to the timed dispatches the record names
 #   D  FETCH_SIZE / WRITE_SIZE passes over the headline alone                          -> r06_traffic.json (bench.py quotes it)
 #   G  per-chunk models: tools/time_adaptive.py under --stats and the two PMC passes (k_encode_adaptive, the decoders)
-#   H  the reference's own layouts on the lane kernels: tools/time_lanes.py word 8-way / byte 2-way, 1024-symbol chunks,
+#   H  the reference's own layouts (decoders: decode_groups.hip; encoders: the lane kernels): tools/time_lanes.py word 8-way / byte 2-way, 1024-symbol chunks,
 #      --stats, the two PMC passes, and the SQ / LDS / TA counter sets of tools/pmc_kernel.sh
 #   I  the same counter sets for the per-chunk-model decoder and encoder (what bounds them)
 set -u
@@ -32,8 +32,8 @@ for w in "word 8 12" "byte 2 14"; do
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$OUT/lanes_$1$2_write" -o pmc -- $L > "$OUT/lanes_$1$2_write.log" 2>&1
 done
 cd "$REPO"
-PMC_CMD="python $REPO/tools/time_lanes.py --fmt word --ways 8 --chunk 1024 --log2n 30 --sb 12 --steps 5" bash tools/pmc_kernel.sh r06p/cnt_word8 k_decode_lanes_staged > "$OUT/cnt_word8.log" 2>&1
-PMC_CMD="python $REPO/tools/time_lanes.py --fmt byte --ways 2 --chunk 1024 --log2n 30 --sb 14 --steps 5" bash tools/pmc_kernel.sh r06p/cnt_byte2 k_decode_lanes_staged > "$OUT/cnt_byte2.log" 2>&1
+PMC_CMD="python $REPO/tools/time_lanes.py --fmt word --ways 8 --chunk 1024 --log2n 30 --sb 12 --steps 5" bash tools/pmc_kernel.sh r06p/cnt_word8 k_decode_word_groups > "$OUT/cnt_word8.log" 2>&1
+PMC_CMD="python $REPO/tools/time_lanes.py --fmt byte --ways 2 --chunk 1024 --log2n 30 --sb 14 --steps 5" bash tools/pmc_kernel.sh r06p/cnt_byte2 k_decode_byte_pairs > "$OUT/cnt_byte2.log" 2>&1
 PMC_CMD="python $REPO/tools/time_adaptive.py 30" bash tools/pmc_kernel.sh r06p/cnt_adec "k_decode<12, 1" > "$OUT/cnt_adec.log" 2>&1
 PMC_CMD="python $REPO/tools/time_adaptive.py 30" bash tools/pmc_kernel.sh r06p/cnt_aenc "k_encode_adaptive<1, 1, 16" > "$OUT/cnt_aenc.log" 2>&1
 # keep the merge-back small: csv / json / log / txt only, and no per-dispatch traces but the headline's

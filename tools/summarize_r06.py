@@ -190,14 +190,15 @@ def main():
         fe = pmc_avg(os.path.join(src, "lanes_%s_fetch" % tag), "FETCH_SIZE")
         wr = pmc_avg(os.path.join(src, "lanes_%s_write" % tag), "WRITE_SIZE")
         for nme, calls, avg, mn, mx in trace_rows(os.path.join(src, "lanes_%s_stats" % tag)):
-            if not (nme.startswith("k_decode_lanes") or nme.startswith("k_encode_lanes") or nme.startswith("k_compact")):
+            if not (nme.startswith("k_decode_lanes") or nme.startswith("k_encode_lanes") or nme.startswith("k_compact") or
+                    nme.startswith("k_decode_word_groups") or nme.startswith("k_decode_byte_pairs")):
                 continue
             rd, w = fe.get(nme, 0) * 1024, wr.get(nme, 0) * 1024  # (x 1: 64-byte quad requests, calibrated in round 4)
             rows_h.append("| %s | `%s` | %d | %.1f | %.1f | %.4f | %.4g | %.4g | %s |" % (
                 what, nme, calls, avg, mn, alg / (avg * 1e-6) / 8e12, rd, w, "%.3f" % ((rd + w) / alg) if rd + w else "-"))
             out["lanes"]["%s %s" % (tag, nme)] = {"avg_us": avg, "min_us": mn, "read": rd, "write": w, "algorithmic": alg}
     if rows_h:
-        L += ["## H. the reference's own layouts: 1 GiB Zipf(256), one LANE per chunk (`tools/time_lanes.py --chunk 1024 --encode`)", "",
+        L += ["## H. the reference's own layouts: 1 GiB Zipf(256); decoders 8 / 32 chunks per wave (`decode_groups.hip`), encoders one LANE per chunk (`tools/time_lanes.py --chunk 1024 --encode`)", "",
               "| layout | kernel | calls | avg us | min us | frac of 8 TB/s | read B | write B | traffic / algorithmic |", "|---|---|---|---|---|---|---|---|---|"] + rows_h + [""]
 
     # I: counters of the kernels whose bound DESIGN states -- derived as in rounds 2-5 (tools/summarize_counters.py)
@@ -213,7 +214,7 @@ def main():
                "cycles; per-round counts = SQ_INSTS_* / 2^24 (64-symbol rounds of a 1 GiB launch); waves per CU = SQ_WAVES / 256 (persistent grids).", "",
                "| kernel | ms under counters | waves per CU | VALU busy | LDS pipe | conflict share | waiting / issue stall / issuing (share of wave cycles) | VALU / SALU / LDS instr per round |",
                "|---|---|---|---|---|---|---|---|"]
-    for tag, what in (("cnt_word8", "`k_decode_lanes_staged`, word 8-way, 1024-symbol chunks"), ("cnt_byte2", "`k_decode_lanes_staged`, byte 2-way"),
+    for tag, what in (("cnt_word8", "`k_decode_word_groups`, word 8-way, 1024-symbol chunks"), ("cnt_byte2", "`k_decode_byte_pairs`, byte 2-way"),
                       ("cnt_adec", "`k_decode<word, per-chunk models>`"), ("cnt_aenc", "`k_encode_adaptive<word>`")):
         f = os.path.join(src, tag + "_sq_summary.txt")
         if not os.path.exists(f):
@@ -228,7 +229,7 @@ def main():
             100 * v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_INSTS_VALU"] / 2 ** 24, v["SQ_INSTS_SALU"] / 2 ** 24, v["SQ_INSTS_LDS"] / 2 ** 24))
     if len(derived) > 6:
         L += derived + [""]
-    for tag, what in (("cnt_word8", "k_decode_lanes_staged, word 8-way"), ("cnt_byte2", "k_decode_lanes_staged, byte 2-way"),
+    for tag, what in (("cnt_word8", "k_decode_word_groups, word 8-way"), ("cnt_byte2", "k_decode_byte_pairs, byte 2-way"),
                       ("cnt_adec", "k_decode<word, per-chunk models>"), ("cnt_aenc", "k_encode_adaptive<word>")):
         f = os.path.join(src, tag + "_sq_summary.txt")
         if os.path.exists(f):
