@@ -213,6 +213,14 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
             const u32x4 b0 = load16(ld), b1 = load16(ld + kGrpBlock);
             u32x4 pend = load16(ld + 2u * kGrpBlock); // block 2; the ring holds blocks nb - 2 and nb - 1, pend is block nb
             ld += 3u * kGrpBlock;
+            // 16-byte pieces at ld, ld + 128, ... that still lie inside the container's granules: the refills count them down instead
+            // of comparing addresses (a piece beyond the end is not fetched; the ring then keeps what it had -- only a damaged
+            // stream reads that far, and the integrity check is what catches those)
+            uint32_t left = 0;
+            if (ld < glimit) {
+                const uint64_t pieces = (glimit - ld + (kGrpBlock - 1u)) / kGrpBlock;
+                left = pieces < 0x7fffffffu ? (uint32_t)pieces : 0x7fffffffu;
+            }
             *reinterpret_cast<RANS_LDS u32x4 *>((uintptr_t)(ring | ((16u * i + bias) & 255u))) = b0;
             *reinterpret_cast<RANS_LDS u32x4 *>((uintptr_t)(ring | ((kGrpBlock + 16u * i + bias) & 255u))) = b1;
             uint32_t wr = ring | ((16u * i + bias) & 255u); // where block nb goes
@@ -222,7 +230,10 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
                     *reinterpret_cast<RANS_LDS u32x4 *>((uintptr_t)wr) = pend;
                     wr ^= kGrpBlock;
                     thr += kGrpBlock / 2u;
-                    pend = load16(ld);
+                    if (left) {
+                        pend = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(ld));
+                        left--;
+                    }
                     ld += kGrpBlock;
                 }
             };
@@ -587,6 +598,11 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
             const u32x4 b0 = load16(ld), b1 = load16(ld + kPairBlock);
             u32x4 pend = load16(ld + 2u * kPairBlock); // block 2; the ring holds blocks nb - 2 and nb - 1, pend is block nb
             ld += 3u * kPairBlock;
+            uint32_t left = 0; // pieces at ld, ld + 32, ... inside the container's granules (as in k_decode_word_groups)
+            if (ld < glimit) {
+                const uint64_t pieces = (glimit - ld + (kPairBlock - 1u)) / kPairBlock;
+                left = pieces < 0x7fffffffu ? (uint32_t)pieces : 0x7fffffffu;
+            }
             auto put = [&](uint32_t at, const u32x4 &v) { // (rows are 4-byte aligned: four dword writes)
                 RANS_LDS uint32_t *d = reinterpret_cast<RANS_LDS uint32_t *>((uintptr_t)(ring_c + at + 16u * i));
                 d[0] = v.x;
@@ -603,7 +619,10 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
                 if (cur >= thr) { // (the same for both lanes of a pair)
                     put(~thr & kPairBlock, pend);
                     thr += kPairBlock;
-                    pend = load16(ld);
+                    if (left) {
+                        pend = __builtin_nontemporal_load(reinterpret_cast<gvec_cptr>(ld));
+                        left--;
+                    }
                     ld += kPairBlock;
                 }
             };

@@ -193,7 +193,10 @@ def main():
             if not (nme.startswith("k_decode_lanes") or nme.startswith("k_encode_lanes") or nme.startswith("k_compact") or
                     nme.startswith("k_decode_word_groups") or nme.startswith("k_decode_byte_pairs")):
                 continue
-            rd, w = fe.get(nme, 0) * 1024, wr.get(nme, 0) * 1024  # (x 1: 64-byte quad requests, calibrated in round 4)
+            # FETCH_SIZE counts fabric read requests at 64 bytes each (MI355X_MICROARCH.md): x 1 for the lane kernels' 64-byte
+            # quad requests (calibrated in round 4) and for the pair decoder's 32-byte blocks (taken as 64-byte sector fetches),
+            # x 2 for the word group decoder, whose groups read whole 128-byte lines like the headline's waves
+            rd, w = fe.get(nme, 0) * 1024 * (2 if nme.startswith("k_decode_word_groups") else 1), wr.get(nme, 0) * 1024
             rows_h.append("| %s | `%s` | %d | %.1f | %.1f | %.4f | %.4g | %.4g | %s |" % (
                 what, nme, calls, avg, mn, alg / (avg * 1e-6) / 8e12, rd, w, "%.3f" % ((rd + w) / alg) if rd + w else "-"))
             out["lanes"]["%s %s" % (tag, nme)] = {"avg_us": avg, "min_us": mn, "read": rd, "write": w, "algorithmic": alg}
