@@ -774,6 +774,8 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
     const uint64_t ring_waves = (uint64_t)ctx->num_cus * kEncRingMaxWavesPerCu;
     const bool ring = fused && !lanes && fits == 1 && ctx->scratch_ring && slot <= kEncRingMaxSlotBytes && nchunks > ring_waves * kEncRingSlots;
     bool use_lanes = lanes;
+    // the 8-way word layout's group encoder (encode_groups.hip): octets of chunks handed out through the claim counters
+    const bool groups = lanes && !fused && enc_format == RANS_AMD_FMT_WORD && encode_word_groups_applicable(ep);
     if (slots) { // the caller's container is where the chunks are coded: no scratch at all
         ep.scratch = static_cast<uint8_t *>(d_out);
         ep.slot_layout = 1u;
@@ -784,7 +786,7 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
             use_lanes = false;
             ep.no_lanes = 1u;
         }
-        if (!use_lanes && nchunks > 0 && nchunks < (1ull << 32)) { // wave encoders hand their chunks out dynamically
+        if ((!use_lanes || groups) && nchunks > 0 && nchunks < (1ull << 32)) { // wave / group encoders hand their chunks out dynamically
             // claim counters; sized slots: + the overflow count and the redo launch's claim counter (a line each) + the list
             const size_t claim_bytes = (size_t)(kWorkPools + 2) * kWorkPoolStride * 4;
             rc = ctx->enc_status.reserve(claim_bytes + (sized ? (size_t)nchunks * 4 : 0));
@@ -810,6 +812,14 @@ static int encode_impl(rans_amd_ctx *ctx, const rans_amd_model *model, const voi
         if (rc)
             return rc;
         ep.scratch = static_cast<uint8_t *>(ctx->scratch.ptr);
+        if (groups && nchunks < (1ull << 32)) {
+            const size_t claim_bytes = (size_t)(kWorkPools + 2) * kWorkPoolStride * 4;
+            rc = ctx->enc_status.reserve(claim_bytes);
+            if (rc)
+                return rc;
+            HIP_TRY(zero.add(ctx->enc_status.ptr, claim_bytes));
+            ep.claims = static_cast<unsigned int *>(ctx->enc_status.ptr);
+        }
     }
     ep.ring_slots = ring ? kEncRingSlots : 0u;
     if (fused) {

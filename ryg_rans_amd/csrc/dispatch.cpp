@@ -58,8 +58,11 @@ bool encode_uses_lanes(int format, uint64_t nchunks, uint32_t n_ways)
            format != kKernelFormatWord16;
 }
 
+// (the 8-way word layout's group encoder, encode_groups.hip, has no placement of its own: k_layout / k_compact_small behind it)
 bool encode_lanes_can_fuse(int format, const EncParams &p, int num_cus)
 {
+    if (format == (int)RANS_AMD_FMT_WORD && encode_word_groups_applicable(p))
+        return false;
     return encode_uses_lanes(format, p.nchunks, p.n_ways) && encode_lanes_fused(p, num_cus);
 }
 
@@ -70,6 +73,8 @@ hipError_t launch_encode(int format, const EncParams &p, int num_cus, hipStream_
         return launch_encode_wave((int)RANS_AMD_FMT_BYTE, p, num_cus, stream, name);
     if (format == kKernelFormatWordAdaptive)
         return launch_encode_wave(kKernelFormatWordAdaptive, p, num_cus, stream, name);
+    if (format == (int)RANS_AMD_FMT_WORD && encode_word_groups_applicable(p)) // the reference's 8-way word layout: eight chunks per wave
+        return launch_encode_word_groups(p, num_cus, stream, name);
     if (!p.no_lanes && lanes_applicable(p.nchunks, p.n_ways) && format != kKernelFormatR64Search && format != kKernelFormatWord16)
         return launch_encode_lanes(format == kKernelFormatAliasLds ? (int)RANS_AMD_FMT_ALIAS : format, p, num_cus, stream, name);
     // (word format over u16 symbols: the wave encoder's general path, whatever the interleave)

@@ -2272,6 +2272,8 @@ bool encode_lanes_fused(const EncParams &p, int num_cus) { return encode_lanes_s
 // tell that a chunk does not fit.  (The same predicate as the launcher's, r64x2 shape and all.)
 bool encode_lanes_sized_ok(int format, const EncParams &p, int num_cus)
 {
+    if (format == FMT_WORD && encode_word_groups_applicable(p)) // (its block stores stop at the slot's first byte: encode_groups.hip)
+        return true;
     const bool r64x2_shape = format == FMT_R64 && p.n_ways == 2 && !p.status && (p.chunk_syms & 63u) == 0 && p.scale_bits >= 7 &&
                              p.scale_bits <= 16 && p.nsyms <= 256 && (p.n / p.chunk_syms) / 64 >= (uint64_t)num_cus;
     return encode_lanes_staged_waves(p, num_cus, r64x2_shape ? 1 : 6) >= 1;

@@ -1138,6 +1138,72 @@ def test_word_eight_way_octet_decoder(gpu, oracle):
         assert ctx.decode_errors() > 0 or np.array_equal(out.cpu().numpy(), data), trial
 
 
+def test_word_eight_way_octet_encoder(gpu, oracle):
+    """The mirror image, k_encode_word_groups (eight chunks per wave): every chunk's stream == the oracle's, in all three
+    placements -- compact (k_layout + k_compact_small behind the launch), the slot layout, sized slots with and without chunks
+    that do not fit (those are coded again into the overflow region) -- for models with Alverson reciprocals, with a frequency
+    above 2048 (round-up reciprocals) and with byte values that have no record; chunk counts that are no multiple of eight; a
+    stray symbol is RANS_AMD_E_MODEL; shapes the kernel does not take (a ragged last chunk, chunks off 128 symbols) still
+    code through the lane kernels."""
+    R, ctx, torch = gpu
+    rng = np.random.default_rng(3)
+    zipf = oracle.gen_zipf(1 << 20, K=256, s=1.0, seed=5)
+    flat = rng.integers(0, 256, 300000).astype(np.uint8)
+    heavy = np.where(rng.random(300000) < 0.7, 3, rng.integers(0, 256, 300000)).astype(np.uint8)
+    sparse = (rng.integers(0, 40, 300000) * 3).astype(np.uint8)
+
+    def same(got, goffs, glens, want, offs, lens, what):
+        assert np.array_equal(glens.astype(np.uint32), lens.astype(np.uint32)), what
+        for c in range(len(lens)):
+            a, b, ln = int(goffs[c]), int(offs[c]), int(lens[c])
+            assert np.array_equal(got[a:a + ln], want[b:b + ln]), (what, c)
+
+    for name, data in (("zipf", zipf), ("flat", flat), ("heavy", heavy), ("sparse", sparse)):
+        for chunk, nch in ((1024, 64), (128, 100), (4096, 17), (256, 1000), (384, 9)):
+            d = data[:chunk * nch]
+            f, _ = R.normalize_freqs(np.bincount(d, minlength=256), 1 << 12)
+            om, gm = oracle.model(f, 12), ctx.model(FMT_WORD, f, 12)
+            want, offs, lens = oracle.encode_chunked(FMT_WORD, om, d, 8, chunk, align=16)
+            d_syms = torch.from_numpy(d).cuda()
+            cont, o, l, total = ctx.encode(gm, d_syms, 8, chunk)
+            if nch >= 64:  # (fewer chunks: the wave encoder with its own placement)
+                assert ctx.last_encode_kernel() == ("k_encode_word_groups", False), ctx.last_encode_kernel()
+            assert total == want.size and np.array_equal(o.cpu().numpy().astype(np.uint64), offs)
+            same(cont[:total].cpu().numpy(), o.cpu().numpy(), l.cpu().numpy(), want, offs, lens, (name, chunk, nch, "compact"))
+            cont, o, l, total = ctx.encode_slots(gm, d_syms, 8, chunk)
+            assert ctx.last_encode_kernel()[0] == "k_encode_word_groups", ctx.last_encode_kernel()
+            same(cont.cpu().numpy(), o.cpu().numpy(), l.cpu().numpy(), want, offs, lens, (name, chunk, nch, "slots"))
+            worst = R.slot_bytes(FMT_WORD, d.size, 8, chunk)
+            for slot in (None, 64 * ((int(lens.mean()) - 8 + 63) // 64), 64):
+                cont, o, l, total, sl = ctx.encode_sized(gm, d_syms, 8, chunk, slot=slot, overflow_chunks=nch)
+                assert ctx.last_encode_kernel()[0] == "k_encode_word_groups", ctx.last_encode_kernel()
+                go = o.cpu().numpy().astype(np.uint64)
+                same(cont.cpu().numpy(), go, l.cpu().numpy(), want, offs, lens, (name, chunk, nch, "sized", sl))
+                over = int((lens > sl).sum()) if sl < worst else 0
+                assert int(go[-1]) == total == nch * min(sl, worst) + over * worst, (name, chunk, nch, sl, over)
+                fits = np.nonzero(lens <= sl)[0]
+                assert np.array_equal(go[fits] + lens[fits].astype(np.uint64), (fits.astype(np.uint64) + 1) * np.uint64(min(sl, worst)))
+                out = ctx.decode(gm, cont, total, o, l, d.size, 8, chunk)
+                assert np.array_equal(out.cpu().numpy(), d) and ctx.decode_errors() == 0, (name, chunk, nch, sl)
+    # a symbol without a record, deep inside a chunk
+    d = sparse[:64 * 1024].copy()
+    f, _ = R.normalize_freqs(np.bincount(d, minlength=256), 1 << 12)
+    gm = ctx.model(FMT_WORD, f, 12)
+    d[37 * 1024 + 555] = 1
+    for call in (ctx.encode, ctx.encode_slots):
+        with pytest.raises(R.RansAmdError) as e:
+            call(gm, torch.from_numpy(d).cuda(), 8, 1024)
+        assert e.value.status == R.E_MODEL
+    # shapes for the lane kernels: a ragged last chunk, chunks of 1000 symbols
+    for data, chunk in ((zipf[:100 * 1024 + 77], 1024), (zipf[:128 * 1000], 1000)):
+        f, _ = R.normalize_freqs(np.bincount(data, minlength=256), 1 << 12)
+        om, gm = oracle.model(f, 12), ctx.model(FMT_WORD, f, 12)
+        want, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, 8, chunk, align=16)
+        cont, o, l, total = ctx.encode(gm, torch.from_numpy(data).cuda(), 8, chunk)
+        assert ctx.last_encode_kernel()[0].startswith("k_encode_lanes"), ctx.last_encode_kernel()
+        same(cont[:total].cpu().numpy(), o.cpu().numpy(), l.cpu().numpy(), want, offs, lens, ("lanes", chunk))
+
+
 @pytest.mark.parametrize("sb", [14, 8, 12, 16])
 def test_byte_two_way_pair_decoder(gpu, oracle, sb):
     """The reference's 2-way byte layout (main.cpp:226-280) through k_decode_byte_pairs, 32 chunks per wave: chunk sizes of one

@@ -9,7 +9,7 @@ O=../../build/obj
 if [ -n "$MEASURE" ]; then make -s measure >/dev/null; O=../../build/obj_measure; set -- -DRANS_AMD_MEASURE "$@"; fi
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-const-variable --offload-arch=gfx950 "$@" -c $FILE -o $O/variant_$NAME.o
 OBJS=""
-for f in decode_wave decode_dual decode_groups encode_wave encode_adaptive lanes container_kernels dispatch api model container; do
+for f in decode_wave decode_dual decode_groups encode_groups encode_wave encode_adaptive lanes container_kernels dispatch api model container; do
   if [ "$f.hip" = "$FILE" ] || [ "$f.cpp" = "$FILE" ]; then OBJS="$OBJS $O/variant_$NAME.o"; else OBJS="$OBJS $O/$f.o"; fi
 done
 /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -shared -o ../../build/libexp_$NAME.so $OBJS -Wl,-rpath,/opt/rocm/lib

@@ -34,6 +34,7 @@ done
 cd "$REPO"
 PMC_CMD="python $REPO/tools/time_lanes.py --fmt word --ways 8 --chunk 1024 --log2n 30 --sb 12 --steps 5" bash tools/pmc_kernel.sh r06p/cnt_word8 k_decode_word_groups > "$OUT/cnt_word8.log" 2>&1
 PMC_CMD="python $REPO/tools/time_lanes.py --fmt byte --ways 2 --chunk 1024 --log2n 30 --sb 14 --steps 5" bash tools/pmc_kernel.sh r06p/cnt_byte2 k_decode_byte_pairs > "$OUT/cnt_byte2.log" 2>&1
+PMC_CMD="python $REPO/tools/time_lanes.py --fmt word --ways 8 --chunk 1024 --log2n 30 --sb 12 --steps 2 --encode" bash tools/pmc_kernel.sh r06p/cnt_word8enc k_encode_word_groups > "$OUT/cnt_word8enc.log" 2>&1
 PMC_CMD="python $REPO/tools/time_adaptive.py 30" bash tools/pmc_kernel.sh r06p/cnt_adec "k_decode<12, 1" > "$OUT/cnt_adec.log" 2>&1
 PMC_CMD="python $REPO/tools/time_adaptive.py 30" bash tools/pmc_kernel.sh r06p/cnt_aenc "k_encode_adaptive<1, 1, 16" > "$OUT/cnt_aenc.log" 2>&1
 # keep the merge-back small: csv / json / log / txt only, and no per-dispatch traces but the headline's

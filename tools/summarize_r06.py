@@ -191,17 +191,17 @@ def main():
         wr = pmc_avg(os.path.join(src, "lanes_%s_write" % tag), "WRITE_SIZE")
         for nme, calls, avg, mn, mx in trace_rows(os.path.join(src, "lanes_%s_stats" % tag)):
             if not (nme.startswith("k_decode_lanes") or nme.startswith("k_encode_lanes") or nme.startswith("k_compact") or
-                    nme.startswith("k_decode_word_groups") or nme.startswith("k_decode_byte_pairs")):
+                    nme.startswith("k_decode_word_groups") or nme.startswith("k_decode_byte_pairs") or nme.startswith("k_encode_word_groups")):
                 continue
             # FETCH_SIZE counts fabric read requests at 64 bytes each (MI355X_MICROARCH.md): x 1 for the lane kernels' 64-byte
             # quad requests (calibrated in round 4) and for the pair decoder's 32-byte blocks (taken as 64-byte sector fetches),
-            # x 2 for the word group decoder, whose groups read whole 128-byte lines like the headline's waves
-            rd, w = fe.get(nme, 0) * 1024 * (2 if nme.startswith("k_decode_word_groups") else 1), wr.get(nme, 0) * 1024
+            # x 2 for the word group decoder and encoder, whose groups read whole 128-byte lines like the headline's waves
+            rd, w = fe.get(nme, 0) * 1024 * (2 if nme.startswith(("k_decode_word_groups", "k_encode_word_groups")) else 1), wr.get(nme, 0) * 1024
             rows_h.append("| %s | `%s` | %d | %.1f | %.1f | %.4f | %.4g | %.4g | %s |" % (
                 what, nme, calls, avg, mn, alg / (avg * 1e-6) / 8e12, rd, w, "%.3f" % ((rd + w) / alg) if rd + w else "-"))
             out["lanes"]["%s %s" % (tag, nme)] = {"avg_us": avg, "min_us": mn, "read": rd, "write": w, "algorithmic": alg}
     if rows_h:
-        L += ["## H. the reference's own layouts: 1 GiB Zipf(256); decoders 8 / 32 chunks per wave (`decode_groups.hip`), encoders one LANE per chunk (`tools/time_lanes.py --chunk 1024 --encode`)", "",
+        L += ["## H. the reference's own layouts: 1 GiB Zipf(256); decoders 8 / 32 chunks per wave (`decode_groups.hip`), the word encoder 8 chunks per wave (`encode_groups.hip`), the byte encoder one LANE per chunk (`tools/time_lanes.py --chunk 1024 --encode`)", "",
               "| layout | kernel | calls | avg us | min us | frac of 8 TB/s | read B | write B | traffic / algorithmic |", "|---|---|---|---|---|---|---|---|---|"] + rows_h + [""]
 
     # I: counters of the kernels whose bound DESIGN states -- derived as in rounds 2-5 (tools/summarize_counters.py)
@@ -218,6 +218,7 @@ def main():
                "| kernel | ms under counters | waves per CU | VALU busy | LDS pipe | conflict share | waiting / issue stall / issuing (share of wave cycles) | VALU / SALU / LDS instr per round |",
                "|---|---|---|---|---|---|---|---|"]
     for tag, what in (("cnt_word8", "`k_decode_word_groups`, word 8-way, 1024-symbol chunks"), ("cnt_byte2", "`k_decode_byte_pairs`, byte 2-way"),
+                      ("cnt_word8enc", "`k_encode_word_groups`, word 8-way (scratch slots)"),
                       ("cnt_adec", "`k_decode<word, per-chunk models>`"), ("cnt_aenc", "`k_encode_adaptive<word>`")):
         f = os.path.join(src, tag + "_sq_summary.txt")
         if not os.path.exists(f):
@@ -232,7 +233,7 @@ def main():
             100 * v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_INSTS_VALU"] / 2 ** 24, v["SQ_INSTS_SALU"] / 2 ** 24, v["SQ_INSTS_LDS"] / 2 ** 24))
     if len(derived) > 6:
         L += derived + [""]
-    for tag, what in (("cnt_word8", "k_decode_word_groups, word 8-way"), ("cnt_byte2", "k_decode_byte_pairs, byte 2-way"),
+    for tag, what in (("cnt_word8", "k_decode_word_groups, word 8-way"), ("cnt_byte2", "k_decode_byte_pairs, byte 2-way"), ("cnt_word8enc", "k_encode_word_groups, word 8-way"),
                       ("cnt_adec", "k_decode<word, per-chunk models>"), ("cnt_aenc", "k_encode_adaptive<word>")):
         f = os.path.join(src, tag + "_sq_summary.txt")
         if os.path.exists(f):
