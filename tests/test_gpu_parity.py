@@ -1553,6 +1553,54 @@ print("capture rules ok")
     assert r.returncode == 0 and "capture rules ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_group_kernels_inside_a_hip_graph(gpu, oracle):
+    """The kernels of decode_groups.hip / encode_groups.hip hand their octets and batches out through claim counters: captured
+    launches get counters of their own, zeroed by a node in front of the kernel, so that every replay starts from zero -- the
+    compact and the sized encode of the 8-way word layout and both group decoders, three replays each, against the oracle."""
+    R, ctx, torch = gpu
+    data = oracle.gen_zipf(512 * 1024, K=256, s=1.0, seed=12)
+    n = data.size
+    d = torch.from_numpy(data).cuda()
+    for fmt, sb, ways, chunk, enc_kernel, dec_kernel in ((FMT_WORD, 12, 8, 1024, "k_encode_word_groups", "k_decode_word_groups"),
+                                                         (FMT_BYTE, 14, 2, 1024, "k_encode_lanes", "k_decode_byte_pairs")):
+        om, gm = _models(R, ctx, oracle, fmt, sb, data)
+        want, w_offs, w_lens = oracle.encode_chunked(fmt, om, data, ways, chunk, align=16)
+        nchunks = len(w_lens)
+        cont, offs, lens, total = ctx.encode(gm, d, ways, chunk)  # once outside the capture: the workspaces exist afterwards
+        assert total == want.size and ctx.last_encode_kernel()[0].startswith(enc_kernel), ctx.last_encode_kernel()
+        s_cont, s_offs, s_lens, s_total, slot = ctx.encode_sized(gm, d, ways, chunk)
+        out = ctx.decode(gm, s_cont, s_total, s_offs, s_lens, n, ways, chunk)
+        assert torch.equal(out, d) and ctx.last_decode_kernel() == dec_kernel, ctx.last_decode_kernel()
+        cont2, offs2, lens2 = torch.zeros_like(cont), torch.zeros_like(offs), torch.zeros_like(lens)
+        s_cont2, s_offs2, s_lens2 = torch.zeros_like(s_cont), torch.zeros_like(s_offs), torch.zeros_like(s_lens)
+        out2, out3 = torch.zeros_like(out), torch.zeros_like(out)
+        stream = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            ctx.encode(gm, d, ways, chunk, d_out=cont2, sync=False, d_offsets=offs2, d_lengths=lens2)
+            ctx.decode(gm, cont2, total, offs2, lens2, n, ways, chunk, d_out=out2, sync=False)
+            ctx.encode_sized(gm, d, ways, chunk, slot=slot, d_out=s_cont2, sync=False, d_offsets=s_offs2, d_lengths=s_lens2)
+            ctx.decode(gm, s_cont2, s_total, s_offs2, s_lens2, n, ways, chunk, d_out=out3, sync=False)
+        for rep in range(3):
+            for t in (cont2, offs2, lens2, s_cont2, s_offs2, s_lens2, out2, out3):
+                t.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            ctx.encode_status()
+            assert ctx.decode_errors() == 0
+            assert np.array_equal(offs2.cpu().numpy().astype(np.uint64)[:nchunks], w_offs[:nchunks]) and int(offs2[nchunks].item()) == total
+            assert np.array_equal(lens2.cpu().numpy().astype(np.uint32), w_lens) and np.array_equal(s_lens2.cpu().numpy().astype(np.uint32), w_lens)
+            got, sgot, so = cont2[:total].cpu().numpy(), s_cont2.cpu().numpy(), s_offs2.cpu().numpy()
+            for c in range(nchunks):
+                o, ln, a = int(w_offs[c]), int(w_lens[c]), int(so[c])
+                assert np.array_equal(got[o:o + ln], want[o:o + ln]), (fmt, rep, c)
+                assert np.array_equal(sgot[a:a + ln], want[o:o + ln]), (fmt, rep, c, "sized")
+            assert torch.equal(out2, d) and torch.equal(out3, d), (fmt, rep)
+            ctx.decode(gm, cont2, total, offs2, lens2, n, ways, chunk, d_out=out)  # an eager launch between the replays
+            assert torch.equal(out, d)
+        del g
+
+
 def test_byte_encoder_staging_extremes(gpu, oracle):
     """The byte encoder's staged sub-step (enc_byte_full_staged, models up to 15 bits) at the edges of its window: every
     symbol the rarest one (15 bits each: 1920 bytes per sixteen rounds of a wave, the 2 KiB window nearly full, both passes
