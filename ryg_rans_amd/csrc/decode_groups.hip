@@ -1,5 +1,7 @@
-// decode_groups.hip -- the reference's 8-way word layout (rans_word_sse41.h:151-227: two SSE registers of four states,
-// one shared cursor), EIGHT chunks per wave: lane 8 g + i holds state i of chunk g of the wave's octet.
+// decode_groups.hip -- decoders for two of the reference's own narrow layouts with 64 / N chunks per wave and ONE STATE PER
+// LANE: k_decode_word_groups, the 8-way word layout (rans_word_sse41.h:151-227: two SSE registers of four states, one shared
+// cursor) with lane 8 g + i = state i of chunk g of the wave's octet, and further down k_decode_byte_pairs, the 2-way byte
+// layout of main.cpp:226-280 with lane 2 g + i.
 //
 // The lane-per-chunk kernels (lanes.hip) give every lane a whole chunk: 64 private streams per wave, a 136-byte ring
 // row per lane in LDS (8.7 KiB per wave beside the 32 KiB slot table: 13..14 waves per CU), and their pace is set by
@@ -14,9 +16,12 @@
 //     in aligned 128-byte blocks, 16 bytes per lane, the next block parked in registers one refill ahead.  Eight rounds
 //     consume at most 8 x 8 x 2 = 128 bytes per group, so a group needs at most one block per eight rounds: one
 //     compare per lane every eight rounds, the refill itself runs under the exec mask of the groups that need it;
-//   * four rounds of symbols are transposed inside the quads (as in decode_wave.hip) and every lane stores a dword:
-//     32 contiguous bytes per group and store.
-// Full chunks of a multiple of 32 symbols only (the launcher hands everything else to the lane kernel).
+//   * sixteen rounds are one 128-byte line of the chunk: four rounds of symbols are transposed inside the quads (as in
+//     decode_wave.hip), the halves of the group exchange dwords (v_cndmask_b32_dpp), and every lane stores 16 bytes -- pieces
+//     of a line that leave at different times reach memory as partial lines (profiles/r06_word8_groups.md: 2.05 ms with
+//     one dword per lane every four rounds, 0.51 with whole lines).
+// Full chunks of a multiple of 32 symbols (the launcher hands everything else to the lane kernel, a ragged last chunk to the
+// wave-per-chunk decoder).  The mirror image, the 8-way encoder: encode_groups.hip.
 //
 // No MFMA: integer, table-driven, serial per state.
 
