@@ -202,12 +202,15 @@ __global__ void __launch_bounds__(kEncGrpThreads, 8) k_encode_word_groups(const 
             a1 = quad_transpose(a1, sel1, sel2);
             a2 = quad_transpose(a2, sel1, sel2);
             a3 = quad_transpose(a3, sel1, sel2);
+            // (the block that the LAST eight rounds of the line before may have finished leaves here, behind the wait for this
+            //  line's symbols: in front of it the wait -- s_waitcnt vmcnt(0), the compiler cannot count conditional stores -- would
+            //  be for a store that has only just been issued)
+            if (c >= 64u * (fb + 1u))
+                flush_block(2u * c);
             encode_octet_8rounds<SMALL, TRACK>(x, c, worst, a2, a3, k4, gm_lo, gm_hi, k255, ring); // rounds 15 .. 8
             if (c >= 64u * (fb + 1u))
                 flush_block(2u * c);
             encode_octet_8rounds<SMALL, TRACK>(x, c, worst, a0, a1, k4, gm_lo, gm_hi, k255, ring); // rounds 7 .. 0
-            if (c >= 64u * (fb + 1u))
-                flush_block(2u * c);
         };
         u32x4 next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (lines - 1u), kAuxNt);
         for (uint32_t q = lines; q-- > 0;) {
@@ -216,6 +219,8 @@ __global__ void __launch_bounds__(kEncGrpThreads, 8) k_encode_word_groups(const 
                 next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (q - 1u), kAuxNt);
             sixteen(cur);
         }
+        if (c >= 64u * (fb + 1u)) // (the last eight rounds' block)
+            flush_block(2u * c);
         // the final states, state 0 lowest (RansWordEncFlush: rans_word_sse41.h:104-113 reads them back in that order): lane
         // i's dword ends 32 - 4 i bytes ... starts 2 c + 32 - 4 i bytes below the slot's end
         {
