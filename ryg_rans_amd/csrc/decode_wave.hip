@@ -361,6 +361,12 @@ __global__ void __launch_bounds__(kDecBlockThreads, (K <= 2 ? 8 : 4)) k_decode(c
                 RANS_ROUND(2)
                 RANS_ROUND(3)
 #undef RANS_ROUND
+                // One state per lane: one more refill check here, in FRONT of the group's stores.  A refill waits for the prefetched
+                // block with s_waitcnt vmcnt(0) -- the compiler cannot tell what else is in flight -- and the check at the top of the
+                // next group comes right behind these stores: it would wait for them as well (per-chunk models, word: 0.692 ->
+                // 0.673 ms; byte: 0.755 -> 0.748; with two states per lane, whose checks sit inside the group, it costs 2-6 %)
+                if constexpr (K == 1)
+                    W.checkpoint(lane);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const uint32_t v = quad_transpose(acc[k], sel1, sel2);
