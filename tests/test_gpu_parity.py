@@ -1143,8 +1143,8 @@ def test_word_eight_way_octet_encoder(gpu, oracle):
     placements -- compact (k_layout + k_compact_small behind the launch), the slot layout, sized slots with and without chunks
     that do not fit (those are coded again into the overflow region) -- for models with Alverson reciprocals, with a frequency
     above 2048 (round-up reciprocals) and with byte values that have no record; chunk counts that are no multiple of eight; a
-    stray symbol is RANS_AMD_E_MODEL; shapes the kernel does not take (a ragged last chunk, chunks off 128 symbols) still
-    code through the lane kernels."""
+    stray symbol is RANS_AMD_E_MODEL; a ragged last chunk (its octet goes round by round); chunks off 128 symbols still code
+    through the lane kernels."""
     R, ctx, torch = gpu
     rng = np.random.default_rng(3)
     zipf = oracle.gen_zipf(1 << 20, K=256, s=1.0, seed=5)
@@ -1194,8 +1194,24 @@ def test_word_eight_way_octet_encoder(gpu, oracle):
         with pytest.raises(R.RansAmdError) as e:
             call(gm, torch.from_numpy(d).cuda(), 8, 1024)
         assert e.value.status == R.E_MODEL
-    # shapes for the lane kernels: a ragged last chunk, chunks of 1000 symbols
-    for data, chunk in ((zipf[:100 * 1024 + 77], 1024), (zipf[:128 * 1000], 1000)):
+    # a ragged last chunk: the input's last octet goes round by round, lanes without a symbol sit their rounds out
+    for extra in (1, 7, 8, 9, 77, 1023):
+        for nch in (64, 69):
+            data = heavy[:nch * 1024 + extra] if extra == 9 else zipf[:nch * 1024 + extra]
+            f, _ = R.normalize_freqs(np.bincount(data, minlength=256), 1 << 12)
+            om, gm = oracle.model(f, 12), ctx.model(FMT_WORD, f, 12)
+            want, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, 8, 1024, align=16)
+            d_syms = torch.from_numpy(data).cuda()
+            cont, o, l, total = ctx.encode(gm, d_syms, 8, 1024)
+            assert ctx.last_encode_kernel()[0] == "k_encode_word_groups" and total == want.size, ctx.last_encode_kernel()
+            same(cont[:total].cpu().numpy(), o.cpu().numpy(), l.cpu().numpy(), want, offs, lens, ("ragged", extra, nch))
+            cont, o, l, total, sl = ctx.encode_sized(gm, d_syms, 8, 1024, overflow_chunks=nch + 1)
+            assert ctx.last_encode_kernel()[0] == "k_encode_word_groups"
+            same(cont.cpu().numpy(), o.cpu().numpy(), l.cpu().numpy(), want, offs, lens, ("ragged, sized", extra, nch))
+            out = ctx.decode(gm, cont, total, o, l, data.size, 8, 1024)
+            assert np.array_equal(out.cpu().numpy(), data) and ctx.decode_errors() == 0, (extra, nch)
+    # a shape for the lane kernels: chunks of 1000 symbols
+    for data, chunk in ((zipf[:128 * 1000], 1000),):
         f, _ = R.normalize_freqs(np.bincount(data, minlength=256), 1 << 12)
         om, gm = oracle.model(f, 12), ctx.model(FMT_WORD, f, 12)
         want, offs, lens = oracle.encode_chunked(FMT_WORD, om, data, 8, chunk, align=16)
