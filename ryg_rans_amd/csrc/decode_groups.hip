@@ -20,8 +20,9 @@
 //     decode_wave.hip), the halves of the group exchange dwords (v_cndmask_b32_dpp), and every lane stores 16 bytes -- pieces
 //     of a line that leave at different times reach memory as partial lines (profiles/r06_word8_groups.md: 2.05 ms with
 //     one dword per lane every four rounds, 0.51 with whole lines).
-// Full chunks of a multiple of 32 symbols (the launcher hands everything else to the lane kernel, a ragged last chunk to the
-// wave-per-chunk decoder).  The mirror image, the 8-way encoder: encode_groups.hip.
+// Full chunks of a multiple of 4 symbols -- the output is stored in dwords -- (the launcher hands everything else to the lane
+// kernel, a ragged last chunk to the wave-per-chunk decoder); what a chunk size off 128 leaves goes four rounds, then one round
+// at a time.  The mirror image, the 8-way encoder: encode_groups.hip.
 //
 // No MFMA: integer, table-driven, serial per state.
 
@@ -154,6 +155,7 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
     const uint32_t sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
     const uint32_t groups16 = uniform(p.chunk_syms >> 7);      // 16 rounds of 8 symbols
     const uint32_t rem4 = uniform((p.chunk_syms >> 5) & 3u);   // + up to three times 4 rounds
+    const uint32_t left_syms = uniform(p.chunk_syms & 31u);    // + up to 31 symbols
     const uint64_t octets = (p.nchunks + 7u) >> 3; // (the last one may hold fewer than eight chunks)
     const uint32_t per_claim = uniform(p.chunk_syms >= kGrpClaimSyms / 8u ? 1u : (kGrpClaimSyms / 8u + p.chunk_syms - 1u) / p.chunk_syms);
     const uint64_t claims = (octets + per_claim - 1u) / per_claim;
@@ -309,6 +311,23 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
                 osoff += 32u;
             }
 #undef RANS_GROUP_ROUND
+            // what a chunk size off 32 leaves (at most 31 symbols: three rounds and a partial one, main_simd.cpp:313-332 with
+            // in_size % 8 != 0): lanes without a symbol sit the round out, a byte store per lane
+            for (uint32_t r0 = 0; r0 < left_syms; r0 += 8u) {
+                const bool active = r0 + i < left_syms;
+                uint32_t raw = 0;
+                if (active)
+                    raw = dec_step<FMT_WORD>(T, x);
+                const bool need = active && x < k65536;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(need);
+                const uint32_t t_lo = (uint32_t)m & gm_lo, t_hi = (uint32_t)(m >> 32) & gm_hi;
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi(t_hi, __builtin_amdgcn_mbcnt_lo(t_lo, curw));
+                curw += __builtin_popcount(t_lo) + __builtin_popcount(t_hi);
+                if (need)
+                    x = (x << 16) | lds_u16(((at << 1) & k255) | ring);
+                if (active)
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(raw >> 24), orsrc, out_off16 - 16u * i + r0 + i, osoff, 0);
+            }
             // integrity: every state back at L, the cursor exactly at the end of the chunk's stream
             const bool bad = valid && (x != Tr::kL || 2u * curw - bias - (start - 8u * 4u) != len);
             const uint64_t bm = __builtin_amdgcn_ballot_w64(bad);
@@ -354,7 +373,7 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
 //   * four rounds of a state's symbols are one dword; the pair interleaves them (DPP swap + v_perm), sixteen rounds are 32
 //     bytes of the chunk, 16 per lane, and after thirty-two rounds two 16-byte stores per lane leave back to back: 64
 //     contiguous bytes per chunk.
-// Full chunks of a multiple of 64 symbols.
+// Full chunks of a multiple of 4 symbols (what a size off 64 leaves goes one round at a time).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kPairBlock = 32;              // bytes a pair fetches at a time: 2 lanes x 16 B
 constexpr uint32_t kPairRing = 2 * kPairBlock;   // per pair
@@ -553,6 +572,7 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
     const uint64_t glo = cbase & ~uint64_t(15), glimit = (cbase + p.container_bytes + 15u) & ~uint64_t(15);
     const uint32_t groups64 = uniform(p.chunk_syms >> 7);    // 64 rounds of 2 symbols
     const uint32_t rem32 = uniform((p.chunk_syms >> 6) & 1u); // + 32 rounds
+    const uint32_t left_syms = uniform(p.chunk_syms & 63u);   // + up to 31 rounds, one at a time
     const uint64_t batches = (p.nchunks + 31u) >> 5;      // (the last one may hold fewer than 32 chunks)
     const uint32_t per_claim = uniform(p.chunk_syms >= kGrpClaimSyms / 32u ? 1u : (kGrpClaimSyms / 32u + p.chunk_syms - 1u) / p.chunk_syms);
     const uint64_t claims = (batches + per_claim - 1u) / per_claim;
@@ -672,6 +692,25 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
                 __builtin_amdgcn_raw_buffer_store_b128(v0, orsrc, out_off16, osoff, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(v1, orsrc, out_off16, osoff + 32u, 0);
             }
+            // what a chunk size off 64 leaves (at most 31 rounds): compiler-scheduled, one round at a time, a byte store per lane
+            for (uint32_t r = 0; 2u * r < left_syms; ++r) {
+                if ((r & 7u) == 0)
+                    checkpoint();
+                const uint32_t cf = x & maskv; // rans_byte.h:125-128 (get), :291-298 (advance)
+                const uint32_t sy = *reinterpret_cast<RANS_LDS const uint8_t *>((uintptr_t)cf);
+                const u32x2 fr = *reinterpret_cast<RANS_LDS const u32x2 *>((uintptr_t)(rec + 8u * sy));
+                x = (fr.x & 0xffffffu) * ((x >> sbv) & 0xffffffu) + cf - fr.y;
+                const bool n1 = x < l23, n2 = x < l15; // rans_byte.h:307-318: state 0's bytes first
+                const uint32_t n = (uint32_t)n1 + (uint32_t)n2;
+                const uint32_t n_other = (uint32_t)__shfl_xor((int)n, 1, 64);
+                const uint32_t pos = cur + (i ? n_other : 0u);
+                cur += n + n_other;
+                if (n1)
+                    x = (x << 8) | *reinterpret_cast<RANS_LDS const uint8_t *>((uintptr_t)(ring_c + (pos & 63u)));
+                if (n2)
+                    x = (x << 8) | *reinterpret_cast<RANS_LDS const uint8_t *>((uintptr_t)(ring_c + ((pos + 1u) & 63u)));
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)sy, orsrc, out_off16 - 16u * i + (p.chunk_syms - left_syms) + 2u * r + i, 0, 0);
+            }
             // integrity: both states back at L, the cursor exactly at the end of the chunk's stream
             const bool bad = valid && (x != Tr::kL || cur - (start - 2u * 4u) != len);
             const uint64_t bm = __builtin_amdgcn_ballot_w64(bad);
@@ -690,7 +729,7 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
 // one LANE for the whole chunk, takes four times that).
 bool decode_word_groups_applicable(const DecParams &p)
 {
-    return p.n_ways == 8 && p.sym_bytes == 1 && p.scale_bits == 12 && (p.chunk_syms & 31u) == 0 && p.chunk_syms <= (1u << 20) &&
+    return p.n_ways == 8 && p.sym_bytes == 1 && p.scale_bits == 12 && (p.chunk_syms & 3u) == 0 && p.chunk_syms >= 32 && p.chunk_syms <= (1u << 20) &&
            (reinterpret_cast<uintptr_t>(p.out) & 3u) == 0 && p.n / p.chunk_syms >= 8 && !p.trace &&
            ((p.table0_bytes + 15u) & ~15u) % kGrpRing == 0;
 }
@@ -735,8 +774,8 @@ hipError_t launch_decode_word_groups(const DecParams &p, int num_cus, hipStream_
 bool decode_byte_pairs_applicable(const DecParams &p)
 {
     const size_t tables = (size_t)((p.table0_bytes + 15u) & ~15u) + ((p.table1_bytes + 15u) & ~15u);
-    return p.n_ways == 2 && p.sym_bytes == 1 && p.scale_bits >= 8 && p.scale_bits <= 16 && (p.chunk_syms & 63u) == 0 &&
-           p.chunk_syms <= (1u << 20) && (reinterpret_cast<uintptr_t>(p.out) & 3u) == 0 && p.n / p.chunk_syms >= 32 && !p.trace &&
+    return p.n_ways == 2 && p.sym_bytes == 1 && p.scale_bits >= 8 && p.scale_bits <= 16 && (p.chunk_syms & 3u) == 0 &&
+           p.chunk_syms >= 64 && p.chunk_syms <= (1u << 20) && (reinterpret_cast<uintptr_t>(p.out) & 3u) == 0 && p.n / p.chunk_syms >= 32 && !p.trace &&
            tables + (size_t)(kGrpThreads / 64) * kPairWaveLds <= 160u * 1024u;
 }
 

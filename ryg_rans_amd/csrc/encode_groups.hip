@@ -20,7 +20,8 @@
 // Slots: worst-case scratch slots (k_layout / k_compact_small behind the launch), the caller's container (slot layout), or
 // sized slots -- a store that would start below the slot's first byte is dropped, and a chunk whose stream turns out longer
 // than its slot is listed for the redo launch exactly as the lane encoders list theirs (EncParams::ovf_ctl).
-// Chunks of a multiple of 128 symbols (launcher); a ragged last chunk sends the input's last octet round by round.
+// Chunks of a multiple of 4 symbols (launcher: the symbol loads are dword-aligned); what a chunk size off 128 leaves, and the
+// input's last octet when its last chunk is a ragged one, go round by round.
 //
 // No MFMA: integer, table-driven, serial per state.
 
@@ -213,45 +214,55 @@ __global__ void __launch_bounds__(kEncGrpThreads, 8) k_encode_word_groups(const 
                 flush_block(2u * c);
             encode_octet_8rounds<SMALL, TRACK>(x, c, worst, a0, a1, k4, gm_lo, gm_hi, k255, ring); // rounds 7 .. 0
         };
-        if (octet + 1u == octets && ragged) {
-            // The input's last octet when its last chunk is a ragged one: round by round, lanes without a symbol sit the round
-            // out (main_simd.cpp:287-300 with in_size % 8 != 0: the first, partial round belongs to states 0 .. in_size % 8 - 1).
-            // One octet of the whole input: compiler-scheduled, a byte load per lane and round.
+        // one round of the compiler-scheduled kind: lanes without a symbol sit it out (main_simd.cpp:287-300 with in_size % 8 !=
+        // 0: the partial round belongs to states 0 .. in_size % 8 - 1).  For what a chunk size off 128 leaves, and for the
+        // input's last octet when its last chunk is a ragged one.
+        auto one_round = [&](uint32_t sym, bool active) {
+            const u32x4 rec = *reinterpret_cast<RANS_LDS const u32x4 *>((uintptr_t)(sym << 4));
+            const bool emit = active && x > rec.y; // rans_word_sse41.h:85
+            const uint64_t m = __builtin_amdgcn_ballot_w64(emit);
+            const uint32_t t_lo = (uint32_t)m & gm_lo, t_hi = (uint32_t)(m >> 32) & gm_hi;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(t_hi, __builtin_amdgcn_mbcnt_lo(t_lo, 0u));
+            c += (uint32_t)__builtin_popcount(t_lo) + (uint32_t)__builtin_popcount(t_hi);
+            if (emit) {
+                *reinterpret_cast<RANS_LDS uint16_t *>((uintptr_t)(ring_c | ((2u * (rank - c)) & 255u))) = (uint16_t)x;
+                x >>= 16;
+            }
+            if (active) { // encode_common.hpp RANS_ENC_WORD_TAIL_*: x += bias + (x / freq) * cmpl
+                uint32_t q = __umulhi(x, rec.x);
+                if constexpr (!SMALL)
+                    q += (x - q) >> 1;
+                q >>= rec.z >> 24;
+                x = x + rec.w + (q & 0xffffffu) * (rec.z & 0xffffffu);
+                worst |= rec.z;
+            }
+        };
+        const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + chunk * p.chunk_syms;
+        if (octet + 1u == octets && ragged) { // one octet of the whole input: a byte load per lane and round
             uint32_t nsym = 0;
             if (valid)
                 nsym = chunk + 1u == p.nchunks ? (uint32_t)(p.n - chunk * p.chunk_syms) : p.chunk_syms;
-            const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + chunk * p.chunk_syms;
-            for (uint32_t r = p.chunk_syms >> 3; r-- > 0;) {
+            for (uint32_t r = (p.chunk_syms + 7u) >> 3; r-- > 0;) {
                 const bool active = r * 8u + i < nsym;
-                const uint32_t sym = active ? (uint32_t)src[r * 8u + i] : 0u;
-                const u32x4 rec = *reinterpret_cast<RANS_LDS const u32x4 *>((uintptr_t)(sym << 4));
-                const bool emit = active && x > rec.y; // rans_word_sse41.h:85
-                const uint64_t m = __builtin_amdgcn_ballot_w64(emit);
-                const uint32_t t_lo = (uint32_t)m & gm_lo, t_hi = (uint32_t)(m >> 32) & gm_hi;
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(t_hi, __builtin_amdgcn_mbcnt_lo(t_lo, 0u));
-                c += (uint32_t)__builtin_popcount(t_lo) + (uint32_t)__builtin_popcount(t_hi);
-                if (emit) {
-                    *reinterpret_cast<RANS_LDS uint16_t *>((uintptr_t)(ring_c | ((2u * (rank - c)) & 255u))) = (uint16_t)x;
-                    x >>= 16;
-                }
-                if (active) { // encode_common.hpp RANS_ENC_WORD_TAIL_*: x += bias + (x / freq) * cmpl
-                    uint32_t q = __umulhi(x, rec.x);
-                    if constexpr (!SMALL)
-                        q += (x - q) >> 1;
-                    q >>= rec.z >> 24;
-                    x = x + rec.w + (q & 0xffffffu) * (rec.z & 0xffffffu);
-                    worst |= rec.z;
-                }
+                one_round(active ? (uint32_t)src[r * 8u + i] : 0u, active);
                 if ((r & 7u) == 0 && c >= 64u * (fb + 1u))
                     flush_block(2u * c);
             }
         } else {
-            u32x4 next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (lines - 1u), kAuxNt);
-            for (uint32_t q = lines; q-- > 0;) {
-                const u32x4 cur = next;
-                if (q)
-                    next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (q - 1u), kAuxNt);
-                sixteen(cur);
+            for (uint32_t r = (p.chunk_syms + 7u) >> 3; r-- > 16u * lines;) { // the rounds behind the chunk's last whole line
+                const bool active = valid && r * 8u + i < p.chunk_syms;
+                one_round(active ? (uint32_t)src[r * 8u + i] : 0u, active);
+                if ((r & 7u) == 0 && c >= 64u * (fb + 1u))
+                    flush_block(2u * c);
+            }
+            if (lines) {
+                u32x4 next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (lines - 1u), kAuxNt);
+                for (uint32_t q = lines; q-- > 0;) {
+                    const u32x4 cur = next;
+                    if (q)
+                        next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (q - 1u), kAuxNt);
+                    sixteen(cur);
+                }
             }
         }
         if (c >= 64u * (fb + 1u)) // (the last eight rounds' block)
@@ -292,8 +303,8 @@ __global__ void __launch_bounds__(kEncGrpThreads, 8) k_encode_word_groups(const 
 //  slot size, and that neither the fused placement nor a redo is asked for; scratch and container are 16-byte aligned by then)
 bool encode_word_groups_applicable(const EncParams &p)
 {
-    return p.n_ways == 8 && p.sym_bytes == 1 && !p.status && !p.redo && !p.no_lanes && p.nsyms <= 256 && (p.chunk_syms & 127u) == 0 &&
-           p.chunk_syms <= (1u << 20) && p.nchunks >= 8 && (reinterpret_cast<uintptr_t>(p.syms) & 15u) == 0 &&
+    return p.n_ways == 8 && p.sym_bytes == 1 && !p.status && !p.redo && !p.no_lanes && p.nsyms <= 256 && (p.chunk_syms & 3u) == 0 &&
+           p.chunk_syms >= 32 && p.chunk_syms <= (1u << 20) && p.nchunks >= 8 && (reinterpret_cast<uintptr_t>(p.syms) & 15u) == 0 &&
            (p.slot_bytes & 15u) == 0 && p.slot_bytes >= 48 && p.slot_bytes < (1ull << 28);
 }
 

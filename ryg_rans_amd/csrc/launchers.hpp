@@ -48,7 +48,7 @@ hipError_t launch_decode_word_groups(const DecParams &p, int num_cus, hipStream_
 bool decode_byte_pairs_applicable(const DecParams &p);
 hipError_t launch_decode_byte_pairs(const DecParams &p, int num_cus, hipStream_t stream, const char **name);
 
-// the 8-way word layout's encoder, eight chunks per wave (encode_groups.hip): chunks of a multiple of 128 u8 symbols, the
+// the 8-way word layout's encoder, eight chunks per wave (encode_groups.hip): chunks of a multiple of 4 u8 symbols, the
 // three-kernel placement, the slot layout or sized slots (no fused placement)
 bool encode_word_groups_applicable(const EncParams &p);
 hipError_t launch_encode_word_groups(const EncParams &p, int num_cus, hipStream_t stream, const char **name);
