@@ -165,133 +165,133 @@ __global__ void __launch_bounds__(kEncGrpThreads, 8) k_encode_word_groups(const 
         const uint64_t claim = uniform64(octet_v);
         octet_v += total_waves;
         const uint64_t o_end = (claim + 1u) * per_claim < octets ? (claim + 1u) * per_claim : octets;
-      for (uint64_t octet = claim * per_claim; octet < o_end; ++octet) {
-        const uint64_t chunk = octet * 8u + g;
-        const bool valid = chunk < p.nchunks;
-        // symbols through a descriptor of the octet's input (the running offset is an SGPR), stream blocks through one of its slots
-        const rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t *>(p.syms) + octet * 8u * p.chunk_syms, 0, 8u * p.chunk_syms, kRsrcFlags);
-        const rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.scratch + octet * 8u * p.slot_bytes, 0, 8u * slot, kRsrcFlags);
-        const uint32_t in_off = valid ? g * p.chunk_syms + 16u * i : 0x80000000u; // (a chunk that does not exist reads zeros)
-        const uint32_t slot_end = (g + 1u) * slot;                                 // offset of the END of my chunk's slot in the octet's
-        uint32_t x = Tr::kL, c = 0, fb = 0; // state, words emitted so far (the group's), blocks flushed
-        // block fb of the ring -> its place below the slot's end; a piece that would start below the slot's first byte is dropped
-        // (sized slots: the chunk then does not fit, its length says so at the end)
-        auto flush_block = [&](uint32_t have_bytes) { // have_bytes: the group's stream so far
-            const uint32_t below = kEncGrpBlock * (fb + 1u) - 16u * i; // this lane's piece starts `below` bytes under the slot's end
-            if (valid && below <= slot && below - 16u < have_bytes) {
-                const u32x4 v = *reinterpret_cast<RANS_LDS const u32x4 *>((uintptr_t)(ring_c + ((fb & 1u) ? 0u : kEncGrpBlock) + 16u * i));
-                __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, slot_end - below, 0, 0);
-            }
-            fb += 1u;
-        };
-        auto sixteen = [&](const u32x4 &v) { // one 128-byte line of the chunk, last round first
-            uint32_t a0, a1, a2, a3;
-            // rows 2 i, 2 i + 1 of the line -> this state's column: the halves of the group swap what the decoder's output
-            // exchange gave them (decode_groups.hip), then the quad transposes
-            asm volatile("s_nop 1\n\t"
-                         "s_mov_b64 vcc, %[lower]\n\t"
-                         "v_cndmask_b32_dpp %[a0], %[vy], %[vx], vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" // lower ? mine : y of lane - 4
-                         "v_cndmask_b32_dpp %[a1], %[vw], %[vz], vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                         "s_mov_b64 vcc, %[upper]\n\t"
-                         "v_cndmask_b32_dpp %[a2], %[vx], %[vy], vcc row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" // upper ? mine : x of lane + 4
-                         "v_cndmask_b32_dpp %[a3], %[vz], %[vw], vcc row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                         : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
-                         : [vx] "v"(v.x), [vy] "v"(v.y), [vz] "v"(v.z), [vw] "v"(v.w), [lower] "s"(0x0f0f0f0f0f0f0f0full),
-                           [upper] "s"(0xf0f0f0f0f0f0f0f0ull)
-                         : "vcc");
-            a0 = quad_transpose(a0, sel1, sel2); // byte J of a_k: round 8 (k >> 1) + 2 J + (k & 1)
-            a1 = quad_transpose(a1, sel1, sel2);
-            a2 = quad_transpose(a2, sel1, sel2);
-            a3 = quad_transpose(a3, sel1, sel2);
-            // (the block that the LAST eight rounds of the line before may have finished leaves here, behind the wait for this
-            //  line's symbols: in front of it the wait -- s_waitcnt vmcnt(0), the compiler cannot count conditional stores -- would
-            //  be for a store that has only just been issued)
-            if (c >= 64u * (fb + 1u))
-                flush_block(2u * c);
-            encode_octet_8rounds<SMALL, TRACK>(x, c, worst, a2, a3, k4, gm_lo, gm_hi, k255, ring); // rounds 15 .. 8
-            if (c >= 64u * (fb + 1u))
-                flush_block(2u * c);
-            encode_octet_8rounds<SMALL, TRACK>(x, c, worst, a0, a1, k4, gm_lo, gm_hi, k255, ring); // rounds 7 .. 0
-        };
-        // one round of the compiler-scheduled kind: lanes without a symbol sit it out (main_simd.cpp:287-300 with in_size % 8 !=
-        // 0: the partial round belongs to states 0 .. in_size % 8 - 1).  For what a chunk size off 128 leaves, and for the
-        // input's last octet when its last chunk is a ragged one.
-        auto one_round = [&](uint32_t sym, bool active) {
-            const u32x4 rec = *reinterpret_cast<RANS_LDS const u32x4 *>((uintptr_t)(sym << 4));
-            const bool emit = active && x > rec.y; // rans_word_sse41.h:85
-            const uint64_t m = __builtin_amdgcn_ballot_w64(emit);
-            const uint32_t t_lo = (uint32_t)m & gm_lo, t_hi = (uint32_t)(m >> 32) & gm_hi;
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(t_hi, __builtin_amdgcn_mbcnt_lo(t_lo, 0u));
-            c += (uint32_t)__builtin_popcount(t_lo) + (uint32_t)__builtin_popcount(t_hi);
-            if (emit) {
-                *reinterpret_cast<RANS_LDS uint16_t *>((uintptr_t)(ring_c | ((2u * (rank - c)) & 255u))) = (uint16_t)x;
-                x >>= 16;
-            }
-            if (active) { // encode_common.hpp RANS_ENC_WORD_TAIL_*: x += bias + (x / freq) * cmpl
-                uint32_t q = __umulhi(x, rec.x);
-                if constexpr (!SMALL)
-                    q += (x - q) >> 1;
-                q >>= rec.z >> 24;
-                x = x + rec.w + (q & 0xffffffu) * (rec.z & 0xffffffu);
-                worst |= rec.z;
-            }
-        };
-        const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + chunk * p.chunk_syms;
-        if (octet + 1u == octets && ragged) { // one octet of the whole input: a byte load per lane and round
-            uint32_t nsym = 0;
-            if (valid)
-                nsym = chunk + 1u == p.nchunks ? (uint32_t)(p.n - chunk * p.chunk_syms) : p.chunk_syms;
-            for (uint32_t r = (p.chunk_syms + 7u) >> 3; r-- > 0;) {
-                const bool active = r * 8u + i < nsym;
-                one_round(active ? (uint32_t)src[r * 8u + i] : 0u, active);
-                if ((r & 7u) == 0 && c >= 64u * (fb + 1u))
+        for (uint64_t octet = claim * per_claim; octet < o_end; ++octet) {
+            const uint64_t chunk = octet * 8u + g;
+            const bool valid = chunk < p.nchunks;
+            // symbols through a descriptor of the octet's input (the running offset is an SGPR), stream blocks through one of its slots
+            const rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t *>(p.syms) + octet * 8u * p.chunk_syms, 0, 8u * p.chunk_syms, kRsrcFlags);
+            const rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.scratch + octet * 8u * p.slot_bytes, 0, 8u * slot, kRsrcFlags);
+            const uint32_t in_off = valid ? g * p.chunk_syms + 16u * i : 0x80000000u; // (a chunk that does not exist reads zeros)
+            const uint32_t slot_end = (g + 1u) * slot;                                 // offset of the END of my chunk's slot in the octet's
+            uint32_t x = Tr::kL, c = 0, fb = 0; // state, words emitted so far (the group's), blocks flushed
+            // block fb of the ring -> its place below the slot's end; a piece that would start below the slot's first byte is dropped
+            // (sized slots: the chunk then does not fit, its length says so at the end)
+            auto flush_block = [&](uint32_t have_bytes) { // have_bytes: the group's stream so far
+                const uint32_t below = kEncGrpBlock * (fb + 1u) - 16u * i; // this lane's piece starts `below` bytes under the slot's end
+                if (valid && below <= slot && below - 16u < have_bytes) {
+                    const u32x4 v = *reinterpret_cast<RANS_LDS const u32x4 *>((uintptr_t)(ring_c + ((fb & 1u) ? 0u : kEncGrpBlock) + 16u * i));
+                    __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, slot_end - below, 0, 0);
+                }
+                fb += 1u;
+            };
+            auto sixteen = [&](const u32x4 &v) { // one 128-byte line of the chunk, last round first
+                uint32_t a0, a1, a2, a3;
+                // rows 2 i, 2 i + 1 of the line -> this state's column: the halves of the group swap what the decoder's output
+                // exchange gave them (decode_groups.hip), then the quad transposes
+                asm volatile("s_nop 1\n\t"
+                             "s_mov_b64 vcc, %[lower]\n\t"
+                             "v_cndmask_b32_dpp %[a0], %[vy], %[vx], vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" // lower ? mine : y of lane - 4
+                             "v_cndmask_b32_dpp %[a1], %[vw], %[vz], vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "s_mov_b64 vcc, %[upper]\n\t"
+                             "v_cndmask_b32_dpp %[a2], %[vx], %[vy], vcc row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" // upper ? mine : x of lane + 4
+                             "v_cndmask_b32_dpp %[a3], %[vz], %[vw], vcc row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                             : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+                             : [vx] "v"(v.x), [vy] "v"(v.y), [vz] "v"(v.z), [vw] "v"(v.w), [lower] "s"(0x0f0f0f0f0f0f0f0full),
+                               [upper] "s"(0xf0f0f0f0f0f0f0f0ull)
+                             : "vcc");
+                a0 = quad_transpose(a0, sel1, sel2); // byte J of a_k: round 8 (k >> 1) + 2 J + (k & 1)
+                a1 = quad_transpose(a1, sel1, sel2);
+                a2 = quad_transpose(a2, sel1, sel2);
+                a3 = quad_transpose(a3, sel1, sel2);
+                // (the block that the LAST eight rounds of the line before may have finished leaves here, behind the wait for this
+                //  line's symbols: in front of it the wait -- s_waitcnt vmcnt(0), the compiler cannot count conditional stores -- would
+                //  be for a store that has only just been issued)
+                if (c >= 64u * (fb + 1u))
                     flush_block(2u * c);
-            }
-        } else {
-            for (uint32_t r = (p.chunk_syms + 7u) >> 3; r-- > 16u * lines;) { // the rounds behind the chunk's last whole line
-                const bool active = valid && r * 8u + i < p.chunk_syms;
-                one_round(active ? (uint32_t)src[r * 8u + i] : 0u, active);
-                if ((r & 7u) == 0 && c >= 64u * (fb + 1u))
+                encode_octet_8rounds<SMALL, TRACK>(x, c, worst, a2, a3, k4, gm_lo, gm_hi, k255, ring); // rounds 15 .. 8
+                if (c >= 64u * (fb + 1u))
                     flush_block(2u * c);
+                encode_octet_8rounds<SMALL, TRACK>(x, c, worst, a0, a1, k4, gm_lo, gm_hi, k255, ring); // rounds 7 .. 0
+            };
+            // one round of the compiler-scheduled kind: lanes without a symbol sit it out (main_simd.cpp:287-300 with in_size % 8 !=
+            // 0: the partial round belongs to states 0 .. in_size % 8 - 1).  For what a chunk size off 128 leaves, and for the
+            // input's last octet when its last chunk is a ragged one.
+            auto one_round = [&](uint32_t sym, bool active) {
+                const u32x4 rec = *reinterpret_cast<RANS_LDS const u32x4 *>((uintptr_t)(sym << 4));
+                const bool emit = active && x > rec.y; // rans_word_sse41.h:85
+                const uint64_t m = __builtin_amdgcn_ballot_w64(emit);
+                const uint32_t t_lo = (uint32_t)m & gm_lo, t_hi = (uint32_t)(m >> 32) & gm_hi;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(t_hi, __builtin_amdgcn_mbcnt_lo(t_lo, 0u));
+                c += (uint32_t)__builtin_popcount(t_lo) + (uint32_t)__builtin_popcount(t_hi);
+                if (emit) {
+                    *reinterpret_cast<RANS_LDS uint16_t *>((uintptr_t)(ring_c | ((2u * (rank - c)) & 255u))) = (uint16_t)x;
+                    x >>= 16;
+                }
+                if (active) { // encode_common.hpp RANS_ENC_WORD_TAIL_*: x += bias + (x / freq) * cmpl
+                    uint32_t q = __umulhi(x, rec.x);
+                    if constexpr (!SMALL)
+                        q += (x - q) >> 1;
+                    q >>= rec.z >> 24;
+                    x = x + rec.w + (q & 0xffffffu) * (rec.z & 0xffffffu);
+                    worst |= rec.z;
+                }
+            };
+            const uint8_t RANS_GLOBAL *src = (const uint8_t RANS_GLOBAL *)p.syms + chunk * p.chunk_syms;
+            if (octet + 1u == octets && ragged) { // one octet of the whole input: a byte load per lane and round
+                uint32_t nsym = 0;
+                if (valid)
+                    nsym = chunk + 1u == p.nchunks ? (uint32_t)(p.n - chunk * p.chunk_syms) : p.chunk_syms;
+                for (uint32_t r = (p.chunk_syms + 7u) >> 3; r-- > 0;) {
+                    const bool active = r * 8u + i < nsym;
+                    one_round(active ? (uint32_t)src[r * 8u + i] : 0u, active);
+                    if ((r & 7u) == 0 && c >= 64u * (fb + 1u))
+                        flush_block(2u * c);
+                }
+            } else {
+                for (uint32_t r = (p.chunk_syms + 7u) >> 3; r-- > 16u * lines;) { // the rounds behind the chunk's last whole line
+                    const bool active = valid && r * 8u + i < p.chunk_syms;
+                    one_round(active ? (uint32_t)src[r * 8u + i] : 0u, active);
+                    if ((r & 7u) == 0 && c >= 64u * (fb + 1u))
+                        flush_block(2u * c);
+                }
+                if (lines) {
+                    u32x4 next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (lines - 1u), kAuxNt);
+                    for (uint32_t q = lines; q-- > 0;) {
+                        const u32x4 cur = next;
+                        if (q)
+                            next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (q - 1u), kAuxNt);
+                        sixteen(cur);
+                    }
+                }
             }
-            if (lines) {
-                u32x4 next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (lines - 1u), kAuxNt);
-                for (uint32_t q = lines; q-- > 0;) {
-                    const u32x4 cur = next;
-                    if (q)
-                        next = __builtin_amdgcn_raw_buffer_load_b128(irsrc, in_off, 128u * (q - 1u), kAuxNt);
-                    sixteen(cur);
+            if (c >= 64u * (fb + 1u)) // (the last eight rounds' block)
+                flush_block(2u * c);
+            // the final states, state 0 lowest (RansWordEncFlush: rans_word_sse41.h:104-113 reads them back in that order): lane
+            // i's dword ends 32 - 4 i bytes ... starts 2 c + 32 - 4 i bytes below the slot's end
+            {
+                const uint32_t at = 0u - (2u * c + 32u - 4u * i);
+                *reinterpret_cast<RANS_LDS uint16_t *>((uintptr_t)(ring_c | (at & 255u))) = (uint16_t)x;
+                *reinterpret_cast<RANS_LDS uint16_t *>((uintptr_t)(ring_c | ((at + 2u) & 255u))) = (uint16_t)(x >> 16);
+                c += 16u;
+            }
+            const uint32_t len = 2u * c;
+            if (64u * fb < c)
+                flush_block(len);
+            if (64u * fb < c)
+                flush_block(len);
+            if (valid && i == 0) {
+                p.lengths[chunk] = len;
+                if (len > slot) { // (sized slots only: a worst-case slot holds every stream)
+                    if (p.ovf_ctl)
+                        p.ovf_list[atomicAdd(p.ovf_ctl, 1u)] = (uint32_t)chunk;
+                } else if (p.slot_layout) {
+                    p.offsets[chunk] = (chunk + 1u) * p.slot_bytes - len;
+                    if (chunk + 1 == p.nchunks)
+                        p.offsets[p.nchunks] = p.nchunks * p.slot_bytes;
                 }
             }
         }
-        if (c >= 64u * (fb + 1u)) // (the last eight rounds' block)
-            flush_block(2u * c);
-        // the final states, state 0 lowest (RansWordEncFlush: rans_word_sse41.h:104-113 reads them back in that order): lane
-        // i's dword ends 32 - 4 i bytes ... starts 2 c + 32 - 4 i bytes below the slot's end
-        {
-            const uint32_t at = 0u - (2u * c + 32u - 4u * i);
-            *reinterpret_cast<RANS_LDS uint16_t *>((uintptr_t)(ring_c | (at & 255u))) = (uint16_t)x;
-            *reinterpret_cast<RANS_LDS uint16_t *>((uintptr_t)(ring_c | ((at + 2u) & 255u))) = (uint16_t)(x >> 16);
-            c += 16u;
-        }
-        const uint32_t len = 2u * c;
-        if (64u * fb < c)
-            flush_block(len);
-        if (64u * fb < c)
-            flush_block(len);
-        if (valid && i == 0) {
-            p.lengths[chunk] = len;
-            if (len > slot) { // (sized slots only: a worst-case slot holds every stream)
-                if (p.ovf_ctl)
-                    p.ovf_list[atomicAdd(p.ovf_ctl, 1u)] = (uint32_t)chunk;
-            } else if (p.slot_layout) {
-                p.offsets[chunk] = (chunk + 1u) * p.slot_bytes - len;
-                if (chunk + 1 == p.nchunks)
-                    p.offsets[p.nchunks] = p.nchunks * p.slot_bytes;
-            }
-        }
-      }
     }
     if (TRACK && __builtin_amdgcn_ballot_w64((worst >> 31) != 0) != 0 && lane == 0)
         atomicOr(p.flags, 1u);
