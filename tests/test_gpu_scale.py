@@ -195,6 +195,7 @@ def test_full_size_per_chunk_models_every_chunk_equals_oracle(gpu, oracle, fmt, 
 @pytest.mark.parametrize("name,fmt,sb,ways,chunk,n", [
     ("word-64-way", FMT_WORD, 12, 64, 32768, 5 << 30),                 # 5 Gi symbols: 163 840 chunks, 32 768 of them past 2^32
     ("r64-2-way", FMT_R64, 14, 2, 512, (1 << 32) + (1 << 20) + 77),    # config 2's shape: 8 390 657 chunks (> 2^23), a ragged last one
+    ("word-8-way", FMT_WORD, 12, 8, 1024, (5 << 30) + 77),             # the group kernels (8 chunks per wave): 5 242 881 chunks, a ragged last one
 ])
 def test_more_than_2_to_the_32_symbols(gpu, oracle, name, fmt, sb, ways, chunk, n):
     """n >= 2^32: the ABI takes uint64_t n and the kernels form 64-bit bases; here they meet symbols, chunks
