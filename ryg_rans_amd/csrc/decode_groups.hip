@@ -20,8 +20,8 @@
 //     decode_wave.hip), the halves of the group exchange dwords (v_cndmask_b32_dpp), and every lane stores 16 bytes -- pieces
 //     of a line that leave at different times reach memory as partial lines (profiles/r06_word8_groups.md: 2.05 ms with
 //     one dword per lane every four rounds, 0.51 with whole lines).
-// Full chunks of a multiple of 4 symbols -- the output is stored in dwords -- (the launcher hands everything else to the lane
-// kernel, a ragged last chunk to the wave-per-chunk decoder); what a chunk size off 128 leaves goes four rounds, then one round
+// Chunks of a multiple of 4 symbols -- the output is stored in dwords -- (the launcher hands everything else to the lane
+// kernel); a ragged last chunk sends the input's last octet one round at a time; what a chunk size off 128 leaves goes four rounds, then one round
 // at a time.  The mirror image, the 8-way encoder: encode_groups.hip.
 //
 // No MFMA: integer, table-driven, serial per state.
@@ -188,22 +188,28 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
         claim_v += total_waves;
         return uniform64(c);
     };
-    uint64_t octet, o_end;
+    // A ragged last chunk (p.n % p.chunk_syms != 0) is decoded here as well: its octet, the input's last, goes one round at a
+    // time with the lanes that have no symbol sitting out -- three times an octet's usual time, so the octets are handed out
+    // back to front then and that one starts first.
+    const bool ragged = p.n % p.chunk_syms != 0;
+    auto octet_of = [&](uint64_t k) -> uint64_t { return ragged ? octets - 1u - k : k; }; // k: the order of the hand-out
+    uint64_t vk, o_end;
     bool have;
     {
         const uint64_t c = claim_take();
         have = c < claims;
-        octet = c * per_claim;
+        vk = c * per_claim;
         o_end = (c + 1u) * per_claim < octets ? (c + 1u) * per_claim : octets;
     }
     uint64_t off = 0;
     uint32_t len = 0;
-    if (have && octet * 8u + g < p.nchunks) {
-        off = p.offsets[octet * 8u + g];
-        len = p.lengths[octet * 8u + g];
+    if (have && octet_of(vk) * 8u + g < p.nchunks) {
+        off = p.offsets[octet_of(vk) * 8u + g];
+        len = p.lengths[octet_of(vk) * 8u + g];
     }
     while (have) {
         {
+            const uint64_t octet = octet_of(vk);
             const bool exists = octet * 8u + g < p.nchunks;
             const bool valid = exists && (off & 1u) == 0 && len >= 8u * 4u && off <= p.container_bytes && len <= p.container_bytes - off;
             if (exists && !valid && i == 0)
@@ -268,7 +274,8 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
             // (row 2 m + 1, half h), (row 8 + 2 m, h), (row 9 + 2 m, h) of the line's sixteen 8-byte rows; the halves h = 0
             // keep the first two and take their other halves from lane i + 4, the halves h = 1 the last two from lane i - 4:
             // lane i then holds bytes [16 i, 16 i + 16) of the line, one 16-byte store per lane.
-            for (uint32_t q = 0; q < groups16; ++q) {
+            const bool by_rounds = ragged && octet + 1u == octets; // (wave-uniform)
+            for (uint32_t q = 0; q < (by_rounds ? 0u : groups16); ++q) {
                 uint32_t a0, a1, a2, a3;
                 // (the refill check BEHIND each eight rounds, not in front: the store of the line before then is eight rounds old when a
                 //  refill's s_waitcnt vmcnt(0) comes -- in front of the rounds it had just been issued; 0.519 -> 0.503 ms)
@@ -297,7 +304,7 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
                 __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, out_off16, osoff, kAuxStore);
                 osoff += 128u;
             }
-            for (uint32_t q = 0; q < rem4; ++q) { // what is left of a chunk that is not a multiple of 128 symbols: 4 rounds a time
+            for (uint32_t q = 0; q < (by_rounds ? 0u : rem4); ++q) { // what is left of a chunk that is not a multiple of 128 symbols: 4 rounds a time
                 uint32_t acc = 0;
                 RANS_GROUP_ROUND(acc, 0)
                 RANS_GROUP_ROUND(acc, 1)
@@ -312,9 +319,18 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
             }
 #undef RANS_GROUP_ROUND
             // what a chunk size off 32 leaves (at most 31 symbols: three rounds and a partial one, main_simd.cpp:313-332 with
-            // in_size % 8 != 0): lanes without a symbol sit the round out, a byte store per lane
-            for (uint32_t r0 = 0; r0 < left_syms; r0 += 8u) {
-                const bool active = r0 + i < left_syms;
+            // in_size % 8 != 0) -- or, in the ragged chunk's octet, every round: lanes without a symbol sit the round out, a byte
+            // store per lane
+            uint32_t nsym = valid ? p.chunk_syms : 0u, r_first = p.chunk_syms - left_syms;
+            if (by_rounds) {
+                r_first = 0u;
+                if (valid && octet * 8u + g + 1u == p.nchunks)
+                    nsym = (uint32_t)(p.n - (octet * 8u + g) * p.chunk_syms);
+            }
+            for (uint32_t r0 = r_first; r0 < p.chunk_syms; r0 += 8u) {
+                if (by_rounds && (r0 & 63u) == 0)
+                    checkpoint();
+                const bool active = r0 + i < nsym;
                 uint32_t raw = 0;
                 if (active)
                     raw = dec_step<FMT_WORD>(T, x);
@@ -326,7 +342,7 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
                 if (need)
                     x = (x << 16) | lds_u16(((at << 1) & k255) | ring);
                 if (active)
-                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(raw >> 24), orsrc, out_off16 - 16u * i + r0 + i, osoff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(raw >> 24), orsrc, out_off16 - 16u * i + r0 + i, 0, 0);
             }
             // integrity: every state back at L, the cursor exactly at the end of the chunk's stream
             const bool bad = valid && (x != Tr::kL || 2u * curw - bias - (start - 8u * 4u) != len);
@@ -334,21 +350,21 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
             if (i == 0 && ((bm >> (8u * g)) & 0xffu) != 0)
                 nbad++;
             // the octet after this one
-            uint64_t n_octet = octet + 1u, n_end = o_end;
+            uint64_t n_vk = vk + 1u, n_end = o_end;
             bool n_have = true;
-            if (n_octet >= o_end) {
+            if (n_vk >= o_end) {
                 const uint64_t c = claim_take();
                 n_have = c < claims;
-                n_octet = c * per_claim;
+                n_vk = c * per_claim;
                 n_end = (c + 1u) * per_claim < octets ? (c + 1u) * per_claim : octets;
             }
             uint64_t n_off = 0;
             uint32_t n_len = 0;
-            if (n_have && n_octet * 8u + g < p.nchunks) {
-                n_off = p.offsets[n_octet * 8u + g];
-                n_len = p.lengths[n_octet * 8u + g];
+            if (n_have && octet_of(n_vk) * 8u + g < p.nchunks) {
+                n_off = p.offsets[octet_of(n_vk) * 8u + g];
+                n_len = p.lengths[octet_of(n_vk) * 8u + g];
             }
-            octet = n_octet;
+            vk = n_vk;
             o_end = n_end;
             have = n_have;
             off = n_off;
@@ -600,12 +616,14 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
         claim_v += total_waves;
         return uniform64(c);
     };
+    const bool ragged = p.n % p.chunk_syms != 0; // (as in k_decode_word_groups)
     for (;;) {
         const uint64_t claim = claim_take();
         if (claim >= claims)
             break;
         const uint64_t b_end = (claim + 1u) * per_claim < batches ? (claim + 1u) * per_claim : batches;
-        for (uint64_t batch = claim * per_claim; batch < b_end; ++batch) {
+        for (uint64_t vb = claim * per_claim; vb < b_end; ++vb) {
+            const uint64_t batch = ragged ? batches - 1u - vb : vb; // (a ragged last chunk: its batch goes round by round -- first)
             const uint64_t chunk = batch * 32u + g;
             const bool exists = chunk < p.nchunks;
             const uint64_t off = exists ? p.offsets[chunk] : 0u;
@@ -674,7 +692,8 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
             // 64 rounds = one 128-byte line of the chunk: four 16-byte stores per lane leave back to back (a pair writes 32
             // contiguous bytes per instruction; pieces of a line that leave 16 or 32 rounds apart reach memory as partial
             // lines -- measured 1.18 ms against 0.70 without stores)
-            for (uint32_t q = 0; q < groups64; ++q) {
+            const bool by_rounds = ragged && batch + 1u == batches; // (wave-uniform)
+            for (uint32_t q = 0; q < (by_rounds ? 0u : groups64); ++q) {
                 const u32x4 v0 = sixteen();
                 const u32x4 v1 = sixteen();
                 const u32x4 v2 = sixteen();
@@ -686,30 +705,41 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
                 __builtin_amdgcn_raw_buffer_store_b128(quad_half<1>(v2, v3), orsrc, off_b, osoff + 64u, kPairAux);
                 osoff += 128u;
             }
-            if (rem32) { // a chunk of an odd multiple of 64 symbols: its last half line
+            if (rem32 && !by_rounds) { // a chunk of an odd multiple of 64 symbols: its last half line
                 const u32x4 v0 = sixteen();
                 const u32x4 v1 = sixteen();
                 __builtin_amdgcn_raw_buffer_store_b128(v0, orsrc, out_off16, osoff, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(v1, orsrc, out_off16, osoff + 32u, 0);
             }
-            // what a chunk size off 64 leaves (at most 31 rounds): compiler-scheduled, one round at a time, a byte store per lane
-            for (uint32_t r = 0; 2u * r < left_syms; ++r) {
-                if ((r & 7u) == 0)
+            // what a chunk size off 64 leaves (at most 31 rounds) -- or, in the ragged chunk's batch, every round: compiler-scheduled,
+            // one round at a time, lanes without a symbol sit the round out, a byte store per lane
+            uint32_t nsym = valid ? p.chunk_syms : 0u, s_first = p.chunk_syms - left_syms;
+            if (by_rounds) {
+                s_first = 0u;
+                if (valid && chunk + 1u == p.nchunks)
+                    nsym = (uint32_t)(p.n - chunk * p.chunk_syms);
+            }
+            for (uint32_t s0 = s_first; s0 < p.chunk_syms; s0 += 2u) {
+                if (((s0 - s_first) & 15u) == 0)
                     checkpoint();
-                const uint32_t cf = x & maskv; // rans_byte.h:125-128 (get), :291-298 (advance)
-                const uint32_t sy = *reinterpret_cast<RANS_LDS const uint8_t *>((uintptr_t)cf);
-                const u32x2 fr = *reinterpret_cast<RANS_LDS const u32x2 *>((uintptr_t)(rec + 8u * sy));
-                x = (fr.x & 0xffffffu) * ((x >> sbv) & 0xffffffu) + cf - fr.y;
-                const bool n1 = x < l23, n2 = x < l15; // rans_byte.h:307-318: state 0's bytes first
-                const uint32_t n = (uint32_t)n1 + (uint32_t)n2;
+                const bool active = s0 + i < nsym;
+                uint32_t sy = 0, n = 0;
+                if (active) {
+                    const uint32_t cf = x & maskv; // rans_byte.h:125-128 (get), :291-298 (advance)
+                    sy = *reinterpret_cast<RANS_LDS const uint8_t *>((uintptr_t)cf);
+                    const u32x2 fr = *reinterpret_cast<RANS_LDS const u32x2 *>((uintptr_t)(rec + 8u * sy));
+                    x = (fr.x & 0xffffffu) * ((x >> sbv) & 0xffffffu) + cf - fr.y;
+                    n = (uint32_t)(x < l23) + (uint32_t)(x < l15); // rans_byte.h:307-318: state 0's bytes first
+                }
                 const uint32_t n_other = (uint32_t)__shfl_xor((int)n, 1, 64);
                 const uint32_t pos = cur + (i ? n_other : 0u);
                 cur += n + n_other;
-                if (n1)
+                if (n >= 1u)
                     x = (x << 8) | *reinterpret_cast<RANS_LDS const uint8_t *>((uintptr_t)(ring_c + (pos & 63u)));
-                if (n2)
+                if (n >= 2u)
                     x = (x << 8) | *reinterpret_cast<RANS_LDS const uint8_t *>((uintptr_t)(ring_c + ((pos + 1u) & 63u)));
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)sy, orsrc, out_off16 - 16u * i + (p.chunk_syms - left_syms) + 2u * r + i, 0, 0);
+                if (active)
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)sy, orsrc, out_off16 - 16u * i + s0 + i, 0, 0);
             }
             // integrity: both states back at L, the cursor exactly at the end of the chunk's stream
             const bool bad = valid && (x != Tr::kL || cur - (start - 2u * 4u) != len);
@@ -724,9 +754,7 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
 
 } // namespace
 
-// Every full chunk goes through k_decode_word_groups; a ragged last chunk through the wave-per-chunk decoder in a second launch
-// (one wave, eight of its lanes at work: a chunk's rounds one after the other, ~20 us per thousand symbols -- the lane kernel,
-// one LANE for the whole chunk, takes four times that).
+// (a ragged last chunk included: its octet goes one round at a time and is handed out first)
 bool decode_word_groups_applicable(const DecParams &p)
 {
     return p.n_ways == 8 && p.sym_bytes == 1 && p.scale_bits == 12 && (p.chunk_syms & 3u) == 0 && p.chunk_syms >= 32 && p.chunk_syms <= (1u << 20) &&
@@ -736,38 +764,20 @@ bool decode_word_groups_applicable(const DecParams &p)
 
 hipError_t launch_decode_word_groups(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
-    const uint64_t full = p.n / p.chunk_syms; // chunks the group kernel takes
     const size_t table_lds = (p.table0_bytes + 15u) & ~15u;
     const size_t lds = table_lds + (size_t)(kGrpThreads / 64) * kGrpWaveLds;
     auto kern = k_decode_word_groups;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 160 * 1024, lds_ok); e != hipSuccess)
         return e;
-    DecParams q = p;
-    q.nchunks = full;
-    q.n = full * p.chunk_syms;
     const uint32_t per_cu = 2u * lds <= 160u * 1024u ? 2u : 1u;
-    const uint64_t want_blocks = ((full + 7u) / 8u + kGrpThreads / 64 - 1) / (kGrpThreads / 64);
+    const uint64_t want_blocks = ((p.nchunks + 7u) / 8u + kGrpThreads / 64 - 1) / (kGrpThreads / 64);
     const uint64_t cap = (uint64_t)num_cus * per_cu;
     const uint32_t grid = (uint32_t)(want_blocks < cap ? want_blocks : cap);
     if (name)
         *name = "k_decode_word_groups";
-    RANS_LAUNCH(kern, dim3(grid), dim3(kGrpThreads), lds, stream, q);
-    if (hipError_t e = hipGetLastError(); e != hipSuccess)
-        return e;
-    if (full == p.nchunks)
-        return hipSuccess;
-    DecParams r = p; // the ragged last chunk
-    r.offsets = p.offsets + full;
-    r.lengths = p.lengths + full;
-    r.out = static_cast<uint8_t *>(p.out) + full * p.chunk_syms;
-    r.n = p.n - full * p.chunk_syms;
-    r.nchunks = p.nchunks - full;
-    r.work_counter = nullptr;
-    r.work_counter_reset = nullptr;
-    r.span = nullptr;
-    r.span_reset = nullptr;
-    return launch_decode_wave(FMT_WORD, r, num_cus, stream, nullptr);
+    RANS_LAUNCH(kern, dim3(grid), dim3(kGrpThreads), lds, stream, p);
+    return hipGetLastError();
 }
 
 // The same for the byte format's 2-way layout (cum2sym tables, scale_bits 8..16, u8 symbols).
@@ -781,38 +791,20 @@ bool decode_byte_pairs_applicable(const DecParams &p)
 
 hipError_t launch_decode_byte_pairs(const DecParams &p, int num_cus, hipStream_t stream, const char **name)
 {
-    const uint64_t full = p.n / p.chunk_syms;
     const size_t tables = (size_t)((p.table0_bytes + 15u) & ~15u) + ((p.table1_bytes + 15u) & ~15u);
     const size_t lds = tables + (size_t)(kGrpThreads / 64) * kPairWaveLds;
     auto kern = k_decode_byte_pairs;
     static std::atomic<uint64_t> lds_ok{0};
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), 160 * 1024, lds_ok); e != hipSuccess)
         return e;
-    DecParams q = p;
-    q.nchunks = full;
-    q.n = full * p.chunk_syms;
     const uint32_t per_cu = 2u * lds <= 160u * 1024u ? 2u : 1u;
-    const uint64_t want_blocks = ((full + 31u) / 32u + kGrpThreads / 64 - 1) / (kGrpThreads / 64);
+    const uint64_t want_blocks = ((p.nchunks + 31u) / 32u + kGrpThreads / 64 - 1) / (kGrpThreads / 64);
     const uint64_t cap = (uint64_t)num_cus * per_cu;
     const uint32_t grid = (uint32_t)(want_blocks < cap ? want_blocks : cap);
     if (name)
         *name = "k_decode_byte_pairs";
-    RANS_LAUNCH(kern, dim3(grid), dim3(kGrpThreads), lds, stream, q);
-    if (hipError_t e = hipGetLastError(); e != hipSuccess)
-        return e;
-    if (full == p.nchunks)
-        return hipSuccess;
-    DecParams r = p; // the ragged last chunk
-    r.offsets = p.offsets + full;
-    r.lengths = p.lengths + full;
-    r.out = static_cast<uint8_t *>(p.out) + full * p.chunk_syms;
-    r.n = p.n - full * p.chunk_syms;
-    r.nchunks = p.nchunks - full;
-    r.work_counter = nullptr;
-    r.work_counter_reset = nullptr;
-    r.span = nullptr;
-    r.span_reset = nullptr;
-    return launch_decode_wave(FMT_BYTE, r, num_cus, stream, nullptr);
+    RANS_LAUNCH(kern, dim3(grid), dim3(kGrpThreads), lds, stream, p);
+    return hipGetLastError();
 }
 
 } // namespace rans_amd

@@ -1049,7 +1049,7 @@ def test_rans64_two_way_lane_kernel(gpu, oracle):
 def test_word_eight_way_octet_decoder(gpu, oracle):
     """The reference's 8-way word layout (rans_word_sse41.h:151-227, main_simd.cpp:313-332) through k_decode_word_groups, eight
     chunks per wave: chunk sizes of one and many 16-round lines, sizes that leave one to three 4-round groups behind the last
-    line, sizes off 32 (any multiple of 4), chunk counts that are no multiple of eight and a ragged last chunk (a second launch), chunks that
+    line, sizes off 32 (any multiple of 4), chunk counts that are no multiple of eight and a ragged last chunk (its octet goes round by round), chunks that
     start on any 2-byte boundary, in any order; the ORACLE's container and the GPU's own; streams that consume the most a
     valid one can (16 bytes per round) and next to nothing; damage is flagged, never a crash."""
     R, ctx, torch = gpu
@@ -1225,7 +1225,7 @@ def test_word_eight_way_octet_encoder(gpu, oracle):
 def test_byte_two_way_pair_decoder(gpu, oracle, sb):
     """The reference's 2-way byte layout (main.cpp:226-280) through k_decode_byte_pairs, 32 chunks per wave: chunk sizes of one
     and many 64-round lines, of an odd number of half lines and of any multiple of 4 symbols, chunk counts that are no multiple of 32 and a ragged last
-    chunk (the wave decoder's second launch), chunks on any byte boundary and in any order, the ORACLE's container and the
+    chunk (its batch goes round by round), chunks on any byte boundary and in any order, the ORACLE's container and the
     GPU's own, streams that take two bytes per state and round and streams that take next to none; damage is flagged."""
     R, ctx, torch = gpu
     rng = np.random.default_rng(80 + sb)

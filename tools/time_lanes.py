@@ -1,7 +1,7 @@
 """Sustained decode (and encode) timing of one lane-per-stream configuration; one process per variant so that the
 library's environment knobs (RANS_AMD_DEBUG, RANS_AMD_LANES, RANS_AMD_LIB) can differ between runs.
 
-    python tools/time_lanes.py [--fmt r64] [--ways 2] [--chunk 512] [--log2n 28] [--sb 14] [--steps 20] [--no-check]
+    python tools/time_lanes.py [--fmt r64] [--ways 2] [--chunk 512] [--log2n 28] [--extra 0] [--sb 14] [--steps 20] [--no-check] [--encode]
 """
 import argparse
 import os
@@ -26,11 +26,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--encode", action="store_true")
+    ap.add_argument("--extra", type=int, default=0, help="symbols on top of 2^log2n (a ragged last chunk)")
     a = ap.parse_args()
     fmt = {"r64": R.FMT_R64, "word": R.FMT_WORD, "byte": R.FMT_BYTE, "alias": R.FMT_ALIAS}[a.fmt]
     ctx = R.Context(0)
     dev = torch.device("cuda", 0)
-    n = 1 << a.log2n
+    n = (1 << a.log2n) + a.extra
     d = gen_zipf(torch, n, 256, 1.0, 1, dev)
     f, _ = R.normalize_freqs(ctx.count_freqs_device(d, 256), 1 << a.sb)
     m = ctx.model(fmt, f, a.sb)
@@ -47,8 +48,8 @@ def main():
         ms.append(ctx.last_kernel_ms()[0])
     bad = ctx.decode_errors()
     ok = a.no_check or (bool(torch.equal(out, d)) and bad == 0)
-    line = "decode %s %d-way chunk %d n 2^%d sb %d: mean %.4f ms min %.4f ms  frac %.3f  %s" % (
-        a.fmt, a.ways, a.chunk, a.log2n, a.sb, float(np.mean(ms)), float(np.min(ms)),
+    line = "decode %s %d-way chunk %d n 2^%d%s sb %d: mean %.4f ms min %.4f ms  frac %.3f  %s" % (
+        a.fmt, a.ways, a.chunk, a.log2n, " + %d" % a.extra if a.extra else "", a.sb, float(np.mean(ms)), float(np.min(ms)),
         (n + total) / (np.mean(ms) * 1e-3) / 8e12, "ok" if ok else "MISMATCH (bad=%d)" % bad)
     if a.encode:
         es = []
