@@ -165,7 +165,10 @@ __global__ void __launch_bounds__(kEncGrpThreads, 8) k_encode_word_groups(const 
         const uint64_t claim = uniform64(octet_v);
         octet_v += total_waves;
         const uint64_t o_end = (claim + 1u) * per_claim < octets ? (claim + 1u) * per_claim : octets;
-        for (uint64_t octet = claim * per_claim; octet < o_end; ++octet) {
+        for (uint64_t vk = claim * per_claim; vk < o_end; ++vk) {
+            // (a ragged last chunk: its octet takes three times an octet's usual time -- the work is dealt back to front then, and
+            //  that one starts first; 1 GiB + 8191 symbols in 16 Ki-symbol chunks: 0.76 -> 0.63 ms)
+            const uint64_t octet = ragged ? octets - 1u - vk : vk;
             const uint64_t chunk = octet * 8u + g;
             const bool valid = chunk < p.nchunks;
             // symbols through a descriptor of the octet's input (the running offset is an SGPR), stream blocks through one of its slots
