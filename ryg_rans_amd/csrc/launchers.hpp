@@ -40,8 +40,8 @@ hipError_t launch_encode_wave(int format, const EncParams &p, int num_cus, hipSt
 // two chunks per wave, 64-way, byte-stream formats (decode_dual.hip); format: kKernelFormatAlias2[W] or RANS_AMD_FMT_BYTE
 hipError_t launch_decode_dual(int format, const DecParams &p, int num_cus, hipStream_t stream, const char **name);
 
-// eight chunks per wave, the reference's 8-way word layout over u8 symbols (decode_groups.hip); everything the kernel does not
-// take (fewer than eight full chunks at the end, a ragged last one) goes on to launch_decode_lanes from inside
+// eight chunks per wave, the reference's 8-way word layout over u8 symbols (decode_groups.hip): chunks of a multiple of 4
+// symbols on a 4-byte aligned output, a partial last octet and a ragged last chunk included
 bool decode_word_groups_applicable(const DecParams &p);
 hipError_t launch_decode_word_groups(const DecParams &p, int num_cus, hipStream_t stream, const char **name);
 // 32 chunks per wave, the byte format's 2-way layout over u8 symbols (cum2sym tables), same file
