@@ -301,7 +301,13 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_word_groups(const Dec
                              : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [lower] "s"(0x0f0f0f0f0f0f0f0full),
                                [upper] "s"(0xf0f0f0f0f0f0f0f0ull)
                              : "vcc");
-                __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, out_off16, osoff, kAuxStore);
+                // (chunk sizes off 64: a chunk's lines straddle the memory's at odd places, and the pieces of a memory line arrive
+                //  sixteen rounds apart -- plain stores let L2 put them together: 1000-symbol chunks 1.10 -> 0.77 ms, 4000: 0.90 ->
+                //  0.65; on the 64-byte grid `nt sc1` wins: 960-symbol chunks 0.52 against 0.59)
+                if (p.chunk_syms & 63u)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, out_off16, osoff, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, out_off16, osoff, kAuxStore);
                 osoff += 128u;
             }
             for (uint32_t q = 0; q < (by_rounds ? 0u : rem4); ++q) { // what is left of a chunk that is not a multiple of 128 symbols: 4 rounds a time
@@ -699,10 +705,19 @@ __global__ void __launch_bounds__(kGrpThreads, 8) k_decode_byte_pairs(const DecP
                 const u32x4 v2 = sixteen();
                 const u32x4 v3 = sixteen();
                 // a quad writes 64 contiguous bytes per instruction, a chunk's line with two instructions back to back
-                __builtin_amdgcn_raw_buffer_store_b128(quad_half<0>(v0, v1), orsrc, off_a, osoff, kPairAux);
-                __builtin_amdgcn_raw_buffer_store_b128(quad_half<0>(v2, v3), orsrc, off_a, osoff + 64u, kPairAux);
-                __builtin_amdgcn_raw_buffer_store_b128(quad_half<1>(v0, v1), orsrc, off_b, osoff, kPairAux);
-                __builtin_amdgcn_raw_buffer_store_b128(quad_half<1>(v2, v3), orsrc, off_b, osoff + 64u, kPairAux);
+                // (64-byte pieces off the 64-byte grid: plain stores, as in k_decode_word_groups -- 1000-symbol chunks 1.67 -> 1.42 ms;
+                //  on the grid `nt sc1` wins: 960-symbol chunks 0.79 against 1.15)
+                if (p.chunk_syms & 63u) {
+                    __builtin_amdgcn_raw_buffer_store_b128(quad_half<0>(v0, v1), orsrc, off_a, osoff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(quad_half<0>(v2, v3), orsrc, off_a, osoff + 64u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(quad_half<1>(v0, v1), orsrc, off_b, osoff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(quad_half<1>(v2, v3), orsrc, off_b, osoff + 64u, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(quad_half<0>(v0, v1), orsrc, off_a, osoff, kPairAux);
+                    __builtin_amdgcn_raw_buffer_store_b128(quad_half<0>(v2, v3), orsrc, off_a, osoff + 64u, kPairAux);
+                    __builtin_amdgcn_raw_buffer_store_b128(quad_half<1>(v0, v1), orsrc, off_b, osoff, kPairAux);
+                    __builtin_amdgcn_raw_buffer_store_b128(quad_half<1>(v2, v3), orsrc, off_b, osoff + 64u, kPairAux);
+                }
                 osoff += 128u;
             }
             if (rem32 && !by_rounds) { // a chunk of an odd multiple of 64 symbols: its last half line
